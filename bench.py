@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Headline bench of the encoder hot path (BASELINE.json metric / SURVEY.md section 8d).
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over one synthetic batch that is already resident in HBM:
+  --mode fwd    BertImgModelwithLocationEmbeds.forward (embeddings + region projection + 12-layer
+                encoder + pooler), bf16, B=64 x (128 text + 100 region) per GPU   [BASELINE configs[1]]
+Prints ONE JSON line (rank 0) with whole-job samples/s, the live per-kernel roofline of the
+dominant kernel (the MFMA GEMM), and -- at N=1 -- the CPU oracle timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+
+def enc_flops_per_seq(S, H=768, L=12, I=3072):
+    """F_enc(S) = L * (24 S H^2 + 4 S^2 H) for I = 4H (multiply-add = 2)."""
+    return L * (2 * S * H * (3 * H) + 2 * S * H * H + 2 * 2 * S * H * I + 4 * S * S * H)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="fwd", choices=["fwd"])
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--text", type=int, default=128)
+    ap.add_argument("--regions", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (a.gpus, world)
+
+    from visitron_amd import ops
+    from visitron_amd.config import BertConfig
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.synth import make_batch
+
+    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)  # reference init N(0, 0.02) (BertPreTrainedModel.init_weights), identical on every rank
+    model = BertImgModelwithLocationEmbeds(cfg).eval().to(dev)
+    batch = make_batch(cfg, a.batch, a.text, a.regions, seed=1234 + rank, device=dev, with_labels=False)
+    S = a.text + a.regions
+
+    def step():
+        with torch.no_grad():
+            return model(**batch)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sync_all()
+
+    ms_per_step = elapsed / a.steps * 1e3
+    value = world * a.batch * a.steps / elapsed
+    f_enc = enc_flops_per_seq(S, cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size)
+
+    # ---- live per-kernel timing (HIP events on the launch stream), outside the timed region ----
+    roofline = None
+    kernels = None
+    if rank == 0 and not a.no_kernel_timing:
+        ops.profile_begin()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        kernels = ops.profile_end()
+        gemm = kernels.get("gemm_nt_bf16_128x128")
+        if gemm and gemm["ms"] > 0:
+            achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+            roofline = {
+                "kernel": "gemm_nt_bf16_128x128", "bound": "mfma", "achieved": round(achieved, 2),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                "traffic": None, "launches": gemm["n"], "avg_us": round(gemm["ms"] * 1e3 / gemm["n"], 2),
+                "flops_per_launch": gemm["flops"] / gemm["n"],
+            }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(cfg, a.text, a.regions)
+
+    if rank == 0:
+        out = {
+            "metric": "encoder fwd samples/sec (seq=%d, 12L base)" % S,
+            "value": round(value, 2),
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: oscar base (12L/768d/12h), %d text + %d region tokens, "
+                            "batch %d per GPU, trunk forward (embeddings + region projection + encoder + pooler)"
+                            % (a.text, a.regions, a.batch),
+                "global_batch": world * a.batch, "seq_len": S, "parallelism": "dp%d (replicas, no collective in forward)" % world,
+                "weights": "random init N(0,0.02), seed 0",
+            },
+            "encoder_flops_per_seq": f_enc,
+            "mfma_frac_whole_forward": round(f_enc * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernels_ms_per_step": None if kernels is None else {
+                k: round(v["ms"] / 3, 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(cfg, T, R):
+    """The oracle (a port of the reference's CPU path) on this box's host cores: bounded sample."""
+    from oracle.modeling import BertImgModelwithLocationEmbeds as OracleTrunk
+    from visitron_amd.synth import make_batch
+
+    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    ncores = min(ncores, 32)  # torch CPU GEMMs at this size stop scaling (and oversubscribe) beyond that
+    torch.set_num_threads(ncores)
+    torch.manual_seed(0)
+    m = OracleTrunk(cfg).eval()
+    B = 2  # BASELINE configs[0]: batch=2
+    b = make_batch(cfg, B, T, R, seed=1234, with_labels=False)
+    with torch.no_grad():
+        m(**b)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 50):
+            m(**b)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {
+        "value": round(B * n / dt, 3), "unit": "samples/s", "cores": ncores, "kind": "port",
+        "sample": "oracle fp32 trunk forward (torch CPU ops), B=%d x S=%d, %d iterations in %.1f s" % (B, T + R, n, dt),
+    }
+
+
+if __name__ == "__main__":
+    main()

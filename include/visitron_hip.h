@@ -1,0 +1,122 @@
+/* visitron_hip.h -- C ABI of the MI355X (gfx950) encoder hot path.
+ *
+ * The reference (alexa/visitron) has no FFI: its hot path is a stack of Python nn.Modules calling
+ * stock torch ops.  This library is the drop-in boundary BELOW those modules: every entry point
+ * replaces the torch-op sequence of the cited reference lines, takes plain device pointers, sizes
+ * and a hipStream_t, and returns an int status.  Contract for all entry points:
+ *   - pointers are DEVICE pointers (HBM) unless named host_*; 16-byte aligned; row strides (ld*)
+ *     are in ELEMENTS and must keep rows 16-byte aligned;
+ *   - "bf16" buffers hold raw bfloat16 bits (uint16_t); fp32 accumulation everywhere;
+ *   - nothing is allocated, freed or synchronised here: the caller owns every buffer (workspace
+ *     included) and the work is enqueued on `stream` (0 = the null stream);
+ *   - re-entrant: no global mutable state besides one-time kernel attribute setup;
+ *   - return 0 (VT_OK) or a negative VT_ERR_* code; vt_error_string() names it.
+ */
+#ifndef VISITRON_HIP_H
+#define VISITRON_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vt_stream_t; /* hipStream_t */
+
+#define VT_OK 0
+#define VT_ERR_BAD_SHAPE (-1)
+#define VT_ERR_BAD_ALIGN (-2)
+#define VT_ERR_NULL (-3)
+#define VT_ERR_UNSUPPORTED (-4)
+#define VT_ERR_HIP (-5)
+
+#define VT_ACT_NONE 0
+#define VT_ACT_GELU 1 /* erf-GELU, hidden_act == "gelu" */
+#define VT_ACT_TANH 2
+
+const char* vt_error_string(int code);
+/* ABI version of this header; bumped on any signature change. */
+int vt_abi_version(void);
+
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R[M,N]);  A, W, R bf16; C bf16 (out_f32 == 0) or
+ * fp32.  Replaces every nn.Linear call on the path -- query/key/value oscar/modeling_bert.py:43-45
+ * (packed into one [3H,H] weight), BertSelfOutput.dense :94, BertIntermediate.dense + gelu :119,
+ * BertOutput.dense :120, img_embedding + location_embeds tasks/viewpoint_select/encoder.py:277-279,
+ * pooler :296, mlmhead :377, token_head :381, next_action :391 -- with bias, activation and the
+ * residual add fused.  K % 64 == 0 (pad K with zeros); M, N arbitrary.  If grp_rows > 0 the
+ * output (and residual) row of GEMM row m is (m / grp_rows) * grp_stride + m % grp_rows, which
+ * lets the region projection write rows T..T+R-1 of every sequence of the [B,S,H] buffer in
+ * place of torch.cat (encoder.py:287). */
+int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                   const void* R, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int act,
+                   int out_f32, int grp_rows, int grp_stride, vt_stream_t stream);
+
+/* Fused scaled-dot-product attention, head size 64 (oscar/modeling_bert.py:47-72):
+ * ctx[b,s,h*64:(h+1)*64] = softmax_k(q.k / 8 + (1 - mask[b,k]) * -10000) . v  [* head_scale[h]].
+ * qkv is the packed projection output [B*S, ld_qkv] = q | k | v (each nh*64 wide).  mask is the
+ * caller's raw 2-D mask as fp32 [B,S] (null = all ones) when mask_additive == 0 -- the -10000
+ * arithmetic of tasks/viewpoint_select/encoder.py:238-241 then happens in the kernel -- or the
+ * already-additive [B,S] bias when mask_additive == 1 (what CaptionBertEncoder.forward receives).  lse (optional, [B,nh,S]) gets
+ * the natural-log log-sum-exp of the masked scores for the backward pass. */
+int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive,
+                          const float* head_scale, void* ctx, int64_t ld_ctx, float* lse, int B, int S,
+                          int nh, int head_size, vt_stream_t stream);
+
+/* y = BertLayerNorm(x) over rows of H (biased variance, eps inside the sqrt); x already holds
+ * dense(h) + bias + residual.  BertSelfOutput / BertOutput LayerNorm (called at
+ * oscar/modeling_bert.py:94,120) and the optional image LayerNorm (encoder.py:280-281; use
+ * grp_rows/grp_stride as in vt_linear_bf16).  mean / rstd: optional [M] outputs. */
+int vt_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma,
+                      const float* beta, float* mean, float* rstd, int M, int H, float eps,
+                      int grp_rows, int grp_stride, vt_stream_t stream);
+
+/* BertEmbeddings (called at tasks/viewpoint_select/encoder.py:267-269): y[b*S + t, :] =
+ * LayerNorm(word[ids[b,t]] + pos[pos_ids[b,t] or t] + type[type_ids[b,t] or 0]); tables fp32,
+ * y bf16 rows of the [B,S,H] buffer (S >= T).  err_flag (device int, optional) is set to 1 if an
+ * index is out of range. */
+int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
+                       const float* word, const float* pos, const float* type, const float* gamma,
+                       const float* beta, void* y, int64_t ldy, int B, int T, int S, int H,
+                       int n_word, int n_pos, int n_type, float eps, int* err_flag,
+                       vt_stream_t stream);
+
+/* out[row, :] = bf16([s0[row, 0:d0] | s1[row, 0:d1] | zeros to kpad]) -- builds the K-concatenated
+ * operand that turns img_embedding(img_feats) + location_embeds(loc) (encoder.py:277-279) into
+ * one GEMM. */
+int vt_pack_concat_bf16(const float* s0, int d0, const float* s1, int d1, void* out, int kpad,
+                        int64_t rows, vt_stream_t stream);
+
+/* ---- whole encoder stack: CaptionBertEncoder.forward, oscar/modeling_bert.py:140-169 ---------- */
+typedef struct vt_layer_weights {
+  const void* w_qkv;  const float* b_qkv;   /* [3H,H] bf16 = query|key|value weights, [3H] */
+  const void* w_ao;   const float* b_ao;    /* attention.output.dense [H,H] */
+  const float* ln1_g; const float* ln1_b;   /* attention.output.LayerNorm */
+  const void* w_in;   const float* b_in;    /* intermediate.dense [I,H] */
+  const void* w_out;  const float* b_out;   /* output.dense [H,I] */
+  const float* ln2_g; const float* ln2_b;   /* output.LayerNorm */
+} vt_layer_weights;
+
+/* Per-layer activation buffers.  Inference: every layer may point at the same scratch (and `out`
+ * may alias the layer input).  Training: distinct buffers per layer are what backward reads. */
+typedef struct vt_layer_acts {
+  void* qkv;       /* [M,3H] bf16 */
+  void* ctx;       /* [M,H]  bf16 attention context */
+  void* attn_pre;  /* [M,H]  bf16 dense(ctx)+bias+x (pre-LayerNorm) */
+  void* attn_out;  /* [M,H]  bf16 LayerNorm output */
+  void* mid;       /* [M,I]  bf16 gelu(intermediate) */
+  void* out_pre;   /* [M,H]  bf16 dense(mid)+bias+attn_out */
+  void* out;       /* [M,H]  bf16 layer output */
+  float* lse;      /* [B,nh,S] or null */
+  float* ln1_mean; float* ln1_rstd; float* ln2_mean; float* ln2_rstd; /* [M] or null */
+} vt_layer_acts;
+
+/* x: [B*S, H] bf16 embedding output (layer-0 input).  head_scale: [L, nh] fp32 or null.
+ * The output of the last layer is acts[L-1].out. */
+int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers,
+                            const void* x, const float* mask, int mask_additive, const float* head_scale,
+                            int B, int S, int H, int nh, int I, float ln_eps, vt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISITRON_HIP_H */

@@ -1,0 +1,165 @@
+"""End-to-end parity of the drop-in modules against the CPU oracle on identical synthetic inputs
+and weights.  Tolerance from BASELINE.json north_star: 5e-2 for the bf16 path."""
+import pytest
+import torch
+
+from helpers import maxabs, model_pair
+
+pytestmark = pytest.mark.gpu
+
+TOL_BF16 = 5e-2
+
+
+def _to(batch, dev):
+    return {k: v.to(dev) for k, v in batch.items()}
+
+
+def test_encoder_stack_matches_oracle(dev):
+    from oracle.modeling import CaptionBertEncoder as OEnc
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import CaptionBertEncoder
+
+    cfg = mini_config(num_hidden_layers=3, output_hidden_states=True)
+    ref, prod = model_pair(OEnc, CaptionBertEncoder, cfg, seed=1, device=dev)
+    g = torch.Generator().manual_seed(0)
+    B, S, H = 3, 45, cfg.hidden_size
+    x = torch.randn(B, S, H, generator=g)
+    keep = (torch.rand(B, S, generator=g) > 0.3).float()
+    keep[:, 0] = 1
+    ext = (1.0 - keep)[:, None, None, :] * -10000.0
+    with torch.no_grad():
+        want = ref(x, ext, head_mask=[None] * 3)
+        got = prod(x.to(dev), ext.to(dev), head_mask=[None] * 3)
+    assert maxabs(got[0], want[0]) < TOL_BF16
+    assert len(got[1]) == len(want[1]) == 4
+    for a, b in zip(got[1], want[1]):
+        assert maxabs(a, b) < TOL_BF16
+
+
+def test_sublayer_forwards_match_oracle(dev):
+    """CaptionBertLayer / CaptionBertAttention / CaptionBertSelfAttention are callable on their own."""
+    from oracle.modeling import CaptionBertLayer as OLayer
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import CaptionBertLayer
+
+    cfg = mini_config()
+    ref, prod = model_pair(OLayer, CaptionBertLayer, cfg, seed=2, device=dev)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 19, cfg.hidden_size, generator=g)
+    ext = torch.zeros(2, 1, 1, 19)
+    ext[1, 0, 0, 10:] = -10000.0
+    hm = torch.tensor([1.0, 0.5]).view(1, 2, 1, 1)
+    with torch.no_grad():
+        assert maxabs(prod(x.to(dev), ext.to(dev))[0], ref(x, ext)[0]) < TOL_BF16
+        assert maxabs(prod.attention(x.to(dev), ext.to(dev))[0], ref.attention(x, ext)[0]) < TOL_BF16
+        assert maxabs(prod.attention.self(x.to(dev), ext.to(dev), hm.to(dev))[0], ref.attention.self(x, ext, hm)[0]) < TOL_BF16
+
+
+@pytest.mark.parametrize("text_only", [False, True])
+def test_trunk_matches_oracle_mini(dev, text_only):
+    from oracle.modeling import BertImgModelwithLocationEmbeds as OTrunk
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config()
+    ref, prod = model_pair(OTrunk, BertImgModelwithLocationEmbeds, cfg, seed=4, device=dev)
+    b = make_batch(cfg, 4, text_len=21, region_len=0 if text_only else 13, seed=7, with_labels=False)
+    with torch.no_grad():
+        want = ref(**b)
+        got = prod(**_to(b, dev))
+    assert got[0].shape == want[0].shape and got[1].shape == want[1].shape
+    assert maxabs(got[0], want[0]) < TOL_BF16
+    assert maxabs(got[1], want[1]) < TOL_BF16
+
+
+def test_trunk_defaults_and_errors(dev):
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+
+    cfg = mini_config()
+    prod = BertImgModelwithLocationEmbeds(cfg).eval().to(dev)
+    ids = torch.randint(1, cfg.vocab_size, (2, 8), device=dev)
+    with torch.no_grad():
+        a = prod(ids)  # mask defaults to ones, types to zeros (encoder.py:215-219)
+        b = prod(ids, token_type_ids=torch.zeros_like(ids), attention_mask=torch.ones_like(ids))
+    assert torch.equal(a[0], b[0])
+    with pytest.raises(NotImplementedError):
+        prod(ids, attention_mask=torch.ones(2, 1, 1, 8, device=dev))  # rank not in {2,3}: encoder.py:230-231
+    with pytest.raises(IndexError):
+        prod(torch.full((2, 8), cfg.vocab_size + 1, device=dev))
+    with pytest.raises(RuntimeError):
+        prod(ids.cpu())  # no CPU fallback
+
+
+def test_trunk_uint8_inverted_mask_quirk(dev):
+    """the rollout caller passes ~mask of a uint8 tensor (values 255/254);
+    the trunk must do (1 - m) * -10000 literally."""
+    from oracle.modeling import BertImgModelwithLocationEmbeds as OTrunk
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+
+    cfg = mini_config()
+    ref, prod = model_pair(OTrunk, BertImgModelwithLocationEmbeds, cfg, seed=5, device=dev)
+    ids = torch.randint(1, cfg.vocab_size, (2, 12))
+    pad = torch.zeros(2, 12, dtype=torch.uint8)
+    pad[1, 7:] = 1
+    m = ~pad
+    with torch.no_grad():
+        want = ref(ids, attention_mask=m)
+        got = prod(ids.to(dev), attention_mask=m.to(dev))
+    assert maxabs(got[0], want[0]) < TOL_BF16
+
+
+def test_pretrain_heads_and_losses_match_oracle_mini(dev):
+    from oracle.modeling import PreTrainOscar as OModel
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config(use_img_layernorm=True, img_layer_norm_eps=1e-12)
+    ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=6, device=dev)
+    b = make_batch(cfg, 5, text_len=24, region_len=11, seed=3)
+    with torch.no_grad():
+        want = ref(**b)
+        got = prod(**_to(b, dev))
+        seq, pooled = ref.bert(**{k: v for k, v in b.items() if k in ("input_ids", "attention_mask", "img_feats", "img_location_embeddings")})[:2]
+        w_scores, w_tok, w_act = ref.heads(seq, pooled)
+        outs, p_pooled, _, B, S = prod.bert.run_trunk(
+            b["input_ids"].to(dev), attention_mask=b["attention_mask"].to(dev), img_feats=b["img_feats"].to(dev),
+            img_location_embeddings=b["img_location_embeddings"].to(dev))
+        g_scores, g_tok, g_act = prod.head_outputs(outs[-1], p_pooled)
+    assert maxabs(g_scores.view_as(w_scores.view(B * S, -1)), w_scores.view(B * S, -1)) < TOL_BF16
+    assert maxabs(g_tok, w_tok.view(B * S, -1)) < TOL_BF16
+    assert maxabs(g_act, w_act) < TOL_BF16
+    for i in range(4):  # loss, mask_loss, next_loss, token_loss
+        assert abs(float(got[i]) - float(want[i])) < TOL_BF16, (i, float(got[i]), float(want[i]))
+    assert len(got) == 7 and all(torch.is_tensor(t) and t.dim() == 0 for t in got)
+
+
+def test_base_config_cfg1_matches_oracle(dev):
+    """BASELINE config 1/2 shape: 12L/768d, 128 text + 100 region tokens, B=2."""
+    from oracle.modeling import PreTrainOscar as OModel
+    from visitron_amd.config import BertConfig
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import make_batch
+
+    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=0, device=dev, weight_std=0.03)
+    b = make_batch(cfg, 2, seed=1234)
+    trunk_keys = ("input_ids", "attention_mask", "img_feats", "img_location_embeddings")
+    with torch.no_grad():
+        want = ref(**b)
+        got = prod(**_to(b, dev))
+        w_seq, w_pool = ref.bert(**{k: b[k] for k in trunk_keys})[:2]
+        g_seq, g_pool = prod.bert(**{k: b[k].to(dev) for k in trunk_keys})[:2]
+        w_scores, _, w_act = ref.heads(w_seq, w_pool)
+        g_scores = prod.mlmhead(g_seq)
+        g_act = prod.next_action(g_pool)
+    assert maxabs(g_seq, w_seq) < TOL_BF16 * 2  # 12 layers of bf16 rounding on O(1..3) activations
+    assert maxabs(g_pool, w_pool) < TOL_BF16
+    assert maxabs(g_act, w_act) < TOL_BF16
+    rel = (g_scores.cpu() - w_scores).abs().max() / w_scores.abs().max()
+    assert float(rel) < TOL_BF16
+    for i in range(4):
+        assert abs(float(got[i]) - float(want[i])) < TOL_BF16 * max(1.0, abs(float(want[i])))

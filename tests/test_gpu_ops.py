@@ -1,0 +1,220 @@
+"""Parity of each HIP kernel (through the C ABI) against plain fp32 torch math on the same
+bf16-rounded inputs.  Tolerances: bf16 outputs carry 2^-8 relative rounding."""
+import math
+
+import pytest
+import torch
+
+from helpers import bf16_round, maxabs
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+def _rand(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale)
+
+
+def _gelu(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+@pytest.mark.parametrize(
+    "M,N,K,act,res,f32out",
+    [
+        (256, 256, 128, 0, False, False),
+        (456, 768, 768, 0, True, False),      # cfg1 rows (B=2 x 228): M tail
+        (456, 2304, 768, 0, False, False),    # packed qkv
+        (300, 3072, 768, 1, False, False),    # FFN up + GELU
+        (300, 768, 3072, 0, True, False),     # FFN down + residual
+        (130, 36, 128, 0, False, True),       # action head: N tail, fp32 out
+        (200, 1601, 768, 0, False, True),     # token head: N tail not multiple of 16
+        (64, 768, 768, 2, False, True),       # pooler tanh
+        (128, 30522, 768, 0, False, True),    # MLM decoder width
+    ],
+)
+def test_linear_matches_fp32(dev, M, N, K, act, res, f32out):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = bf16_round(_rand((M, K), g))
+    w = bf16_round(_rand((N, K), g, 0.05))
+    b = _rand((N,), g, 0.1)
+    r = bf16_round(_rand((M, N), g)) if res else None
+    want = a @ w.t() + b
+    if act == 1:
+        want = _gelu(want)
+    elif act == 2:
+        want = torch.tanh(want)
+    if res:
+        want = want + r
+    ldc = (N + 7) // 8 * 8
+    out = torch.full((M, ldc), 7.0, dtype=torch.float32 if f32out else BF16, device=dev)
+    ops.linear(a.to(dev, BF16), w.to(dev, BF16), b.to(dev), residual=None if r is None else r.to(dev, BF16),
+               act=act, out=out, out_f32=f32out)
+    torch.cuda.synchronize()
+    got = out[:, :N].float().cpu()
+    tol = 2e-3 if f32out else 1.5e-2
+    err = (got - want).abs() / (1.0 + want.abs())
+    assert float(err.max()) < tol, float(err.max())
+    if ldc > N:  # padding columns untouched
+        assert bool((out[:, N:].float() == 7.0).all())
+
+
+def test_linear_asymmetric_identity(dev):
+    """A = I against an ASYMMETRIC W catches a transposed or permuted accumulator write-out."""
+    from visitron_amd import ops
+
+    K = 128
+    a = torch.eye(K)
+    w = (torch.arange(256 * K, dtype=torch.float32).reshape(256, K) % 251) / 64.0 - 2.0
+    w = bf16_round(w)
+    got = ops.linear(a.to(dev, BF16), w.to(dev, BF16), out_f32=True).cpu()
+    assert torch.equal(got, w.t().contiguous())
+
+
+def test_linear_row_remap(dev):
+    """grp_rows/grp_stride: GEMM row b*R+r lands on buffer row b*S+T+r (replaces torch.cat)."""
+    from visitron_amd import ops
+
+    B, T, R, H, K = 3, 5, 7, 128, 64
+    S = T + R
+    g = torch.Generator().manual_seed(5)
+    a = bf16_round(_rand((B * R, K), g))
+    w = bf16_round(_rand((H, K), g, 0.1))
+    x = torch.zeros((B * S, H), dtype=BF16, device=dev)
+    ops.linear(a.to(dev, BF16), w.to(dev, BF16), out=x[T:], ldc=H, grp_rows=R, grp_stride=S)
+    got = x.float().cpu().view(B, S, H)
+    want = (a @ w.t()).view(B, R, H)
+    assert float(got[:, :T].abs().max()) == 0.0
+    assert maxabs(got[:, T:], bf16_round(want)) < 2e-2
+
+
+def test_linear_rejects_bad_arguments(dev):
+    from visitron_amd import ops
+
+    a = torch.zeros((8, 100), dtype=BF16, device=dev)  # K not a multiple of 64
+    w = torch.zeros((16, 100), dtype=BF16, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.linear(a, w)
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros((8, 64), dtype=BF16), torch.zeros((16, 64), dtype=BF16))  # CPU tensors
+
+
+def _attention_ref(q, k, v, add_mask):
+    # oscar/modeling_bert.py:52-68 in fp32
+    s = q @ k.transpose(-1, -2) / math.sqrt(q.shape[-1]) + add_mask[:, None, None, :]
+    return torch.softmax(s, dim=-1) @ v
+
+
+@pytest.mark.parametrize("B,S,nh", [(2, 228, 12), (3, 37, 2), (1, 300, 4), (2, 656, 2), (1, 128, 1), (2, 1, 2)])
+def test_attention_matches_fp32(dev, B, S, nh):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(S)
+    H = nh * 64
+    qkv = bf16_round(_rand((B * S, 3 * H), g, 1.5))
+    mask = (torch.rand(B, S, generator=g) > 0.25).float()
+    mask[:, 0] = 1.0
+    if B > 1:
+        mask[1] = 0.0  # a fully masked sequence: uniform attention, as the -10000 arithmetic gives
+    t = qkv.view(B, S, 3, nh, 64).permute(2, 0, 3, 1, 4)
+    want = _attention_ref(t[0], t[1], t[2], (1.0 - mask) * -10000.0).permute(0, 2, 1, 3).reshape(B * S, H)
+    lse = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
+    got = ops.attention_fwd(qkv.to(dev, BF16), B, S, nh, mask=mask.to(dev), lse=lse)
+    torch.cuda.synchronize()
+    assert maxabs(got, want) < 3e-2
+    # additive-mask entry (what CaptionBertEncoder.forward receives) gives the same numbers
+    got2 = ops.attention_fwd(qkv.to(dev, BF16), B, S, nh, mask=((1.0 - mask) * -10000.0).to(dev), mask_additive=True)
+    assert torch.equal(got, got2)
+    # log-sum-exp saved for backward
+    s = (t[0] @ t[1].transpose(-1, -2)) / 8.0 + ((1.0 - mask) * -10000.0)[:, None, None, :]
+    want_lse = torch.logsumexp(s, dim=-1)
+    assert maxabs(lse, want_lse) < 2e-2 * (1 + float(want_lse.abs().max()) * 1e-3)
+
+
+def test_attention_known_answers(dev):
+    """Q = 0 -> context = masked mean of V; a masked key contributes exactly 0."""
+    from visitron_amd import ops
+
+    B, S, nh = 1, 70, 1
+    g = torch.Generator().manual_seed(1)
+    qkv = torch.zeros((S, 192))
+    qkv[:, 64:128] = bf16_round(_rand((S, 64), g))
+    qkv[:, 128:] = bf16_round(_rand((S, 64), g))
+    mask = torch.ones(1, S)
+    mask[0, 40:] = 0
+    qkv[50, 128:] = 1000.0  # masked key with a huge value must not leak
+    got = ops.attention_fwd(qkv.to(dev, BF16), B, S, nh, mask=mask.to(dev)).float().cpu()
+    want = qkv[:40, 128:].mean(0, keepdim=True).expand(S, 64)
+    assert maxabs(got, want) < 1e-2
+
+
+def test_attention_head_scale(dev):
+    from visitron_amd import ops
+
+    B, S, nh = 2, 50, 3
+    g = torch.Generator().manual_seed(2)
+    qkv = bf16_round(_rand((B * S, 3 * nh * 64), g)).to(dev, BF16)
+    base = ops.attention_fwd(qkv, B, S, nh).float()
+    hs = torch.tensor([1.0, 0.0, 0.5], device=dev)
+    got = ops.attention_fwd(qkv, B, S, nh, head_scale=hs).float()
+    want = (base.view(B * S, nh, 64) * hs[None, :, None]).reshape(B * S, -1)
+    assert maxabs(got, want) < 1e-2
+
+
+@pytest.mark.parametrize("M,H", [(5, 128), (456, 768), (33, 1024), (7, 64)])
+def test_layernorm_matches_fp32(dev, M, H):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(H)
+    x = bf16_round(_rand((M, H), g, 3.0) + 0.7)
+    gamma, beta = 1 + 0.1 * _rand((H,), g), 0.1 * _rand((H,), g)
+    u = x.mean(-1, keepdim=True)
+    s = (x - u).pow(2).mean(-1, keepdim=True)
+    want = (x - u) / torch.sqrt(s + 1e-12) * gamma + beta
+    mean = torch.zeros(M, device=dev)
+    rstd = torch.zeros(M, device=dev)
+    got = ops.layernorm(x.to(dev, BF16), gamma.to(dev), beta.to(dev), 1e-12, mean=mean, rstd=rstd)
+    assert maxabs(got, want) < 3e-2
+    assert maxabs(mean, u[:, 0]) < 1e-4
+    assert maxabs(rstd, 1 / torch.sqrt(s[:, 0] + 1e-12)) < 1e-3
+
+
+def test_embed_layernorm_matches_fp32(dev):
+    from visitron_amd import ops
+
+    B, T, R, H, V = 3, 9, 4, 128, 50
+    S = T + R
+    g = torch.Generator().manual_seed(3)
+    word, pos, typ = _rand((V, H), g), _rand((16, H), g), _rand((2, H), g)
+    gamma, beta = 1 + 0.1 * _rand((H,), g), 0.1 * _rand((H,), g)
+    ids = torch.randint(0, V, (B, T), generator=g)
+    tt = torch.randint(0, 2, (B, T), generator=g)
+    e = word[ids] + pos[torch.arange(T)][None] + typ[tt]
+    want = torch.nn.functional.layer_norm(e, (H,), gamma, beta, 1e-12)
+    out = torch.zeros((B * S, H), dtype=BF16, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.embed_layernorm(ids.to(dev), tt.to(dev), None, word.to(dev), pos.to(dev), typ.to(dev), gamma.to(dev),
+                        beta.to(dev), 1e-12, out, S, err_flag=err)
+    got = out.float().cpu().view(B, S, H)
+    assert maxabs(got[:, :T], want) < 3e-2
+    assert float(got[:, T:].abs().max()) == 0.0
+    assert int(err.item()) == 0
+    bad = ids.clone()
+    bad[0, 0] = V + 3
+    ops.embed_layernorm(bad.to(dev), tt.to(dev), None, word.to(dev), pos.to(dev), typ.to(dev), gamma.to(dev),
+                        beta.to(dev), 1e-12, out, S, err_flag=err)
+    assert int(err.item()) == 1
+
+
+def test_pack_concat(dev):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    a, b = _rand((11, 2054), g), _rand((11, 128), g)
+    got = ops.pack_concat(a.to(dev), b.to(dev), 2240).float().cpu()
+    assert torch.equal(got[:, :2054], bf16_round(a))
+    assert torch.equal(got[:, 2054:2182], bf16_round(b))
+    assert float(got[:, 2182:].abs().max()) == 0.0

@@ -1,0 +1,70 @@
+"""ctypes binding of ``libvisitron_hip.so`` (the C ABI in ``include/visitron_hip.h``).
+
+There is NO fallback: if the shared library is missing this module raises, and every
+op in ``visitron_amd.ops`` refuses tensors that are not on a HIP device.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvisitron_hip.so")
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+
+class LayerWeights(ctypes.Structure):  # vt_layer_weights
+    _fields_ = [(n, c_void_p) for n in (
+        "w_qkv", "b_qkv", "w_ao", "b_ao", "ln1_g", "ln1_b", "w_in", "b_in", "w_out", "b_out", "ln2_g", "ln2_b")]
+
+
+class LayerActs(ctypes.Structure):  # vt_layer_acts
+    _fields_ = [(n, c_void_p) for n in (
+        "qkv", "ctx", "attn_pre", "attn_out", "mid", "out_pre", "out", "lse",
+        "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd")]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/visitron_hip.h
+SIGNATURES = {
+    "vt_error_string": (ctypes.c_char_p, [c_int]),
+    "vt_abi_version": (c_int, []),
+    "vt_linear_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_attention_fwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_layernorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "vt_embed_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                   c_void_p, c_void_p]),
+    "vt_pack_concat_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "vt_encoder_forward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerActs), c_int, c_void_p,
+                                        c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                        c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "visitron_amd: %s not found. Build it first: `make -C visitron_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().vt_error_string(int(rc)).decode()
+        raise RuntimeError("visitron_hip %s failed: %s (code %d)" % (what, msg, rc))

@@ -1,0 +1,219 @@
+// Fused multi-head self-attention forward over the mixed [text | region] sequence, head size 64.
+//
+// Replaces, per layer, oscar/modeling_bert.py:47-72 (CaptionBertSelfAttention.forward after the
+// three projections): head split (:47-49), scores = Q.K^T (:52), / sqrt(64) (:53), + additive
+// mask (:55), softmax over keys (:58), [* head_mask (:65-66)], context = P.V (:68), head merge
+// (:70-72).  The [B,12,S,S] score/prob tensors and the four permute copies never exist in HBM.
+// The additive mask is computed here from the caller's raw mask exactly as
+// tasks/viewpoint_select/encoder.py:238-241 does: (1.0 - mask) * -10000.0 (any numeric mask).
+//
+// gfx950 design.  One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32
+// queries and keeps the QUERY on the MFMA lane for both products (v_mfma_f32_32x32x16_bf16):
+//   S^T[key][query]  = K . Q^T        A = K rows (ds_read_b128 from a swizzled LDS tile), B = Q (registers)
+//   O^T[d][query]   += V^T . P^T      B = P^T taken straight from the S^T accumulators (no LDS,
+//                                     no lane movement), A = V^T via ds_read_b64_tr_b16 from the
+//                                     row-major V tile (hardware transpose)
+// so the softmax row statistics are lane-local (16 keys per lane per tile + one cross-half
+// shuffle), and the normalised context row is stored as 2 x 32 contiguous bytes per lane.
+// K and V of the (batch, head) are staged once per 256-key chunk by global_load_lds_dwordx4
+// (swizzles applied on the source address).  Online softmax in fp32; the masked score is formed
+// with the reference's roundings (fma(acc, 1/8, mask)) and (score - max) is exact before exp2.
+#include "common.hpp"
+
+struct AttnArgs {
+  const bf16_t* qkv;        // [B*S, ld_qkv]  q | k | v, each nh*64 wide
+  const float* mask;        // [B, S] raw mask (1 = attend) or additive bias, or null
+  int mask_additive;        // 0: mask is raw, bias = (1-mask)*-10000;  1: mask already is the additive bias
+  const float* head_scale;  // [nh] head_mask multipliers, or null
+  bf16_t* ctx;              // [B*S, ld_ctx]
+  float* lse;               // [B, nh, S] natural-log log-sum-exp of the masked scores (for backward), or null
+  long ld_qkv, ld_ctx;
+  int B, S, nh;
+  float scale;              // 1 / sqrt(head_size)
+};
+
+#define LOG2E 1.4426950408889634f
+#define ATT_KCHUNK 256
+#define ATT_SK 0
+#define ATT_SV (ATT_KCHUNK * 128)
+#define ATT_SBIAS (2 * ATT_KCHUNK * 128)
+#define ATT_LDS_BYTES (2 * ATT_KCHUNK * 128 + ATT_KCHUNK * 4)
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* p) {
+  // two transposed 4x16 block reads (keys k..k+3 and k+8..k+11), 8 bf16 per lane
+  short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p));
+  short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p + 1024));
+  typedef __attribute__((ext_vector_type(8))) short short8v;
+  short8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void attention_fwd_d64(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h2 = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int S = a.S, H = a.nh * 64;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool wave_active = q0 < S;  // wave-uniform
+
+  const bf16_t* base = a.qkv + (long)b * S * a.ld_qkv + head * 64;
+
+  // Q fragments: B operand, lane (r, h2) holds Q[q0+r][16*ds + 8*h2 .. +7]
+  bf16x8 qf[4];
+  {
+    int qr = q0 + r;
+    qr = qr < S ? qr : S - 1;
+    const bf16_t* qp = base + (long)qr * a.ld_qkv + 8 * h2;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(qp + 16 * ds);
+  }
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // lane-constant LDS offsets
+  const int k_row_off = r * 128;                       // + kt*4096
+  const int k_swz = (r >> 1) & 7;                      // (row>>1)&7 with row = 32kt + r  (32kt adds a multiple of 16 to row>>1)
+  const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, dhalf = (lane >> 4) & 1;
+  const int v_row = 4 * h2 + q4;                       // + 32kt + 16s2
+  const int v_colb = 2 * (16 * (p4 & 1) + 8 * dhalf + 4 * (p4 >> 1));  // + 64dt
+  const int v_swz = ((v_row >> 1) & 1) << 6;           // 64-B half swizzle; invariant under +16s2 / +32kt / +8
+
+  for (int kc = 0; kc < S; kc += ATT_KCHUNK) {
+    const int rows = (S - kc) < ATT_KCHUNK ? (S - kc) : ATT_KCHUNK;
+    const int ntiles = (rows + 31) >> 5;
+    if (kc > 0) __syncthreads();  // previous chunk fully consumed
+
+    // ---- stage K, V (8-row pieces, one 1-KiB DMA each) and the additive bias ----
+    for (int j = wave; j < ntiles * 4; j += 4) {
+      const int row = 8 * j + (lane >> 3);
+      int kr = kc + row;
+      kr = kr < S ? kr : S - 1;
+      const bf16_t* src = base + (long)kr * a.ld_qkv;
+      const int cs = lane & 7;
+      glds16(src + H + ((cs ^ ((row >> 1) & 7)) << 3), smem + ATT_SK + j * 1024);
+      glds16(src + 2 * H + ((cs ^ (((row >> 1) & 1) << 2)) << 3), smem + ATT_SV + j * 1024);
+    }
+    {
+      const int key = kc + tid;
+      float bias = -INFINITY;
+      if (key < S) {
+        float add = 0.f;
+        if (a.mask) {
+          const float mval = a.mask[(long)b * S + key];
+          add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
+        }
+        bias = add;
+      }
+      ((float*)(smem + ATT_SBIAS))[tid] = bias;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (wave_active) {
+      for (int kt = 0; kt < ntiles; ++kt) {
+        // ---- S^T tile = K[32 keys] . Q^T ----
+        f32x16 sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+        const char* kp = smem + ATT_SK + kt * 4096 + k_row_off;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+          const bf16x8 kf = *(const bf16x8*)(kp + (((2 * ds + h2) ^ k_swz) << 4));
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc, 0, 0, 0);
+        }
+        // ---- scale + mask, online softmax (exp2 domain) ----
+        const float* bp = (const float*)(smem + ATT_SBIAS) + kt * 32 + 4 * h2;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 bv = *(const f32x4*)(bp + 8 * g4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // same two roundings as the reference's scores / sqrt(d) + mask (the division by 8 is exact)
+            const float s = fmaf(sacc[4 * g4 + e], a.scale, bv[e]);
+            sacc[4 * g4 + e] = s;
+            tmax = fmaxf(tmax, s);
+          }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float p = __builtin_amdgcn_exp2f((sacc[i] - m_new) * LOG2E);  // (s - max) is exact
+          sacc[i] = p;
+          psum += p;
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          typedef __attribute__((ext_vector_type(8))) short short8v;
+          short8v pbs;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pbs[j] = (short)f32_to_bf16(sacc[8 * s2 + j]);
+          const bf16x8 pb = __builtin_bit_cast(bf16x8, pbs);
+          const char* vp = smem + ATT_SV + (kt * 32 + 16 * s2 + v_row) * 128;
+          const bf16x8 vf0 = tr_pair(vp + ((v_colb) ^ v_swz));
+          const bf16x8 vf1 = tr_pair(vp + ((v_colb + 64) ^ v_swz));
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pb, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pb, o1, 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (!wave_active) return;
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const int q = q0 + r;
+  if (q >= S) return;
+  float inv = 1.0f / l_tot;
+  if (a.lse && h2 == 0) a.lse[((long)b * a.nh + head) * S + q] = m_run + __builtin_amdgcn_logf(l_tot) * 0.6931471805599453f;
+  if (a.head_scale) inv *= a.head_scale[head];
+  bf16_t* op = a.ctx + ((long)b * S + q) * a.ld_ctx + head * 64 + 16 * h2;
+  u32x4 w0, w1, w2, w3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w0[i] = pack_bf16x2(o0[2 * i] * inv, o0[2 * i + 1] * inv);
+    w1[i] = pack_bf16x2(o0[8 + 2 * i] * inv, o0[8 + 2 * i + 1] * inv);
+    w2[i] = pack_bf16x2(o1[2 * i] * inv, o1[2 * i + 1] * inv);
+    w3[i] = pack_bf16x2(o1[8 + 2 * i] * inv, o1[8 + 2 * i + 1] * inv);
+  }
+  ((u32x4*)op)[0] = w0;
+  ((u32x4*)op)[1] = w1;
+  ((u32x4*)(op + 32))[0] = w2;
+  ((u32x4*)(op + 32))[1] = w3;
+}
+
+int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
+                              long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream) {
+  if (!qkv || !ctx) return VT_ERR_NULL;
+  if (head_size != 64) return VT_ERR_UNSUPPORTED;
+  if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
+  if ((ld_qkv % 8) || (ld_ctx % 8) || ld_qkv < 3L * nh * 64 || ld_ctx < (long)nh * 64) return VT_ERR_BAD_ALIGN;
+  if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return VT_ERR_BAD_ALIGN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)attention_fwd_d64, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES) != hipSuccess)
+      return VT_ERR_HIP;
+    attr_set = true;
+  }
+  AttnArgs a;
+  a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = (bf16_t*)ctx; a.lse = lse;
+  a.ld_qkv = ld_qkv; a.ld_ctx = ld_ctx; a.B = B; a.S = S; a.nh = nh;
+  a.scale = 1.0f / sqrtf((float)head_size);
+  dim3 grid((S + 127) / 128, nh, B);
+  hipLaunchKernelGGL(attention_fwd_d64, grid, dim3(256), ATT_LDS_BYTES, stream, a);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

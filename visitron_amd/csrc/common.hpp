@@ -1,0 +1,75 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in memory
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// 16-byte asynchronous global -> LDS copy (global_load_lds_dwordx4).  The LDS destination is
+// wave-uniform base + lane*16; the global source address is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even f32 -> bf16 via the hardware convert (keeps NaN a NaN)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), enough for fp32-tolerance parity
+// (1e-3) and far below bf16 resolution; ~12 VALU ops instead of libm's erff.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float y = 1.061405429f;
+  y = y * t - 1.453152027f;
+  y = y * t + 1.421413741f;
+  y = y * t - 0.284496736f;
+  y = y * t + 0.254829592f;
+  y = 1.0f - y * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+// erf-GELU, the reference's hidden_act == "gelu": 0.5 x (1 + erf(x / sqrt 2))
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); saturates cleanly for |x| large
+  const float e = __expf(2.0f * x);
+  return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// error codes of the C ABI (include/visitron_hip.h)
+#define VT_OK 0
+#define VT_ERR_BAD_SHAPE (-1)
+#define VT_ERR_BAD_ALIGN (-2)
+#define VT_ERR_NULL (-3)
+#define VT_ERR_UNSUPPORTED (-4)
+#define VT_ERR_HIP (-5)

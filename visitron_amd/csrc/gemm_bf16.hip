@@ -1,0 +1,266 @@
+// C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R[M,N])   bf16 in, fp32 accumulate, bf16|fp32 out.
+//
+// The "NT" contraction of every nn.Linear on the hot path (weights are [out,in], K-contiguous):
+//   K1  query/key/value        oscar/modeling_bert.py:43-45     (one packed [3H,H] weight)
+//   K5  BertSelfOutput.dense   (+bias +residual)                called at oscar/modeling_bert.py:94
+//   K6  BertIntermediate.dense (+bias +erf-GELU)                called at oscar/modeling_bert.py:119
+//   K7  BertOutput.dense       (+bias +residual)                called at oscar/modeling_bert.py:120
+//   K9  img_embedding + location_embeds  tasks/viewpoint_select/encoder.py:277-279 (K-concatenated)
+//   K11/K12/K13/K14 pooler and heads     tasks/viewpoint_select/encoder.py:296,377,381,391
+// With pre-transposed operands the same kernel serves dgrad (dX = dY . W) and wgrad (dW = dY^T . X).
+//
+// gfx950 design (one workgroup = 4 waves = one 128x128 output tile, BK = 64):
+//   * operands go HBM -> LDS with global_load_lds_dwordx4 (no VGPR staging); LDS tiles are
+//     [128 rows][64 k] bf16 with the 16-B chunk index XOR-swizzled by (row>>1)&7, applied on the
+//     per-lane SOURCE address (the DMA destination is lane-linear), which makes every
+//     ds_read_b128 fragment read conflict-free;
+//   * two LDS buffers, one s_barrier per K-step: fragments of tile k are read to registers, then
+//     the DMA of tile k+1 is issued and flies under the 32 MFMAs of tile k;
+//   * MFMA v_mfma_f32_16x16x32_bf16 with the operands SWAPPED (W rows feed the A port, activation
+//     rows the B port) so that a lane's accumulators are 4 consecutive output columns of one
+//     output row; W rows are permuted at staging time so the 4 N-subtiles of a wave interleave to
+//     16 consecutive columns per lane -> the epilogue stores 32 contiguous bytes per lane and
+//     bias / GELU / residual are applied in registers, no LDS round trip;
+//   * block ids are remapped so that the tiles sharing an activation row-panel run on one XCD
+//     (one L2).
+#include "common.hpp"
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* W;
+  const float* bias;
+  const bf16_t* R;
+  void* C;
+  long lda, ldw, ldr, ldc;
+  int M, N, K;
+  int grp_rows, grp_stride;  // output row = (m / grp_rows) * grp_stride + m % grp_rows  (0: identity)
+  int tiles_m, tiles_n;
+};
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2 };
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 64
+#define GEMM_TILE_BYTES (128 * 64 * 2)
+#define GEMM_LDS_BYTES (4 * GEMM_TILE_BYTES)
+
+template <int ACT>
+__device__ __forceinline__ float apply_act(float x) {
+  if (ACT == ACT_GELU) return gelu_erf(x);
+  if (ACT == ACT_TANH) return tanh_fast(x);
+  return x;
+}
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_128x128(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap: blocks b and b+8 share an XCD; give each XCD a contiguous tile range.
+  const int nwg = gridDim.x;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int bm = t_id / g.tiles_n, bn = t_id - bm * g.tiles_n;
+  const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
+
+  // ---- per-lane DMA source pointers (4 pieces of A, 4 of W per K-step) ----
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = (wave * 4 + i) * 64 + lane;  // 16-B chunk index inside the 128x64 tile
+    const int row = p >> 3;
+    const int c = (p & 7) ^ ((row >> 1) & 7);  // logical chunk stored at this LDS slot
+    int am = m0 + row;
+    am = am < g.M ? am : g.M - 1;
+    a_src[i] = g.A + (long)am * g.lda + c * 8;
+    // LDS row -> output column permutation (see header): lane ends up with 16 consecutive columns
+    int wnrow = n0 + (row & 64) + 16 * ((row >> 2) & 3) + 4 * ((row >> 4) & 3) + (row & 3);
+    wnrow = wnrow < g.N ? wnrow : g.N - 1;
+    w_src[i] = g.W + (long)wnrow * g.ldw + c * 8;
+  }
+
+  // ---- per-lane fragment read offsets (bytes inside a tile), k-substep 0; substep 1 = ^64 ----
+  int x_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int xr = 64 * wm + 16 * i + (lane & 15);
+    x_off[i] = xr * 128 + (((lane >> 4) ^ ((xr >> 1) & 7)) << 4);
+    const int wr = 64 * wn + 16 * i + (lane & 15);
+    w_off[i] = wr * 128 + (((lane >> 4) ^ ((wr >> 1) & 7)) << 4);
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / GEMM_BK;
+
+  // prologue: tile 0 -> buffer 0
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    glds16(a_src[i], smem + (wave * 4 + i) * 1024);
+    glds16(w_src[i], smem + GEMM_TILE_BYTES + (wave * 4 + i) * 1024);
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // my pieces of tile kt have landed; after the barrier everybody's have, and everybody has
+    // finished reading the other buffer (its fragments were consumed by the previous MFMAs).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    char* sX = smem + (kt & 1) * (2 * GEMM_TILE_BYTES);
+    char* sW = sX + GEMM_TILE_BYTES;
+
+    bf16x8 xf[2][4], wf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[ks][i] = *(const bf16x8*)(sW + (w_off[i] ^ (ks * 64)));
+        xf[ks][i] = *(const bf16x8*)(sX + (x_off[i] ^ (ks * 64)));
+      }
+    }
+
+    if (kt + 1 < nk) {  // DMA of the next tile into the other buffer, in flight during the MFMAs
+      char* nX = smem + ((kt + 1) & 1) * (2 * GEMM_TILE_BYTES);
+      const int koff = (kt + 1) * GEMM_BK;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        glds16(a_src[i] + koff, nX + (wave * 4 + i) * 1024);
+        glds16(w_src[i] + koff, nX + GEMM_TILE_BYTES + (wave * 4 + i) * 1024);
+      }
+    }
+
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][t], xf[ks][mt], acc[mt][t], 0, 0, 0);
+  }
+
+  // ---- epilogue: lane (j = lane&15, gq = lane>>4) owns rows m0+64wm+16mt+j, columns nb..nb+15 ----
+  const int gq = lane >> 4;
+  const int nb = n0 + 64 * wn + 16 * gq;
+  if (nb >= g.N) return;
+  const bool full = (nb + 16 <= g.N);
+
+  float bv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bv[i] = 0.f;
+  if (g.bias) {
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 t4 = *(const f32x4*)(g.bias + nb + 4 * i);
+        bv[4 * i + 0] = t4[0]; bv[4 * i + 1] = t4[1]; bv[4 * i + 2] = t4[2]; bv[4 * i + 3] = t4[3];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (nb + i < g.N) bv[i] = g.bias[nb + i];
+    }
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + 64 * wm + 16 * mt + (lane & 15);
+    if (m >= g.M) continue;
+    const long orow = g.grp_rows ? (long)(m / g.grp_rows) * g.grp_stride + (m % g.grp_rows) : (long)m;
+    float v[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * t + e] = apply_act<ACT>(acc[mt][t][e] + bv[4 * t + e]);
+
+    if (full) {
+      if (g.R) {
+        const u32x4* rp = (const u32x4*)(g.R + orow * g.ldr + nb);
+        const u32x4 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[2 * i] += bf16lo(r0[i]);
+          v[2 * i + 1] += bf16hi(r0[i]);
+          v[8 + 2 * i] += bf16lo(r1[i]);
+          v[8 + 2 * i + 1] += bf16hi(r1[i]);
+        }
+      }
+      if (OUT_F32) {
+        f32x4* cp = (f32x4*)((float*)g.C + orow * g.ldc + nb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cp[i] = (f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+      } else {
+        u32x4* cp = (u32x4*)((bf16_t*)g.C + orow * g.ldc + nb);
+        u32x4 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+          o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+        }
+        cp[0] = o0;
+        cp[1] = o1;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (nb + i < g.N) {
+          float x = v[i];
+          if (g.R) x += bf16_to_f32(g.R[orow * g.ldr + nb + i]);
+          if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;
+          else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = f32_to_bf16(x);
+        }
+      }
+    }
+  }
+}
+
+template <int ACT, bool OUT_F32>
+static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = gemm_nt_bf16_128x128<ACT, OUT_F32>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) != hipSuccess)
+      return VT_ERR_HIP;
+    attr_set = true;
+  }
+  const int nwg = g.tiles_m * g.tiles_n;
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), GEMM_LDS_BYTES, stream, g);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// Host entry used by the C ABI (capi.hip).  Returns a VT_* code; never synchronises.
+int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const void* R, long ldr,
+                     void* C, long ldc, int M, int N, int K, int act, int out_f32, int grp_rows, int grp_stride,
+                     hipStream_t stream) {
+  if (!A || !W || !C) return VT_ERR_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % GEMM_BK) != 0) return VT_ERR_BAD_SHAPE;
+  if ((lda % 8) || (ldw % 8) || (R && (ldr % 8)) || (ldc % (out_f32 ? 4 : 8))) return VT_ERR_BAD_ALIGN;
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) return VT_ERR_BAD_ALIGN;
+  if (grp_rows < 0 || (grp_rows > 0 && grp_stride < grp_rows)) return VT_ERR_BAD_SHAPE;
+  GemmArgs g;
+  g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.R = (const bf16_t*)R; g.C = C;
+  g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K;
+  g.grp_rows = grp_rows; g.grp_stride = grp_stride;
+  g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
+  g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+  switch (act * 2 + (out_f32 ? 1 : 0)) {
+    case 0: return launch_gemm<ACT_NONE, false>(g, stream);
+    case 1: return launch_gemm<ACT_NONE, true>(g, stream);
+    case 2: return launch_gemm<ACT_GELU, false>(g, stream);
+    case 3: return launch_gemm<ACT_GELU, true>(g, stream);
+    case 4: return launch_gemm<ACT_TANH, false>(g, stream);
+    case 5: return launch_gemm<ACT_TANH, true>(g, stream);
+    default: return VT_ERR_UNSUPPORTED;
+  }
+}

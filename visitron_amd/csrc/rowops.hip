@@ -1,0 +1,239 @@
+// HBM-bound row kernels of the hot path (one wave64 per row, 16-byte vector accesses, wave-shuffle
+// reductions, fp32 statistics):
+//   layernorm_rows      BertLayerNorm over a row that already holds dense(h)+bias+residual (the GEMM
+//                       epilogue added them): (x-u)/sqrt(var+eps)*w+b, biased variance, eps inside the
+//                       sqrt -- BertSelfOutput / BertOutput, called at oscar/modeling_bert.py:94,120;
+//                       also the optional image LayerNorm, tasks/viewpoint_select/encoder.py:280-281.
+//   embed_layernorm     BertEmbeddings: word + position + token_type gather-sum -> LayerNorm, called at
+//                       tasks/viewpoint_select/encoder.py:267-269; writes rows b*S+t of the [B,S,H]
+//                       sequence buffer directly (no torch.cat, :287).
+//   pack_region_inputs  [img_feats | img_location_embeddings | 0-pad] fp32 -> bf16 K-concatenated GEMM
+//                       operand, so img_embedding + location_embeds (encoder.py:277-279) is ONE GEMM.
+#include "common.hpp"
+
+struct LnArgs {
+  const bf16_t* x; long ldx;
+  bf16_t* y; long ldy;
+  const float* gamma; const float* beta;
+  float* mean; float* rstd;  // optional [M] outputs for backward
+  int M, H;
+  int grp_rows, grp_stride;  // row remap as in the GEMM (0: identity); applies to x and y
+  float eps;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void layernorm_rows(LnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const long prow = a.grp_rows ? (long)(row / a.grp_rows) * a.grp_stride + (row % a.grp_rows) : (long)row;
+  const bf16_t* xp = a.x + prow * a.ldx;
+  float v[CH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (lane + 64 * c) * 8;
+    if (col < a.H) {
+      const u32x4 w = *(const u32x4*)(xp + col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[c][2 * i] = bf16lo(w[i]); v[c][2 * i + 1] = bf16hi(w[i]); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[c][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+    }
+  }
+  const float invH = 1.0f / (float)a.H;
+  const float u = wave_sum(s) * invH;
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (lane + 64 * c) * 8;
+    if (col < a.H) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[c][i] - u; ss += d * d; }
+    }
+  }
+  const float var = wave_sum(ss) * invH;
+  const float rs = 1.0f / sqrtf(var + a.eps);
+  if (lane == 0) {
+    if (a.mean) a.mean[row] = u;
+    if (a.rstd) a.rstd[row] = rs;
+  }
+  bf16_t* yp = a.y + prow * a.ldy;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (lane + 64 * c) * 8;
+    if (col < a.H) {
+      const f32x4 g0 = *(const f32x4*)(a.gamma + col), g1 = *(const f32x4*)(a.gamma + col + 4);
+      const f32x4 b0 = *(const f32x4*)(a.beta + col), b1 = *(const f32x4*)(a.beta + col + 4);
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i] = (v[c][i] - u) * rs * g0[i] + b0[i];
+        o[4 + i] = (v[c][4 + i] - u) * rs * g1[i] + b1[i];
+      }
+      u32x4 w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
+      *(u32x4*)(yp + col) = w;
+    }
+  }
+}
+
+int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
+                          float* mean, float* rstd, int M, int H, float eps, int grp_rows, int grp_stride,
+                          hipStream_t stream) {
+  if (!x || !y || !gamma || !beta) return VT_ERR_NULL;
+  if (M <= 0 || H <= 0 || (H % 8) || H > 64 * 8 * 4) return VT_ERR_BAD_SHAPE;
+  if ((ldx % 8) || (ldy % 8) || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15)) return VT_ERR_BAD_ALIGN;
+  LnArgs a;
+  a.x = (const bf16_t*)x; a.ldx = ldx; a.y = (bf16_t*)y; a.ldy = ldy; a.gamma = gamma; a.beta = beta;
+  a.mean = mean; a.rstd = rstd; a.M = M; a.H = H; a.grp_rows = grp_rows; a.grp_stride = grp_stride; a.eps = eps;
+  const dim3 grid((M + 3) / 4), block(256);
+  const int ch = (H + 511) / 512;
+  if (ch == 1) hipLaunchKernelGGL(layernorm_rows<1>, grid, block, 0, stream, a);
+  else if (ch == 2) hipLaunchKernelGGL(layernorm_rows<2>, grid, block, 0, stream, a);
+  else if (ch == 3) hipLaunchKernelGGL(layernorm_rows<3>, grid, block, 0, stream, a);
+  else hipLaunchKernelGGL(layernorm_rows<4>, grid, block, 0, stream, a);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct EmbArgs {
+  const int64_t* ids; const int64_t* type_ids; const int64_t* pos_ids;  // [B,T]; type/pos may be null
+  const float* word; const float* pos; const float* type;               // fp32 tables [*, H]
+  const float* gamma; const float* beta;
+  bf16_t* y; long ldy;                                                  // row b*S + t
+  int B, T, S, H;
+  int n_word, n_pos, n_type;
+  float eps;
+  int* err;  // set to 1 when an index is out of range (the torch reference would raise)
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void embed_layernorm(EmbArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= a.B * a.T) return;
+  const int b = tok / a.T, t = tok - b * a.T;
+  long wi = a.ids[tok];
+  long pi = a.pos_ids ? a.pos_ids[tok] : (long)t;
+  long ti = a.type_ids ? a.type_ids[tok] : 0L;
+  if (wi < 0 || wi >= a.n_word || pi < 0 || pi >= a.n_pos || ti < 0 || ti >= a.n_type) {
+    if (lane == 0 && a.err) *a.err = 1;
+    wi = wi < 0 ? 0 : (wi >= a.n_word ? a.n_word - 1 : wi);
+    pi = pi < 0 ? 0 : (pi >= a.n_pos ? a.n_pos - 1 : pi);
+    ti = ti < 0 ? 0 : (ti >= a.n_type ? a.n_type - 1 : ti);
+  }
+  const float* wp = a.word + wi * a.H;
+  const float* pp = a.pos + pi * a.H;
+  const float* tp = a.type + ti * a.H;
+  float v[CH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (lane + 64 * c) * 8;
+    if (col < a.H) {
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+        const f32x4 w4 = *(const f32x4*)(wp + col + 4 * hlf);
+        const f32x4 p4 = *(const f32x4*)(pp + col + 4 * hlf);
+        const f32x4 t4 = *(const f32x4*)(tp + col + 4 * hlf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[c][4 * hlf + i] = (w4[i] + p4[i]) + t4[i]; s += v[c][4 * hlf + i]; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+    }
+  }
+  const float invH = 1.0f / (float)a.H;
+  const float u = wave_sum(s) * invH;
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (lane + 64 * c) * 8;
+    if (col < a.H) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[c][i] - u; ss += d * d; }
+    }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(ss) * invH + a.eps);
+  bf16_t* yp = a.y + ((long)b * a.S + t) * a.ldy;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (lane + 64 * c) * 8;
+    if (col < a.H) {
+      const f32x4 g0 = *(const f32x4*)(a.gamma + col), g1 = *(const f32x4*)(a.gamma + col + 4);
+      const f32x4 b0 = *(const f32x4*)(a.beta + col), b1 = *(const f32x4*)(a.beta + col + 4);
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i] = (v[c][i] - u) * rs * g0[i] + b0[i];
+        o[4 + i] = (v[c][4 + i] - u) * rs * g1[i] + b1[i];
+      }
+      u32x4 w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
+      *(u32x4*)(yp + col) = w;
+    }
+  }
+}
+
+int vt_embed_layernorm_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
+                                const float* pos, const float* type, const float* gamma, const float* beta, void* y,
+                                long ldy, int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
+                                int* err_flag, hipStream_t stream) {
+  if (!ids || !word || !pos || !type || !gamma || !beta || !y) return VT_ERR_NULL;
+  if (B <= 0 || T <= 0 || S < T || H <= 0 || (H % 8) || H > 2048) return VT_ERR_BAD_SHAPE;
+  if ((ldy % 8) || (((uintptr_t)word | (uintptr_t)pos | (uintptr_t)type | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15))
+    return VT_ERR_BAD_ALIGN;
+  EmbArgs a;
+  a.ids = ids; a.type_ids = type_ids; a.pos_ids = pos_ids; a.word = word; a.pos = pos; a.type = type;
+  a.gamma = gamma; a.beta = beta; a.y = (bf16_t*)y; a.ldy = ldy; a.B = B; a.T = T; a.S = S; a.H = H;
+  a.n_word = n_word; a.n_pos = n_pos; a.n_type = n_type; a.eps = eps; a.err = err_flag;
+  const dim3 grid((B * T + 3) / 4), block(256);
+  const int ch = (H + 511) / 512;
+  if (ch == 1) hipLaunchKernelGGL(embed_layernorm<1>, grid, block, 0, stream, a);
+  else if (ch == 2) hipLaunchKernelGGL(embed_layernorm<2>, grid, block, 0, stream, a);
+  else if (ch == 3) hipLaunchKernelGGL(embed_layernorm<3>, grid, block, 0, stream, a);
+  else hipLaunchKernelGGL(embed_layernorm<4>, grid, block, 0, stream, a);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[row, :] = bf16([src0[row, 0:d0] | src1[row, 0:d1] | zeros up to kpad]); 8 columns per thread.
+__global__ __launch_bounds__(256) void pack_concat_bf16(const float* __restrict__ s0, int d0, const float* __restrict__ s1,
+                                                        int d1, bf16_t* __restrict__ out, int kpad, long rows) {
+  const int cpr = kpad >> 3;  // 8-column groups per row
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= rows * cpr) return;
+  const long row = gid / cpr;
+  const int col = (int)(gid - row * cpr) * 8;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = col + i;
+    float x = 0.f;
+    if (c < d0) x = s0[row * d0 + c];
+    else if (c < d0 + d1) x = s1[row * d1 + (c - d0)];
+    v[i] = x;
+  }
+  u32x4 w;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+  *(u32x4*)(out + row * kpad + col) = w;
+}
+
+int vt_pack_concat_dispatch(const float* s0, int d0, const float* s1, int d1, void* out, int kpad, long rows,
+                            hipStream_t stream) {
+  if (!s0 || !out || (d1 > 0 && !s1)) return VT_ERR_NULL;
+  if (rows <= 0 || d0 <= 0 || d1 < 0 || kpad < d0 + d1 || (kpad % 8)) return VT_ERR_BAD_SHAPE;
+  if (((uintptr_t)out) & 15) return VT_ERR_BAD_ALIGN;
+  const long n = rows * (kpad >> 3);
+  hipLaunchKernelGGL(pack_concat_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s0, d0, s1, d1,
+                     (bf16_t*)out, kpad, rows);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

@@ -1,0 +1,744 @@
+"""Drop-in modules for the VISITRON encoder hot path, running on MI355X HIP kernels.
+
+Same constructor ``(config)``, ``forward`` signatures, returned tuples and ``state_dict`` key
+names as the reference classes, so the reference's pretrain / agent loops can use these in place
+of their own:
+
+  CaptionBertSelfAttention / CaptionBertAttention / CaptionBertLayer / CaptionBertEncoder
+        oscar/modeling_bert.py:26-169
+  NextActionPrediction, BertImgModelwithLocationEmbeds, PreTrainOscar
+        tasks/viewpoint_select/encoder.py:142-158, 161-303, 306-441
+  (their BERT building blocks -- BertEmbeddings, BertSelfOutput, BertIntermediate, BertOutput,
+   BertPooler, BertOnlyMLMHead, BertLayerNorm, BertPreTrainedModel -- come from the reference's
+   un-vendored pytorch-transformers dependency; here they are parameter containers with the
+   upstream attribute names.)
+
+The parameters stay fp32 ``nn.Parameter``s (checkpoint / optimizer / DDP compatible); the kernels
+consume bf16 packed copies (query|key|value fused into one [3H,H] weight, image + location
+projections K-concatenated) that are rebuilt whenever a parameter's version or storage changes.
+
+There is no CPU path: every forward requires HIP tensors and ``libvisitron_hip.so``.
+"""
+import ctypes
+import logging
+import os
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .config import BertConfig
+from .ops import ACT_GELU, ACT_NONE, ACT_TANH, BF16, round_up
+
+logger = logging.getLogger(__name__)
+
+WEIGHTS_NAME = "pytorch_model.bin"
+
+
+# --------------------------------------------------------------------------------------------
+# parameter containers (upstream attribute names => reference state_dict keys)
+# --------------------------------------------------------------------------------------------
+class BertLayerNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-12):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.bias = nn.Parameter(torch.zeros(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        shp = x.shape
+        y = ops.layernorm(_as_bf16_2d(x), _f32(self.weight), _f32(self.bias), self.variance_epsilon)
+        return y.view(shp).to(x.dtype)
+
+
+class BertEmbeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def write_rows(self, out, S, input_ids, token_type_ids=None, position_ids=None):
+        """Fused gather-sum-LayerNorm into rows b*S+t of ``out`` [B*S,H] bf16."""
+        _no_train_dropout(self, self.dropout.p)
+        err = torch.zeros(1, dtype=torch.int32, device=out.device)
+        ops.embed_layernorm(
+            _i64(input_ids), _i64(token_type_ids), _i64(position_ids),
+            _f32(self.word_embeddings.weight), _f32(self.position_embeddings.weight),
+            _f32(self.token_type_embeddings.weight), _f32(self.LayerNorm.weight), _f32(self.LayerNorm.bias),
+            self.LayerNorm.variance_epsilon, out, S, err_flag=err)
+        self._last_err = err
+        return out
+
+    def forward(self, input_ids, token_type_ids=None, position_ids=None):
+        B, T = input_ids.shape
+        out = torch.empty((B * T, self.word_embeddings.weight.shape[1]), dtype=BF16, device=input_ids.device)
+        self.write_rows(out, T, input_ids, token_type_ids, position_ids)
+        _check_index_error(self)
+        return out.view(B, T, -1).to(self.word_embeddings.weight.dtype)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, hidden_states, input_tensor):
+        return _dense_residual_ln(self, hidden_states, input_tensor)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+        if config.hidden_act != "gelu":
+            raise NotImplementedError("the HIP path implements hidden_act='gelu' (erf form) only")
+
+    def forward(self, hidden_states):
+        shp = hidden_states.shape
+        y = ops.linear(_as_bf16_2d(hidden_states), _bf16(self.dense.weight), _f32(self.dense.bias), act=ACT_GELU)
+        return y.view(shp[:-1] + (y.shape[-1],)).to(hidden_states.dtype)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, hidden_states, input_tensor):
+        return _dense_residual_ln(self, hidden_states, input_tensor)
+
+
+class BertPooler(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.activation = nn.Tanh()
+
+    def pooled(self, seq_bf16, B, S):
+        """tanh(dense(h[:,0])) -> fp32 [B,H]; reads token 0 of each sequence via the row stride."""
+        H = self.dense.weight.shape[0]
+        return ops.linear(seq_bf16, _bf16(self.dense.weight), _f32(self.dense.bias), act=ACT_TANH, out_f32=True,
+                          M=B, lda=S * H)
+
+    def forward(self, hidden_states):
+        B, S, H = hidden_states.shape
+        return self.pooled(_as_bf16_2d(hidden_states), B, S).to(hidden_states.dtype)
+
+
+class BertPredictionHeadTransform(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class BertLMPredictionHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+
+
+class BertOnlyMLMHead(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.predictions = BertLMPredictionHead(config)
+
+    def scores(self, seq_bf16):
+        """decoder(LN(gelu(dense(h)))) + bias -> fp32 [M, V] (view of a 16-B-row-aligned buffer)."""
+        p = self.predictions
+        t = ops.linear(seq_bf16, _bf16(p.transform.dense.weight), _f32(p.transform.dense.bias), act=ACT_GELU)
+        t = ops.layernorm(t, _f32(p.transform.LayerNorm.weight), _f32(p.transform.LayerNorm.bias),
+                          p.transform.LayerNorm.variance_epsilon, out=t)
+        V = p.decoder.weight.shape[0]
+        buf = torch.empty((seq_bf16.shape[0], round_up(V, 4)), dtype=torch.float32, device=seq_bf16.device)
+        ops.linear(t, _bf16(p.decoder.weight), _f32(p.bias), out=buf, out_f32=True)
+        return buf[:, :V]
+
+    def forward(self, sequence_output):
+        shp = sequence_output.shape
+        s = self.scores(_as_bf16_2d(sequence_output))
+        return s.reshape(shp[:-1] + (s.shape[-1],)).to(sequence_output.dtype)
+
+
+class BertPreTrainedModel(nn.Module):
+    """The base-class services the reference uses (init / tie / resize / save / load)."""
+
+    config_class = BertConfig
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+
+    def init_weights(self, module):
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        elif isinstance(module, BertLayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    def _tie_or_clone_weights(self, first_module, second_module):
+        if getattr(self.config, "torchscript", False):
+            first_module.weight = nn.Parameter(second_module.weight.clone())
+        else:
+            first_module.weight = second_module.weight
+
+    def _get_resized_embeddings(self, old_embeddings, new_num_tokens=None):
+        if new_num_tokens is None:
+            return old_embeddings
+        old_num_tokens, dim = old_embeddings.weight.size()
+        if old_num_tokens == new_num_tokens:
+            return old_embeddings
+        new_embeddings = nn.Embedding(new_num_tokens, dim).to(old_embeddings.weight.device)
+        self.init_weights(new_embeddings)
+        n = min(old_num_tokens, new_num_tokens)
+        new_embeddings.weight.data[:n, :] = old_embeddings.weight.data[:n, :]
+        return new_embeddings
+
+    def save_pretrained(self, save_directory):
+        """config.json + pytorch_model.bin, the layout tasks/viewpoint_select/pretrain.py:263-269 writes."""
+        assert os.path.isdir(save_directory), "Saving path should be a directory where the model and configuration can be saved"
+        model_to_save = self.module if hasattr(self, "module") else self
+        model_to_save.config.save_pretrained(save_directory)
+        torch.save(model_to_save.state_dict(), os.path.join(save_directory, WEIGHTS_NAME))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, **kwargs):
+        """Load ``pytorch_model.bin`` by key name (model_utils.py:89-93); keys absent from the file keep
+        their fresh init, unexpected keys are ignored, as upstream does; TF checkpoints are not read."""
+        config = kwargs.pop("config", None)
+        if kwargs.pop("from_tf", False):
+            raise NotImplementedError("TensorFlow checkpoints are not supported")
+        if config is None:
+            config = cls.config_class.from_pretrained(pretrained_model_name_or_path)
+        model = cls(config, *model_args)
+        path = pretrained_model_name_or_path
+        if os.path.isdir(path):
+            path = os.path.join(path, WEIGHTS_NAME)
+        state = torch.load(path, map_location="cpu")
+        # old-checkpoint LayerNorm naming, as upstream
+        state = {k.replace("gamma", "weight").replace("beta", "bias") if k.endswith(("gamma", "beta")) else k: v
+                 for k, v in state.items()}
+        own = model.state_dict()
+        prefix = ""
+        if not any(k.startswith("bert.") for k in own) and any(k.startswith("bert.") for k in state):
+            prefix = "bert."  # loading a trunk from a full-model checkpoint
+        filtered = {}
+        for k, v in state.items():
+            kk = k[len(prefix):] if prefix and k.startswith(prefix) else k
+            if kk in own and own[kk].shape == v.shape:
+                filtered[kk] = v
+        missing = [k for k in own if k not in filtered]
+        if missing:
+            logger.info("Weights of %s not initialized from pretrained model: %s", cls.__name__, missing)
+        model.load_state_dict(filtered, strict=False)
+        if hasattr(model, "tie_weights"):
+            model.tie_weights()
+        model.eval()
+        return model
+
+
+# --------------------------------------------------------------------------------------------
+# small host helpers
+# --------------------------------------------------------------------------------------------
+def _f32(t):
+    if t is None:
+        return None
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _bf16(t):
+    return t.detach().to(BF16).contiguous()
+
+
+def _i64(t):
+    if t is None:
+        return None
+    return t if (t.dtype == torch.int64 and t.is_contiguous()) else t.to(torch.int64).contiguous()
+
+
+def _as_bf16_2d(x):
+    ops._require_hip(x)
+    return x.detach().reshape(-1, x.shape[-1]).to(BF16).contiguous()
+
+
+def _no_train_dropout(module, p):
+    if module.training and p > 0.0:
+        raise NotImplementedError(
+            "dropout p=%g in training mode is not implemented in the HIP path yet; "
+            "use model.eval() or set the dropout probabilities to 0" % p
+        )
+
+
+def _check_index_error(emb):
+    err = getattr(emb, "_last_err", None)
+    if err is not None and int(err.item()) != 0:
+        raise IndexError("index out of range in BertEmbeddings (input_ids / position_ids / token_type_ids)")
+
+
+def _dense_residual_ln(mod, hidden_states, input_tensor):
+    """LN(dropout(dense(h)) + residual) for BertSelfOutput / BertOutput (eval or p == 0)."""
+    _no_train_dropout(mod, mod.dropout.p)
+    shp = input_tensor.shape
+    pre = ops.linear(_as_bf16_2d(hidden_states), _bf16(mod.dense.weight), _f32(mod.dense.bias),
+                     residual=_as_bf16_2d(input_tensor))
+    y = ops.layernorm(pre, _f32(mod.LayerNorm.weight), _f32(mod.LayerNorm.bias), mod.LayerNorm.variance_epsilon, out=pre)
+    return y.view(shp).to(input_tensor.dtype)
+
+
+def _additive_mask_2d(attention_mask, B, S):
+    """[B,1,1,S] (or [B,S]) additive mask -> contiguous fp32 [B,S]; other ranks are not served yet."""
+    m = attention_mask
+    if m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1:
+        m = m[:, 0, 0, :]
+    elif m.dim() != 2:
+        raise NotImplementedError(
+            "attention masks that vary per query ([B,1,S,S]) are not implemented in the HIP path yet; got shape %s"
+            % (tuple(attention_mask.shape),)
+        )
+    if m.shape[0] != B:
+        m = m.expand(B, -1)
+    if m.shape[1] != S:
+        raise RuntimeError("attention mask length %d does not match sequence length %d" % (m.shape[1], S))
+    return m.to(torch.float32).contiguous()
+
+
+def _head_scale(head_mask, L, nh, device):
+    """The reference's head_mask list/tensor -> fp32 [L, nh] per-head multipliers (or None)."""
+    if head_mask is None:
+        return None
+    if isinstance(head_mask, (list, tuple)):
+        if all(h is None for h in head_mask):
+            return None
+        rows = []
+        for h in head_mask:
+            if h is None:
+                rows.append(torch.ones(nh, device=device))
+            else:
+                if h.numel() != nh:
+                    raise NotImplementedError("head_mask entries must hold one multiplier per head")
+                rows.append(h.reshape(nh).to(device=device, dtype=torch.float32))
+        return torch.stack(rows).contiguous()
+    if head_mask.numel() == L * nh:
+        return head_mask.reshape(L, nh).to(device=device, dtype=torch.float32).contiguous()
+    if head_mask.numel() == nh:
+        return head_mask.reshape(1, nh).expand(L, nh).to(device=device, dtype=torch.float32).contiguous()
+    raise NotImplementedError("head_mask must broadcast from [heads] or [layers, heads]")
+
+
+# --------------------------------------------------------------------------------------------
+# oscar/modeling_bert.py:26-169
+# --------------------------------------------------------------------------------------------
+class CaptionBertSelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError(
+                "The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                % (config.hidden_size, config.num_attention_heads)
+            )
+        self.output_attentions = config.output_attentions
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = config.hidden_size // config.num_attention_heads
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        self.key = nn.Linear(config.hidden_size, self.all_head_size)
+        self.value = nn.Linear(config.hidden_size, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+
+    def packed_qkv(self):
+        w = torch.cat([self.query.weight, self.key.weight, self.value.weight], 0).detach().to(BF16).contiguous()
+        b = torch.cat([self.query.bias, self.key.bias, self.value.bias], 0).detach().float().contiguous()
+        return w, b
+
+    def forward(self, hidden_states, attention_mask, head_mask=None, history_state=None):
+        """oscar/modeling_bert.py:34-79 for one layer: packed QKV GEMM + fused attention kernel."""
+        if self.attention_head_size != 64:
+            raise NotImplementedError("the fused attention kernel serves head size 64")
+        if history_state is not None:
+            raise NotImplementedError("history_state is not implemented in the HIP path yet")
+        if self.output_attentions:
+            raise NotImplementedError("output_attentions is not implemented in the HIP path yet")
+        _no_train_dropout(self, self.dropout.p)
+        B, S, H = hidden_states.shape
+        w, b = self.packed_qkv()
+        qkv = ops.linear(_as_bf16_2d(hidden_states), w, b)
+        mask = _additive_mask_2d(attention_mask, B, S) if attention_mask is not None else None
+        hs = _head_scale([head_mask], 1, self.num_attention_heads, hidden_states.device)
+        ctx = ops.attention_fwd(qkv, B, S, self.num_attention_heads, mask=mask, mask_additive=True,
+                                head_scale=None if hs is None else hs[0].contiguous())
+        return (ctx.view(B, S, H).to(hidden_states.dtype),)
+
+
+class CaptionBertAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = CaptionBertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+    def forward(self, input_tensor, attention_mask, head_mask=None, history_state=None):
+        self_outputs = self.self(input_tensor, attention_mask, head_mask, history_state)
+        attention_output = self.output(self_outputs[0], input_tensor)
+        return (attention_output,) + self_outputs[1:]
+
+
+class CaptionBertLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.attention = CaptionBertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def forward(self, hidden_states, attention_mask, head_mask=None, history_state=None):
+        attention_outputs = self.attention(hidden_states, attention_mask, head_mask, history_state)
+        attention_output = attention_outputs[0]
+        intermediate_output = self.intermediate(attention_output)
+        layer_output = self.output(intermediate_output, attention_output)
+        return (layer_output,) + attention_outputs[1:]
+
+
+class _PackedEncoder(object):
+    """bf16 weight copies + the ctypes weight table for the C layer loop; rebuilt on change."""
+
+    def __init__(self, encoder):
+        keep, table = [], (_lib.LayerWeights * len(encoder.layer))()
+        for i, layer in enumerate(encoder.layer):
+            att, so = layer.attention.self, layer.attention.output
+            w_qkv, b_qkv = att.packed_qkv()
+            t = dict(
+                w_qkv=w_qkv, b_qkv=b_qkv,
+                w_ao=_bf16(so.dense.weight), b_ao=_f32(so.dense.bias),
+                ln1_g=_f32(so.LayerNorm.weight), ln1_b=_f32(so.LayerNorm.bias),
+                w_in=_bf16(layer.intermediate.dense.weight), b_in=_f32(layer.intermediate.dense.bias),
+                w_out=_bf16(layer.output.dense.weight), b_out=_f32(layer.output.dense.bias),
+                ln2_g=_f32(layer.output.LayerNorm.weight), ln2_b=_f32(layer.output.LayerNorm.bias),
+            )
+            keep.append(t)
+            for k, v in t.items():
+                setattr(table[i], k, v.data_ptr())
+        self.tensors, self.table = keep, table
+
+
+def _param_key(module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+class CaptionBertEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.output_attentions = config.output_attentions
+        self.output_hidden_states = config.output_hidden_states
+        self.layer = nn.ModuleList([CaptionBertLayer(config) for _ in range(config.num_hidden_layers)])
+        self._hidden = config.hidden_size
+        self._heads = config.num_attention_heads
+        self._inter = config.intermediate_size
+        self._eps = config.layer_norm_eps
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+
+    # ---- cached state -----------------------------------------------------------------
+    def packed(self):
+        key = _param_key(self)
+        if self._packed is None or key != self._packed_key:
+            self._packed = _PackedEncoder(self)
+            self._packed_key = key
+        return self._packed
+
+    def _workspace(self, M, B, device, keep_all):
+        """Activation buffers + ctypes table.  keep_all: one `out` buffer per layer
+        (output_hidden_states); otherwise all layers share one scratch set and run in place."""
+        key = (M, B, str(device), bool(keep_all))
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        H, I, L = self._hidden, self._inter, len(self.layer)
+        mk = lambda n: torch.empty((M, n), dtype=BF16, device=device)
+        shared = dict(qkv=mk(3 * H), ctx=mk(H), attn_pre=mk(H), attn_out=mk(H), mid=mk(I), out_pre=mk(H))
+        outs = [mk(H) for _ in range(L)] if keep_all else [mk(H)] * L
+        table = (_lib.LayerActs * L)()
+        for i in range(L):
+            for k, v in shared.items():
+                setattr(table[i], k, v.data_ptr())
+            table[i].out = outs[i].data_ptr()
+        ws = dict(shared=shared, outs=outs, table=table)
+        if len(self._ws) > 4:
+            self._ws.clear()
+        self._ws[key] = ws
+        return ws
+
+    # ---- fused run --------------------------------------------------------------------
+    def run(self, x_bf16, B, S, mask_f32, mask_additive, head_scale=None):
+        """x_bf16 [B*S,H] -> list of per-layer outputs (len L if output_hidden_states else 1 shared)."""
+        if self._hidden != self._heads * 64:
+            raise NotImplementedError("the fused encoder serves head size 64 (hidden = 64 * heads)")
+        if self.output_attentions:
+            raise NotImplementedError("output_attentions is not implemented in the HIP path yet")
+        for layer in self.layer:
+            _no_train_dropout(layer, layer.attention.self.dropout.p)
+            _no_train_dropout(layer, layer.output.dropout.p)
+        pk = self.packed()
+        ws = self._workspace(B * S, B, x_bf16.device, self.output_hidden_states)
+        if ops.profiling():  # bench.py's per-kernel timing: the same launches, issued one by one
+            return self._run_unrolled(pk, ws, x_bf16, B, S, mask_f32, mask_additive, head_scale)
+        ops.encoder_forward(pk.table, ws["table"], x_bf16, mask_f32, mask_additive, head_scale, B, S,
+                            self._hidden, self._heads, self._inter, self._eps)
+        return ws["outs"]
+
+    def _run_unrolled(self, pk, ws, x, B, S, mask, mask_additive, head_scale):
+        """The launch sequence of vt_encoder_forward_bf16 issued op by op (same kernels, same buffers)."""
+        sh, nh, eps = ws["shared"], self._heads, self._eps
+        cur = x
+        for i, t in enumerate(pk.tensors):
+            out = ws["outs"][i]
+            ops.linear(cur, t["w_qkv"], t["b_qkv"], out=sh["qkv"])
+            ops.attention_fwd(sh["qkv"], B, S, nh, mask=mask, mask_additive=mask_additive,
+                              head_scale=None if head_scale is None else head_scale[i].contiguous(), out=sh["ctx"])
+            ops.linear(sh["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=sh["attn_pre"])
+            ops.layernorm(sh["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=sh["attn_out"])
+            ops.linear(sh["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=sh["mid"])
+            ops.linear(sh["mid"], t["w_out"], t["b_out"], residual=sh["attn_out"], out=sh["out_pre"])
+            ops.layernorm(sh["out_pre"], t["ln2_g"], t["ln2_b"], eps, out=out)
+            cur = out
+        return ws["outs"]
+
+    def forward(self, hidden_states, attention_mask, head_mask=None, encoder_history_states=None):
+        """oscar/modeling_bert.py:140-169.  attention_mask is the ADDITIVE extended mask [B,1,1,S]."""
+        if encoder_history_states is not None:
+            raise NotImplementedError("encoder_history_states is not implemented in the HIP path yet")
+        B, S, H = hidden_states.shape
+        x = _as_bf16_2d(hidden_states)
+        mask = _additive_mask_2d(attention_mask, B, S) if attention_mask is not None else None
+        hs = _head_scale(head_mask, len(self.layer), self._heads, hidden_states.device)
+        outs = self.run(x, B, S, mask, True, hs)
+        dt = hidden_states.dtype
+        last = outs[-1].view(B, S, H).to(dt)
+        outputs = (last,)
+        if self.output_hidden_states:
+            outputs = outputs + ((hidden_states,) + tuple(o.view(B, S, H).to(dt) for o in outs[:-1]) + (last,),)
+        return outputs
+
+
+# --------------------------------------------------------------------------------------------
+# tasks/viewpoint_select/encoder.py:142-441
+# --------------------------------------------------------------------------------------------
+class NextActionPrediction(nn.Module):
+    def __init__(self, hidden, actionspace):
+        super().__init__()
+        self.linear = nn.Linear(hidden, actionspace)
+        self.softmax = nn.LogSoftmax(dim=-1)
+
+    def forward(self, x):
+        ops._require_hip(x)
+        a = x.detach().reshape(-1, x.shape[-1]).to(BF16)
+        K = a.shape[1]
+        buf = torch.empty((a.shape[0], round_up(self.linear.weight.shape[0], 4)), dtype=torch.float32, device=x.device)
+        ops.linear(a.contiguous(), _bf16(self.linear.weight), _f32(self.linear.bias), out=buf, out_f32=True)
+        return self.softmax(buf[:, : self.linear.weight.shape[0]])
+
+
+class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
+    """Expand from BertModel to handle image region features as input (encoder.py:161-303)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = CaptionBertEncoder(config)
+        self.pooler = BertPooler(config)
+
+        self.img_dim = config.img_feature_dim
+        logger.info("BertImgModel Image Dimension: {}".format(self.img_dim))
+        self.img_feature_type = config.img_feature_type
+        self.use_img_layernorm = config.use_img_layernorm if hasattr(config, "use_img_layernorm") else None
+
+        self.img_embedding = nn.Linear(self.img_dim, self.config.hidden_size, bias=True)
+        self.location_embeds = nn.Linear(128, self.config.hidden_size, bias=True)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        if self.use_img_layernorm:
+            self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.img_layer_norm_eps)
+        self.apply(self.init_weights)
+        self._img_pack = None
+        self._img_pack_key = None
+
+    def resize_specific_embeddings(self, embedding_type, new_num_tokens):
+        old_embeddings = getattr(self.embeddings, embedding_type)
+        new_embeddings = self._get_resized_embeddings(old_embeddings, new_num_tokens)
+        setattr(self.embeddings, embedding_type, new_embeddings)
+        return getattr(self.embeddings, embedding_type)
+
+    def _packed_img(self):
+        """[H, Kpad] bf16 = [img_embedding.weight | location_embeds.weight | 0], bias = b_img + b_loc."""
+        ps = (self.img_embedding.weight, self.img_embedding.bias, self.location_embeds.weight, self.location_embeds.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._img_pack is None or key != self._img_pack_key:
+            D = self.img_dim
+            kpad = round_up(D + 128, 64)
+            H = self.config.hidden_size
+            w = torch.zeros((H, kpad), dtype=BF16, device=ps[0].device)
+            w[:, :D] = ps[0].detach().to(BF16)
+            w[:, D : D + 128] = ps[2].detach().to(BF16)
+            b = (ps[1].detach().float() + ps[3].detach().float()).contiguous()
+            self._img_pack, self._img_pack_key = (w, b, kpad), key
+        return self._img_pack
+
+    def run_trunk(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, head_mask=None,
+                  img_feats=None, img_location_embeddings=None, encoder_history_states=None):
+        """Internal: returns (per-layer bf16 outputs list, pooled fp32 [B,H], embedding bf16, B, S)."""
+        ops._require_hip(input_ids)
+        dev = input_ids.device
+        B, T = input_ids.shape
+        if encoder_history_states:
+            assert img_feats is None, "Cannot take image features while using encoder history states"
+            raise NotImplementedError("encoder_history_states is not implemented in the HIP path yet")
+        R = 0 if img_feats is None else img_feats.shape[1]
+        S = T + R
+        H = self.config.hidden_size
+
+        # mask: encoder.py:215-241.  The -10000 arithmetic runs in the attention kernel on the raw fp32 mask.
+        mask_f32 = None
+        if attention_mask is not None:
+            if attention_mask.dim() == 2:
+                if attention_mask.shape != (B, S):
+                    raise RuntimeError(
+                        "attention_mask shape %s does not match [batch, text+region] = [%d, %d]"
+                        % (tuple(attention_mask.shape), B, S))
+                mask_f32 = attention_mask.to(device=dev, dtype=torch.float32).contiguous()
+            elif attention_mask.dim() == 3:
+                raise NotImplementedError("3-D attention masks are not implemented in the HIP path yet")
+            else:
+                raise NotImplementedError
+        hs = _head_scale(head_mask, self.config.num_hidden_layers, self.config.num_attention_heads, dev)
+
+        x = torch.empty((B * S, H), dtype=BF16, device=dev)
+        self.embeddings.write_rows(x, S, input_ids, token_type_ids, position_ids)  # rows b*S + [0,T)
+        if img_feats is not None:
+            _no_train_dropout(self, self.dropout.p)
+            w, b, kpad = self._packed_img()
+            a = ops.pack_concat(
+                img_feats.reshape(B * R, -1).float().contiguous(),
+                img_location_embeddings.reshape(B * R, -1).float().contiguous(), kpad)
+            # rows b*S + T + r : the GEMM epilogue remaps its row m = b*R + r (replaces torch.cat, :287)
+            ops.linear(a, w, b, out=x[T:], ldc=H, grp_rows=R, grp_stride=S)
+            if self.use_img_layernorm:
+                ops.layernorm(x[T:], _f32(self.LayerNorm.weight), _f32(self.LayerNorm.bias),
+                              self.LayerNorm.variance_epsilon, out=x[T:], M=B * R, grp_rows=R, grp_stride=S)
+        outs = self.encoder.run(x, B, S, mask_f32, False, hs)
+        pooled = self.pooler.pooled(outs[-1], B, S)
+        _check_index_error(self.embeddings)
+        return outs, pooled, x, B, S
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, head_mask=None,
+                img_feats=None, img_location_embeddings=None, encoder_history_states=None):
+        outs, pooled, x, B, S = self.run_trunk(input_ids, token_type_ids, attention_mask, position_ids, head_mask,
+                                               img_feats, img_location_embeddings, encoder_history_states)
+        dt = next(self.parameters()).dtype
+        H = self.config.hidden_size
+        sequence_output = outs[-1].view(B, S, H).to(dt)
+        outputs = (sequence_output, pooled.to(dt))
+        if self.encoder.output_hidden_states:
+            hidden = (x.view(B, S, H).to(dt),) + tuple(o.view(B, S, H).to(dt) for o in outs[:-1]) + (sequence_output,)
+            outputs = outputs + (hidden,)
+        return outputs
+
+
+class PreTrainOscar(BertPreTrainedModel):
+    """Trunk + MLM / masked-region-token / 1-in-36 action heads (encoder.py:306-441)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.config = config
+        self.bert = BertImgModelwithLocationEmbeds(config)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.next_action = NextActionPrediction(self.config.hidden_size, self.config.action_space)
+        self.criterion = nn.CrossEntropyLoss(ignore_index=-1)
+        self.mlmhead = BertOnlyMLMHead(self.config)
+        self.token_head = nn.Sequential(
+            nn.Linear(self.config.hidden_size, self.config.detector_classes),
+            nn.Softmax(dim=-1),
+        )
+        self.apply(self.init_weights)
+        self.tie_weights()
+
+    def tie_weights(self):
+        self._tie_or_clone_weights(self.mlmhead.predictions.decoder, self.bert.embeddings.word_embeddings)
+
+    def resize_embeddings(self, embedding_size_dict):
+        for embedding_type, new_embedding_size in embedding_size_dict.items():
+            assert embedding_type in ["word_embeddings", "position_embeddings", "token_type_embeddings"]
+            self.bert.resize_specific_embeddings(embedding_type, new_embedding_size)
+            logger.info(f"Resized {embedding_type} to {new_embedding_size}")
+
+    def head_outputs(self, seq_bf16, pooled_f32):
+        """(prediction_scores [M,V] fp32, token probabilities [M,C] fp32, action log-probs [B,A] fp32)."""
+        scores = self.mlmhead.scores(seq_bf16)
+        lin = self.token_head[0]
+        C = lin.weight.shape[0]
+        buf = torch.empty((seq_bf16.shape[0], round_up(C, 4)), dtype=torch.float32, device=seq_bf16.device)
+        ops.linear(seq_bf16, _bf16(lin.weight), _f32(lin.bias), out=buf, out_f32=True)
+        token_prob = torch.softmax(buf[:, :C], dim=-1)
+        action = self.next_action(pooled_f32)
+        return scores, token_prob, action
+
+    def forward(self, input_ids, token_type_ids=None, attention_mask=None, labels=None, token_labels=None,
+                position_ids=None, head_mask=None, img_feats=None, img_location_embeddings=None, next_action=None,
+                text_only=False):
+        if text_only:
+            return self.bert(input_ids, position_ids=position_ids, token_type_ids=token_type_ids,
+                             attention_mask=attention_mask, head_mask=head_mask, img_feats=img_feats,
+                             img_location_embeddings=img_location_embeddings)
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the HIP backward pass is not implemented yet; call under torch.no_grad() / eval()")
+        outs, pooled, _, B, S = self.bert.run_trunk(
+            input_ids, token_type_ids, attention_mask, position_ids, head_mask, img_feats, img_location_embeddings)
+        prediction_scores, token_prob, action_scores = self.head_outputs(outs[-1], pooled)
+        V, C = self.config.vocab_size, self.config.detector_classes
+
+        token_loss = 0
+        if token_labels is not None:
+            token_prediction = token_prob.view(B, S, C)
+            token_loss = self.criterion(token_prob.reshape(-1, C), token_labels.view(-1))
+        mask_loss = self.criterion(prediction_scores.reshape(-1, V), labels.view(-1))
+        next_loss = 0
+        if next_action is not None:
+            next_loss = self.criterion(action_scores, next_action)
+        loss = mask_loss + next_loss + token_loss
+
+        predicted_action = torch.argmax(action_scores, dim=1)
+        predicted_words = torch.argmax(prediction_scores.view(B, S, -1), dim=2)
+        token_prediction = torch.argmax(token_prediction, dim=2)  # NameError if token_labels is None, as the reference
+
+        predicted_words[labels == -1] = -1
+        ignored_words_no = torch.sum(labels == -1)
+        words_left = ((labels.shape[0] * labels.shape[1]) - ignored_words_no).type(torch.float)
+        words_accuracy = (torch.sum(predicted_words == labels) - ignored_words_no) / words_left
+
+        if next_action is not None:
+            action_accuracy = torch.sum(predicted_action == next_action).type(torch.float) / predicted_action.shape[0]
+        else:
+            action_accuracy = 0
+
+        token_prediction[token_labels == -1] = -1
+        ignored_tokens_no = torch.sum(token_labels == -1)
+        tokens_left = ((token_prediction.shape[0] * token_prediction.shape[1]) - ignored_tokens_no).type(torch.float)
+        token_accuracy = (torch.sum(token_prediction == token_labels).type(torch.float) - ignored_tokens_no) / tokens_left
+
+        return (loss, mask_loss, next_loss, token_loss, words_accuracy, action_accuracy, token_accuracy)
+
+
+# tasks/viewpoint_select/model_utils.py:15-26 -- the registry the reference's loader indexes by name.
+# (ImageBertForSequenceClassificationwithAction is dead code in the reference: it names undefined classes.)
+MODEL_CLASS = {
+    "PreTrainOscar": (BertConfig, PreTrainOscar, None),
+    "BertImgModelwithLocationEmbeds": (BertConfig, BertImgModelwithLocationEmbeds, None),
+}

@@ -1,0 +1,181 @@
+"""Tensor-level wrappers over the C ABI: torch tensors in, torch tensors out.
+
+torch is plumbing here (device memory + the current HIP stream); all arithmetic of the
+hot path runs in ``libvisitron_hip.so``.  Every function raises on CPU tensors.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+ACT_NONE, ACT_GELU, ACT_TANH = 0, 1, 2
+
+
+# ---- optional per-launch timing (HIP events on the launch stream); used by bench.py only ----------
+_prof = None
+
+
+def profile_begin():
+    global _prof
+    _prof = []
+
+
+def profile_end():
+    """-> {kernel: {"ms": total, "n": launches, "flops": algorithmic flops, "bytes": algorithmic bytes}}"""
+    global _prof
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1, flops, nbytes in _prof:
+        d = out.setdefault(name, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["n"] += 1
+        d["flops"] += flops
+        d["bytes"] += nbytes
+    _prof = None
+    return out
+
+
+def profiling():
+    return _prof is not None
+
+
+class _timed(object):
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if _prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _prof is not None:
+            self.e1.record()
+            _prof.append((self.name, self.e0, self.e1, self.flops, self.nbytes))
+        return False
+
+
+def _require_hip(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "visitron_amd ops run on a HIP device only (got a %s tensor); there is no CPU fallback" % t.device
+            )
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False, grp_rows=0, grp_stride=0,
+           M=None, lda=None, ldc=None):
+    """out = act(a @ w.T + bias) (+ residual).  a [M,K] bf16 (row stride lda), w [N,K] bf16."""
+    _require_hip(a, w, bias, residual, out)
+    assert a.dtype == BF16 and w.dtype == BF16
+    N, K = w.shape
+    if M is None:
+        M = a.shape[0]
+    if lda is None:
+        assert a.stride(-1) == 1
+        lda = a.stride(0)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    if ldc is None:
+        ldc = out.stride(0)
+    ldr = residual.stride(0) if residual is not None else 0
+    with _timed("gemm_nt_bf16_128x128", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
+        rc = _lib.load().vt_linear_bf16(
+            _ptr(a), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(residual), ldr, _ptr(out), ldc,
+            M, N, K, act, 1 if out_f32 else 0, grp_rows, grp_stride, _stream())
+    _lib.check(rc, "vt_linear_bf16")
+    return out
+
+
+def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None, out=None, lse=None):
+    """qkv [B*S, 3*nh*64] bf16, mask fp32 [B,S] -> context [B*S, nh*64] bf16."""
+    _require_hip(qkv, mask, head_scale, out, lse)
+    assert qkv.dtype == BF16
+    H = nh * 64
+    if out is None:
+        out = torch.empty((B * S, H), dtype=BF16, device=qkv.device)
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.numel() == B * S
+    with _timed("attention_fwd_d64", 4.0 * B * nh * S * S * 64, 2.0 * B * S * 4 * H):
+        rc = _lib.load().vt_attention_fwd_bf16(
+            _ptr(qkv), qkv.stride(0), _ptr(mask), 1 if mask_additive else 0, _ptr(head_scale), _ptr(out),
+            out.stride(0), _ptr(lse), B, S, nh, 64, _stream())
+    _lib.check(rc, "vt_attention_fwd_bf16")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out=None, mean=None, rstd=None, M=None, grp_rows=0, grp_stride=0):
+    _require_hip(x, gamma, beta, out)
+    assert x.dtype == BF16 and gamma.dtype == torch.float32
+    H = gamma.numel()
+    if M is None:
+        M = x.shape[0]
+    if out is None:
+        out = torch.empty_like(x)
+    with _timed("layernorm_rows", 0.0, 4.0 * M * H):
+        rc = _lib.load().vt_layernorm_bf16(
+            _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
+            M, H, float(eps), grp_rows, grp_stride, _stream())
+    _lib.check(rc, "vt_layernorm_bf16")
+    return out
+
+
+def embed_layernorm(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, eps, out, S, err_flag=None):
+    """Writes rows b*S + t (t < T) of ``out`` [B*S, H] bf16."""
+    _require_hip(ids, word, out)
+    B, T = ids.shape
+    H = word.shape[1]
+    for t in (ids, type_ids, pos_ids):
+        assert t is None or (t.dtype == torch.int64 and t.is_contiguous() and t.shape == ids.shape)
+    for t in (word, pos, typ):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    with _timed("embed_layernorm", 0.0, B * T * H * 14.0):
+        rc = _lib.load().vt_embed_layernorm(
+            _ptr(ids), _ptr(type_ids), _ptr(pos_ids), _ptr(word), _ptr(pos), _ptr(typ), _ptr(gamma), _ptr(beta),
+            _ptr(out), out.stride(0), B, T, S, H, word.shape[0], pos.shape[0], typ.shape[0], float(eps),
+            _ptr(err_flag), _stream())
+    _lib.check(rc, "vt_embed_layernorm")
+    return out
+
+
+def pack_concat(s0, s1, kpad, out=None):
+    """bf16([s0 | s1 | 0-pad]) row-wise; s0 [rows,d0], s1 [rows,d1] fp32 contiguous."""
+    _require_hip(s0, s1, out)
+    assert s0.dtype == torch.float32 and s0.is_contiguous()
+    rows, d0 = s0.shape
+    d1 = 0
+    if s1 is not None:
+        assert s1.dtype == torch.float32 and s1.is_contiguous() and s1.shape[0] == rows
+        d1 = s1.shape[1]
+    if out is None:
+        out = torch.empty((rows, kpad), dtype=BF16, device=s0.device)
+    with _timed("pack_concat_bf16", 0.0, rows * (4.0 * (d0 + d1) + 2.0 * kpad)):
+        rc = _lib.load().vt_pack_concat_bf16(_ptr(s0), d0, _ptr(s1), d1, _ptr(out), kpad, rows, _stream())
+    _lib.check(rc, "vt_pack_concat_bf16")
+    return out
+
+
+def encoder_forward(layer_weights, layer_acts, x, mask, mask_additive, head_scale, B, S, H, nh, I, eps):
+    """Run the layer loop in C.  layer_weights / layer_acts: ctypes arrays built by the caller
+    (``visitron_amd.modeling`` keeps them alive together with the tensors they point into)."""
+    _require_hip(x, mask, head_scale)
+    L = len(layer_weights)
+    rc = _lib.load().vt_encoder_forward_bf16(
+        layer_weights, layer_acts, L, _ptr(x), _ptr(mask), 1 if mask_additive else 0, _ptr(head_scale),
+        B, S, H, nh, I, float(eps), _stream())
+    _lib.check(rc, "vt_encoder_forward_bf16")
