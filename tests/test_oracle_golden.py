@@ -1,0 +1,109 @@
+"""CPU: the oracle reproduces the committed golden fixtures, and its un-vendored blocks agree with
+the independent implementation recorded in tests/golden/hf_crosscheck.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TRUNK_KEYS = ("input_ids", "attention_mask", "img_feats", "img_location_embeddings")
+
+
+def _oracle(cfg, seed, std):
+    from oracle.modeling import PreTrainOscar
+    from visitron_amd.synth import deterministic_state_dict
+
+    m = PreTrainOscar(cfg).eval()
+    m.load_state_dict(deterministic_state_dict(m, seed=seed, weight_std=std))
+    return m
+
+
+def test_mini_fixture_reproduced_by_oracle():
+    from visitron_amd.config import mini_config
+    from visitron_amd.synth import make_batch
+
+    g = np.load(os.path.join(GOLD, "mini_pretrain.npz"))
+    cfg = mini_config()
+    b = make_batch(cfg, 3, text_len=20, region_len=17, seed=11)
+    for k, v in b.items():  # the synthetic generator is itself reproducible
+        assert np.array_equal(g["in_" + k], v.numpy()), k
+    m = _oracle(cfg, 3, 0.05)
+    with torch.no_grad():
+        seq, pooled = m.bert(**{k: b[k] for k in TRUNK_KEYS})[:2]
+        scores, tokp, act = m.heads(seq, pooled)
+        out7 = m(**b)
+    np.testing.assert_allclose(seq.numpy(), g["sequence_output"], atol=2e-5)
+    np.testing.assert_allclose(pooled.numpy(), g["pooled_output"], atol=2e-5)
+    np.testing.assert_allclose(scores.numpy(), g["prediction_scores"], atol=5e-5)
+    np.testing.assert_allclose(tokp.numpy(), g["token_probs"], atol=1e-6)
+    np.testing.assert_allclose(act.numpy(), g["action_scores"], atol=2e-5)
+    np.testing.assert_allclose([float(x) for x in out7], g["tuple7"], atol=1e-4)
+
+
+def test_mini_fixture_gradients_and_adamw_step():
+    from oracle.optim import AdamW, grouped_parameters
+    from visitron_amd.config import mini_config
+    from visitron_amd.synth import make_batch
+
+    g = np.load(os.path.join(GOLD, "mini_pretrain.npz"))
+    cfg = mini_config()
+    b = make_batch(cfg, 3, text_len=20, region_len=17, seed=11)
+    m = _oracle(cfg, 3, 0.05)
+    m(**b)[0].backward()
+    grads = {n: p.grad for n, p in m.named_parameters()}
+    names = list(g["grad_names"])
+    assert names == sorted(grads)
+    np.testing.assert_allclose([float(grads[n].norm()) for n in names], g["grad_norms"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(grads["bert.encoder.layer.0.attention.self.query.weight"].numpy(), g["grad_query0"], atol=2e-5)
+    # word_embeddings is built with padding_idx=0 upstream: the lookup leaves row 0 without gradient,
+    # only the tied decoder contributes there.
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    AdamW(grouped_parameters(m, 0.05), lr=5e-5, eps=1e-8).step()
+    after = dict(m.named_parameters())
+    np.testing.assert_allclose([float((after[n].detach() - before[n]).norm()) for n in names], g["adamw_delta_norms"],
+                               rtol=1e-3, atol=1e-7)
+
+
+def test_base_cfg1_fixture_reproduced_by_oracle():
+    from visitron_amd.config import BertConfig
+    from visitron_amd.synth import make_batch
+
+    g = np.load(os.path.join(GOLD, "base_cfg1.npz"))
+    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    b = make_batch(cfg, 2, seed=1234)
+    assert np.array_equal(g["in_input_ids"], b["input_ids"].numpy())
+    assert np.array_equal(g["in_attention_mask"], b["attention_mask"].numpy())
+    assert abs(float(b["img_feats"].double().sum()) - g["in_img_feats_checksum"][0]) < 1e-6 * abs(g["in_img_feats_checksum"][0])
+    m = _oracle(cfg, 0, 0.03)
+    with torch.no_grad():
+        seq, pooled = m.bert(**{k: b[k] for k in TRUNK_KEYS})[:2]
+        scores, tokp, act = m.heads(seq, pooled)
+        out7 = m(**b)
+    np.testing.assert_allclose(seq[:, ::19, ::31].numpy(), g["sequence_output_slice"], atol=1e-4)
+    np.testing.assert_allclose(pooled.numpy(), g["pooled_output"], atol=1e-4)
+    np.testing.assert_allclose(scores[:, ::23, ::1009].numpy(), g["prediction_scores_slice"], atol=5e-4)
+    np.testing.assert_allclose(act.numpy(), g["action_scores"], atol=1e-4)
+    np.testing.assert_allclose([float(x) for x in out7], g["tuple7"], atol=5e-4)
+
+
+def test_crosscheck_report_is_green():
+    with open(os.path.join(GOLD, "hf_crosscheck.json")) as f:
+        r = json.load(f)
+    assert r["encoder_param_names_equal"] is True
+    for k, v in r.items():
+        if k.endswith("maxabs"):
+            assert v < 1e-9, (k, v)
+
+
+def test_crosscheck_against_installed_transformers():
+    """Re-run the independent cross-check where the third-party package exists (build container)."""
+    pytest.importorskip("transformers.models.bert.modeling_bert")
+    from oracle import crosscheck_hf
+
+    r = crosscheck_hf.run()
+    assert r["encoder_param_names_equal"]
+    for k, v in r.items():
+        if k.endswith("maxabs"):
+            assert v < crosscheck_hf.TOL, (k, v)
