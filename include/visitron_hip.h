@@ -37,6 +37,8 @@ typedef void* vt_stream_t; /* hipStream_t */
 const char* vt_error_string(int code);
 /* ABI version of this header; bumped on any signature change. */
 int vt_abi_version(void);
+/* Tuning hook (benchmarks only): force the GEMM kernel variant, -1 = built-in choice.  Process-global. */
+void vt_debug_set_gemm_variant(int variant);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R[M,N]);  A, W, R bf16; C bf16 (out_f32 == 0) or
  * fp32.  Replaces every nn.Linear call on the path -- query/key/value oscar/modeling_bert.py:43-45
@@ -85,6 +87,21 @@ int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_
  * one GEMM. */
 int vt_pack_concat_bf16(const float* s0, int d0, const float* s1, int d1, void* out, int kpad,
                         int64_t rows, vt_stream_t stream);
+
+/* Weight (and bias) gradients of nn.Linear layers -- the wgrad half of loss.backward()
+ * (tasks/viewpoint_select/pretrain.py:191):  dW[N,K] (+)= dY[M,N]^T . X[M,K],  db[N] (+)= colsum(dY).
+ * dY, X bf16 row-major over the same M token rows; dW, db fp32.  Up to 8 problems sharing M are
+ * computed by ONE grouped launch (e.g. the four matrices of an encoder layer).  K % 4 == 0,
+ * M * ld * 2 < 2^31 bytes per operand. */
+typedef struct vt_wgrad_problem {
+  const void* dY; int64_t ldy;
+  const void* X;  int64_t ldx;
+  float* dW;      int64_t ldw;
+  float* db;      /* or NULL */
+  int N, K;
+  int accumulate; /* 0: overwrite, 1: add into dW / db */
+} vt_wgrad_problem;
+int vt_wgrad_bf16(const vt_wgrad_problem* problems, int nprob, int M, vt_stream_t stream);
 
 /* ---- whole encoder stack: CaptionBertEncoder.forward, oscar/modeling_bert.py:140-169 ---------- */
 typedef struct vt_layer_weights {

@@ -218,3 +218,50 @@ def test_pack_concat(dev):
     assert torch.equal(got[:, :2054], bf16_round(a))
     assert torch.equal(got[:, 2054:2182], bf16_round(b))
     assert float(got[:, 2182:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M", [456, 64, 1000, 14592])
+def test_wgrad_grouped_matches_fp32(dev, M):
+    """dW = dY^T X and db = colsum(dY) for several problems in ONE launch; M tail zero-filled."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(M)
+    specs = [(256, 128, True), (768, 768, True), (36, 128, True), (130, 2240, False), (1601, 64, True)]
+    if M > 2000:
+        specs = [(2304, 768, True), (768, 768, True), (3072, 768, True), (768, 3072, True)]
+    probs, wants = [], []
+    for N, K, bias in specs:
+        ldy = (N + 7) // 8 * 8
+        dy = torch.zeros(M, ldy)
+        dy[:, :N] = bf16_round(_rand((M, N), g, 0.5))
+        x = bf16_round(_rand((M, K), g))
+        dw = torch.full((N, K), 3.0, device=dev)
+        db = torch.full((N,), 3.0, device=dev) if bias else None
+        probs.append(dict(dy=dy.to(dev, BF16)[:, :N], x=x.to(dev, BF16), dw=dw, db=db))
+        wants.append((dy[:, :N].double().t() @ x.double(), dy[:, :N].double().sum(0)))
+    ops.wgrad(probs, M)
+    torch.cuda.synchronize()
+    for p, (w_dw, w_db) in zip(probs, wants):
+        scale = float(w_dw.abs().max())
+        assert float((p["dw"].cpu().double() - w_dw).abs().max()) < 2e-4 * scale + 1e-3
+        if p["db"] is not None:
+            assert float((p["db"].cpu().double() - w_db).abs().max()) < 2e-4 * float(w_db.abs().max()) + 1e-3
+    # accumulate mode adds on top
+    for p in probs:
+        p["accumulate"] = True
+    ops.wgrad(probs, M)
+    torch.cuda.synchronize()
+    for p, (w_dw, w_db) in zip(probs, wants):
+        assert float((p["dw"].cpu().double() - 2 * w_dw).abs().max()) < 4e-4 * float(w_dw.abs().max()) + 2e-3
+
+
+def test_wgrad_asymmetric_identity(dev):
+    """dY = I (M = N) against an asymmetric X: dW must equal X exactly (catches transposed writes)."""
+    from visitron_amd import ops
+
+    M = N = 128
+    K = 256
+    x = bf16_round((torch.arange(M * K, dtype=torch.float32).reshape(M, K) % 253) / 32.0 - 3.0)
+    dw = torch.zeros((N, K), device=dev)
+    ops.wgrad([dict(dy=torch.eye(M).to(dev, BF16), x=x.to(dev, BF16), dw=dw)], M)
+    assert torch.equal(dw.cpu(), x)

@@ -23,10 +23,16 @@ class LayerActs(ctypes.Structure):  # vt_layer_acts
         "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd")]
 
 
+class WgradProblem(ctypes.Structure):  # vt_wgrad_problem
+    _fields_ = [("dY", c_void_p), ("ldy", c_int64), ("X", c_void_p), ("ldx", c_int64), ("dW", c_void_p),
+                ("ldw", c_int64), ("db", c_void_p), ("N", c_int), ("K", c_int), ("accumulate", c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/visitron_hip.h
 SIGNATURES = {
     "vt_error_string": (ctypes.c_char_p, [c_int]),
     "vt_abi_version": (c_int, []),
+    "vt_debug_set_gemm_variant": (None, [c_int]),
     "vt_linear_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_attention_fwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p,
@@ -37,6 +43,7 @@ SIGNATURES = {
                                    c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p, c_void_p]),
     "vt_pack_concat_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "vt_wgrad_bf16": (c_int, [ctypes.POINTER(WgradProblem), c_int, c_int, c_void_p]),
     "vt_encoder_forward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerActs), c_int, c_void_p,
                                         c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                         c_void_p]),

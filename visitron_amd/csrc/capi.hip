@@ -18,6 +18,26 @@ int vt_embed_layernorm_dispatch(const int64_t* ids, const int64_t* type_ids, con
 int vt_pack_concat_dispatch(const float* s0, int d0, const float* s1, int d1, void* out, int kpad, long rows,
                             hipStream_t stream);
 
+void vt_gemm_set_variant(int v);
+
+#define WG_MAX_PROBLEMS 8
+struct WgradProblem {
+  const bf16_t* dY; long ldy;
+  const bf16_t* X; long ldx;
+  float* dW; long ldw;
+  float* db;
+  int N, K;
+  int tiles_k;
+  int tile_begin;
+  int accumulate;
+};
+struct WgradArgs {
+  WgradProblem p[WG_MAX_PROBLEMS];
+  int nprob;
+  int M;
+};
+int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream);
+
 extern "C" {
 
 const char* vt_error_string(int code) {
@@ -33,6 +53,8 @@ const char* vt_error_string(int code) {
 }
 
 int vt_abi_version(void) { return 1; }
+
+void vt_debug_set_gemm_variant(int variant) { vt_gemm_set_variant(variant); }
 
 int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* R,
                    int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int act, int out_f32, int grp_rows,
@@ -65,6 +87,23 @@ int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_
 int vt_pack_concat_bf16(const float* s0, int d0, const float* s1, int d1, void* out, int kpad, int64_t rows,
                         vt_stream_t stream) {
   return vt_pack_concat_dispatch(s0, d0, s1, d1, out, kpad, rows, (hipStream_t)stream);
+}
+
+int vt_wgrad_bf16(const vt_wgrad_problem* problems, int nprob, int M, vt_stream_t stream) {
+  if (!problems) return VT_ERR_NULL;
+  if (nprob <= 0 || nprob > WG_MAX_PROBLEMS) return VT_ERR_BAD_SHAPE;
+  WgradArgs a;
+  a.nprob = nprob;
+  a.M = M;
+  for (int i = 0; i < nprob; ++i) {
+    const vt_wgrad_problem& q = problems[i];
+    WgradProblem& P = a.p[i];
+    P.dY = (const bf16_t*)q.dY; P.ldy = q.ldy; P.X = (const bf16_t*)q.X; P.ldx = q.ldx;
+    P.dW = q.dW; P.ldw = q.ldw; P.db = q.db; P.N = q.N; P.K = q.K; P.accumulate = q.accumulate;
+    P.tiles_k = 0; P.tile_begin = 0;
+  }
+  for (int i = nprob; i < WG_MAX_PROBLEMS; ++i) a.p[i] = a.p[0];
+  return vt_wgrad_dispatch(a, (hipStream_t)stream);
 }
 
 // CaptionBertEncoder.forward (oscar/modeling_bert.py:140-169): the Python loop over layers, each

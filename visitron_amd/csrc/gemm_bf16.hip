@@ -44,12 +44,92 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2 };
 #define GEMM_BK 64
 #define GEMM_TILE_BYTES (128 * 64 * 2)
 #define GEMM_LDS_BYTES (4 * GEMM_TILE_BYTES)
+#define GEMM_DEFAULT_VARIANT 1
 
 template <int ACT>
 __device__ __forceinline__ float apply_act(float x) {
   if (ACT == ACT_GELU) return gelu_erf(x);
   if (ACT == ACT_TANH) return tanh_fast(x);
   return x;
+}
+
+// Epilogue shared by the GEMM kernels: lane (j = lane&15, gq = lane>>4) owns output rows
+// row0+16mt+j (mt = 0..3) and the 16 consecutive columns col0+16gq .. +15; bias, activation and
+// residual are applied in registers and each lane stores 32 (bf16) or 64 (fp32) contiguous bytes.
+template <int ACT, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int lane, int row0, int col0) {
+  const int gq = lane >> 4;
+  const int nb = col0 + 16 * gq;
+  if (nb >= g.N) return;
+  const bool full = (nb + 16 <= g.N);
+
+  float bv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bv[i] = 0.f;
+  if (g.bias) {
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 t4 = *(const f32x4*)(g.bias + nb + 4 * i);
+        bv[4 * i + 0] = t4[0]; bv[4 * i + 1] = t4[1]; bv[4 * i + 2] = t4[2]; bv[4 * i + 3] = t4[3];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (nb + i < g.N) bv[i] = g.bias[nb + i];
+    }
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = row0 + 16 * mt + (lane & 15);
+    if (m >= g.M) continue;
+    const long orow = g.grp_rows ? (long)(m / g.grp_rows) * g.grp_stride + (m % g.grp_rows) : (long)m;
+    float v[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * t + e] = apply_act<ACT>(acc[mt][t][e] + bv[4 * t + e]);
+
+    if (full) {
+      if (g.R) {
+        const u32x4* rp = (const u32x4*)(g.R + orow * g.ldr + nb);
+        const u32x4 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[2 * i] += bf16lo(r0[i]);
+          v[2 * i + 1] += bf16hi(r0[i]);
+          v[8 + 2 * i] += bf16lo(r1[i]);
+          v[8 + 2 * i + 1] += bf16hi(r1[i]);
+        }
+      }
+      if (OUT_F32) {
+        f32x4* cp = (f32x4*)((float*)g.C + orow * g.ldc + nb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cp[i] = (f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+      } else {
+        u32x4* cp = (u32x4*)((bf16_t*)g.C + orow * g.ldc + nb);
+        u32x4 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+          o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+        }
+        cp[0] = o0;
+        cp[1] = o1;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (nb + i < g.N) {
+          float x = v[i];
+          if (g.R) x += bf16_to_f32(g.R[orow * g.ldr + nb + i]);
+          if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;
+          else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = f32_to_bf16(x);
+        }
+      }
+    }
+  }
 }
 
 template <int ACT, bool OUT_F32>
@@ -149,93 +229,194 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_128x128(GemmArgs g) {
           acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][t], xf[ks][mt], acc[mt][t], 0, 0, 0);
   }
 
-  // ---- epilogue: lane (j = lane&15, gq = lane>>4) owns rows m0+64wm+16mt+j, columns nb..nb+15 ----
-  const int gq = lane >> 4;
-  const int nb = n0 + 64 * wn + 16 * gq;
-  if (nb >= g.N) return;
-  const bool full = (nb + 16 <= g.N);
+  gemm_epilogue<ACT, OUT_F32>(g, acc, lane, m0 + 64 * wm, n0 + 64 * wn);
+}
 
-  float bv[16];
+// ================================================================================================
+// v2: the same tile / fragment / epilogue design with
+//   * a NSTAGE-deep LDS ring fed by global_load_lds, retired by a COUNTED s_waitcnt vmcnt(N) so the
+//     DMA of the next NSTAGE-2 tiles stays in flight across the barrier;
+//   * fragment reads as inline-asm ds_read_b128 (hipcc would otherwise put a vmcnt(0) in front of
+//     every LDS read that follows an LDS-DMA and drain the ring), waited for by hand;
+//   * BK = 64 (2 or 3 stages) or BK = 32 with 3 stages = 48 KiB LDS -> 3 workgroups per CU, which
+//     also softens wave quantisation (768 slots instead of 512);
+//   * grouped tile order: each XCD walks bands of 8 row-tiles, column-tile major inside a band, so
+//     the ~64 tiles resident on an XCD share 8 activation panels and ~8 weight panels in its L2.
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+  return BK == 64 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3);
+}
+
+__device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+template <int BK, int NSTAGE, int ACT, bool OUT_F32>
+__global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_nt_bf16_v2(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CH = BK / 8;             // 16-B chunks per tile row
+  constexpr int ROWB = BK * 2;           // bytes per tile row
+  constexpr int TILE = 128 * ROWB;       // bytes per operand tile
+  constexpr int STAGE = 2 * TILE;        // X tile then W tile
+  constexpr int NP = BK / 16;            // 1-KiB DMA pieces per operand per wave per stage
+  constexpr int G = 2 * NP;              // DMA instructions per stage per wave
+  constexpr int KS = BK / 32;            // MFMA k-substeps per stage
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-contiguous chunk of the grouped tile order
+  const int nwg = gridDim.x;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int band_tiles = 8 * g.tiles_n;
+  const int band = t_id / band_tiles;
+  const int within = t_id - band * band_tiles;
+  const int rows_left = g.tiles_m - band * 8;
+  const int band_h = rows_left < 8 ? rows_left : 8;
+  const int bn = within / band_h;
+  const int bm = band * 8 + (within - bn * band_h);
+  const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
+
+  const bf16_t* a_src[NP];
+  const bf16_t* w_src[NP];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) bv[i] = 0.f;
-  if (g.bias) {
-    if (full) {
+  for (int i = 0; i < NP; ++i) {
+    const int p = (wave * NP + i) * 64 + lane;
+    const int row = p / CH;
+    const int c = (p % CH) ^ swz<BK>(row);
+    int am = m0 + row;
+    am = am < g.M ? am : g.M - 1;
+    a_src[i] = g.A + (long)am * g.lda + c * 8;
+    int wnrow = n0 + (row & 64) + 16 * ((row >> 2) & 3) + 4 * ((row >> 4) & 3) + (row & 3);
+    wnrow = wnrow < g.N ? wnrow : g.N - 1;
+    w_src[i] = g.W + (long)wnrow * g.ldw + c * 8;
+  }
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned x_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int xr = 64 * wm + 16 * i + (lane & 15);
+    x_off[i] = lds0 + xr * ROWB + (((lane >> 4) ^ swz<BK>(xr)) << 4);
+    const int wr = 64 * wn + 16 * i + (lane & 15);
+    w_off[i] = lds0 + TILE + wr * ROWB + (((lane >> 4) ^ swz<BK>(wr)) << 4);
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+
+  // prologue: tiles 0 .. NSTAGE-2
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) {
+    if (st < nk) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        glds16(a_src[i] + st * BK, smem + st * STAGE + (wave * NP + i) * 1024);
+        glds16(w_src[i] + st * BK, smem + st * STAGE + TILE + (wave * NP + i) * 1024);
+      }
+    }
+  }
+
+  int slot = 0;                 // ring slot of tile kt
+  int pslot = NSTAGE - 1;       // ring slot the prefetch of tile kt+NSTAGE-1 goes to
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt landed (mine); tiles kt+1 .. kt+NSTAGE-2 may stay in flight
+    if (NSTAGE > 2 && kt + NSTAGE - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * G) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    const unsigned so = slot * STAGE;
+    u32x4 xf[KS][4], wf[KS][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wf[0][i] = lds_read_b128(w_off[i] + so);
+      xf[0][i] = lds_read_b128(x_off[i] + so);
+    }
+
+    if (kt + NSTAGE - 1 < nk) {
+      char* nX = smem + pslot * STAGE;
+      const int koff = (kt + NSTAGE - 1) * BK;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        glds16(a_src[i] + koff, nX + (wave * NP + i) * 1024);
+        glds16(w_src[i] + koff, nX + TILE + (wave * NP + i) * 1024);
+      }
+    }
+
+    if (KS == 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x4 t4 = *(const f32x4*)(g.bias + nb + 4 * i);
-        bv[4 * i + 0] = t4[0]; bv[4 * i + 1] = t4[1]; bv[4 * i + 2] = t4[2]; bv[4 * i + 3] = t4[3];
+        wf[KS - 1][i] = lds_read_b128((w_off[i] + so) ^ 64);
+        xf[KS - 1][i] = lds_read_b128((x_off[i] + so) ^ 64);
       }
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (nb + i < g.N) bv[i] = g.bias[nb + i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0][t]),
+                                                             __builtin_bit_cast(bf16x8, xf[0][mt]), acc[mt][t], 0, 0, 0);
+    if (KS == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[KS - 1][t]),
+                                                               __builtin_bit_cast(bf16x8, xf[KS - 1][mt]), acc[mt][t], 0, 0, 0);
+    }
+    slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
+    pslot = (pslot + 1 == NSTAGE) ? 0 : pslot + 1;
   }
 
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + 64 * wm + 16 * mt + (lane & 15);
-    if (m >= g.M) continue;
-    const long orow = g.grp_rows ? (long)(m / g.grp_rows) * g.grp_stride + (m % g.grp_rows) : (long)m;
-    float v[16];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[4 * t + e] = apply_act<ACT>(acc[mt][t][e] + bv[4 * t + e]);
+  gemm_epilogue<ACT, OUT_F32>(g, acc, lane, m0 + 64 * wm, n0 + 64 * wn);
+}
 
-    if (full) {
-      if (g.R) {
-        const u32x4* rp = (const u32x4*)(g.R + orow * g.ldr + nb);
-        const u32x4 r0 = rp[0], r1 = rp[1];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[2 * i] += bf16lo(r0[i]);
-          v[2 * i + 1] += bf16hi(r0[i]);
-          v[8 + 2 * i] += bf16lo(r1[i]);
-          v[8 + 2 * i + 1] += bf16hi(r1[i]);
-        }
-      }
-      if (OUT_F32) {
-        f32x4* cp = (f32x4*)((float*)g.C + orow * g.ldc + nb);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cp[i] = (f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-      } else {
-        u32x4* cp = (u32x4*)((bf16_t*)g.C + orow * g.ldc + nb);
-        u32x4 o0, o1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-          o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
-        }
-        cp[0] = o0;
-        cp[1] = o1;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (nb + i < g.N) {
-          float x = v[i];
-          if (g.R) x += bf16_to_f32(g.R[orow * g.ldr + nb + i]);
-          if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;
-          else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = f32_to_bf16(x);
-        }
-      }
-    }
-  }
+// ---- launchers ---------------------------------------------------------------------------------
+// variant: 0 = v1 (BK64, 2 buffers, row-major tiles); 1 = v2 BK64 x 2 stages; 2 = v2 BK64 x 3 stages;
+//          3 = v2 BK32 x 3 stages (3 workgroups / CU); 4 = v2 BK32 x 4 stages.
+static int g_gemm_variant = -1;  // -1: heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
+void vt_gemm_set_variant(int v) { g_gemm_variant = v; }
+
+template <typename K>
+static int launch_kernel(K kern, const GemmArgs& g, int lds_bytes, hipStream_t stream) {
+  // hipFuncSetAttribute is idempotent and cheap; called per launch to stay free of per-kernel statics
+  if (lds_bytes > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+    return VT_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(256), lds_bytes, stream, g);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
 template <int ACT, bool OUT_F32>
-static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
-  static bool attr_set = false;
-  auto kern = gemm_nt_bf16_128x128<ACT, OUT_F32>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES) != hipSuccess)
-      return VT_ERR_HIP;
-    attr_set = true;
+static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
+  switch (variant) {
+    case 0: return launch_kernel(gemm_nt_bf16_128x128<ACT, OUT_F32>, g, GEMM_LDS_BYTES, stream);
+    case 1: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32>, g, 2 * 32768, stream);
+    case 2: return launch_kernel(gemm_nt_bf16_v2<64, 3, ACT, OUT_F32>, g, 3 * 32768, stream);
+    case 3: return launch_kernel(gemm_nt_bf16_v2<32, 3, ACT, OUT_F32>, g, 3 * 16384, stream);
+    case 4: return launch_kernel(gemm_nt_bf16_v2<32, 4, ACT, OUT_F32>, g, 4 * 16384, stream);
+    default: return VT_ERR_UNSUPPORTED;
   }
-  const int nwg = g.tiles_m * g.tiles_n;
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), GEMM_LDS_BYTES, stream, g);
-  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
 // Host entry used by the C ABI (capi.hip).  Returns a VT_* code; never synchronises.
@@ -254,13 +435,14 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   g.grp_rows = grp_rows; g.grp_stride = grp_stride;
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+  const int variant = g_gemm_variant >= 0 ? g_gemm_variant : GEMM_DEFAULT_VARIANT;
   switch (act * 2 + (out_f32 ? 1 : 0)) {
-    case 0: return launch_gemm<ACT_NONE, false>(g, stream);
-    case 1: return launch_gemm<ACT_NONE, true>(g, stream);
-    case 2: return launch_gemm<ACT_GELU, false>(g, stream);
-    case 3: return launch_gemm<ACT_GELU, true>(g, stream);
-    case 4: return launch_gemm<ACT_TANH, false>(g, stream);
-    case 5: return launch_gemm<ACT_TANH, true>(g, stream);
+    case 0: return launch_gemm<ACT_NONE, false>(g, variant, stream);
+    case 1: return launch_gemm<ACT_NONE, true>(g, variant, stream);
+    case 2: return launch_gemm<ACT_GELU, false>(g, variant, stream);
+    case 3: return launch_gemm<ACT_GELU, true>(g, variant, stream);
+    case 4: return launch_gemm<ACT_TANH, false>(g, variant, stream);
+    case 5: return launch_gemm<ACT_TANH, true>(g, variant, stream);
     default: return VT_ERR_UNSUPPORTED;
   }
 }

@@ -1,0 +1,223 @@
+// Weight gradients of the nn.Linear layers on the path:  dW[N,K] (+)= dY[M,N]^T . X[M,K]  (fp32 out),
+// optionally db[N] (+)= column sums of dY.  These are the wgrad halves of `loss.backward()`
+// (tasks/viewpoint_select/pretrain.py:191) for query/key/value, BertSelfOutput.dense,
+// BertIntermediate.dense, BertOutput.dense (oscar/modeling_bert.py:43-45,94,119,120), the region
+// projection, the MLM decoder / transform and the small heads (tasks/viewpoint_select/encoder.py).
+//
+// gfx950 design.  Both operands are row-major with the REDUCTION index (token m) as the row, so
+// neither can feed an MFMA port with a contiguous read; the 64-row x 128-column tiles are staged
+// as they lie in HBM (buffer_load ... lds, 16 B per lane, no VGPR staging, out-of-range rows read
+// as zero through the buffer descriptor's bounds check -- that is the M tail) and the MFMA
+// fragments are taken with ds_read_b64_tr_b16, the hardware transposing LDS read.  LDS rows are
+// 256 B = one full bank window, so the 32-byte group index of a row is XOR-swizzled with
+// (row&3)|((row>>3)&1)<<2 (applied on the DMA source address) to make the transposed reads
+// conflict-free.  One workgroup = 4 waves = a 128(n) x 128(k) tile of dW reduced over ALL of M
+// (no split-K, no atomics, bitwise reproducible); the launch is GROUPED: up to 8 (dY, X, dW)
+// problems -- e.g. the four weight matrices of one encoder layer, 432 tiles -- share one grid so
+// the chip is filled in a single round.  MFMA operands are arranged (A = X^T, B = dY^T) so that a
+// lane ends up with 4 consecutive k of one n: 16-byte fp32 stores.  Bias gradients ride along as
+// an extra MFMA against an all-ones A fragment in the k-tile-0 workgroups.
+#include "common.hpp"
+
+#define WG_MAX_PROBLEMS 8
+
+struct WgradProblem {
+  const bf16_t* dY; long ldy;   // [M, N]
+  const bf16_t* X; long ldx;    // [M, K]
+  float* dW; long ldw;          // [N, K] fp32
+  float* db;                    // [N] fp32 or null
+  int N, K;
+  int tiles_k;                  // ceil(K / 128)
+  int tile_begin;               // first linear tile id of this problem
+  int accumulate;               // 0: overwrite dW/db, 1: add to them
+};
+
+struct WgradArgs {
+  WgradProblem p[WG_MAX_PROBLEMS];
+  int nprob;
+  int M;
+};
+
+#define WG_TILE_BYTES (64 * 256)
+#define WG_STAGE_BYTES (2 * WG_TILE_BYTES)
+#define WG_LDS_BYTES (2 * WG_STAGE_BYTES)
+
+__device__ __forceinline__ int wg_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+__device__ __forceinline__ bf16x8 tr_frag(unsigned addr) {
+  // rows m..m+3 and m+4..m+7 of a 16-column block, delivered column-major: 8 bf16 along m per lane
+  short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)addr);
+  short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(addr + 4 * 256));
+  typedef __attribute__((ext_vector_type(8))) short short8v;
+  short8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_tn_bf16(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+
+  // which problem / tile (wave-uniform scan over <= 8 problems)
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WG_MAX_PROBLEMS; ++i)
+    if (i < a.nprob && (int)blockIdx.x >= a.p[i].tile_begin) pi = i;
+  const WgradProblem& P = a.p[pi];
+  const int lt = blockIdx.x - P.tile_begin;
+  const int bn = lt / P.tiles_k, bk = lt - bn * P.tiles_k;
+  const int n0 = bn * 128, k0 = bk * 128;
+  const int M = a.M;
+
+  // buffer descriptors: base at the tile's first column; rows >= M (and columns past the row end of
+  // the last row) fall outside num_records and read as zero
+  const int ncols_y = (P.N - n0) < 128 ? (P.N - n0) : 128;
+  const int ncols_x = (P.K - k0) < 128 ? (P.K - k0) : 128;
+  // whole 16-B chunks must be in range (a partially out-of-range dwordx4 reads as zero): round the
+  // column count up to 8; ld % 8 == 0 keeps that inside the last row's storage
+  const long bytes_y = ((long)(M - 1) * P.ldy + ((ncols_y + 7) & ~7)) * 2;
+  const long bytes_x = ((long)(M - 1) * P.ldx + ((ncols_x + 7) & ~7)) * 2;
+  __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dY + n0), 0, (int)bytes_y, 0x00020000);
+  __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(P.X + k0), 0, (int)bytes_x, 0x00020000);
+
+  // DMA pieces: a 64x256B tile = 16 pieces of 1 KiB (4 rows each); wave w moves pieces 4w..4w+3.
+  // LDS slot (row, cs) holds logical 16-B chunk c = cs ^ (swz(row) << 1).  Columns past the matrix
+  // edge are redirected out of range (zero fill).
+  int voff_y[4], voff_x[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pce = wave * 4 + i;
+    const int row = pce * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ (wg_swz(row) << 1);
+    voff_y[i] = (c * 8 < ncols_y) ? (int)(row * P.ldy * 2 + c * 16) : 0x7fffffff;
+    voff_x[i] = (c * 8 < ncols_x) ? (int)(row * P.ldx * 2 + c * 16) : 0x7fffffff;
+  }
+  const int step_y = (int)(64 * P.ldy * 2), step_x = (int)(64 * P.ldx * 2);
+
+  // fragment read addresses (k-substep 0, first 4-row block): lane (i16 = lane&15 -> q = i16>>2 row in
+  // block, p = i16&3 4-column piece; g = lane>>4 -> rows 8g..8g+7 of the 32-row substep)
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, g = lane >> 4;
+  const int frow = 8 * g + q4;  // + 32*ks (+4 for the second block: same swizzle)
+  const int fsw = wg_swz(frow) << 5;
+  unsigned y_addr[4], x_addr[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    y_addr[t] = lds0 + frow * 256 + ((((64 * wn + 16 * t) * 2) + 8 * p4) ^ fsw);
+    x_addr[t] = lds0 + WG_TILE_BYTES + frow * 256 + ((((64 * wk + 16 * t) * 2) + 8 * p4) ^ fsw);
+  }
+
+  f32x4 acc[4][4];
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = (P.db != nullptr) && (bk == 0) && (wk == 0);  // wave-uniform
+  typedef __attribute__((ext_vector_type(8))) short short8v;
+  const short one = (short)0x3F80;  // bf16 1.0
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, (short8v){one, one, one, one, one, one, one, one});
+
+  const int nk = (M + 63) >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, LDS_PTR(smem + (wave * 4 + i) * 1024), 16, voff_y[i], 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + WG_TILE_BYTES + (wave * 4 + i) * 1024), 16, voff_x[i], 0, 0, 0);
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned so = (kt & 1) * WG_STAGE_BYTES;
+
+    bf16x8 yf[2][4], xf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        yf[ks][t] = tr_frag(y_addr[t] + so + ks * (32 * 256));
+        xf[ks][t] = tr_frag(x_addr[t] + so + ks * (32 * 256));
+      }
+
+    if (kt + 1 < nk) {
+      char* nb = smem + ((kt + 1) & 1) * WG_STAGE_BYTES;
+      const int sy = (kt + 1) * step_y, sx = (kt + 1) * step_x;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, LDS_PTR(nb + (wave * 4 + i) * 1024), 16, voff_y[i], sy, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(nb + WG_TILE_BYTES + (wave * 4 + i) * 1024), 16, voff_x[i], sx, 0, 0);
+      }
+    }
+
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ks][t], yf[ks][nt], acc[nt][t], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[ks][nt], accb[nt], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: lane (j = lane&15, g) holds dW[n0 + 64wn + 16nt + j][k0 + 64wk + 16t + 4g .. +3]
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int n = n0 + 64 * wn + 16 * nt + (lane & 15);
+    if (n >= P.N) continue;
+    float* orow = P.dW + (long)n * P.ldw;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = k0 + 64 * wk + 16 * t + 4 * g;
+      if (k + 4 <= P.K) {
+        f32x4 v = acc[nt][t];
+        if (P.accumulate) {
+          const f32x4 o = *(const f32x4*)(orow + k);
+          v = (f32x4){v[0] + o[0], v[1] + o[1], v[2] + o[2], v[3] + o[3]};
+        }
+        *(f32x4*)(orow + k) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < P.K) orow[k + e] = acc[nt][t][e] + (P.accumulate ? orow[k + e] : 0.f);
+      }
+    }
+    if (do_bias && g == 0) {
+      const float s = accb[nt][0];  // every row of the ones-product is the column sum; take row 0
+      P.db[n] = P.accumulate ? P.db[n] + s : s;
+    }
+  }
+}
+
+// Host entry.  problems: array of `nprob` WgradProblem-like records filled by capi.hip.
+int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream) {
+  if (a.nprob <= 0 || a.nprob > WG_MAX_PROBLEMS || a.M <= 0) return VT_ERR_BAD_SHAPE;
+  int total = 0;
+  for (int i = 0; i < a.nprob; ++i) {
+    WgradProblem& P = a.p[i];
+    if (!P.dY || !P.X || !P.dW) return VT_ERR_NULL;
+    if (P.N <= 0 || P.K <= 0) return VT_ERR_BAD_SHAPE;
+    if ((P.ldy % 8) || (P.ldx % 8) || (P.ldw % 4) || (P.K % 4)) return VT_ERR_BAD_ALIGN;
+    if (((uintptr_t)P.dY | (uintptr_t)P.X | (uintptr_t)P.dW) & 15) return VT_ERR_BAD_ALIGN;
+    if ((long)a.M * P.ldy * 2 >= (1L << 31) || (long)a.M * P.ldx * 2 >= (1L << 31)) return VT_ERR_UNSUPPORTED;
+    P.tiles_k = (P.K + 127) / 128;
+    P.tile_begin = total;
+    total += ((P.N + 127) / 128) * P.tiles_k;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_wgrad_tn_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES) != hipSuccess)
+      return VT_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_wgrad_tn_bf16, dim3(total), dim3(256), WG_LDS_BYTES, stream, a);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

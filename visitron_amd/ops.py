@@ -170,6 +170,28 @@ def pack_concat(s0, s1, kpad, out=None):
     return out
 
 
+def wgrad(problems, M):
+    """Grouped weight gradients.  problems: list of dicts(dy, x, dw, db=None, accumulate=False) with
+    dy [M,N] bf16, x [M,K] bf16, dw [N,K] fp32, db [N] fp32; one launch for up to 8 problems."""
+    arr = (_lib.WgradProblem * len(problems))()
+    flops = 0.0
+    for i, p in enumerate(problems):
+        dy, x, dw, db = p["dy"], p["x"], p["dw"], p.get("db")
+        _require_hip(dy, x, dw, db)
+        assert dy.dtype == BF16 and x.dtype == BF16 and dw.dtype == torch.float32
+        N, K = dw.shape
+        arr[i].dY, arr[i].ldy = dy.data_ptr(), dy.stride(0)
+        arr[i].X, arr[i].ldx = x.data_ptr(), x.stride(0)
+        arr[i].dW, arr[i].ldw = dw.data_ptr(), dw.stride(0)
+        arr[i].db = None if db is None else db.data_ptr()
+        arr[i].N, arr[i].K = N, K
+        arr[i].accumulate = 1 if p.get("accumulate") else 0
+        flops += 2.0 * M * N * K
+    with _timed("gemm_wgrad_tn_bf16", flops, 0.0):
+        rc = _lib.load().vt_wgrad_bf16(arr, len(problems), M, _stream())
+    _lib.check(rc, "vt_wgrad_bf16")
+
+
 def encoder_forward(layer_weights, layer_acts, x, mask, mask_additive, head_scale, B, S, H, nh, I, eps):
     """Run the layer loop in C.  layer_weights / layer_acts: ctypes arrays built by the caller
     (``visitron_amd.modeling`` keeps them alive together with the tensors they point into)."""
