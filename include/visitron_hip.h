@@ -33,6 +33,7 @@ typedef void* vt_stream_t; /* hipStream_t */
 #define VT_ACT_NONE 0
 #define VT_ACT_GELU 1 /* erf-GELU, hidden_act == "gelu" */
 #define VT_ACT_TANH 2
+#define VT_ACT_DGELU 3 /* out = acc * gelu'(R): dgrad through the erf-GELU, R = saved pre-activation */
 
 const char* vt_error_string(int code);
 /* ABI version of this header; bumped on any signature change. */
@@ -53,6 +54,12 @@ int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const
                    const void* R, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int act,
                    int out_f32, int grp_rows, int grp_stride, vt_stream_t stream);
 
+/* Same, plus C2: optional bf16 copy of the pre-activation (acc + bias), row stride ldc2 -- what the
+ * backward of BertIntermediate needs -- and act == VT_ACT_DGELU (R = pre-activation, multiplied in). */
+int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                      const void* R, int64_t ldr, void* C, int64_t ldc, void* C2, int64_t ldc2, int M, int N,
+                      int K, int act, int out_f32, int grp_rows, int grp_stride, vt_stream_t stream);
+
 /* Fused scaled-dot-product attention, head size 64 (oscar/modeling_bert.py:47-72):
  * ctx[b,s,h*64:(h+1)*64] = softmax_k(q.k / 8 + (1 - mask[b,k]) * -10000) . v  [* head_scale[h]].
  * qkv is the packed projection output [B*S, ld_qkv] = q | k | v (each nh*64 wide).  mask is the
@@ -64,6 +71,15 @@ int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, in
                           const float* head_scale, void* ctx, int64_t ld_ctx, float* lse, int B, int S,
                           int nh, int head_size, vt_stream_t stream);
 
+/* Backward of vt_attention_fwd_bf16 (S <= 256): dqkv = dq | dk | dv packed like qkv.  ctx is the
+ * forward output, lse its saved log-sum-exp, delta_ws a [B,nh,S] fp32 scratch (rowsum(dctx*ctx) is
+ * computed into it).  Autograd of oscar/modeling_bert.py:47-72 inside loss.backward()
+ * (tasks/viewpoint_select/pretrain.py:191).  No atomics: bitwise reproducible. */
+int vt_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
+                          int64_t ld_ctx, const float* mask, int mask_additive, const float* lse,
+                          float* delta_ws, void* dqkv, int64_t ld_dqkv, int B, int S, int nh, int head_size,
+                          vt_stream_t stream);
+
 /* y = BertLayerNorm(x) over rows of H (biased variance, eps inside the sqrt); x already holds
  * dense(h) + bias + residual.  BertSelfOutput / BertOutput LayerNorm (called at
  * oscar/modeling_bert.py:94,120) and the optional image LayerNorm (encoder.py:280-281; use
@@ -71,6 +87,15 @@ int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, in
 int vt_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma,
                       const float* beta, float* mean, float* rstd, int M, int H, float eps,
                       int grp_rows, int grp_stride, vt_stream_t stream);
+
+/* Backward of vt_layernorm_bf16: dx, and dgamma / dbeta (fp32, overwritten or accumulated).  x is the
+ * pre-LayerNorm input (statistics are recomputed).  partial_ws: fp32 scratch of 512 * 2 * H floats. */
+int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* gamma,
+                          void* dx, int64_t lddx, float* dgamma, float* dbeta, float* partial_ws, int M, int H,
+                          float eps, int accumulate, vt_stream_t stream);
+
+/* out = g * gelu'(h), bf16, n elements (n % 8 == 0): the dGELU of the MLM-head transform. */
+int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_stream_t stream);
 
 /* BertEmbeddings (called at tasks/viewpoint_select/encoder.py:267-269): y[b*S + t, :] =
  * LayerNorm(word[ids[b,t]] + pos[pos_ids[b,t] or t] + type[type_ids[b,t] or 0]); tables fp32,
@@ -120,6 +145,7 @@ typedef struct vt_layer_acts {
   void* ctx;       /* [M,H]  bf16 attention context */
   void* attn_pre;  /* [M,H]  bf16 dense(ctx)+bias+x (pre-LayerNorm) */
   void* attn_out;  /* [M,H]  bf16 LayerNorm output */
+  void* mid_pre;   /* [M,I]  bf16 intermediate pre-activation (training) or NULL */
   void* mid;       /* [M,I]  bf16 gelu(intermediate) */
   void* out_pre;   /* [M,H]  bf16 dense(mid)+bias+attn_out */
   void* out;       /* [M,H]  bf16 layer output */
@@ -132,6 +158,38 @@ typedef struct vt_layer_acts {
 int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers,
                             const void* x, const float* mask, int mask_additive, const float* head_scale,
                             int B, int S, int H, int nh, int I, float ln_eps, vt_stream_t stream);
+
+/* ---- backward of the encoder stack (the encoder part of loss.backward(), pretrain.py:191) ------ */
+typedef struct vt_layer_weights_t { /* transposed bf16 copies consumed by the dgrad GEMMs */
+  const void* wt_qkv; /* [H,3H] = w_qkv^T */
+  const void* wt_ao;  /* [H,H]  */
+  const void* wt_in;  /* [H,I]  = w_in^T  */
+  const void* wt_out; /* [I,H]  = w_out^T */
+} vt_layer_weights_t;
+
+typedef struct vt_layer_grads { /* fp32 gradient destinations, same shapes as the parameters */
+  float* d_w_qkv; float* d_b_qkv; float* d_w_ao; float* d_b_ao; float* d_ln1_g; float* d_ln1_b;
+  float* d_w_in;  float* d_b_in;  float* d_w_out; float* d_b_out; float* d_ln2_g; float* d_ln2_b;
+} vt_layer_grads;
+
+typedef struct vt_bwd_workspace {
+  void* g_pre;   /* [M,H]  bf16 */
+  void* g_pre2;  /* [M,H]  bf16 */
+  void* g_mid;   /* [M,I]  bf16 */
+  void* g_ctx;   /* [M,H]  bf16 */
+  void* g_qkv;   /* [M,3H] bf16 */
+  float* delta;      /* [B,nh,S] */
+  float* ln_partial; /* [512*2*H] */
+} vt_bwd_workspace;
+
+/* g: [M,H] bf16, IN dL/d(last layer output), OUT dL/d(x) (layer-0 input).  acts must come from a
+ * forward run with per-layer buffers, lse and mid_pre set.  accumulate != 0 adds into the gradient
+ * destinations instead of overwriting them. */
+int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weights_t* layers_t,
+                             const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers,
+                             const void* x, const float* mask, int mask_additive, void* g,
+                             const vt_bwd_workspace* ws, int B, int S, int H, int nh, int I, float ln_eps,
+                             int accumulate, vt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -265,3 +265,75 @@ def test_wgrad_asymmetric_identity(dev):
     dw = torch.zeros((N, K), device=dev)
     ops.wgrad([dict(dy=torch.eye(M).to(dev, BF16), x=x.to(dev, BF16), dw=dw)], M)
     assert torch.equal(dw.cpu(), x)
+
+
+@pytest.mark.parametrize("B,S,nh", [(2, 228, 3), (1, 37, 2), (2, 256, 1), (3, 64, 2), (1, 5, 1)])
+def test_attention_bwd_matches_autograd(dev, B, S, nh):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(S + nh)
+    H = nh * 64
+    qkv = bf16_round(_rand((B * S, 3 * H), g, 1.2)).requires_grad_(True)
+    dctx = bf16_round(_rand((B * S, H), g, 0.7))
+    mask = (torch.rand(B, S, generator=g) > 0.25).float()
+    mask[:, 0] = 1.0
+    t = qkv.view(B, S, 3, nh, 64).permute(2, 0, 3, 1, 4)
+    ctx_ref = _attention_ref(t[0], t[1], t[2], (1.0 - mask) * -10000.0).permute(0, 2, 1, 3).reshape(B * S, H)
+    ctx_ref.backward(dctx)
+    want = qkv.grad
+    qd = qkv.detach().to(dev, BF16)
+    lse = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
+    ctx = ops.attention_fwd(qd, B, S, nh, mask=mask.to(dev), lse=lse)
+    got = ops.attention_bwd(qd, dctx.to(dev, BF16), ctx, lse, B, S, nh, mask=mask.to(dev))
+    torch.cuda.synchronize()
+    got = got.float().cpu()
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        w = want[:, sl]
+        err = float((got[:, sl] - w).abs().max())
+        assert err < 2.5e-2 * (1.0 + float(w.abs().max())), (name, err, float(w.abs().max()))
+
+
+@pytest.mark.parametrize("M,H", [(456, 768), (37, 128), (5000, 768), (3, 1024)])
+def test_layernorm_bwd_matches_autograd(dev, M, H):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(M)
+    x = bf16_round(_rand((M, H), g, 2.0) + 0.3).requires_grad_(True)
+    dy = bf16_round(_rand((M, H), g))
+    gamma = (1 + 0.1 * _rand((H,), g)).requires_grad_(True)
+    beta = torch.zeros(H, requires_grad=True)
+    torch.nn.functional.layer_norm(x, (H,), gamma, beta, 1e-12).backward(dy)
+    dgamma = torch.full((H,), 5.0, device=dev)
+    dbeta = torch.full((H,), 5.0, device=dev)
+    dx = ops.layernorm_bwd(x.detach().to(dev, BF16), dy.to(dev, BF16), gamma.detach().to(dev), 1e-12, dgamma, dbeta)
+    torch.cuda.synchronize()
+    assert maxabs(dx, x.grad) < 2e-2 * (1 + float(x.grad.abs().max()))
+    assert maxabs(dgamma, gamma.grad) < 1e-3 * (1 + float(gamma.grad.abs().max()))
+    assert maxabs(dbeta, beta.grad) < 1e-3 * (1 + float(beta.grad.abs().max()))
+    ops.layernorm_bwd(x.detach().to(dev, BF16), dy.to(dev, BF16), gamma.detach().to(dev), 1e-12, dgamma, dbeta, accumulate=True)
+    assert maxabs(dgamma, 2 * gamma.grad) < 2e-3 * (1 + float(gamma.grad.abs().max()))
+
+
+def test_linear_pre_activation_output_and_dgelu(dev):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 200, 256, 128
+    a = bf16_round(_rand((M, K), g))
+    w = bf16_round(_rand((N, K), g, 0.1))
+    b = _rand((N,), g, 0.1)
+    pre = torch.zeros((M, N), dtype=BF16, device=dev)
+    out = ops.linear(a.to(dev, BF16), w.to(dev, BF16), b.to(dev), act=1, pre_act_out=pre)
+    h = a @ w.t() + b
+    assert maxabs(pre, h) < 2e-2
+    assert maxabs(out, _gelu(h)) < 2e-2
+    # dgrad through the GELU: (dy @ W2) * gelu'(h)
+    hh = bf16_round(h).requires_grad_(True)
+    dyv = bf16_round(_rand((M, K), g))
+    w2t = bf16_round(_rand((N, K), g, 0.1))  # plays W2^T: [I, H]
+    upstream = dyv @ w2t.t()
+    _gelu(hh).backward(upstream)
+    got = ops.linear(dyv.to(dev, BF16), w2t.to(dev, BF16), residual=hh.detach().to(dev, BF16), act=3)
+    assert maxabs(got, hh.grad) < 3e-2 * (1 + float(hh.grad.abs().max()))
+    got2 = ops.dgelu_mul(bf16_round(upstream).to(dev, BF16), hh.detach().to(dev, BF16))
+    assert maxabs(got2, hh.grad) < 3e-2 * (1 + float(hh.grad.abs().max()))

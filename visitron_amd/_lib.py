@@ -19,8 +19,22 @@ class LayerWeights(ctypes.Structure):  # vt_layer_weights
 
 class LayerActs(ctypes.Structure):  # vt_layer_acts
     _fields_ = [(n, c_void_p) for n in (
-        "qkv", "ctx", "attn_pre", "attn_out", "mid", "out_pre", "out", "lse",
+        "qkv", "ctx", "attn_pre", "attn_out", "mid_pre", "mid", "out_pre", "out", "lse",
         "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd")]
+
+
+class LayerWeightsT(ctypes.Structure):  # vt_layer_weights_t
+    _fields_ = [(n, c_void_p) for n in ("wt_qkv", "wt_ao", "wt_in", "wt_out")]
+
+
+class LayerGrads(ctypes.Structure):  # vt_layer_grads
+    _fields_ = [(n, c_void_p) for n in (
+        "d_w_qkv", "d_b_qkv", "d_w_ao", "d_b_ao", "d_ln1_g", "d_ln1_b", "d_w_in", "d_b_in", "d_w_out", "d_b_out",
+        "d_ln2_g", "d_ln2_b")]
+
+
+class BwdWorkspace(ctypes.Structure):  # vt_bwd_workspace
+    _fields_ = [(n, c_void_p) for n in ("g_pre", "g_pre2", "g_mid", "g_ctx", "g_qkv", "delta", "ln_partial")]
 
 
 class WgradProblem(ctypes.Structure):  # vt_wgrad_problem
@@ -35,6 +49,17 @@ SIGNATURES = {
     "vt_debug_set_gemm_variant": (None, [c_int]),
     "vt_linear_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_linear_bf16_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                  c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_attention_bwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_layernorm_bwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
+    "vt_dgelu_mul_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "vt_encoder_backward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerWeightsT),
+                                         ctypes.POINTER(LayerActs), ctypes.POINTER(LayerGrads), c_int, c_void_p,
+                                         c_void_p, c_int, c_void_p, ctypes.POINTER(BwdWorkspace), c_int, c_int, c_int,
+                                         c_int, c_int, c_float, c_int, c_void_p]),
     "vt_attention_fwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_int, c_int, c_int, c_int, c_void_p]),
     "vt_layernorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -5,7 +5,14 @@
 
 int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const void* R, long ldr,
                      void* C, long ldc, int M, int N, int K, int act, int out_f32, int grp_rows, int grp_stride,
-                     hipStream_t stream);
+                     hipStream_t stream, void* C2 = nullptr, long ldc2 = 0);
+int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
+                              const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
+                              long ld_dqkv, int B, int S, int nh, int head_size, hipStream_t stream);
+int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
+                              float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
+                              hipStream_t stream);
+int vt_dgelu_mul_dispatch(const void* g, const void* h, void* out, long n, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                               long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream);
 int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
@@ -61,6 +68,31 @@ int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const
                    int grp_stride, vt_stream_t stream) {
   return vt_gemm_dispatch(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, out_f32, grp_rows, grp_stride,
                           (hipStream_t)stream);
+}
+
+int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* R,
+                      int64_t ldr, void* C, int64_t ldc, void* C2, int64_t ldc2, int M, int N, int K, int act,
+                      int out_f32, int grp_rows, int grp_stride, vt_stream_t stream) {
+  return vt_gemm_dispatch(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, out_f32, grp_rows, grp_stride,
+                          (hipStream_t)stream, C2, ldc2);
+}
+
+int vt_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
+                          int64_t ld_ctx, const float* mask, int mask_additive, const float* lse, float* delta_ws,
+                          void* dqkv, int64_t ld_dqkv, int B, int S, int nh, int head_size, vt_stream_t stream) {
+  return vt_attention_bwd_dispatch(qkv, ld_qkv, dctx, ld_d, ctx, ld_ctx, mask, mask_additive, lse, delta_ws, dqkv,
+                                   ld_dqkv, B, S, nh, head_size, (hipStream_t)stream);
+}
+
+int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* gamma, void* dx,
+                          int64_t lddx, float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps,
+                          int accumulate, vt_stream_t stream) {
+  return vt_layernorm_bwd_dispatch(x, ldx, dy, ldy, gamma, dx, lddx, dgamma, dbeta, partial_ws, M, H, eps, accumulate,
+                                   (hipStream_t)stream);
+}
+
+int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_stream_t stream) {
+  return vt_dgelu_mul_dispatch(g, h, out, n, (hipStream_t)stream);
 }
 
 int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
@@ -132,13 +164,78 @@ int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts*
     if (rc) return rc;
     rc = vt_layernorm_dispatch(a.attn_pre, H, a.attn_out, H, w.ln1_g, w.ln1_b, a.ln1_mean, a.ln1_rstd, M, H, ln_eps, 0, 0, stream);
     if (rc) return rc;
-    rc = vt_gemm_dispatch(a.attn_out, H, w.w_in, H, w.b_in, nullptr, 0, a.mid, I, M, I, H, VT_ACT_GELU, 0, 0, 0, stream);
+    rc = vt_gemm_dispatch(a.attn_out, H, w.w_in, H, w.b_in, nullptr, 0, a.mid, I, M, I, H, VT_ACT_GELU, 0, 0, 0, stream,
+                          a.mid_pre, I);
     if (rc) return rc;
     rc = vt_gemm_dispatch(a.mid, I, w.w_out, I, w.b_out, a.attn_out, H, a.out_pre, H, M, H, I, VT_ACT_NONE, 0, 0, 0, stream);
     if (rc) return rc;
     rc = vt_layernorm_dispatch(a.out_pre, H, a.out, H, w.ln2_g, w.ln2_b, a.ln2_mean, a.ln2_rstd, M, H, ln_eps, 0, 0, stream);
     if (rc) return rc;
     cur = a.out;
+  }
+  return VT_OK;
+}
+
+// Backward of CaptionBertEncoder (oscar/modeling_bert.py:140-169) = the reverse layer loop; per layer
+// 4 dgrad GEMMs (residual adds and the dGELU fused in their epilogues), 2 LayerNorm backwards, the
+// fused attention backward and ONE grouped weight-gradient launch for the layer's four matrices
+// (bias gradients ride along in it).
+int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weights_t* layers_t,
+                             const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers, const void* x,
+                             const float* mask, int mask_additive, void* g, const vt_bwd_workspace* ws, int B, int S,
+                             int H, int nh, int I, float ln_eps, int accumulate, vt_stream_t stream_) {
+  if (!layers || !layers_t || !acts || !grads || !x || !g || !ws) return VT_ERR_NULL;
+  if (num_layers <= 0 || B <= 0 || S <= 0 || nh <= 0 || H != nh * 64 || (I % 64)) return VT_ERR_BAD_SHAPE;
+  if (!ws->g_pre || !ws->g_pre2 || !ws->g_mid || !ws->g_ctx || !ws->g_qkv || !ws->delta || !ws->ln_partial) return VT_ERR_NULL;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int M = B * S;
+  for (int l = num_layers - 1; l >= 0; --l) {
+    const vt_layer_weights& w = layers[l];
+    const vt_layer_weights_t& wt = layers_t[l];
+    const vt_layer_acts& a = acts[l];
+    const vt_layer_grads& d = grads[l];
+    if (!a.mid_pre || !a.lse) return VT_ERR_NULL;
+    const void* x_in = l == 0 ? x : acts[l - 1].out;
+    int rc;
+    // LayerNorm 2 backward: dL/d(out_pre)
+    rc = vt_layernorm_bwd_dispatch(a.out_pre, H, g, H, w.ln2_g, ws->g_pre, H, d.d_ln2_g, d.d_ln2_b, ws->ln_partial, M, H,
+                                   ln_eps, accumulate, stream);
+    if (rc) return rc;
+    // through output.dense and the GELU: g_mid = (g_pre . W_out) * gelu'(mid_pre)
+    rc = vt_gemm_dispatch(ws->g_pre, H, wt.wt_out, H, nullptr, a.mid_pre, I, ws->g_mid, I, M, I, H, VT_ACT_DGELU, 0, 0, 0, stream);
+    if (rc) return rc;
+    // through intermediate.dense, plus the residual branch: dL/d(attn_out) -> g
+    rc = vt_gemm_dispatch(ws->g_mid, I, wt.wt_in, I, nullptr, ws->g_pre, H, g, H, M, H, I, VT_ACT_NONE, 0, 0, 0, stream);
+    if (rc) return rc;
+    // LayerNorm 1 backward: dL/d(attn_pre)
+    rc = vt_layernorm_bwd_dispatch(a.attn_pre, H, g, H, w.ln1_g, ws->g_pre2, H, d.d_ln1_g, d.d_ln1_b, ws->ln_partial, M, H,
+                                   ln_eps, accumulate, stream);
+    if (rc) return rc;
+    // through attention.output.dense: dL/d(ctx)
+    rc = vt_gemm_dispatch(ws->g_pre2, H, wt.wt_ao, H, nullptr, nullptr, 0, ws->g_ctx, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream);
+    if (rc) return rc;
+    rc = vt_attention_bwd_dispatch(a.qkv, 3L * H, ws->g_ctx, H, a.ctx, H, mask, mask_additive, a.lse, ws->delta, ws->g_qkv,
+                                   3L * H, B, S, nh, 64, stream);
+    if (rc) return rc;
+    // through the packed q|k|v projection, plus the residual branch: dL/d(layer input) -> g
+    rc = vt_gemm_dispatch(ws->g_qkv, 3L * H, wt.wt_qkv, 3L * H, nullptr, ws->g_pre2, H, g, H, M, H, 3 * H, VT_ACT_NONE, 0, 0, 0, stream);
+    if (rc) return rc;
+    // the four weight (+bias) gradients of this layer in one grouped launch
+    WgradArgs wa;
+    wa.nprob = 4;
+    wa.M = M;
+    auto set = [&](int i, const void* dY, long ldy, const void* X, long ldx, float* dW, float* db, int N, int K) {
+      WgradProblem& P = wa.p[i];
+      P.dY = (const bf16_t*)dY; P.ldy = ldy; P.X = (const bf16_t*)X; P.ldx = ldx; P.dW = dW; P.ldw = K; P.db = db;
+      P.N = N; P.K = K; P.accumulate = accumulate; P.tiles_k = 0; P.tile_begin = 0;
+    };
+    set(0, ws->g_mid, I, a.attn_out, H, d.d_w_in, d.d_b_in, I, H);
+    set(1, ws->g_pre, H, a.mid, I, d.d_w_out, d.d_b_out, H, I);
+    set(2, ws->g_qkv, 3L * H, x_in, H, d.d_w_qkv, d.d_b_qkv, 3 * H, H);
+    set(3, ws->g_pre2, H, a.ctx, H, d.d_w_ao, d.d_b_ao, H, H);
+    for (int i = 4; i < WG_MAX_PROBLEMS; ++i) wa.p[i] = wa.p[0];
+    rc = vt_wgrad_dispatch(wa, stream);
+    if (rc) return rc;
   }
   return VT_OK;
 }

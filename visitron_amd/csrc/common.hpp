@@ -49,6 +49,12 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 // erf-GELU, the reference's hidden_act == "gelu": 0.5 x (1 + erf(x / sqrt 2))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+// d/dx of the erf-GELU: Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
 __device__ __forceinline__ float tanh_fast(float x) {
   // tanh(x) = 1 - 2/(exp(2x)+1); saturates cleanly for |x| large
   const float e = __expf(2.0f * x);

@@ -29,15 +29,16 @@ struct GemmArgs {
   const bf16_t* A;
   const bf16_t* W;
   const float* bias;
-  const bf16_t* R;
+  const bf16_t* R;   // residual added after the activation; for ACT_DGELU: the saved pre-activation
   void* C;
-  long lda, ldw, ldr, ldc;
+  bf16_t* C2;        // optional second output: the pre-activation (acc + bias) in bf16, for backward
+  long lda, ldw, ldr, ldc, ldc2;
   int M, N, K;
   int grp_rows, grp_stride;  // output row = (m / grp_rows) * grp_stride + m % grp_rows  (0: identity)
   int tiles_m, tiles_n;
 };
 
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_DGELU = 3 };  // DGELU: out = acc * gelu'(R)
 
 #define GEMM_BM 128
 #define GEMM_BN 128
@@ -50,7 +51,7 @@ template <int ACT>
 __device__ __forceinline__ float apply_act(float x) {
   if (ACT == ACT_GELU) return gelu_erf(x);
   if (ACT == ACT_TANH) return tanh_fast(x);
-  return x;
+  return x;  // ACT_NONE and ACT_DGELU (the latter multiplies by gelu'(R) where R is read)
 }
 
 // Epilogue shared by the GEMM kernels: lane (j = lane&15, gq = lane>>4) owns output rows
@@ -89,19 +90,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[4 * t + e] = apply_act<ACT>(acc[mt][t][e] + bv[4 * t + e]);
+      for (int e = 0; e < 4; ++e) v[4 * t + e] = acc[mt][t][e] + bv[4 * t + e];
 
     if (full) {
+      if (g.C2) {  // pre-activation copy for the backward pass
+        u32x4* cp2 = (u32x4*)(g.C2 + orow * g.ldc2 + nb);
+        u32x4 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+          o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+        }
+        cp2[0] = o0;
+        cp2[1] = o1;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);
       if (g.R) {
         const u32x4* rp = (const u32x4*)(g.R + orow * g.ldr + nb);
         const u32x4 r0 = rp[0], r1 = rp[1];
+        float rv[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[2 * i] += bf16lo(r0[i]);
-          v[2 * i + 1] += bf16hi(r0[i]);
-          v[8 + 2 * i] += bf16lo(r1[i]);
-          v[8 + 2 * i + 1] += bf16hi(r1[i]);
+          rv[2 * i] = bf16lo(r0[i]);
+          rv[2 * i + 1] = bf16hi(r0[i]);
+          rv[8 + 2 * i] = bf16lo(r1[i]);
+          rv[8 + 2 * i + 1] = bf16hi(r1[i]);
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (ACT == ACT_DGELU) ? v[i] * gelu_erf_grad(rv[i]) : v[i] + rv[i];
       }
       if (OUT_F32) {
         f32x4* cp = (f32x4*)((float*)g.C + orow * g.ldc + nb);
@@ -122,8 +139,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (nb + i < g.N) {
-          float x = v[i];
-          if (g.R) x += bf16_to_f32(g.R[orow * g.ldr + nb + i]);
+          if (g.C2) g.C2[orow * g.ldc2 + nb + i] = f32_to_bf16(v[i]);
+          float x = apply_act<ACT>(v[i]);
+          if (g.R) {
+            const float rr = bf16_to_f32(g.R[orow * g.ldr + nb + i]);
+            x = (ACT == ACT_DGELU) ? x * gelu_erf_grad(rr) : x + rr;
+          }
           if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;
           else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = f32_to_bf16(x);
         }
@@ -422,15 +443,16 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
 // Host entry used by the C ABI (capi.hip).  Returns a VT_* code; never synchronises.
 int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const void* R, long ldr,
                      void* C, long ldc, int M, int N, int K, int act, int out_f32, int grp_rows, int grp_stride,
-                     hipStream_t stream) {
+                     hipStream_t stream, void* C2 = nullptr, long ldc2 = 0) {
   if (!A || !W || !C) return VT_ERR_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K % GEMM_BK) != 0) return VT_ERR_BAD_SHAPE;
-  if ((lda % 8) || (ldw % 8) || (R && (ldr % 8)) || (ldc % (out_f32 ? 4 : 8))) return VT_ERR_BAD_ALIGN;
+  if ((lda % 8) || (ldw % 8) || (R && (ldr % 8)) || (ldc % (out_f32 ? 4 : 8)) || (C2 && (ldc2 % 8))) return VT_ERR_BAD_ALIGN;
+  if (act == ACT_DGELU && !R) return VT_ERR_NULL;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) return VT_ERR_BAD_ALIGN;
   if (grp_rows < 0 || (grp_rows > 0 && grp_stride < grp_rows)) return VT_ERR_BAD_SHAPE;
   GemmArgs g;
   g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.R = (const bf16_t*)R; g.C = C;
-  g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
+  g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc; g.C2 = (bf16_t*)C2; g.ldc2 = ldc2;
   g.M = M; g.N = N; g.K = K;
   g.grp_rows = grp_rows; g.grp_stride = grp_stride;
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
@@ -443,6 +465,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
     case 3: return launch_gemm<ACT_GELU, true>(g, variant, stream);
     case 4: return launch_gemm<ACT_TANH, false>(g, variant, stream);
     case 5: return launch_gemm<ACT_TANH, true>(g, variant, stream);
+    case 6: return launch_gemm<ACT_DGELU, false>(g, variant, stream);
     default: return VT_ERR_UNSUPPORTED;
   }
 }

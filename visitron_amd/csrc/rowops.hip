@@ -237,3 +237,173 @@ int vt_pack_concat_dispatch(const float* s0, int d0, const float* s1, int d1, vo
                      (bf16_t*)out, kpad, rows);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward (autograd of BertLayerNorm inside loss.backward(), pretrain.py:191):
+//   xhat = (x - u) * rstd;  g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+//   dgamma = sum_rows dy * xhat;  dbeta = sum_rows dy
+// One wave per row (statistics recomputed from x: no saved mean/rstd needed), rows strided over a
+// fixed grid; each wave keeps its dgamma/dbeta partial sums in registers, the block combines them
+// through LDS and writes ONE partial row per block (no atomics: reproducible); ln_bwd_reduce sums
+// the partial rows.
+struct LnBwdArgs {
+  const bf16_t* x; long ldx;
+  const bf16_t* dy; long ldy;
+  const float* gamma;
+  bf16_t* dx; long lddx;
+  float* partial;  // [gridDim.x][2][H]
+  int M, H;
+  float eps;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void layernorm_bwd_rows(LnBwdArgs a) {
+  __shared__ float red[4][2][CH * 512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gam[CH][8], dg[CH][8], db[CH][8];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (lane + 64 * c) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      dg[c][i] = 0.f; db[c][i] = 0.f;
+      gam[c][i] = col < a.H ? a.gamma[col + i] : 0.f;
+    }
+  }
+  const float invH = 1.0f / (float)a.H;
+  for (long row = (long)blockIdx.x * 4 + wave; row < a.M; row += (long)gridDim.x * 4) {
+    float xv[CH][8], gv[CH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      if (col < a.H) {
+        const u32x4 w = *(const u32x4*)(a.x + row * a.ldx + col);
+        const u32x4 d = *(const u32x4*)(a.dy + row * a.ldy + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xv[c][2 * i] = bf16lo(w[i]); xv[c][2 * i + 1] = bf16hi(w[i]);
+          gv[c][2 * i] = bf16lo(d[i]); gv[c][2 * i + 1] = bf16hi(d[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += xv[c][i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xv[c][i] = 0.f; gv[c][i] = 0.f; }
+      }
+    }
+    const float u = wave_sum(s) * invH;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      if (col < a.H) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = xv[c][i] - u; ss += d * d; }
+      }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(ss) * invH + a.eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      if (col < a.H) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (xv[c][i] - u) * rs;
+          const float dyv = gv[c][i];
+          dg[c][i] += dyv * xh;
+          db[c][i] += dyv;
+          const float gg = dyv * gam[c][i];
+          xv[c][i] = xh;
+          gv[c][i] = gg;
+          s1 += gg;
+          s2 += gg * xh;
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      if (col < a.H) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rs * (gv[c][i] - m1 - xv[c][i] * m2);
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
+        *(u32x4*)(a.dx + row * a.lddx + col) = w;
+      }
+    }
+  }
+  // block combine: 4 waves -> one partial row
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      red[wave][0][(lane + 64 * c) * 8 + i] = dg[c][i];
+      red[wave][1][(lane + 64 * c) * 8 + i] = db[c][i];
+    }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * a.H; idx += 256) {
+    const int which = idx / a.H, col = idx - which * a.H;
+    const float v = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+    a.partial[((long)blockIdx.x * 2 + which) * a.H + col] = v;
+  }
+}
+
+// out[j] (+)= sum_b partial[b][j], j < n  (n = 2H: dgamma | dbeta)
+__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ partial, int nblocks, int n,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int H,
+                                                     int accumulate) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * n + j];
+  float* dst = j < H ? dgamma + j : dbeta + (j - H);
+  *dst = accumulate ? *dst + s : s;
+}
+
+#define LN_BWD_MAX_BLOCKS 512
+int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
+                              float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
+                              hipStream_t stream) {
+  if (!x || !dy || !gamma || !dx || !dgamma || !dbeta || !partial_ws) return VT_ERR_NULL;
+  if (M <= 0 || H <= 0 || (H % 8) || H > 1024) return VT_ERR_BAD_SHAPE;
+  if ((ldx % 8) || (ldy % 8) || (lddx % 8) || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15)) return VT_ERR_BAD_ALIGN;
+  LnBwdArgs a;
+  a.x = (const bf16_t*)x; a.ldx = ldx; a.dy = (const bf16_t*)dy; a.ldy = ldy; a.gamma = gamma;
+  a.dx = (bf16_t*)dx; a.lddx = lddx; a.partial = partial_ws; a.M = M; a.H = H; a.eps = eps;
+  int nblocks = (M + 3) / 4;
+  if (nblocks > LN_BWD_MAX_BLOCKS) nblocks = LN_BWD_MAX_BLOCKS;
+  if (H <= 512) hipLaunchKernelGGL(layernorm_bwd_rows<1>, dim3(nblocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(layernorm_bwd_rows<2>, dim3(nblocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 255) / 256), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
+                     dbeta, H, accumulate);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+// workspace floats needed by vt_layernorm_bwd: LN_BWD_MAX_BLOCKS * 2 * H
+
+// out = g * gelu'(h) elementwise (bf16, 8 per thread): backward through the MLM-head transform's GELU.
+__global__ __launch_bounds__(256) void dgelu_mul_bf16(const bf16_t* __restrict__ g, const bf16_t* __restrict__ h,
+                                                      bf16_t* __restrict__ out, long n8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const u32x4 gv = ((const u32x4*)g)[i], hv = ((const u32x4*)h)[i];
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    o[k] = pack_bf16x2(bf16lo(gv[k]) * gelu_erf_grad(bf16lo(hv[k])), bf16hi(gv[k]) * gelu_erf_grad(bf16hi(hv[k])));
+  ((u32x4*)out)[i] = o;
+}
+
+int vt_dgelu_mul_dispatch(const void* g, const void* h, void* out, long n, hipStream_t stream) {
+  if (!g || !h || !out) return VT_ERR_NULL;
+  if (n <= 0 || (n % 8)) return VT_ERR_BAD_SHAPE;
+  if (((uintptr_t)g | (uintptr_t)h | (uintptr_t)out) & 15) return VT_ERR_BAD_ALIGN;
+  const long n8 = n / 8;
+  hipLaunchKernelGGL(dgelu_mul_bf16, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)g,
+                     (const bf16_t*)h, (bf16_t*)out, n8);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

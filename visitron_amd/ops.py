@@ -10,7 +10,8 @@ import torch
 from . import _lib
 
 BF16 = torch.bfloat16
-ACT_NONE, ACT_GELU, ACT_TANH = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_TANH, ACT_DGELU = 0, 1, 2, 3
+LN_BWD_WS_ROWS = 512  # vt_layernorm_bwd_bf16 scratch = LN_BWD_WS_ROWS * 2 * H floats
 
 
 # ---- optional per-launch timing (HIP events on the launch stream); used by bench.py only ----------
@@ -79,9 +80,11 @@ def round_up(x, m):
 
 
 def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False, grp_rows=0, grp_stride=0,
-           M=None, lda=None, ldc=None):
-    """out = act(a @ w.T + bias) (+ residual).  a [M,K] bf16 (row stride lda), w [N,K] bf16."""
-    _require_hip(a, w, bias, residual, out)
+           M=None, lda=None, ldc=None, pre_act_out=None):
+    """out = act(a @ w.T + bias) (+ residual).  a [M,K] bf16 (row stride lda), w [N,K] bf16.
+    pre_act_out: optional bf16 [M,N] buffer receiving a @ w.T + bias (saved for backward).
+    act == ACT_DGELU: out = (a @ w.T) * gelu'(residual)."""
+    _require_hip(a, w, bias, residual, out, pre_act_out)
     assert a.dtype == BF16 and w.dtype == BF16
     N, K = w.shape
     if M is None:
@@ -95,10 +98,11 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
         ldc = out.stride(0)
     ldr = residual.stride(0) if residual is not None else 0
     with _timed("gemm_nt_bf16_128x128", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
-        rc = _lib.load().vt_linear_bf16(
+        rc = _lib.load().vt_linear_bf16_ex(
             _ptr(a), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(residual), ldr, _ptr(out), ldc,
+            _ptr(pre_act_out), 0 if pre_act_out is None else pre_act_out.stride(0),
             M, N, K, act, 1 if out_f32 else 0, grp_rows, grp_stride, _stream())
-    _lib.check(rc, "vt_linear_bf16")
+    _lib.check(rc, "vt_linear_bf16_ex")
     return out
 
 
@@ -168,6 +172,62 @@ def pack_concat(s0, s1, kpad, out=None):
         rc = _lib.load().vt_pack_concat_bf16(_ptr(s0), d0, _ptr(s1), d1, _ptr(out), kpad, rows, _stream())
     _lib.check(rc, "vt_pack_concat_bf16")
     return out
+
+
+def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False, out=None, delta_ws=None):
+    """Gradient of attention_fwd w.r.t. the packed qkv: returns dqkv [B*S, 3*nh*64] bf16."""
+    _require_hip(qkv, dctx, ctx, lse, mask, out)
+    H = nh * 64
+    if out is None:
+        out = torch.empty((B * S, 3 * H), dtype=BF16, device=qkv.device)
+    if delta_ws is None:
+        delta_ws = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
+    with _timed("attention_bwd_d64", 10.0 * B * nh * S * S * 64, 2.0 * B * S * 9 * H):
+        rc = _lib.load().vt_attention_bwd_bf16(
+            _ptr(qkv), qkv.stride(0), _ptr(dctx), dctx.stride(0), _ptr(ctx), ctx.stride(0), _ptr(mask),
+            1 if mask_additive else 0, _ptr(lse), _ptr(delta_ws), _ptr(out), out.stride(0), B, S, nh, 64, _stream())
+    _lib.check(rc, "vt_attention_bwd_bf16")
+    return out
+
+
+def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta, dx=None, ws=None, accumulate=False, M=None):
+    """dx (bf16) and dgamma/dbeta (fp32, in place) of BertLayerNorm; x = pre-LayerNorm input."""
+    _require_hip(x, dy, gamma, dgamma, dbeta, dx)
+    H = gamma.numel()
+    if M is None:
+        M = x.shape[0]
+    if dx is None:
+        dx = torch.empty((M, H), dtype=BF16, device=x.device)
+    if ws is None:
+        ws = torch.empty(LN_BWD_WS_ROWS * 2 * H, dtype=torch.float32, device=x.device)
+    with _timed("layernorm_bwd_rows", 0.0, 6.0 * M * H):
+        rc = _lib.load().vt_layernorm_bwd_bf16(
+            _ptr(x), x.stride(0), _ptr(dy), dy.stride(0), _ptr(gamma), _ptr(dx), dx.stride(0), _ptr(dgamma),
+            _ptr(dbeta), _ptr(ws), M, H, float(eps), 1 if accumulate else 0, _stream())
+    _lib.check(rc, "vt_layernorm_bwd_bf16")
+    return dx
+
+
+def dgelu_mul(g, h, out=None):
+    """g * gelu'(h), bf16 contiguous."""
+    _require_hip(g, h, out)
+    assert g.dtype == BF16 and h.dtype == BF16 and g.is_contiguous() and h.is_contiguous()
+    if out is None:
+        out = torch.empty_like(g)
+    rc = _lib.load().vt_dgelu_mul_bf16(_ptr(g), _ptr(h), _ptr(out), g.numel(), _stream())
+    _lib.check(rc, "vt_dgelu_mul_bf16")
+    return out
+
+
+def encoder_backward(layer_weights, layer_weights_t, layer_acts, layer_grads, x, mask, mask_additive, g, ws,
+                     B, S, H, nh, I, eps, accumulate=False):
+    """Reverse layer loop in C; g [B*S,H] bf16 is updated in place to dL/dx."""
+    _require_hip(x, mask, g)
+    rc = _lib.load().vt_encoder_backward_bf16(
+        layer_weights, layer_weights_t, layer_acts, layer_grads, len(layer_weights), _ptr(x), _ptr(mask),
+        1 if mask_additive else 0, _ptr(g), ctypes.byref(ws), B, S, H, nh, I, float(eps), 1 if accumulate else 0,
+        _stream())
+    _lib.check(rc, "vt_encoder_backward_bf16")
 
 
 def wgrad(problems, M):
