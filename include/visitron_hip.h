@@ -107,6 +107,23 @@ int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_
                        int n_word, int n_pos, int n_type, float eps, int* err_flag,
                        vt_stream_t stream);
 
+/* Backward of vt_embed_layernorm: de[B*T,H] fp32 = gradient w.r.t. (word + pos + type) per token (for
+ * the three table scatter-adds), dgamma / dbeta of the embedding LayerNorm.  g: gradient rows b*S+t
+ * of the [B,S,H] bf16 buffer.  partial_ws: 512 * 2 * H floats. */
+int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
+                           const float* word, const float* pos, const float* type, const float* gamma,
+                           const void* g, int64_t ldg, float* de, float* dgamma, float* dbeta, float* partial_ws,
+                           int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
+                           int accumulate, vt_stream_t stream);
+
+/* Fused AdamW over a flat fp32 slab of n parameters (n % 4 == 0), the pytorch-transformers rule of
+ * tasks/viewpoint_select/pretrain.py:128-130: m,v moments; p -= step_size * m / (sqrt(v) + eps) with
+ * step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) supplied by the host; then p -= lr * wd * p.  g is
+ * multiplied by grad_scale first.  p_bf16 (optional) receives the refreshed bf16 working copy. */
+int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                  float step_size, float b1, float b2, float eps, float wd, float grad_scale,
+                  vt_stream_t stream);
+
 /* out[row, :] = bf16([s0[row, 0:d0] | s1[row, 0:d1] | zeros to kpad]) -- builds the K-concatenated
  * operand that turns img_embedding(img_feats) + location_embeds(loc) (encoder.py:277-279) into
  * one GEMM. */

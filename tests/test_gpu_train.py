@@ -1,0 +1,149 @@
+"""GPU: the HIP training path (forward + backward + AdamW) against the CPU oracle's autograd."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import maxabs, model_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_pair(cfg, seed, dev, std=0.05, **kw):
+    from oracle.modeling import PreTrainOscar as OModel
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.training import PretrainEngine
+
+    ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=seed, device=dev, weight_std=std)
+    prod.train()
+    return ref, prod, PretrainEngine(prod, **kw)
+
+
+def _rel(a, b):
+    """Relative L2 error with an absolute floor: attention key biases have an exactly-zero true gradient
+    (softmax is invariant to a per-query shift), so only rounding noise is left on both sides."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    floor = 2e-3 * (b.numel() ** 0.5)
+    return float((a - b).norm() / (b.norm() + floor))
+
+
+def test_gradients_match_oracle_mini(dev):
+    from visitron_amd.config import mini_config
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config()
+    ref, prod, eng = _engine_pair(cfg, 3, dev)
+    b = make_batch(cfg, 3, text_len=20, region_len=17, seed=11)
+    want = ref(**b)
+    want[0].backward()
+    got = eng.forward_backward({k: v.to(dev) for k, v in b.items()})
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert abs(float(got[i]) - float(want[i])) < 5e-2, (i, float(got[i]), float(want[i]))
+    for i in range(4, 7):
+        assert abs(float(got[i]) - float(want[i])) < 1e-6
+    wg = dict(ref.named_parameters())
+    worst = {}
+    for n, p in prod.named_parameters():
+        assert p.grad is not None and p.grad.shape == wg[n].grad.shape, n
+        worst[n] = _rel(p.grad, wg[n].grad)
+    bad = {n: e for n, e in worst.items() if e > 0.08}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    # golden fixture cross-check (no oracle call)
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mini_pretrain.npz"))
+    names = list(g["grad_names"])
+    norms = dict(zip(names, g["grad_norms"]))
+    for n, p in prod.named_parameters():
+        assert abs(float(p.grad.norm()) - norms[n]) < 0.08 * norms[n] + 2e-3 * (p.numel() ** 0.5), n
+    q0 = dict(prod.named_parameters())["bert.encoder.layer.0.attention.self.query.weight"].grad
+    assert _rel(q0, torch.from_numpy(g["grad_query0"])) < 0.08
+
+
+def test_padding_row_and_tied_decoder_gradients(dev):
+    """Row 0 of word_embeddings (padding_idx) gets gradient only through the tied decoder."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config()
+    ref, prod, eng = _engine_pair(cfg, 4, dev)
+    b = make_batch(cfg, 4, text_len=16, region_len=8, seed=5)
+    assert int((b["input_ids"] == 0).sum()) > 0
+    ref(**b)[0].backward()
+    eng.forward_backward({k: v.to(dev) for k, v in b.items()})
+    w = ref.bert.embeddings.word_embeddings.weight.grad
+    gq = prod.bert.embeddings.word_embeddings.weight.grad
+    assert _rel(gq[0], w[0]) < 0.1
+    assert _rel(gq, w) < 0.08
+
+
+def test_adamw_step_matches_oracle(dev):
+    from oracle.optim import AdamW, WarmupLinearSchedule, grouped_parameters
+    from visitron_amd.config import mini_config
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config()
+    ref, prod, eng = _engine_pair(cfg, 6, dev, lr=5e-3, weight_decay=0.05, eps=1e-8, warmup_steps=2, t_total=10)
+    opt = AdamW(grouped_parameters(ref, 0.05), lr=5e-3, eps=1e-8)
+    sch = WarmupLinearSchedule(opt, warmup_steps=2, t_total=10)
+    before = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    for step in range(3):
+        b = make_batch(cfg, 3, text_len=12, region_len=6, seed=20 + step)
+        ref.zero_grad()
+        ref(**b)[0].backward()
+        # feed the oracle's exact gradients to both optimizers: isolates the update rule
+        for n, p in prod.named_parameters():
+            p.grad.copy_(dict(ref.named_parameters())[n].grad)
+        opt.step(); sch.step()
+        eng.optimizer_step()
+    torch.cuda.synchronize()
+    for n, p in prod.named_parameters():
+        w = dict(ref.named_parameters())[n].detach()
+        delta = (w - before[n]).abs().max()
+        assert maxabs(p, w) < 1e-6 + 1e-4 * float(delta), n
+    # the bf16 mirror follows the master weights
+    eng.refresh_derived_weights()
+    assert maxabs(eng.flat.mirror.float(), eng.flat.p) < 1e-2 * float(eng.flat.p.abs().max())
+
+
+def test_training_reduces_loss_and_tracks_oracle(dev):
+    from oracle.optim import AdamW, grouped_parameters
+    from visitron_amd.config import mini_config
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config()
+    ref, prod, eng = _engine_pair(cfg, 8, dev, lr=1e-3, weight_decay=0.05, schedule="constant", warmup_steps=0)
+    opt = AdamW(grouped_parameters(ref, 0.05), lr=1e-3, eps=1e-8)
+    b = make_batch(cfg, 4, text_len=16, region_len=8, seed=2)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    lr_, lh = [], []
+    for _ in range(6):
+        ref.zero_grad()
+        out = ref(**b)
+        out[0].backward()
+        opt.step()
+        lr_.append(float(out[0]))
+        lh.append(float(eng.train_step(bd)[0]))
+    assert lh[-1] < lh[0] - 0.5
+    assert max(abs(a - c) for a, c in zip(lr_, lh)) < 0.15, (lr_, lh)
+
+
+def test_gradients_match_oracle_base_cfg1(dev):
+    from visitron_amd.config import BertConfig
+    from visitron_amd.synth import make_batch
+    import os
+
+    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    _, prod, eng = _engine_pair(cfg, 0, dev, std=0.03)
+    b = make_batch(cfg, 2, seed=1234)
+    got = eng.forward_backward({k: v.to(dev) for k, v in b.items()})
+    torch.cuda.synchronize()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "base_cfg1.npz"))
+    for i in range(4):
+        assert abs(float(got[i]) - g["tuple7"][i]) < 5e-2 * max(1.0, abs(g["tuple7"][i]))
+    norms = dict(zip(list(g["grad_names"]), g["grad_norms"]))
+    bad = {}
+    for n, p in prod.named_parameters():
+        e = abs(float(p.grad.norm()) - norms[n]) / (norms[n] + 2e-3 * (p.numel() ** 0.5))
+        if e > 0.1:
+            bad[n] = (e, norms[n])
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:10]

@@ -13,6 +13,12 @@ int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
                               hipStream_t stream);
 int vt_dgelu_mul_dispatch(const void* g, const void* h, void* out, long n, hipStream_t stream);
+int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
+                                    const float* pos, const float* type, const float* gamma, const void* g, long ldg,
+                                    float* de, float* dgamma, float* dbeta, float* partial_ws, int B, int T, int S, int H,
+                                    int n_word, int n_pos, int n_type, float eps, int accumulate, hipStream_t stream);
+int vt_adamw_dispatch(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float step_size, float b1,
+                      float b2, float eps, float wd, float grad_scale, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                               long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream);
 int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
@@ -89,6 +95,19 @@ int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ld
                           int accumulate, vt_stream_t stream) {
   return vt_layernorm_bwd_dispatch(x, ldx, dy, ldy, gamma, dx, lddx, dgamma, dbeta, partial_ws, M, H, eps, accumulate,
                                    (hipStream_t)stream);
+}
+
+int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
+                           const float* pos, const float* type, const float* gamma, const void* g, int64_t ldg, float* de,
+                           float* dgamma, float* dbeta, float* partial_ws, int B, int T, int S, int H, int n_word, int n_pos,
+                           int n_type, float eps, int accumulate, vt_stream_t stream) {
+  return vt_embed_layernorm_bwd_dispatch(ids, type_ids, pos_ids, word, pos, type, gamma, g, ldg, de, dgamma, dbeta, partial_ws,
+                                         B, T, S, H, n_word, n_pos, n_type, eps, accumulate, (hipStream_t)stream);
+}
+
+int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float step_size, float b1,
+                  float b2, float eps, float wd, float grad_scale, vt_stream_t stream) {
+  return vt_adamw_dispatch(p, g, m, v, p_bf16, n, lr, step_size, b1, b2, eps, wd, grad_scale, (hipStream_t)stream);
 }
 
 int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_stream_t stream) {

@@ -407,3 +407,200 @@ int vt_dgelu_mul_dispatch(const void* g, const void* h, void* out, long n, hipSt
                      (const bf16_t*)h, (bf16_t*)out, n8);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward of embed_layernorm: recompute e = word + pos + type (fp32, as the forward did), run the
+// LayerNorm backward against the incoming gradient rows b*S+t of g, and emit d_e (fp32 [B*T,H]) for
+// the three table scatter-adds, plus dgamma/dbeta partial rows (same scheme as layernorm_bwd_rows).
+struct EmbBwdArgs {
+  const int64_t* ids; const int64_t* type_ids; const int64_t* pos_ids;
+  const float* word; const float* pos; const float* type;
+  const float* gamma;
+  const bf16_t* g; long ldg;   // gradient rows b*S + t
+  float* de;                   // [B*T, H]
+  float* partial;              // [gridDim.x][2][H]
+  int B, T, S, H;
+  int n_word, n_pos, n_type;
+  float eps;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void embed_layernorm_bwd(EmbBwdArgs a) {
+  __shared__ float red[4][2][CH * 512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gam[CH][8], dg[CH][8], db[CH][8];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (lane + 64 * c) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      dg[c][i] = 0.f; db[c][i] = 0.f;
+      gam[c][i] = col < a.H ? a.gamma[col + i] : 0.f;
+    }
+  }
+  const float invH = 1.0f / (float)a.H;
+  const long ntok = (long)a.B * a.T;
+  for (long tok = (long)blockIdx.x * 4 + wave; tok < ntok; tok += (long)gridDim.x * 4) {
+    const int b = (int)(tok / a.T), t = (int)(tok - (long)b * a.T);
+    long wi = a.ids[tok];
+    long pi = a.pos_ids ? a.pos_ids[tok] : (long)t;
+    long ti = a.type_ids ? a.type_ids[tok] : 0L;
+    wi = wi < 0 ? 0 : (wi >= a.n_word ? a.n_word - 1 : wi);
+    pi = pi < 0 ? 0 : (pi >= a.n_pos ? a.n_pos - 1 : pi);
+    ti = ti < 0 ? 0 : (ti >= a.n_type ? a.n_type - 1 : ti);
+    const float* wp = a.word + wi * a.H;
+    const float* pp = a.pos + pi * a.H;
+    const float* tp = a.type + ti * a.H;
+    const bf16_t* gp = a.g + ((long)b * a.S + t) * a.ldg;
+    float xv[CH][8], gv[CH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      if (col < a.H) {
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+          const f32x4 w4 = *(const f32x4*)(wp + col + 4 * hlf);
+          const f32x4 p4 = *(const f32x4*)(pp + col + 4 * hlf);
+          const f32x4 t4 = *(const f32x4*)(tp + col + 4 * hlf);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { xv[c][4 * hlf + i] = (w4[i] + p4[i]) + t4[i]; s += xv[c][4 * hlf + i]; }
+        }
+        const u32x4 d = *(const u32x4*)(gp + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gv[c][2 * i] = bf16lo(d[i]); gv[c][2 * i + 1] = bf16hi(d[i]); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xv[c][i] = 0.f; gv[c][i] = 0.f; }
+      }
+    }
+    const float u = wave_sum(s) * invH;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      if (col < a.H) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = xv[c][i] - u; ss += d * d; }
+      }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(ss) * invH + a.eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      if (col < a.H) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (xv[c][i] - u) * rs;
+          const float dyv = gv[c][i];
+          dg[c][i] += dyv * xh;
+          db[c][i] += dyv;
+          const float gg = dyv * gam[c][i];
+          xv[c][i] = xh;
+          gv[c][i] = gg;
+          s1 += gg;
+          s2 += gg * xh;
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      if (col < a.H) {
+        float* op = a.de + tok * a.H + col;
+        f32x4 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o0[i] = rs * (gv[c][i] - m1 - xv[c][i] * m2);
+          o1[i] = rs * (gv[c][4 + i] - m1 - xv[c][4 + i] * m2);
+        }
+        *(f32x4*)op = o0;
+        *(f32x4*)(op + 4) = o1;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      red[wave][0][(lane + 64 * c) * 8 + i] = dg[c][i];
+      red[wave][1][(lane + 64 * c) * 8 + i] = db[c][i];
+    }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * a.H; idx += 256) {
+    const int which = idx / a.H, col = idx - which * a.H;
+    a.partial[((long)blockIdx.x * 2 + which) * a.H + col] =
+        red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+  }
+}
+
+int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
+                                    const float* pos, const float* type, const float* gamma, const void* g, long ldg,
+                                    float* de, float* dgamma, float* dbeta, float* partial_ws, int B, int T, int S, int H,
+                                    int n_word, int n_pos, int n_type, float eps, int accumulate, hipStream_t stream) {
+  if (!ids || !word || !pos || !type || !gamma || !g || !de || !dgamma || !dbeta || !partial_ws) return VT_ERR_NULL;
+  if (B <= 0 || T <= 0 || S < T || H <= 0 || (H % 8) || H > 1024) return VT_ERR_BAD_SHAPE;
+  if ((ldg % 8) || (((uintptr_t)word | (uintptr_t)pos | (uintptr_t)type | (uintptr_t)g | (uintptr_t)de) & 15)) return VT_ERR_BAD_ALIGN;
+  EmbBwdArgs a;
+  a.ids = ids; a.type_ids = type_ids; a.pos_ids = pos_ids; a.word = word; a.pos = pos; a.type = type; a.gamma = gamma;
+  a.g = (const bf16_t*)g; a.ldg = ldg; a.de = de; a.partial = partial_ws; a.B = B; a.T = T; a.S = S; a.H = H;
+  a.n_word = n_word; a.n_pos = n_pos; a.n_type = n_type; a.eps = eps;
+  long nb = ((long)B * T + 3) / 4;
+  const int nblocks = (int)(nb > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : nb);
+  if (H <= 512) hipLaunchKernelGGL(embed_layernorm_bwd<1>, dim3(nblocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(embed_layernorm_bwd<2>, dim3(nblocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 255) / 256), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
+                     dbeta, H, accumulate);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused AdamW step over a flat fp32 parameter slab, the pytorch-transformers rule used by
+// tasks/viewpoint_select/pretrain.py:128-130,192:
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= step_size * m / (sqrt(v) + eps);  p -= lr*wd*p
+// with step_size = lr * sqrt(1-b2^t) / (1-b1^t) computed on the host (eps is added to the UN-corrected
+// sqrt(v); the decoupled decay uses the already-moved p).  Also refreshes the bf16 working copy the
+// GEMMs read.  grad_scale multiplies g first (1/world_size for the data-parallel mean).
+__global__ __launch_bounds__(256) void adamw_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n4, float lr,
+                                                  float step_size, float b1, float b2, float eps, float wd,
+                                                  float grad_scale) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+    const f32x4 gv = ((const f32x4*)g)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gv[k] * grad_scale;
+      mv[k] = b1 * mv[k] + (1.0f - b1) * gg;
+      vv[k] = b2 * vv[k] + (1.0f - b2) * gg * gg;
+      float x = pv[k] - step_size * (mv[k] / (sqrtf(vv[k]) + eps));
+      if (wd > 0.f) x = x - lr * wd * x;
+      pv[k] = x;
+    }
+    ((f32x4*)p)[i] = pv;
+    ((f32x4*)m)[i] = mv;
+    ((f32x4*)v)[i] = vv;
+    if (p_bf16) {
+      u32x2 o;
+      o[0] = pack_bf16x2(pv[0], pv[1]);
+      o[1] = pack_bf16x2(pv[2], pv[3]);
+      ((u32x2*)p_bf16)[i] = o;
+    }
+  }
+}
+
+int vt_adamw_dispatch(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float step_size, float b1,
+                      float b2, float eps, float wd, float grad_scale, hipStream_t stream) {
+  if (!p || !g || !m || !v) return VT_ERR_NULL;
+  if (n <= 0 || (n % 4)) return VT_ERR_BAD_SHAPE;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)p_bf16 & 7)) return VT_ERR_BAD_ALIGN;
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(adamw_flat, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n4, lr, step_size,
+                     b1, b2, eps, wd, grad_scale);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

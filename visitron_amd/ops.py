@@ -208,6 +208,33 @@ def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta, dx=None, ws=None, accumulate
     return dx
 
 
+def embed_layernorm_bwd(ids, type_ids, pos_ids, word, pos, typ, gamma, eps, g, S, dgamma, dbeta, ws=None,
+                        accumulate=False):
+    """-> de fp32 [B*T, H]: gradient w.r.t. the summed embedding of every text token."""
+    _require_hip(ids, word, g)
+    B, T = ids.shape
+    H = word.shape[1]
+    de = torch.empty((B * T, H), dtype=torch.float32, device=g.device)
+    if ws is None:
+        ws = torch.empty(LN_BWD_WS_ROWS * 2 * H, dtype=torch.float32, device=g.device)
+    rc = _lib.load().vt_embed_layernorm_bwd(
+        _ptr(ids), _ptr(type_ids), _ptr(pos_ids), _ptr(word), _ptr(pos), _ptr(typ), _ptr(gamma), _ptr(g), g.stride(0),
+        _ptr(de), _ptr(dgamma), _ptr(dbeta), _ptr(ws), B, T, S, H, word.shape[0], pos.shape[0], typ.shape[0],
+        float(eps), 1 if accumulate else 0, _stream())
+    _lib.check(rc, "vt_embed_layernorm_bwd")
+    return de
+
+
+def adamw_flat(p, g, m, v, p_bf16, lr, step_size, b1, b2, eps, wd, grad_scale=1.0):
+    """In-place AdamW (pytorch-transformers rule) over flat fp32 slabs; refreshes the bf16 mirror."""
+    _require_hip(p, g, m, v, p_bf16)
+    n = p.numel()
+    with _timed("adamw_flat", 0.0, n * (28.0 + (2.0 if p_bf16 is not None else 0.0))):
+        rc = _lib.load().vt_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), n, float(lr), float(step_size),
+                                       float(b1), float(b2), float(eps), float(wd), float(grad_scale), _stream())
+    _lib.check(rc, "vt_adamw_flat")
+
+
 def dgelu_mul(g, h, out=None):
     """g * gelu'(h), bf16 contiguous."""
     _require_hip(g, h, out)

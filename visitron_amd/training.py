@@ -1,0 +1,492 @@
+"""Training path of the hot loop: tasks/viewpoint_select/pretrain.py:150-193 on HIP kernels.
+
+``PretrainEngine`` owns what the reference's step does around ``model(**batch)``:
+
+    model.zero_grad(); loss, ... = model(**batch); [all-reduce]; loss.backward(); optimizer.step(); scheduler.step()
+
+* parameters are re-pointed into ONE flat fp32 slab (decay group first, then the no-decay group of
+  pretrain.py:109-127), gradients into a second slab of the same layout (``p.grad`` are views), and
+  a bf16 mirror of the parameter slab is what the GEMM kernels read; query/key/value weights (and
+  biases) are laid out adjacently so the packed [3H,H] projection and its gradient are plain views;
+* forward saves per-layer activations; backward = hand-written HIP kernels (encoder: one C call);
+* the MLM / token heads are evaluated on the SUPERVISED rows only (labels != -1): the 7-tuple the
+  reference returns depends on nothing else (encoder.py:377-431), so the result is identical while
+  the 30522-wide decoder GEMM shrinks by ~12x;
+* the optimizer is a fused AdamW kernel with the pytorch-transformers update rule;
+* data parallelism: one process per GPU, bucketed all-reduce of the flat gradient slab
+  (``torch.distributed``; backend "nccl" = RCCL over xGMI), see ``visitron_amd.distributed``.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from .modeling import PreTrainOscar, _i64
+from .ops import ACT_DGELU, ACT_GELU, ACT_NONE, ACT_TANH, BF16, round_up
+
+ALIGN = 64  # elements; keeps every parameter view 256-byte aligned inside the slabs
+
+
+def _is_no_decay(name):
+    return ("bias" in name) or ("LayerNorm.weight" in name)  # pretrain.py:109
+
+
+class FlatParams(object):
+    """Flat fp32 parameter / gradient / moment slabs + bf16 mirror for a PreTrainOscar."""
+
+    def __init__(self, model):
+        named = list(model.named_parameters())
+        dev = named[0][1].device
+        # order: decay params then no-decay params; model order inside each group already puts
+        # query, key, value (weights, and separately their biases) of a layer next to each other
+        decay = [(n, p) for n, p in named if not _is_no_decay(n)]
+        nodecay = [(n, p) for n, p in named if _is_no_decay(n)]
+        self.entries, off = [], 0
+        for grp, items in ((0, decay), (1, nodecay)):
+            for n, p in items:
+                # q|k|v must be exactly adjacent: no padding between them
+                adjacent = n.endswith(("attention.self.key.weight", "attention.self.value.weight",
+                                       "attention.self.key.bias", "attention.self.value.bias"))
+                if not adjacent:
+                    off = round_up(off, ALIGN)
+                self.entries.append((n, p, off, p.numel(), grp))
+                off += p.numel()
+            off = round_up(off, ALIGN)
+            if grp == 0:
+                self.n_decay = off
+        self.total = off
+        self.p = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.mirror = torch.zeros(self.total, dtype=BF16, device=dev)
+        self.off = {}
+        for n, p, o, cnt, _ in self.entries:
+            self.p[o:o + cnt].copy_(p.data.reshape(-1))
+            p.data = self.p[o:o + cnt].view(p.shape)
+            p.grad = self.g[o:o + cnt].view(p.shape)
+            self.off[n] = (o, cnt, tuple(p.shape))
+        self.refresh_mirror()
+
+    def refresh_mirror(self):
+        self.mirror.copy_(self.p)
+        self._versions = self._version_key()
+
+    def _version_key(self):
+        return tuple(p._version for _, p, _, _, _ in self.entries)
+
+    def mirror_is_stale(self):
+        return self._version_key() != self._versions
+
+    def mark_fresh(self):
+        self._versions = self._version_key()
+
+    def view(self, slab, name, count=None, shape=None):
+        o, cnt, shp = self.off[name]
+        if count is not None:
+            return slab[o:o + count].view(shape)
+        return slab[o:o + cnt].view(shp)
+
+    def reattach_grads(self):
+        """optimizer.zero_grad(set_to_none=True) drops p.grad; point them back at the slab."""
+        for n, p, o, cnt, _ in self.entries:
+            if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * o:
+                p.grad = self.g[o:o + cnt].view(p.shape)
+
+
+class _TrainBuffers(object):
+    """Per-(B,S) activation store and gradient scratch, plus the ctypes tables for the C loops."""
+
+    def __init__(self, L, M, B, S, H, I, nh, dev):
+        mk = lambda n: torch.empty((M, n), dtype=BF16, device=dev)
+        self.layers = []
+        self.acts = (_lib.LayerActs * L)()
+        for i in range(L):
+            d = dict(qkv=mk(3 * H), ctx=mk(H), attn_pre=mk(H), attn_out=mk(H), mid_pre=mk(I), mid=mk(I),
+                     out_pre=mk(H), out=mk(H), lse=torch.empty((B, nh, S), dtype=torch.float32, device=dev))
+            self.layers.append(d)
+            for k, v in d.items():
+                setattr(self.acts[i], k, v.data_ptr())
+        self.x0 = mk(H)
+        self.g = mk(H)
+        self.g_seq32 = torch.empty((M, H), dtype=torch.float32, device=dev)
+        self.ws_t = dict(g_pre=mk(H), g_pre2=mk(H), g_mid=mk(I), g_ctx=mk(H), g_qkv=mk(3 * H),
+                         delta=torch.empty((B, nh, S), dtype=torch.float32, device=dev),
+                         ln_partial=torch.empty(ops.LN_BWD_WS_ROWS * 2 * H, dtype=torch.float32, device=dev))
+        self.ws = _lib.BwdWorkspace()
+        for k, v in self.ws_t.items():
+            setattr(self.ws, k, v.data_ptr())
+
+
+class PretrainEngine(object):
+    def __init__(self, model, lr=5e-5, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999), correct_bias=True,
+                 schedule="linear", warmup_steps=0, t_total=20000, process_group=None, bucket_mb=64,
+                 loss_scale_by_world=True):
+        assert isinstance(model, PreTrainOscar)
+        cfg = model.config
+        if cfg.hidden_size != 64 * cfg.num_attention_heads:
+            raise NotImplementedError("the HIP training path serves head size 64")
+        if getattr(model.bert, "use_img_layernorm", None):
+            raise NotImplementedError("use_img_layernorm is not implemented in the HIP training path yet")
+        for p_ in (cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob):
+            if p_ > 0.0:
+                raise NotImplementedError(
+                    "dropout > 0 is not implemented in the HIP training path yet; set hidden_dropout_prob and "
+                    "attention_probs_dropout_prob to 0")
+        self.model, self.cfg = model, cfg
+        self.flat = FlatParams(model)
+        self.lr, self.wd, self.eps, self.betas, self.correct_bias = lr, weight_decay, eps, betas, correct_bias
+        self.schedule, self.warmup_steps, self.t_total = schedule, warmup_steps, t_total
+        self.step_count = 0       # optimizer steps taken (Adam's t)
+        self.sched_step = 0       # scheduler.step() calls (LambdaLR's last_epoch)
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
+        self.loss_scale_by_world = loss_scale_by_world
+        self._bufs = {}
+        self._tables = None
+        self._wt_dirty = True
+        self._build_tables()
+
+    # ------------------------------------------------------------------------------ tables
+    def _build_tables(self):
+        m, f, cfg = self.model, self.flat, self.cfg
+        L, H, I = cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size
+        self.w_tab = (_lib.LayerWeights * L)()
+        self.wt_tab = (_lib.LayerWeightsT * L)()
+        self.g_tab = (_lib.LayerGrads * L)()
+        self._keep, self.wt = [], []
+        for i in range(L):
+            pre = "bert.encoder.layer.%d." % i
+            qw, qb = pre + "attention.self.query.weight", pre + "attention.self.query.bias"
+            names = dict(
+                w_ao=pre + "attention.output.dense.weight", b_ao=pre + "attention.output.dense.bias",
+                ln1_g=pre + "attention.output.LayerNorm.weight", ln1_b=pre + "attention.output.LayerNorm.bias",
+                w_in=pre + "intermediate.dense.weight", b_in=pre + "intermediate.dense.bias",
+                w_out=pre + "output.dense.weight", b_out=pre + "output.dense.bias",
+                ln2_g=pre + "output.LayerNorm.weight", ln2_b=pre + "output.LayerNorm.bias")
+            t = dict(w_qkv=f.view(f.mirror, qw, 3 * H * H, (3 * H, H)), b_qkv=f.view(f.p, qb, 3 * H, (3 * H,)))
+            gr = dict(d_w_qkv=f.view(f.g, qw, 3 * H * H, (3 * H, H)), d_b_qkv=f.view(f.g, qb, 3 * H, (3 * H,)))
+            for k, n in names.items():
+                t[k] = f.view(f.mirror if k.startswith("w_") else f.p, n)
+                gr["d_" + k] = f.view(f.g, n)
+            wt = dict(wt_qkv=torch.empty((H, 3 * H), dtype=BF16, device=f.p.device),
+                      wt_ao=torch.empty((H, H), dtype=BF16, device=f.p.device),
+                      wt_in=torch.empty((H, I), dtype=BF16, device=f.p.device),
+                      wt_out=torch.empty((I, H), dtype=BF16, device=f.p.device))
+            self._keep.append((t, gr))
+            self.wt.append((t, wt))
+            for k, v in t.items():
+                setattr(self.w_tab[i], k, v.data_ptr())
+            for k, v in gr.items():
+                setattr(self.g_tab[i], k, v.data_ptr())
+            for k, v in wt.items():
+                setattr(self.wt_tab[i], k, v.data_ptr())
+        # non-encoder weights: bf16 mirror views and transposed copies
+        V = m.mlmhead.predictions.decoder.weight.shape[0]
+        C = m.token_head[0].weight.shape[0]
+        A = m.next_action.linear.weight.shape[0]
+        self.Vp, self.Cp, self.Ap = round_up(V, 64), round_up(C, 64), round_up(A, 64)
+        dev = f.p.device
+        self.head_t = dict(
+            dec=torch.zeros((H, self.Vp), dtype=BF16, device=dev), tr=torch.empty((H, H), dtype=BF16, device=dev),
+            tok=torch.zeros((H, self.Cp), dtype=BF16, device=dev), act=torch.zeros((H, self.Ap), dtype=BF16, device=dev),
+            pool=torch.empty((H, H), dtype=BF16, device=dev))
+        D = m.bert.img_dim
+        self.kpad = round_up(D + 128, 64)
+        self.w_img = torch.zeros((H, self.kpad), dtype=BF16, device=dev)
+        self.b_img = torch.zeros(H, dtype=torch.float32, device=dev)
+        self.dw_img = torch.zeros((H, self.kpad), dtype=torch.float32, device=dev)
+        self.db_img = torch.zeros(H, dtype=torch.float32, device=dev)
+
+    def _name_of(self, param):
+        for n, p, _, _, _ in self.flat.entries:
+            if p is param:
+                return n
+        raise KeyError("parameter not in the flat layout")
+
+    def _mirror(self, param):
+        return self.flat.view(self.flat.mirror, self._name_of(param))
+
+    def _grad(self, param):
+        return self.flat.view(self.flat.g, self._name_of(param))
+
+    def refresh_derived_weights(self):
+        """Transposed / packed bf16 copies that the dgrad GEMMs and the region projection read."""
+        if self.flat.mirror_is_stale():
+            self.flat.refresh_mirror()
+            self._wt_dirty = True
+        if not self._wt_dirty:
+            return
+        m, D = self.model, self.model.bert.img_dim
+        for t, wt in self.wt:
+            wt["wt_qkv"].copy_(t["w_qkv"].t())
+            wt["wt_ao"].copy_(t["w_ao"].t())
+            wt["wt_in"].copy_(t["w_in"].t())
+            wt["wt_out"].copy_(t["w_out"].t())
+        V = m.mlmhead.predictions.decoder.weight.shape[0]
+        C = m.token_head[0].weight.shape[0]
+        A = m.next_action.linear.weight.shape[0]
+        self.head_t["dec"][:, :V].copy_(self._mirror(m.mlmhead.predictions.decoder.weight).t())
+        self.head_t["tr"].copy_(self._mirror(m.mlmhead.predictions.transform.dense.weight).t())
+        self.head_t["tok"][:, :C].copy_(self._mirror(m.token_head[0].weight).t())
+        self.head_t["act"][:, :A].copy_(self._mirror(m.next_action.linear.weight).t())
+        self.head_t["pool"].copy_(self._mirror(m.bert.pooler.dense.weight).t())
+        self.w_img[:, :D].copy_(self._mirror(m.bert.img_embedding.weight))
+        self.w_img[:, D:D + 128].copy_(self._mirror(m.bert.location_embeds.weight))
+        torch.add(m.bert.img_embedding.bias.detach(), m.bert.location_embeds.bias.detach(), out=self.b_img)
+        self._wt_dirty = False
+
+    def _buffers(self, B, S):
+        key = (B, S)
+        b = self._bufs.get(key)
+        if b is None:
+            cfg = self.cfg
+            if len(self._bufs) >= 2:
+                self._bufs.clear()
+            b = _TrainBuffers(cfg.num_hidden_layers, B * S, B, S, cfg.hidden_size, cfg.intermediate_size,
+                              cfg.num_attention_heads, self.flat.p.device)
+            self._bufs[key] = b
+        return b
+
+    # ------------------------------------------------------------------------------ schedule
+    def lr_factor(self):
+        s = self.sched_step
+        if self.schedule == "constant":
+            return float(s) / float(max(1.0, self.warmup_steps)) if s < self.warmup_steps else 1.0
+        if s < self.warmup_steps:
+            return float(s) / float(max(1, self.warmup_steps))
+        return max(0.0, float(self.t_total - s) / float(max(1.0, self.t_total - self.warmup_steps)))
+
+    # ------------------------------------------------------------------------------ forward + backward
+    def forward_backward(self, batch, grad_scale=1.0, accumulate=False):
+        """One forward + backward; gradients of `grad_scale * loss` land in the flat slab (p.grad).
+        Returns the reference's 7-tuple (0-d fp32 tensors)."""
+        m, cfg, f = self.model, self.cfg, self.flat
+        self.refresh_derived_weights()
+        f.reattach_grads()
+        ids = _i64(batch["input_ids"])
+        dev = ids.device
+        B, T = ids.shape
+        img = batch.get("img_feats")
+        R = 0 if img is None else img.shape[1]
+        S, H, I, nh, L = T + R, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
+        M = B * S
+        labels, token_labels, next_action = batch["labels"], batch["token_labels"], batch.get("next_action")
+        am = batch.get("attention_mask")
+        mask = None if am is None else am.to(torch.float32).contiguous()
+        if mask is not None and mask.shape != (B, S):
+            raise RuntimeError("attention_mask must be [batch, text+region]")
+        tt, pos_ids = _i64(batch.get("token_type_ids")), _i64(batch.get("position_ids"))
+        bufs = self._buffers(B, S)
+        emb = m.bert.embeddings
+        eps = emb.LayerNorm.variance_epsilon
+
+        # ---------------- forward ----------------
+        x0 = bufs.x0
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.embed_layernorm(ids, tt, pos_ids, emb.word_embeddings.weight.detach(), emb.position_embeddings.weight.detach(),
+                            emb.token_type_embeddings.weight.detach(), emb.LayerNorm.weight.detach(),
+                            emb.LayerNorm.bias.detach(), eps, x0, S, err_flag=err)
+        a_img = None
+        if img is not None:
+            a_img = ops.pack_concat(img.reshape(B * R, -1).float().contiguous(),
+                                    batch["img_location_embeddings"].reshape(B * R, -1).float().contiguous(), self.kpad)
+            ops.linear(a_img, self.w_img, self.b_img, out=x0[T:], ldc=H, grp_rows=R, grp_stride=S)
+        ops.encoder_forward(self.w_tab, bufs.acts, x0, mask, False, None, B, S, H, nh, I, cfg.layer_norm_eps)
+        seq = bufs.layers[-1]["out"]
+        pooled = ops.linear(seq, self._mirror(m.bert.pooler.dense.weight), m.bert.pooler.dense.bias.detach(),
+                            act=ACT_TANH, out_f32=True, M=B, lda=S * H)
+        pooled_bf = pooled.to(BF16)
+
+        # heads on supervised rows only
+        V, C, A = cfg.vocab_size, cfg.detector_classes, cfg.action_space
+        lab = labels.reshape(-1)
+        idx_w = torch.nonzero(lab != -1).flatten()
+        Ml = int(idx_w.numel())
+        pr = m.mlmhead.predictions
+        zero = torch.zeros((), dtype=torch.float32, device=dev)
+        if Ml > 0:
+            seq_w = seq.index_select(0, idx_w)
+            y_w = lab.index_select(0, idx_w)
+            h_t = torch.empty((Ml, H), dtype=BF16, device=dev)
+            t1 = ops.linear(seq_w, self._mirror(pr.transform.dense.weight), pr.transform.dense.bias.detach(), act=ACT_GELU,
+                            pre_act_out=h_t)
+            t2 = ops.layernorm(t1, pr.transform.LayerNorm.weight.detach(), pr.transform.LayerNorm.bias.detach(),
+                               pr.transform.LayerNorm.variance_epsilon)
+            logits = torch.empty((Ml, self.Vp), dtype=torch.float32, device=dev)
+            ops.linear(t2, self._mirror(pr.decoder.weight), pr.bias.detach(), out=logits, out_f32=True)
+            lw = logits[:, :V]
+            logp = torch.log_softmax(lw, dim=-1)
+            mask_loss = -logp.gather(1, y_w[:, None]).mean()
+            words_acc = (lw.argmax(1) == y_w).sum().float() / Ml
+        else:
+            mask_loss = zero / zero  # CrossEntropyLoss over no valid target is nan, as in the reference
+            words_acc = zero / zero
+        tl = token_labels.reshape(-1)
+        idx_t = torch.nonzero(tl != -1).flatten()
+        Mt = int(idx_t.numel())
+        lin_tok = m.token_head[0]
+        if Mt > 0:
+            seq_t = seq.index_select(0, idx_t)
+            y_t = tl.index_select(0, idx_t)
+            lt = torch.empty((Mt, self.Cp), dtype=torch.float32, device=dev)
+            ops.linear(seq_t, self._mirror(lin_tok.weight), lin_tok.bias.detach(), out=lt, out_f32=True)
+            p_t = torch.softmax(lt[:, :C], dim=-1)                      # token_head = Linear + Softmax
+            logp_t = torch.log_softmax(p_t, dim=-1)                      # criterion applies log-softmax AGAIN
+            token_loss = -logp_t.gather(1, y_t[:, None]).mean()
+            token_acc = (p_t.argmax(1) == y_t).sum().float() / Mt
+        else:
+            token_loss = zero / zero
+            token_acc = zero / zero
+        la = torch.empty((B, self.Ap), dtype=torch.float32, device=dev)
+        ops.linear(pooled_bf, self._mirror(m.next_action.linear.weight), m.next_action.linear.bias.detach(), out=la,
+                   out_f32=True)
+        lsm = torch.log_softmax(la[:, :A], dim=-1)
+        if next_action is not None:
+            valid_a = next_action != -1
+            n_valid = valid_a.sum()
+            logp_a = torch.log_softmax(lsm, dim=-1)
+            picked = logp_a.gather(1, next_action.clamp(min=0)[:, None])[:, 0]
+            next_loss = -(picked * valid_a).sum() / n_valid
+            action_acc = (lsm.argmax(1) == next_action).sum().float() / B
+        else:
+            next_loss, action_acc = 0, 0
+        loss = mask_loss + next_loss + token_loss
+
+        # ---------------- backward ----------------
+        gs = float(grad_scale)
+        acc = bool(accumulate)
+        g32 = bufs.g_seq32
+        g32.zero_()
+        wg = lambda dy, x, dw, db: dict(dy=dy, x=x, dw=dw, db=db, accumulate=acc)
+        dec_w_is_tied = pr.decoder.weight is emb.word_embeddings.weight
+        word_grad = self._grad(emb.word_embeddings.weight)
+        if not acc:
+            # gradients that receive scatter-adds start from zero; the rest is overwritten by the kernels
+            word_grad.zero_()
+        if Ml > 0:
+            dl = torch.zeros((Ml, self.Vp), dtype=BF16, device=dev)
+            sm = torch.exp(logp)
+            sm.scatter_add_(1, y_w[:, None], torch.full((Ml, 1), -1.0, device=dev))
+            dl[:, :V] = (sm * (gs / Ml)).to(BF16)
+            dec_grad = self._grad(pr.decoder.weight)
+            ops.wgrad([dict(dy=dl[:, :V], x=t2, dw=dec_grad, db=self._grad(pr.bias), accumulate=acc or dec_w_is_tied)], Ml)
+            g_t2 = ops.linear(dl, self.head_t["dec"])
+            g_t1 = ops.layernorm_bwd(t1, g_t2, pr.transform.LayerNorm.weight.detach(), pr.transform.LayerNorm.variance_epsilon,
+                                     self._grad(pr.transform.LayerNorm.weight), self._grad(pr.transform.LayerNorm.bias),
+                                     ws=bufs.ws_t["ln_partial"], accumulate=acc)
+            g_ht = ops.dgelu_mul(g_t1, h_t)
+            ops.wgrad([wg(g_ht, seq_w, self._grad(pr.transform.dense.weight), self._grad(pr.transform.dense.bias))], Ml)
+            g32.index_add_(0, idx_w, ops.linear(g_ht, self.head_t["tr"]).float())
+        if Mt > 0:
+            # d/dp of mean(-log_softmax(p)[y]) is (softmax(p) - onehot)/Mt; then back through p = softmax(logits)
+            dp = torch.exp(logp_t)
+            dp.scatter_add_(1, y_t[:, None], torch.full((Mt, 1), -1.0, device=dev))
+            dp.mul_(gs / Mt)
+            dlt = torch.zeros((Mt, self.Cp), dtype=BF16, device=dev)
+            dlt[:, :C] = (p_t * (dp - (dp * p_t).sum(1, keepdim=True))).to(BF16)
+            ops.wgrad([wg(dlt[:, :C], seq_t, self._grad(lin_tok.weight), self._grad(lin_tok.bias))], Mt)
+            g32.index_add_(0, idx_t, ops.linear(dlt, self.head_t["tok"]).float())
+        if next_action is not None:
+            da = torch.exp(logp_a)
+            da.scatter_add_(1, next_action.clamp(min=0)[:, None], torch.full((B, 1), -1.0, device=dev))
+            da = da * (valid_a[:, None] * (gs / n_valid))
+            # log_softmax of log-probabilities is the identity map's Jacobian: d lsm -> d logits
+            dla = da - torch.exp(lsm) * da.sum(1, keepdim=True)
+            dla_bf = torch.zeros((B, self.Ap), dtype=BF16, device=dev)
+            dla_bf[:, :A] = dla.to(BF16)
+            ops.wgrad([wg(dla_bf[:, :A], pooled_bf, self._grad(m.next_action.linear.weight),
+                          self._grad(m.next_action.linear.bias))], B)
+            g_pooled = ops.linear(dla_bf, self.head_t["act"], out_f32=True)
+            g_z = (g_pooled * (1.0 - pooled * pooled)).to(BF16)
+            ops.wgrad([dict(dy=g_z, x=seq.view(B, S * H)[:, :H], dw=self._grad(m.bert.pooler.dense.weight),
+                            db=self._grad(m.bert.pooler.dense.bias), accumulate=acc)], B)
+            g32.view(B, S, H)[:, 0].add_(ops.linear(g_z, self.head_t["pool"]).float())
+        elif not acc:
+            for prm in (m.next_action.linear.weight, m.next_action.linear.bias, m.bert.pooler.dense.weight,
+                        m.bert.pooler.dense.bias):
+                self._grad(prm).zero_()
+        g = bufs.g
+        g.copy_(g32)
+        ops.encoder_backward(self.w_tab, self.wt_tab, bufs.acts, self.g_tab, x0, mask, False, g, bufs.ws, B, S, H, nh, I,
+                             cfg.layer_norm_eps, accumulate=acc)
+        # embeddings: text rows
+        de = ops.embed_layernorm_bwd(ids, tt, pos_ids, emb.word_embeddings.weight.detach(),
+                                     emb.position_embeddings.weight.detach(), emb.token_type_embeddings.weight.detach(),
+                                     emb.LayerNorm.weight.detach(), eps, g, S, self._grad(emb.LayerNorm.weight),
+                                     self._grad(emb.LayerNorm.bias), ws=bufs.ws_t["ln_partial"], accumulate=acc)
+        pos_grad, type_grad = self._grad(emb.position_embeddings.weight), self._grad(emb.token_type_embeddings.weight)
+        if not acc:
+            pos_grad.zero_()
+            type_grad.zero_()
+        flat_ids = ids.reshape(-1)
+        pad = emb.word_embeddings.padding_idx
+        de_w = de if pad is None else de * (flat_ids != pad)[:, None]
+        word_grad.index_add_(0, flat_ids, de_w)
+        if pos_ids is None:
+            pos_grad[:T].add_(de.view(B, T, H).sum(0))
+        else:
+            pos_grad.index_add_(0, pos_ids.reshape(-1), de)
+        if tt is None:
+            type_grad[0].add_(de.sum(0))
+        else:
+            type_grad.index_add_(0, tt.reshape(-1), de)
+        # region projection
+        if img is not None:
+            g_img = g.view(B, S, H)[:, T:].reshape(B * R, H)
+            ops.wgrad([dict(dy=g_img, x=a_img, dw=self.dw_img, db=self.db_img)], B * R)
+            D = m.bert.img_dim
+            gi, gl = self._grad(m.bert.img_embedding.weight), self._grad(m.bert.location_embeds.weight)
+            gbi, gbl = self._grad(m.bert.img_embedding.bias), self._grad(m.bert.location_embeds.bias)
+            if acc:
+                gi.add_(self.dw_img[:, :D]); gl.add_(self.dw_img[:, D:D + 128]); gbi.add_(self.db_img); gbl.add_(self.db_img)
+            else:
+                gi.copy_(self.dw_img[:, :D]); gl.copy_(self.dw_img[:, D:D + 128]); gbi.copy_(self.db_img); gbl.copy_(self.db_img)
+        self._last_err = err
+        return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
+
+    # ------------------------------------------------------------------------------ optimizer
+    def optimizer_step(self, grad_scale=1.0):
+        """AdamW.step() + scheduler.step() (pretrain.py:192-193) as two fused launches (decay / no-decay)."""
+        f = self.flat
+        self.step_count += 1
+        t = self.step_count
+        lr = self.lr * self.lr_factor()
+        b1, b2 = self.betas
+        step_size = lr
+        if self.correct_bias:
+            step_size = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+        nd = f.n_decay
+        if nd > 0:
+            ops.adamw_flat(f.p[:nd], f.g[:nd], f.m[:nd], f.v[:nd], f.mirror[:nd], lr, step_size, b1, b2, self.eps, self.wd,
+                           grad_scale)
+        if f.total > nd:
+            ops.adamw_flat(f.p[nd:], f.g[nd:], f.m[nd:], f.v[nd:], f.mirror[nd:], lr, step_size, b1, b2, self.eps, 0.0,
+                           grad_scale)
+        self.sched_step += 1
+        f.mark_fresh()
+        self._wt_dirty = True
+
+    def all_reduce_grads(self):
+        """Sum the flat gradient slab over the data-parallel group in fixed-size buckets."""
+        if self.world == 1:
+            return
+        from .distributed import all_reduce_flat
+
+        all_reduce_flat(self.flat.g, self.bucket_elems, self.pg)
+
+    def train_step(self, batch):
+        """zero_grad -> forward -> backward -> gradient all-reduce -> AdamW -> schedule, as pretrain.py:150-193.
+        The reference divides the loss by world_size before backward AND lets DDP average;
+        loss_scale_by_world reproduces that extra 1/world factor."""
+        ws = self.world
+        scale = (1.0 / ws) if (ws > 1 and self.loss_scale_by_world) else 1.0
+        out = self.forward_backward(batch, grad_scale=scale)
+        self.all_reduce_grads()
+        self.optimizer_step(grad_scale=1.0 / ws)  # DDP's mean over ranks
+        return out
