@@ -4,8 +4,13 @@
   python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
 A step = one pass of the hot path over one synthetic batch that is already resident in HBM:
+  --mode train  (default) the pretrain step of tasks/viewpoint_select/pretrain.py:150-193 on
+                PreTrainOscar: forward (trunk + MLM / region-token / action heads + losses), backward,
+                gradient all-reduce over the data-parallel group (RCCL), fused AdamW, LR schedule;
+                bf16 compute, B=64 x (128 text + 100 region) per GPU, weak scaling
   --mode fwd    BertImgModelwithLocationEmbeds.forward (embeddings + region projection + 12-layer
-                encoder + pooler), bf16, B=64 x (128 text + 100 region) per GPU   [BASELINE configs[1]]
+                encoder + pooler), same shapes   [BASELINE configs[1]]
+The train-mode line also carries the forward-only rate measured in the same process.
 Prints ONE JSON line (rank 0) with whole-job samples/s, the live per-kernel roofline of the
 dominant kernel (the MFMA GEMM), and -- at N=1 -- the CPU oracle timed on the host cores.
 """
@@ -34,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default="fwd", choices=["fwd"])
+    ap.add_argument("--mode", default="train", choices=["train", "fwd"])
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
     ap.add_argument("--text", type=int, default=128)
     ap.add_argument("--regions", type=int, default=100)
@@ -59,18 +64,41 @@ def main():
 
     from visitron_amd import ops
     from visitron_amd.config import BertConfig
-    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds, PreTrainOscar
     from visitron_amd.synth import make_batch
+    from visitron_amd.training import PretrainEngine
 
     cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     torch.manual_seed(0)  # reference init N(0, 0.02) (BertPreTrainedModel.init_weights), identical on every rank
-    model = BertImgModelwithLocationEmbeds(cfg).eval().to(dev)
-    batch = make_batch(cfg, a.batch, a.text, a.regions, seed=1234 + rank, device=dev, with_labels=False)
     S = a.text + a.regions
+    train = a.mode == "train"
+    if train:
+        full = PreTrainOscar(cfg).to(dev).train()
+        trunk = full.bert
+        # pretrain.py defaults: lr 5e-5, weight_decay 0.05 (scripts), adam eps 1e-8, linear schedule
+        engine = PretrainEngine(full, lr=5e-5, weight_decay=0.05, eps=1e-8, schedule="linear", warmup_steps=0,
+                                t_total=20000)
+        batch = make_batch(cfg, a.batch, a.text, a.regions, seed=1234 + rank, device=dev, with_labels=True)
+        fwd_batch = {k: batch[k] for k in ("input_ids", "attention_mask", "img_feats", "img_location_embeddings")}
 
-    def step():
+        def step():
+            return engine.train_step(batch)
+    else:
+        trunk = BertImgModelwithLocationEmbeds(cfg).eval().to(dev)
+        batch = make_batch(cfg, a.batch, a.text, a.regions, seed=1234 + rank, device=dev, with_labels=False)
+        fwd_batch = batch
+
+        def step():
+            with torch.no_grad():
+                return trunk(**batch)
+
+    def fwd_step():
+        was = trunk.training
+        trunk.eval()
         with torch.no_grad():
-            return model(**batch)
+            out = trunk(**fwd_batch)
+        trunk.train(was)
+        return out
 
     def sync_all():
         torch.cuda.synchronize()
@@ -96,13 +124,35 @@ def main():
     value = world * a.batch * a.steps / elapsed
     f_enc = enc_flops_per_seq(S, cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size)
 
+    # forward-only rate in the same process (train mode): not part of the timed region above
+    fwd_value = None
+    if train:
+        for _ in range(3):
+            fwd_step()
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            fwd_step()
+        torch.cuda.synchronize()
+        fwd_elapsed = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([fwd_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fwd_elapsed = float(t.item())
+        fwd_value = world * a.batch * a.steps / fwd_elapsed
+        sync_all()
+
     # ---- live per-kernel timing (HIP events on the launch stream), outside the timed region ----
     roofline = None
     kernels = None
     if rank == 0 and not a.no_kernel_timing:
         ops.profile_begin()
         for _ in range(3):
-            step()
+            if train:
+                engine.forward_backward(batch)
+                engine.optimizer_step()
+            else:
+                step()
         torch.cuda.synchronize()
         kernels = ops.profile_end()
         gemm = kernels.get("gemm_nt_bf16_128x128")
@@ -121,7 +171,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "encoder fwd samples/sec (seq=%d, 12L base)" % S,
+            "metric": ("encoder fwd+bwd samples/sec (seq=%d, 12L base)" if train else "encoder fwd samples/sec (seq=%d, 12L base)") % S,
             "value": round(value, 2),
             "unit": "samples/s",
             "n_gpus": world,
@@ -134,14 +184,18 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: oscar base (12L/768d/12h), %d text + %d region tokens, "
-                            "batch %d per GPU, trunk forward (embeddings + region projection + encoder + pooler)"
-                            % (a.text, a.regions, a.batch),
-                "global_batch": world * a.batch, "seq_len": S, "parallelism": "dp%d (replicas, no collective in forward)" % world,
+                "workload": ("oscar base (12L/768d/12h), %d text + %d region tokens, batch %d per GPU; " % (a.text, a.regions, a.batch))
+                            + ("pretrain step = PreTrainOscar fwd (trunk + MLM/region-token/action heads, losses) + bwd + "
+                               "gradient all-reduce + fused AdamW [BASELINE configs[1] shape, configs[2] step]" if train else
+                               "trunk forward (embeddings + region projection + encoder + pooler) [BASELINE configs[1]]"),
+                "global_batch": world * a.batch, "seq_len": S,
+                "parallelism": ("dp%d (flat-slab gradient all-reduce over RCCL)" if train else "dp%d (replicas, no collective)") % world,
                 "weights": "random init N(0,0.02), seed 0",
             },
-            "encoder_flops_per_seq": f_enc,
-            "mfma_frac_whole_forward": round(f_enc * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "encoder_flops_per_seq_fwd": f_enc,
+            "mfma_frac_whole_step": round((3 if train else 1) * f_enc * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "fwd_samples_per_sec": None if fwd_value is None else round(fwd_value, 2),
+            "mfma_frac_whole_forward": round(f_enc * (fwd_value if train else value) / world / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernels_ms_per_step": None if kernels is None else {

@@ -33,7 +33,7 @@ typedef void* vt_stream_t; /* hipStream_t */
 #define VT_ACT_NONE 0
 #define VT_ACT_GELU 1 /* erf-GELU, hidden_act == "gelu" */
 #define VT_ACT_TANH 2
-#define VT_ACT_DGELU 3 /* out = acc * gelu'(R): dgrad through the erf-GELU, R = saved pre-activation */
+#define VT_ACT_MUL 3 /* out = acc * R: dgrad through the erf-GELU, R = gelu'(pre-activation) saved by the forward */
 
 const char* vt_error_string(int code);
 /* ABI version of this header; bumped on any signature change. */
@@ -54,8 +54,9 @@ int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const
                    const void* R, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int act,
                    int out_f32, int grp_rows, int grp_stride, vt_stream_t stream);
 
-/* Same, plus C2: optional bf16 copy of the pre-activation (acc + bias), row stride ldc2 -- what the
- * backward of BertIntermediate needs -- and act == VT_ACT_DGELU (R = pre-activation, multiplied in). */
+/* Same, plus C2: optional second bf16 output saved for backward, row stride ldc2 -- gelu'(acc + bias)
+ * when act == VT_ACT_GELU (what the backward of BertIntermediate multiplies by), else acc + bias --
+ * and act == VT_ACT_MUL (out = acc * R). */
 int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                       const void* R, int64_t ldr, void* C, int64_t ldc, void* C2, int64_t ldc2, int M, int N,
                       int K, int act, int out_f32, int grp_rows, int grp_stride, vt_stream_t stream);
@@ -94,7 +95,7 @@ int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ld
                           void* dx, int64_t lddx, float* dgamma, float* dbeta, float* partial_ws, int M, int H,
                           float eps, int accumulate, vt_stream_t stream);
 
-/* out = g * gelu'(h), bf16, n elements (n % 8 == 0): the dGELU of the MLM-head transform. */
+/* out = g * d, bf16, n elements (n % 8 == 0), d = saved gelu' values: the dGELU of the MLM-head transform. */
 int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_stream_t stream);
 
 /* BertEmbeddings (called at tasks/viewpoint_select/encoder.py:267-269): y[b*S + t, :] =
@@ -123,6 +124,10 @@ int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const in
 int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                   float step_size, float b1, float b2, float eps, float wd, float grad_scale,
                   vt_stream_t stream);
+
+/* out[c, r] = in[r, c] (bf16; R, C multiples of 8): refreshes the transposed weight copies that the
+ * dgrad GEMMs consume (vt_layer_weights_t). */
+int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream);
 
 /* out[row, :] = bf16([s0[row, 0:d0] | s1[row, 0:d1] | zeros to kpad]) -- builds the K-concatenated
  * operand that turns img_embedding(img_feats) + location_embeds(loc) (encoder.py:277-279) into
@@ -162,7 +167,7 @@ typedef struct vt_layer_acts {
   void* ctx;       /* [M,H]  bf16 attention context */
   void* attn_pre;  /* [M,H]  bf16 dense(ctx)+bias+x (pre-LayerNorm) */
   void* attn_out;  /* [M,H]  bf16 LayerNorm output */
-  void* mid_pre;   /* [M,I]  bf16 intermediate pre-activation (training) or NULL */
+  void* mid_pre;   /* [M,I]  bf16 gelu'(intermediate pre-activation), saved for backward (training) or NULL */
   void* mid;       /* [M,I]  bf16 gelu(intermediate) */
   void* out_pre;   /* [M,H]  bf16 dense(mid)+bias+attn_out */
   void* out;       /* [M,H]  bf16 layer output */

@@ -324,16 +324,32 @@ def test_linear_pre_activation_output_and_dgelu(dev):
     b = _rand((N,), g, 0.1)
     pre = torch.zeros((M, N), dtype=BF16, device=dev)
     out = ops.linear(a.to(dev, BF16), w.to(dev, BF16), b.to(dev), act=1, pre_act_out=pre)
-    h = a @ w.t() + b
-    assert maxabs(pre, h) < 2e-2
-    assert maxabs(out, _gelu(h)) < 2e-2
+    h = (a @ w.t() + b).requires_grad_(True)
+    _gelu(h).sum().backward()
+    assert maxabs(pre, h.grad) < 1e-2          # the saved tensor is gelu'(pre-activation)
+    assert maxabs(out, _gelu(h.detach())) < 2e-2
+    h = h.detach()
     # dgrad through the GELU: (dy @ W2) * gelu'(h)
     hh = bf16_round(h).requires_grad_(True)
     dyv = bf16_round(_rand((M, K), g))
     w2t = bf16_round(_rand((N, K), g, 0.1))  # plays W2^T: [I, H]
     upstream = dyv @ w2t.t()
     _gelu(hh).backward(upstream)
-    got = ops.linear(dyv.to(dev, BF16), w2t.to(dev, BF16), residual=hh.detach().to(dev, BF16), act=3)
+    hg = hh.detach().clone().requires_grad_(True)
+    _gelu(hg).sum().backward()
+    dsaved = bf16_round(hg.grad).to(dev, BF16)   # what the forward saves
+    got = ops.linear(dyv.to(dev, BF16), w2t.to(dev, BF16), residual=dsaved, act=3)
     assert maxabs(got, hh.grad) < 3e-2 * (1 + float(hh.grad.abs().max()))
-    got2 = ops.dgelu_mul(bf16_round(upstream).to(dev, BF16), hh.detach().to(dev, BF16))
+    got2 = ops.dgelu_mul(bf16_round(upstream).to(dev, BF16), dsaved)
     assert maxabs(got2, hh.grad) < 3e-2 * (1 + float(hh.grad.abs().max()))
+
+
+@pytest.mark.parametrize("R,C", [(768, 2304), (64, 64), (3072, 768), (136, 200)])
+def test_transpose(dev, R, C):
+    from visitron_amd import ops
+
+    x = torch.arange(R * C, dtype=torch.float32).reshape(R, C) % 509
+    xd = x.to(dev, BF16)
+    out = torch.zeros((C, R), dtype=BF16, device=dev)
+    ops.transpose(xd, out)
+    assert torch.equal(out, xd.t().contiguous())

@@ -17,6 +17,7 @@ int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids,
                                     const float* pos, const float* type, const float* gamma, const void* g, long ldg,
                                     float* de, float* dgamma, float* dbeta, float* partial_ws, int B, int T, int S, int H,
                                     int n_word, int n_pos, int n_type, float eps, int accumulate, hipStream_t stream);
+int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, int C, hipStream_t stream);
 int vt_adamw_dispatch(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float step_size, float b1,
                       float b2, float eps, float wd, float grad_scale, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
@@ -108,6 +109,10 @@ int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const in
 int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float step_size, float b1,
                   float b2, float eps, float wd, float grad_scale, vt_stream_t stream) {
   return vt_adamw_dispatch(p, g, m, v, p_bf16, n, lr, step_size, b1, b2, eps, wd, grad_scale, (hipStream_t)stream);
+}
+
+int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream) {
+  return vt_transpose_dispatch(in, ldi, out, ldo, R, C, (hipStream_t)stream);
 }
 
 int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_stream_t stream) {
@@ -220,8 +225,8 @@ int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weig
     rc = vt_layernorm_bwd_dispatch(a.out_pre, H, g, H, w.ln2_g, ws->g_pre, H, d.d_ln2_g, d.d_ln2_b, ws->ln_partial, M, H,
                                    ln_eps, accumulate, stream);
     if (rc) return rc;
-    // through output.dense and the GELU: g_mid = (g_pre . W_out) * gelu'(mid_pre)
-    rc = vt_gemm_dispatch(ws->g_pre, H, wt.wt_out, H, nullptr, a.mid_pre, I, ws->g_mid, I, M, I, H, VT_ACT_DGELU, 0, 0, 0, stream);
+    // through output.dense and the GELU: g_mid = (g_pre . W_out) * gelu'(pre-activation) (saved in mid_pre)
+    rc = vt_gemm_dispatch(ws->g_pre, H, wt.wt_out, H, nullptr, a.mid_pre, I, ws->g_mid, I, M, I, H, VT_ACT_MUL, 0, 0, 0, stream);
     if (rc) return rc;
     // through intermediate.dense, plus the residual branch: dL/d(attn_out) -> g
     rc = vt_gemm_dispatch(ws->g_mid, I, wt.wt_in, I, nullptr, ws->g_pre, H, g, H, M, H, I, VT_ACT_NONE, 0, 0, 0, stream);

@@ -29,16 +29,16 @@ struct GemmArgs {
   const bf16_t* A;
   const bf16_t* W;
   const float* bias;
-  const bf16_t* R;   // residual added after the activation; for ACT_DGELU: the saved pre-activation
+  const bf16_t* R;   // residual added after the activation; for ACT_MUL: the factor (saved gelu')
   void* C;
-  bf16_t* C2;        // optional second output: the pre-activation (acc + bias) in bf16, for backward
+  bf16_t* C2;        // optional second output for backward: gelu'(acc + bias) if ACT_GELU, else acc + bias
   long lda, ldw, ldr, ldc, ldc2;
   int M, N, K;
   int grp_rows, grp_stride;  // output row = (m / grp_rows) * grp_stride + m % grp_rows  (0: identity)
   int tiles_m, tiles_n;
 };
 
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_DGELU = 3 };  // DGELU: out = acc * gelu'(R)
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_MUL = 3 };  // MUL: out = acc * R (R = saved gelu'(pre-activation))
 
 #define GEMM_BM 128
 #define GEMM_BN 128
@@ -51,7 +51,7 @@ template <int ACT>
 __device__ __forceinline__ float apply_act(float x) {
   if (ACT == ACT_GELU) return gelu_erf(x);
   if (ACT == ACT_TANH) return tanh_fast(x);
-  return x;  // ACT_NONE and ACT_DGELU (the latter multiplies by gelu'(R) where R is read)
+  return x;  // ACT_NONE and ACT_MUL (the latter multiplies by R where R is read)
 }
 
 // Epilogue shared by the GEMM kernels: lane (j = lane&15, gq = lane>>4) owns output rows
@@ -93,13 +93,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
       for (int e = 0; e < 4; ++e) v[4 * t + e] = acc[mt][t][e] + bv[4 * t + e];
 
     if (full) {
-      if (g.C2) {  // pre-activation copy for the backward pass
+      if (g.C2) {  // saved for the backward pass: the activation's derivative (GELU) or the pre-activation
+        float s2[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s2[i] = (ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i];
         u32x4* cp2 = (u32x4*)(g.C2 + orow * g.ldc2 + nb);
         u32x4 o0, o1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-          o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+          o0[i] = pack_bf16x2(s2[2 * i], s2[2 * i + 1]);
+          o1[i] = pack_bf16x2(s2[8 + 2 * i], s2[8 + 2 * i + 1]);
         }
         cp2[0] = o0;
         cp2[1] = o1;
@@ -118,7 +121,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
           rv[8 + 2 * i + 1] = bf16hi(r1[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (ACT == ACT_DGELU) ? v[i] * gelu_erf_grad(rv[i]) : v[i] + rv[i];
+        for (int i = 0; i < 16; ++i) v[i] = (ACT == ACT_MUL) ? v[i] * rv[i] : v[i] + rv[i];
       }
       if (OUT_F32) {
         f32x4* cp = (f32x4*)((float*)g.C + orow * g.ldc + nb);
@@ -139,11 +142,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (nb + i < g.N) {
-          if (g.C2) g.C2[orow * g.ldc2 + nb + i] = f32_to_bf16(v[i]);
+          if (g.C2) g.C2[orow * g.ldc2 + nb + i] = f32_to_bf16((ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i]);
           float x = apply_act<ACT>(v[i]);
           if (g.R) {
             const float rr = bf16_to_f32(g.R[orow * g.ldr + nb + i]);
-            x = (ACT == ACT_DGELU) ? x * gelu_erf_grad(rr) : x + rr;
+            x = (ACT == ACT_MUL) ? x * rr : x + rr;
           }
           if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;
           else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = f32_to_bf16(x);
@@ -447,7 +450,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   if (!A || !W || !C) return VT_ERR_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K % GEMM_BK) != 0) return VT_ERR_BAD_SHAPE;
   if ((lda % 8) || (ldw % 8) || (R && (ldr % 8)) || (ldc % (out_f32 ? 4 : 8)) || (C2 && (ldc2 % 8))) return VT_ERR_BAD_ALIGN;
-  if (act == ACT_DGELU && !R) return VT_ERR_NULL;
+  if (act == ACT_MUL && !R) return VT_ERR_NULL;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)R | (uintptr_t)bias) & 15) return VT_ERR_BAD_ALIGN;
   if (grp_rows < 0 || (grp_rows > 0 && grp_stride < grp_rows)) return VT_ERR_BAD_SHAPE;
   GemmArgs g;
@@ -465,7 +468,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
     case 3: return launch_gemm<ACT_GELU, true>(g, variant, stream);
     case 4: return launch_gemm<ACT_TANH, false>(g, variant, stream);
     case 5: return launch_gemm<ACT_TANH, true>(g, variant, stream);
-    case 6: return launch_gemm<ACT_DGELU, false>(g, variant, stream);
+    case 6: return launch_gemm<ACT_MUL, false>(g, variant, stream);
     default: return VT_ERR_UNSUPPORTED;
   }
 }

@@ -353,16 +353,33 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows(LnBwdArgs a) {
   }
 }
 
-// out[j] (+)= sum_b partial[b][j], j < n  (n = 2H: dgamma | dbeta)
+// out[j] (+)= sum_b partial[b][j], j < n  (n = 2H: dgamma | dbeta).  A block owns 32 columns; its 8
+// thread groups each sum every 8th partial row (independent, unrolled loads), then combine through LDS.
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ partial, int nblocks, int n,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int H,
                                                      int accumulate) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * n + j];
-  float* dst = j < H ? dgamma + j : dbeta + (j - H);
-  *dst = accumulate ? *dst + s : s;
+  if (j < n) {
+    int b = part;
+    for (; b + 24 < nblocks; b += 32) {
+      const float v0 = partial[(long)b * n + j], v1 = partial[(long)(b + 8) * n + j];
+      const float v2 = partial[(long)(b + 16) * n + j], v3 = partial[(long)(b + 24) * n + j];
+      s += (v0 + v1) + (v2 + v3);
+    }
+    for (; b < nblocks; b += 8) s += partial[(long)b * n + j];
+  }
+  red[part][cl] = s;
+  __syncthreads();
+  if (part == 0 && j < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    float* dst = j < H ? dgamma + j : dbeta + (j - H);
+    *dst = accumulate ? *dst + t : t;
+  }
 }
 
 #define LN_BWD_MAX_BLOCKS 512
@@ -379,13 +396,14 @@ int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy,
   if (nblocks > LN_BWD_MAX_BLOCKS) nblocks = LN_BWD_MAX_BLOCKS;
   if (H <= 512) hipLaunchKernelGGL(layernorm_bwd_rows<1>, dim3(nblocks), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(layernorm_bwd_rows<2>, dim3(nblocks), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 255) / 256), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 31) / 32), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
                      dbeta, H, accumulate);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 // workspace floats needed by vt_layernorm_bwd: LN_BWD_MAX_BLOCKS * 2 * H
 
-// out = g * gelu'(h) elementwise (bf16, 8 per thread): backward through the MLM-head transform's GELU.
+// out = g * d elementwise (bf16, 8 per thread), d = saved gelu'(pre-activation): backward through the
+// MLM-head transform's GELU.
 __global__ __launch_bounds__(256) void dgelu_mul_bf16(const bf16_t* __restrict__ g, const bf16_t* __restrict__ h,
                                                       bf16_t* __restrict__ out, long n8) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -394,7 +412,7 @@ __global__ __launch_bounds__(256) void dgelu_mul_bf16(const bf16_t* __restrict__
   u32x4 o;
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    o[k] = pack_bf16x2(bf16lo(gv[k]) * gelu_erf_grad(bf16lo(hv[k])), bf16hi(gv[k]) * gelu_erf_grad(bf16hi(hv[k])));
+    o[k] = pack_bf16x2(bf16lo(gv[k]) * bf16lo(hv[k]), bf16hi(gv[k]) * bf16hi(hv[k]));
   ((u32x4*)out)[i] = o;
 }
 
@@ -551,7 +569,7 @@ int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids,
   const int nblocks = (int)(nb > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : nb);
   if (H <= 512) hipLaunchKernelGGL(embed_layernorm_bwd<1>, dim3(nblocks), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(embed_layernorm_bwd<2>, dim3(nblocks), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 255) / 256), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 31) / 32), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
                      dbeta, H, accumulate);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
@@ -602,5 +620,42 @@ int vt_adamw_dispatch(float* p, const float* g, float* m, float* v, void* p_bf16
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(adamw_flat, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n4, lr, step_size,
                      b1, b2, eps, wd, grad_scale);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// out[c][r] = in[r][c], bf16, 64x64 tiles through LDS (both sides 16-byte coalesced).  Refreshes the
+// transposed weight copies the dgrad GEMMs read after every optimizer step.
+__global__ __launch_bounds__(256) void transpose_bf16(const bf16_t* __restrict__ in, long ldi, bf16_t* __restrict__ out,
+                                                      long ldo, int R, int C) {
+  __shared__ bf16_t tile[64][72];  // [c][r], pitch 72 elements = 144 B keeps 16-B row reads aligned
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int chunk = t + 256 * it;          // 512 chunks of 8 elements
+    const int r = chunk >> 3, cc = (chunk & 7) * 8;
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (r0 + r < R && c0 + cc < C) v = *(const u32x4*)(in + (long)(r0 + r) * ldi + c0 + cc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tile[cc + 2 * i][r] = (bf16_t)(v[i] & 0xffffu);
+      tile[cc + 2 * i + 1][r] = (bf16_t)(v[i] >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int chunk = t + 256 * it;
+    const int c = chunk >> 3, rr = (chunk & 7) * 8;
+    if (c0 + c < C && r0 + rr < R) *(u32x4*)(out + (long)(c0 + c) * ldo + r0 + rr) = *(const u32x4*)(&tile[c][rr]);
+  }
+}
+
+int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, int C, hipStream_t stream) {
+  if (!in || !out) return VT_ERR_NULL;
+  if (R <= 0 || C <= 0 || (R % 8) || (C % 8)) return VT_ERR_BAD_SHAPE;
+  if ((ldi % 8) || (ldo % 8) || (((uintptr_t)in | (uintptr_t)out) & 15)) return VT_ERR_BAD_ALIGN;
+  hipLaunchKernelGGL(transpose_bf16, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, (const bf16_t*)in, ldi,
+                     (bf16_t*)out, ldo, R, C);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }

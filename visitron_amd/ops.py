@@ -10,7 +10,7 @@ import torch
 from . import _lib
 
 BF16 = torch.bfloat16
-ACT_NONE, ACT_GELU, ACT_TANH, ACT_DGELU = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_TANH, ACT_MUL = 0, 1, 2, 3
 LN_BWD_WS_ROWS = 512  # vt_layernorm_bwd_bf16 scratch = LN_BWD_WS_ROWS * 2 * H floats
 
 
@@ -82,8 +82,8 @@ def round_up(x, m):
 def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False, grp_rows=0, grp_stride=0,
            M=None, lda=None, ldc=None, pre_act_out=None):
     """out = act(a @ w.T + bias) (+ residual).  a [M,K] bf16 (row stride lda), w [N,K] bf16.
-    pre_act_out: optional bf16 [M,N] buffer receiving a @ w.T + bias (saved for backward).
-    act == ACT_DGELU: out = (a @ w.T) * gelu'(residual)."""
+    pre_act_out: optional bf16 [M,N] buffer saved for backward: gelu'(a @ w.T + bias) when act == ACT_GELU,
+    else a @ w.T + bias.  act == ACT_MUL: out = (a @ w.T) * residual."""
     _require_hip(a, w, bias, residual, out, pre_act_out)
     assert a.dtype == BF16 and w.dtype == BF16
     N, K = w.shape
@@ -235,8 +235,18 @@ def adamw_flat(p, g, m, v, p_bf16, lr, step_size, b1, b2, eps, wd, grad_scale=1.
     _lib.check(rc, "vt_adamw_flat")
 
 
+def transpose(src, out):
+    """out[c, r] = src[r, c] (bf16 2-D, row strides allowed)."""
+    _require_hip(src, out)
+    assert src.dtype == BF16 and out.dtype == BF16 and src.stride(1) == 1 and out.stride(1) == 1
+    R, C = src.shape
+    rc = _lib.load().vt_transpose_bf16(_ptr(src), src.stride(0), _ptr(out), out.stride(0), R, C, _stream())
+    _lib.check(rc, "vt_transpose_bf16")
+    return out
+
+
 def dgelu_mul(g, h, out=None):
-    """g * gelu'(h), bf16 contiguous."""
+    """g * d (d = saved gelu' values), bf16 contiguous."""
     _require_hip(g, h, out)
     assert g.dtype == BF16 and h.dtype == BF16 and g.is_contiguous() and h.is_contiguous()
     if out is None:

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from . import _lib, ops
 from .modeling import PreTrainOscar, _i64
-from .ops import ACT_DGELU, ACT_GELU, ACT_NONE, ACT_TANH, BF16, round_up
+from .ops import ACT_MUL, ACT_GELU, ACT_NONE, ACT_TANH, BF16, round_up
 
 ALIGN = 64  # elements; keeps every parameter view 256-byte aligned inside the slabs
 
@@ -224,18 +224,18 @@ class PretrainEngine(object):
             return
         m, D = self.model, self.model.bert.img_dim
         for t, wt in self.wt:
-            wt["wt_qkv"].copy_(t["w_qkv"].t())
-            wt["wt_ao"].copy_(t["w_ao"].t())
-            wt["wt_in"].copy_(t["w_in"].t())
-            wt["wt_out"].copy_(t["w_out"].t())
+            ops.transpose(t["w_qkv"], wt["wt_qkv"])
+            ops.transpose(t["w_ao"], wt["wt_ao"])
+            ops.transpose(t["w_in"], wt["wt_in"])
+            ops.transpose(t["w_out"], wt["wt_out"])
         V = m.mlmhead.predictions.decoder.weight.shape[0]
         C = m.token_head[0].weight.shape[0]
         A = m.next_action.linear.weight.shape[0]
         self.head_t["dec"][:, :V].copy_(self._mirror(m.mlmhead.predictions.decoder.weight).t())
-        self.head_t["tr"].copy_(self._mirror(m.mlmhead.predictions.transform.dense.weight).t())
+        ops.transpose(self._mirror(m.mlmhead.predictions.transform.dense.weight), self.head_t["tr"])
         self.head_t["tok"][:, :C].copy_(self._mirror(m.token_head[0].weight).t())
         self.head_t["act"][:, :A].copy_(self._mirror(m.next_action.linear.weight).t())
-        self.head_t["pool"].copy_(self._mirror(m.bert.pooler.dense.weight).t())
+        ops.transpose(self._mirror(m.bert.pooler.dense.weight), self.head_t["pool"])
         self.w_img[:, :D].copy_(self._mirror(m.bert.img_embedding.weight))
         self.w_img[:, D:D + 128].copy_(self._mirror(m.bert.location_embeds.weight))
         torch.add(m.bert.img_embedding.bias.detach(), m.bert.location_embeds.bias.detach(), out=self.b_img)
@@ -297,7 +297,10 @@ class PretrainEngine(object):
             a_img = ops.pack_concat(img.reshape(B * R, -1).float().contiguous(),
                                     batch["img_location_embeddings"].reshape(B * R, -1).float().contiguous(), self.kpad)
             ops.linear(a_img, self.w_img, self.b_img, out=x0[T:], ldc=H, grp_rows=R, grp_stride=S)
-        ops.encoder_forward(self.w_tab, bufs.acts, x0, mask, False, None, B, S, H, nh, I, cfg.layer_norm_eps)
+        if ops.profiling():
+            self._encoder_forward_unrolled(bufs, x0, mask, B, S)
+        else:
+            ops.encoder_forward(self.w_tab, bufs.acts, x0, mask, False, None, B, S, H, nh, I, cfg.layer_norm_eps)
         seq = bufs.layers[-1]["out"]
         pooled = ops.linear(seq, self._mirror(m.bert.pooler.dense.weight), m.bert.pooler.dense.bias.detach(),
                             act=ACT_TANH, out_f32=True, M=B, lda=S * H)
@@ -413,8 +416,11 @@ class PretrainEngine(object):
                 self._grad(prm).zero_()
         g = bufs.g
         g.copy_(g32)
-        ops.encoder_backward(self.w_tab, self.wt_tab, bufs.acts, self.g_tab, x0, mask, False, g, bufs.ws, B, S, H, nh, I,
-                             cfg.layer_norm_eps, accumulate=acc)
+        if ops.profiling():
+            self._encoder_backward_unrolled(bufs, x0, mask, g, B, S, acc)
+        else:
+            ops.encoder_backward(self.w_tab, self.wt_tab, bufs.acts, self.g_tab, x0, mask, False, g, bufs.ws, B, S, H, nh,
+                                 I, cfg.layer_norm_eps, accumulate=acc)
         # embeddings: text rows
         de = ops.embed_layernorm_bwd(ids, tt, pos_ids, emb.word_embeddings.weight.detach(),
                                      emb.position_embeddings.weight.detach(), emb.token_type_embeddings.weight.detach(),
@@ -449,6 +455,43 @@ class PretrainEngine(object):
                 gi.copy_(self.dw_img[:, :D]); gl.copy_(self.dw_img[:, D:D + 128]); gbi.copy_(self.db_img); gbl.copy_(self.db_img)
         self._last_err = err
         return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
+
+    # ---- the launch sequences of vt_encoder_forward/backward_bf16 issued op by op (bench.py's per-kernel timing)
+    def _encoder_forward_unrolled(self, bufs, x0, mask, B, S):
+        cfg = self.cfg
+        nh, eps = cfg.num_attention_heads, cfg.layer_norm_eps
+        cur = x0
+        for (t, _), a in zip(self._keep, bufs.layers):
+            ops.linear(cur, t["w_qkv"], t["b_qkv"], out=a["qkv"])
+            ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, out=a["ctx"], lse=a["lse"])
+            ops.linear(a["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=a["attn_pre"])
+            ops.layernorm(a["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=a["attn_out"])
+            ops.linear(a["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=a["mid"], pre_act_out=a["mid_pre"])
+            ops.linear(a["mid"], t["w_out"], t["b_out"], residual=a["attn_out"], out=a["out_pre"])
+            ops.layernorm(a["out_pre"], t["ln2_g"], t["ln2_b"], eps, out=a["out"])
+            cur = a["out"]
+
+    def _encoder_backward_unrolled(self, bufs, x0, mask, g, B, S, acc):
+        cfg = self.cfg
+        nh, eps, M = cfg.num_attention_heads, cfg.layer_norm_eps, B * S
+        w = bufs.ws_t
+        for l in range(cfg.num_hidden_layers - 1, -1, -1):
+            (t, gr), a, (_, wt) = self._keep[l], bufs.layers[l], self.wt[l]
+            x_in = x0 if l == 0 else bufs.layers[l - 1]["out"]
+            ops.layernorm_bwd(a["out_pre"], g, t["ln2_g"], eps, gr["d_ln2_g"], gr["d_ln2_b"], dx=w["g_pre"],
+                              ws=w["ln_partial"], accumulate=acc)
+            ops.linear(w["g_pre"], wt["wt_out"], residual=a["mid_pre"], act=ACT_MUL, out=w["g_mid"])
+            ops.linear(w["g_mid"], wt["wt_in"], residual=w["g_pre"], out=g)
+            ops.layernorm_bwd(a["attn_pre"], g, t["ln1_g"], eps, gr["d_ln1_g"], gr["d_ln1_b"], dx=w["g_pre2"],
+                              ws=w["ln_partial"], accumulate=acc)
+            ops.linear(w["g_pre2"], wt["wt_ao"], out=w["g_ctx"])
+            ops.attention_bwd(a["qkv"], w["g_ctx"], a["ctx"], a["lse"], B, S, nh, mask=mask, out=w["g_qkv"],
+                              delta_ws=w["delta"])
+            ops.linear(w["g_qkv"], wt["wt_qkv"], residual=w["g_pre2"], out=g)
+            ops.wgrad([dict(dy=w["g_mid"], x=a["attn_out"], dw=gr["d_w_in"], db=gr["d_b_in"], accumulate=acc),
+                       dict(dy=w["g_pre"], x=a["mid"], dw=gr["d_w_out"], db=gr["d_b_out"], accumulate=acc),
+                       dict(dy=w["g_qkv"], x=x_in, dw=gr["d_w_qkv"], db=gr["d_b_qkv"], accumulate=acc),
+                       dict(dy=w["g_pre2"], x=a["ctx"], dw=gr["d_w_ao"], db=gr["d_b_ao"], accumulate=acc)], M)
 
     # ------------------------------------------------------------------------------ optimizer
     def optimizer_step(self, grad_scale=1.0):
