@@ -1,0 +1,124 @@
+"""CPU, world_size 2, gloo: the data-parallel plumbing (flat-slab bucketed all-reduce, coalesced metric
+all-reduce, batch sharding) and the equivalence  sum_r grad_r / world == DDP-averaged gradient."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from visitron_amd.distributed import all_reduce_flat, all_reduce_metrics, bucket_ranges, shard_batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        # 1) bucketed all-reduce of a flat slab with a ragged last bucket
+        n = 1000 * 7 + 13
+        flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        all_reduce_flat(flat, bucket_elems=1024)
+        want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        assert torch.equal(flat, want)
+        # async form
+        flat2 = torch.ones(5000) * (rank + 1)
+        handles = []
+        all_reduce_flat(flat2, 777, async_handles=handles)
+        assert len(handles) == len(bucket_ranges(5000, 777))
+        for h in handles:
+            h.wait()
+        assert torch.equal(flat2, torch.full((5000,), float(sum(r + 1 for r in range(world)))))
+        # 2) the reference's seven metric all-reduces as one message
+        vals = [torch.tensor(float(rank + i)) for i in range(6)] + [0]
+        red = all_reduce_metrics(vals)
+        for i in range(6):
+            assert abs(float(red[i]) - sum(r + i for r in range(world)) / world) < 1e-6
+        assert float(red[6]) == 0.0
+        # 3) data-parallel gradient == mean of per-rank gradients (oracle model on CPU as the test body)
+        from oracle.config import TINY, make_config
+        from oracle.modeling import PreTrainOscar
+        from visitron_amd.synth import deterministic_state_dict, make_batch
+
+        cfg = make_config(TINY)
+        m = PreTrainOscar(cfg).eval()
+        m.load_state_dict(deterministic_state_dict(m, seed=1))
+        gb = make_batch(cfg, 4, text_len=10, region_len=4, seed=3)
+        mine = shard_batch(gb, rank, world)
+        assert mine["input_ids"].shape[0] == 2
+        m(**mine)[0].backward()
+        slab = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        all_reduce_flat(slab, 4096)
+        slab /= world
+        # serial recomputation of both shards
+        ref = torch.zeros_like(slab)
+        for r in range(world):
+            m.zero_grad()
+            m(**shard_batch(gb, r, world))[0].backward()
+            ref += torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        ref /= world
+        assert torch.allclose(slab, ref, atol=1e-6)
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_bucket_ranges():
+    assert bucket_ranges(10, 4) == [(0, 4), (4, 8), (8, 10)]
+    assert bucket_ranges(8, 8) == [(0, 8)]
+    with pytest.raises(ValueError):
+        bucket_ranges(8, 0)
+
+
+def test_flat_param_layout_cpu():
+    """FlatParams: q|k|v adjacency, decay / no-decay split (pretrain.py:109-127), grads as slab views."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.training import FlatParams, _is_no_decay
+
+    cfg = mini_config()
+    m = PreTrainOscar(cfg)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    f = FlatParams(m)
+    H = cfg.hidden_size
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), before[n])
+        o, cnt, _ = f.off[n]
+        assert p.data_ptr() == f.p.data_ptr() + 4 * o and p.grad.data_ptr() == f.g.data_ptr() + 4 * o
+        assert (o < f.n_decay) == (not _is_no_decay(n)), n
+        assert (p.data_ptr() % 16) == 0
+    for layer in range(cfg.num_hidden_layers):
+        pre = "bert.encoder.layer.%d.attention.self." % layer
+        for kind, width in (("weight", H * H), ("bias", H)):
+            oq, ok, ov = (f.off[pre + x + "." + kind][0] for x in ("query", "key", "value"))
+            assert ok == oq + width and ov == ok + width
+        w = f.view(f.p, pre + "query.weight", 3 * H * H, (3 * H, H))
+        assert torch.equal(w[H:2 * H], m.bert.encoder.layer[layer].attention.self.key.weight.detach())
+    # tied decoder shares the word-embedding entry; zero_grad(set_to_none) is survivable
+    assert "mlmhead.predictions.decoder.weight" not in f.off
+    for p in m.parameters():
+        p.grad = None
+    f.reattach_grads()
+    assert all(p.grad is not None for p in m.parameters())
+    assert f.total % 64 == 0 and f.n_decay % 64 == 0
+    # optimizer-style in-place update bumps versions -> mirror flagged stale
+    assert not f.mirror_is_stale()
+    with torch.no_grad():
+        m.bert.pooler.dense.weight.add_(1.0)
+    assert f.mirror_is_stale()

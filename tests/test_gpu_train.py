@@ -147,3 +147,46 @@ def test_gradients_match_oracle_base_cfg1(dev):
         if e > 0.1:
             bad[n] = (e, norms[n])
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:10]
+
+
+def test_reference_style_loop_with_torch_optimizer(dev):
+    """The reference's own step (pretrain.py:150-193): model.zero_grad(); loss, ... = model(**batch);
+    loss.backward(); optimizer.step() with a torch-side AdamW (here the oracle's restatement of the
+    pytorch-transformers rule) -- no engine API involved."""
+    from oracle.modeling import PreTrainOscar as OModel
+    from oracle.optim import AdamW, grouped_parameters
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config()
+    ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=12, device=dev)
+    prod.train()
+    ref.train()
+    o_ref = AdamW(grouped_parameters(ref, 0.05), lr=1e-3, eps=1e-8)
+    o_prod = AdamW(grouped_parameters(prod, 0.05), lr=1e-3, eps=1e-8)
+    b = make_batch(cfg, 4, text_len=16, region_len=8, seed=2)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    for it in range(4):
+        ref.zero_grad(); o_ref.zero_grad()
+        lr_ = ref(**b)[0]
+        lr_.backward()
+        o_ref.step()
+        prod.zero_grad(); o_prod.zero_grad()
+        out = prod(**bd)
+        assert len(out) == 7 and out[0].requires_grad
+        loss = out[0]
+        loss /= 1.0  # the reference divides in place before backward (pretrain.py:170)
+        loss.backward()
+        if it == 0:
+            wg = dict(ref.named_parameters())
+            for n, p in prod.named_parameters():
+                assert p.grad is not None, n
+                assert _rel(p.grad, wg[n].grad) < 0.08, n
+        o_prod.step()
+        assert abs(float(loss) - float(lr_)) < 0.15
+    # eval / no_grad still takes the inference path
+    prod.eval()
+    with torch.no_grad():
+        out = prod(**bd)
+    assert not out[0].requires_grad

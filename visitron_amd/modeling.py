@@ -697,8 +697,19 @@ class PreTrainOscar(BertPreTrainedModel):
             return self.bert(input_ids, position_ids=position_ids, token_type_ids=token_type_ids,
                              attention_mask=attention_mask, head_mask=head_mask, img_feats=img_feats,
                              img_location_embeddings=img_location_embeddings)
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the HIP backward pass is not implemented yet; call under torch.no_grad() / eval()")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: HIP forward + backward, bridged to autograd so that `loss.backward()` and any torch
+            # optimizer / DistributedDataParallel wrapper work as in the reference's loop
+            if head_mask is not None:
+                raise NotImplementedError("head_mask is not supported by the HIP training path")
+            from .training import autograd_forward
+
+            batch = dict(input_ids=input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask, labels=labels,
+                         token_labels=token_labels, position_ids=position_ids, img_feats=img_feats,
+                         img_location_embeddings=img_location_embeddings, next_action=next_action)
+            if token_labels is None:
+                raise NameError("token_prediction")  # the reference leaves it unbound (encoder.py:400)
+            return autograd_forward(self, {k: v for k, v in batch.items() if v is not None})
         outs, pooled, _, B, S = self.bert.run_trunk(
             input_ids, token_type_ids, attention_mask, position_ids, head_mask, img_feats, img_location_embeddings)
         prediction_scores, token_prob, action_scores = self.head_outputs(outs[-1], pooled)

@@ -36,7 +36,8 @@ def _is_no_decay(name):
 class FlatParams(object):
     """Flat fp32 parameter / gradient / moment slabs + bf16 mirror for a PreTrainOscar."""
 
-    def __init__(self, model):
+    def __init__(self, model, attach_grads=True):
+        self.attach_grads = attach_grads
         named = list(model.named_parameters())
         dev = named[0][1].device
         # order: decay params then no-decay params; model order inside each group already puts
@@ -66,7 +67,8 @@ class FlatParams(object):
         for n, p, o, cnt, _ in self.entries:
             self.p[o:o + cnt].copy_(p.data.reshape(-1))
             p.data = self.p[o:o + cnt].view(p.shape)
-            p.grad = self.g[o:o + cnt].view(p.shape)
+            if attach_grads:
+                p.grad = self.g[o:o + cnt].view(p.shape)
             self.off[n] = (o, cnt, tuple(p.shape))
         self.refresh_mirror()
 
@@ -91,6 +93,8 @@ class FlatParams(object):
 
     def reattach_grads(self):
         """optimizer.zero_grad(set_to_none=True) drops p.grad; point them back at the slab."""
+        if not self.attach_grads:
+            return
         for n, p, o, cnt, _ in self.entries:
             if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * o:
                 p.grad = self.g[o:o + cnt].view(p.shape)
@@ -123,7 +127,7 @@ class _TrainBuffers(object):
 class PretrainEngine(object):
     def __init__(self, model, lr=5e-5, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999), correct_bias=True,
                  schedule="linear", warmup_steps=0, t_total=20000, process_group=None, bucket_mb=64,
-                 loss_scale_by_world=True):
+                 loss_scale_by_world=True, attach_grads=True):
         assert isinstance(model, PreTrainOscar)
         cfg = model.config
         if cfg.hidden_size != 64 * cfg.num_attention_heads:
@@ -136,7 +140,7 @@ class PretrainEngine(object):
                     "dropout > 0 is not implemented in the HIP training path yet; set hidden_dropout_prob and "
                     "attention_probs_dropout_prob to 0")
         self.model, self.cfg = model, cfg
-        self.flat = FlatParams(model)
+        self.flat = FlatParams(model, attach_grads=attach_grads)
         self.lr, self.wd, self.eps, self.betas, self.correct_bias = lr, weight_decay, eps, betas, correct_bias
         self.schedule, self.warmup_steps, self.t_total = schedule, warmup_steps, t_total
         self.step_count = 0       # optimizer steps taken (Adam's t)
@@ -533,3 +537,38 @@ class PretrainEngine(object):
         self.all_reduce_grads()
         self.optimizer_step(grad_scale=1.0 / ws)  # DDP's mean over ranks
         return out
+
+
+class _LossWithGrads(torch.autograd.Function):
+    """Bridges the engine to torch autograd for the reference's own loop (`loss.backward()` then a torch
+    optimizer, tasks/viewpoint_select/pretrain.py:167-193): forward has already run the HIP forward AND
+    backward for d(loss)/d(params); backward hands those gradients (times the incoming scalar) to
+    autograd, which accumulates them into p.grad and fires DistributedDataParallel's hooks."""
+
+    @staticmethod
+    def forward(ctx, engine, loss, *params):
+        ctx.engine = engine
+        ctx.names = [engine._name_of(p) for p in params]
+        return loss.detach().clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        f = ctx.engine.flat
+        grads = []
+        for n in ctx.names:
+            g = f.view(f.g, n)
+            grads.append(g * grad_out)
+        return (None, None) + tuple(grads)
+
+
+def autograd_forward(model, batch):
+    """PreTrainOscar.forward in training mode with grad enabled: returns the 7-tuple whose first element
+    back-propagates into the model's parameters."""
+    eng = getattr(model, "_vt_engine", None)
+    if eng is None or eng.flat.p.device != next(model.parameters()).device:
+        eng = PretrainEngine(model, attach_grads=False)
+        object.__setattr__(model, "_vt_engine", eng)
+    out = eng.forward_backward(batch)
+    params = [p for p in model.parameters() if p.requires_grad]
+    loss = _LossWithGrads.apply(eng, out[0], *params)
+    return (loss,) + tuple(out[1:])
