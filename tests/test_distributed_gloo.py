@@ -122,3 +122,11 @@ def test_flat_param_layout_cpu():
     with torch.no_grad():
         m.bert.pooler.dense.weight.add_(1.0)
     assert f.mirror_is_stale()
+
+
+def test_range_helpers():
+    from visitron_amd.distributed import complement_ranges
+
+    assert complement_ranges(100, [(10, 20), (40, 60)]) == [(0, 10), (20, 40), (60, 100)]
+    assert complement_ranges(50, [(0, 50)]) == []
+    assert complement_ranges(10, []) == [(0, 10)]

@@ -190,3 +190,36 @@ def test_reference_style_loop_with_torch_optimizer(dev):
     with torch.no_grad():
         out = prod(**bd)
     assert not out[0].requires_grad
+
+
+def test_chunked_backward_equals_single_call_and_ranges_cover_the_slab(dev):
+    """The data-parallel path runs the encoder backward in layer chunks and hands each chunk's gradient
+    ranges to the communicator; gradients must be bit-identical to the single-call path and the ranges
+    (plus their complement) must tile the whole slab exactly once."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config(num_hidden_layers=4)
+    _, prod, eng = _engine_pair(cfg, 21, dev, lr=0.0)
+    b = {k: v.to(dev) for k, v in make_batch(cfg, 3, text_len=14, region_len=6, seed=4).items()}
+    eng.forward_backward(b)
+    want = eng.flat.g.clone()
+    eng.flat.g.fill_(float("nan"))
+    seen = []
+    eng.train_step(b, layers_per_chunk=3, _force_comm=lambda rng: seen.extend(rng))
+    torch.cuda.synchronize()
+    # (torch's index_add_ scatter for the embedding tables uses float atomics: last-bit differences only)
+    got_g, want_g = torch.nan_to_num(eng.flat.g, nan=0.0), torch.nan_to_num(want, nan=0.0)
+    assert float((got_g - want_g).abs().max()) <= 1e-5 * float(want_g.abs().max())
+    for l in range(4):  # the encoder layers' own ranges are bitwise identical
+        for lo_, hi_ in eng.layer_ranges[l]:
+            assert torch.equal(got_g[lo_:hi_], want_g[lo_:hi_])
+    cover = torch.zeros(eng.flat.total, dtype=torch.int32)
+    for s, e in seen:
+        cover[s:e] += 1
+    assert int(cover.min()) == 1 and int(cover.max()) == 1
+    # layer ranges really are the layers' parameters
+    lo, hi = eng.layer_ranges[2][0]
+    name = "bert.encoder.layer.2.intermediate.dense.weight"
+    o, cnt, _ = eng.flat.off[name]
+    assert lo <= o and o + cnt <= hi

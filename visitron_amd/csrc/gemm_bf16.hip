@@ -277,7 +277,7 @@ __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
   return v;
 }
 
-template <int BK, int NSTAGE, int ACT, bool OUT_F32>
+template <int BK, int NSTAGE, int ACT, bool OUT_F32, int DBG = 0>
 __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_nt_bf16_v2(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CH = BK / 8;             // 16-B chunks per tile row
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_nt_bf16_v2(GemmA
       xf[0][i] = lds_read_b128(x_off[i] + so);
     }
 
-    if (kt + NSTAGE - 1 < nk) {
+    if (DBG != 1 && kt + NSTAGE - 1 < nk) {
       char* nX = smem + pslot * STAGE;
       const int koff = (kt + NSTAGE - 1) * BK;
 #pragma unroll
@@ -392,6 +392,14 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_nt_bf16_v2(GemmA
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (DBG == 2) {  // timing experiment: keep the loads alive, skip the matrix work
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[0][i]), "v"(xf[0][i]), "v"(wf[KS - 1][i]), "v"(xf[KS - 1][i]));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
+      pslot = (pslot + 1 == NSTAGE) ? 0 : pslot + 1;
+      continue;
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -415,11 +423,382 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_nt_bf16_v2(GemmA
   gemm_epilogue<ACT, OUT_F32>(g, acc, lane, m0 + 64 * wm, n0 + 64 * wn);
 }
 
+// ================================================================================================
+// v3: register-level software pipelining.  Fragments of tile k+1 are read from LDS while the MFMAs of
+// tile k (already in registers) run, and the DMA of tile k+2 is issued right after those reads into
+// the buffer tile k just vacated: two LDS buffers, ONE barrier per K-step, no LDS read ever waits in
+// front of an MFMA of the same step, and no LDS-DMA is outstanding when hipcc sees an LDS read (so
+// plain loads are safe and the scheduler may interleave them with the MFMAs).
+template <int BK, int ACT, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_v3(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CH = BK / 8;
+  constexpr int ROWB = BK * 2;
+  constexpr int TILE = 128 * ROWB;
+  constexpr int STAGE = 2 * TILE;
+  constexpr int NP = BK / 16;
+  constexpr int KS = BK / 32;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = gridDim.x;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int band_tiles = 8 * g.tiles_n;
+  const int band = t_id / band_tiles;
+  const int within = t_id - band * band_tiles;
+  const int rows_left = g.tiles_m - band * 8;
+  const int band_h = rows_left < 8 ? rows_left : 8;
+  const int bn = within / band_h;
+  const int bm = band * 8 + (within - bn * band_h);
+  const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
+
+  const bf16_t* a_src[NP];
+  const bf16_t* w_src[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = (wave * NP + i) * 64 + lane;
+    const int row = p / CH;
+    const int c = (p % CH) ^ swz<BK>(row);
+    int am = m0 + row;
+    am = am < g.M ? am : g.M - 1;
+    a_src[i] = g.A + (long)am * g.lda + c * 8;
+    int wnrow = n0 + (row & 64) + 16 * ((row >> 2) & 3) + 4 * ((row >> 4) & 3) + (row & 3);
+    wnrow = wnrow < g.N ? wnrow : g.N - 1;
+    w_src[i] = g.W + (long)wnrow * g.ldw + c * 8;
+  }
+  int x_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int xr = 64 * wm + 16 * i + (lane & 15);
+    x_off[i] = xr * ROWB + (((lane >> 4) ^ swz<BK>(xr)) << 4);
+    const int wr = 64 * wn + 16 * i + (lane & 15);
+    w_off[i] = TILE + wr * ROWB + (((lane >> 4) ^ swz<BK>(wr)) << 4);
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  auto stage = [&](int kt, int buf) {
+    char* d = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      glds16(a_src[i] + kt * BK, d + (wave * NP + i) * 1024);
+      glds16(w_src[i] + kt * BK, d + TILE + (wave * NP + i) * 1024);
+    }
+  };
+
+  bf16x8 xa[KS][4], wa[KS][4];   // fragment set A
+  bf16x8 xb[KS][4], wb[KS][4];   // fragment set B (the loop is unrolled by two so the sets swap roles
+                                 // without register copies)
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wa[ks][i] = *(const bf16x8*)(smem + (w_off[i] ^ (ks * 64)));
+      xa[ks][i] = *(const bf16x8*)(smem + (x_off[i] ^ (ks * 64)));
+    }
+  if (nk > 1) stage(1, 1);
+  // retire the prologue reads before the loop header: otherwise hipcc's wait-count merge at the loop
+  // entry keeps an lgkmcnt(0) in front of every step's MFMAs
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wa[ks][i]), "v"(xa[ks][i]));
+
+  // one K-step: multiply the `cur` fragments (tile kt) while the `nxt` fragments (tile kt+1) are read
+  auto kstep = [&](int kt, bf16x8 (&xc)[KS][4], bf16x8 (&wc)[KS][4], bf16x8 (&xn)[KS][4], bf16x8 (&wn_)[KS][4]) {
+    if (kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 landed (its DMA was issued one step ago)
+      __builtin_amdgcn_s_barrier();                      // ... for every wave; and tile kt's buffer is free
+      // pin the (long finished) reads of the current set here, so that the only LDS wait of the step sits
+      // BEFORE the new reads are issued and never between them and the MFMAs
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wc[ks][i]), "v"(xc[ks][i]));
+      const char* sb = smem + ((kt + 1) & 1) * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          wn_[ks][i] = *(const bf16x8*)(sb + (w_off[i] ^ (ks * 64)));
+          xn[ks][i] = *(const bf16x8*)(sb + (x_off[i] ^ (ks * 64)));
+        }
+      if (kt + 2 < nk) stage(kt + 2, kt & 1);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ks][t], xc[ks][mt], acc[mt][t], 0, 0, 0);
+  };
+
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(kt, xa, wa, xb, wb);
+    if (kt + 1 < nk) kstep(kt + 1, xb, wb, xa, wa);
+  }
+
+  gemm_epilogue<ACT, OUT_F32>(g, acc, lane, m0 + 64 * wm, n0 + 64 * wn);
+}
+
+// ================================================================================================
+// v4: 256 x BN tile (BN = 192 or 256), 8 waves as 4(M) x 2(N), wave tile 64 x BN/2.  The 128x128 tile is
+// bound by the L2 -> LDS path (~50 GB/s per CU measured with the MFMAs removed: 64 FLOP per staged
+// byte caps it near 750 TF/s); this tile stages 110-128 FLOP per byte and reads 0.38-0.42 LDS
+// fragments per MFMA instead of 0.5.  Same LDS images, swizzle, swapped-operand MFMA and epilogue
+// scheme as above; the output columns of a wave are handled in 64-column groups of T = 4 (or, for the
+// last 32 columns of the 96-wide wave tile, T = 2) N-subtiles.
+template <int T, int ACT, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue_grp(const GemmArgs& g, f32x4 (&acc)[4][T], int lane, int row0, int col0) {
+  // lane (j = lane&15, gq = lane>>4) owns rows row0+16mt+j and the 4T consecutive columns col0 + 4T*gq ..
+  constexpr int W = 4 * T;
+  const int gq = lane >> 4;
+  const int nb = col0 + W * gq;
+  if (nb >= g.N) return;
+  const bool full = (nb + W <= g.N);
+  float bv[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) bv[i] = 0.f;
+  if (g.bias) {
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+      if (full || nb + i < g.N) bv[i] = g.bias[nb + i];
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = row0 + 16 * mt + (lane & 15);
+    if (m >= g.M) continue;
+    const long orow = g.grp_rows ? (long)(m / g.grp_rows) * g.grp_stride + (m % g.grp_rows) : (long)m;
+    float v[W];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * t + e] = acc[mt][t][e] + bv[4 * t + e];
+    if (full) {
+      if (g.C2) {
+#pragma unroll
+        for (int h = 0; h < W / 8; ++h) {
+          u32x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float a0 = v[8 * h + 2 * i], a1 = v[8 * h + 2 * i + 1];
+            o[i] = pack_bf16x2((ACT == ACT_GELU) ? gelu_erf_grad(a0) : a0, (ACT == ACT_GELU) ? gelu_erf_grad(a1) : a1);
+          }
+          *(u32x4*)(g.C2 + orow * g.ldc2 + nb + 8 * h) = o;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < W; ++i) v[i] = apply_act<ACT>(v[i]);
+      if (g.R) {
+#pragma unroll
+        for (int h = 0; h < W / 8; ++h) {
+          const u32x4 rr = *(const u32x4*)(g.R + orow * g.ldr + nb + 8 * h);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float r0 = bf16lo(rr[i]), r1 = bf16hi(rr[i]);
+            v[8 * h + 2 * i] = (ACT == ACT_MUL) ? v[8 * h + 2 * i] * r0 : v[8 * h + 2 * i] + r0;
+            v[8 * h + 2 * i + 1] = (ACT == ACT_MUL) ? v[8 * h + 2 * i + 1] * r1 : v[8 * h + 2 * i + 1] + r1;
+          }
+        }
+      }
+      if (OUT_F32) {
+        f32x4* cp = (f32x4*)((float*)g.C + orow * g.ldc + nb);
+#pragma unroll
+        for (int i = 0; i < W / 4; ++i) cp[i] = (f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+      } else {
+#pragma unroll
+        for (int h = 0; h < W / 8; ++h) {
+          u32x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(v[8 * h + 2 * i], v[8 * h + 2 * i + 1]);
+          *(u32x4*)((bf16_t*)g.C + orow * g.ldc + nb + 8 * h) = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        if (nb + i < g.N) {
+          if (g.C2) g.C2[orow * g.ldc2 + nb + i] = f32_to_bf16((ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i]);
+          float x = apply_act<ACT>(v[i]);
+          if (g.R) {
+            const float rr = bf16_to_f32(g.R[orow * g.ldr + nb + i]);
+            x = (ACT == ACT_MUL) ? x * rr : x + rr;
+          }
+          if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;
+          else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = f32_to_bf16(x);
+        }
+      }
+    }
+  }
+}
+
+template <int BN, int ACT, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v4(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BK = 64;
+  constexpr int XT = BM * 128;          // X tile bytes
+  constexpr int WT = BN * 128;          // W tile bytes
+  constexpr int STAGE = XT + WT;
+  constexpr int WN = BN / 2;            // columns per wave
+  constexpr int NT = WN / 16;           // N-subtiles per wave (6 or 8)
+  constexpr int NPX = 4;                // X DMA pieces per wave per stage (32 pieces / 8 waves)
+  constexpr int NPW = BN / 64;          // W DMA pieces per wave per stage (3 or 4)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = gridDim.x;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int band_tiles = 4 * g.tiles_n;  // bands of 4 row-tiles (1024 rows)
+  const int band = t_id / band_tiles;
+  const int within = t_id - band * band_tiles;
+  const int rows_left = g.tiles_m - band * 4;
+  const int band_h = rows_left < 4 ? rows_left : 4;
+  const int bn = within / band_h;
+  const int bm = band * 4 + (within - bn * band_h);
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const bf16_t* a_src[NPX];
+  const bf16_t* w_src[NPW];
+#pragma unroll
+  for (int i = 0; i < NPX; ++i) {
+    const int p = (wave * NPX + i) * 64 + lane;
+    const int row = p >> 3;
+    const int c = (p & 7) ^ ((row >> 1) & 7);
+    int am = m0 + row;
+    am = am < g.M ? am : g.M - 1;
+    a_src[i] = g.A + (long)am * g.lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int p = (wave * NPW + i) * 64 + lane;
+    const int row = p >> 3;                       // LDS row 0 .. BN-1
+    const int c = (p & 7) ^ ((row >> 1) & 7);
+    const int wv = row / WN, rr = row - wv * WN;  // owning wave column, row inside its range
+    const int gb = rr < 64 ? 0 : 64;              // 64-column group base
+    const int Tg = (rr < 64 || WN == 128) ? 4 : 2;
+    const int lr = rr - gb, t = lr >> 4, i16 = lr & 15;
+    int wnrow = n0 + wv * WN + gb + (4 * Tg) * (i16 >> 2) + 4 * t + (i16 & 3);
+    wnrow = wnrow < g.N ? wnrow : g.N - 1;
+    w_src[i] = g.W + (long)wnrow * g.ldw + c * 8;
+  }
+
+  int x_off[4], w_off[NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int xr = 64 * wm + 16 * i + (lane & 15);
+    x_off[i] = xr * 128 + (((lane >> 4) ^ ((xr >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int wr = WN * wn + 16 * i + (lane & 15);
+    w_off[i] = XT + wr * 128 + (((lane >> 4) ^ ((wr >> 1) & 7)) << 4);
+  }
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  auto stage = [&](int kt, int buf) {
+    char* d = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) glds16(a_src[i] + kt * BK, d + (wave * NPX + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) glds16(w_src[i] + kt * BK, d + XT + (wave * NPW + i) * 1024);
+  };
+
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* sb = smem + (kt & 1) * STAGE;
+    bf16x8 xf[4], wf[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) wf[i] = *(const bf16x8*)(sb + w_off[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(sb + x_off[i]);
+    bf16x8 xg[4], wg[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) wg[i] = *(const bf16x8*)(sb + (w_off[i] ^ 64));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xg[i] = *(const bf16x8*)(sb + (x_off[i] ^ 64));
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf[mt], acc[mt][t], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[t], xg[mt], acc[mt][t], 0, 0, 0);
+  }
+
+  // epilogue: 64-column groups of the wave's columns
+  {
+    f32x4 a0[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a0[mt][t] = acc[mt][t];
+    gemm_epilogue_grp<4, ACT, OUT_F32>(g, a0, lane, m0 + 64 * wm, n0 + WN * wn);
+  }
+  if (NT == 8) {
+    f32x4 a1[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a1[mt][t] = acc[mt][(NT == 8 ? 4 : 0) + t];
+    gemm_epilogue_grp<4, ACT, OUT_F32>(g, a1, lane, m0 + 64 * wm, n0 + WN * wn + 64);
+  } else {
+    f32x4 a1[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) a1[mt][t] = acc[mt][4 + t];
+    gemm_epilogue_grp<2, ACT, OUT_F32>(g, a1, lane, m0 + 64 * wm, n0 + WN * wn + 64);
+  }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------
 // variant: 0 = v1 (BK64, 2 buffers, row-major tiles); 1 = v2 BK64 x 2 stages; 2 = v2 BK64 x 3 stages;
-//          3 = v2 BK32 x 3 stages (3 workgroups / CU); 4 = v2 BK32 x 4 stages.
+//          3 = v2 BK32 x 3 stages (3 workgroups / CU); 4 = v2 BK32 x 4 stages;
+//          5 = v3 BK64 (register-pipelined fragments); 6 = v3 BK32; 9 = v4 256x192; 10 = v4 256x256;
+//          7, 8 = timing experiments (no DMA / no MFMA in the loop; wrong results).
 static int g_gemm_variant = -1;  // -1: heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
 void vt_gemm_set_variant(int v) { g_gemm_variant = v; }
+
+template <typename K>
+static int launch_kernel_v4(K kern, GemmArgs g, int bn, hipStream_t stream) {
+  const int lds_bytes = 2 * (256 + bn) * 128;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+    return VT_ERR_HIP;
+  g.tiles_m = (g.M + 255) / 256;
+  g.tiles_n = (g.N + bn - 1) / bn;
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), lds_bytes, stream, g);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
 
 template <typename K>
 static int launch_kernel(K kern, const GemmArgs& g, int lds_bytes, hipStream_t stream) {
@@ -439,6 +818,12 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
     case 2: return launch_kernel(gemm_nt_bf16_v2<64, 3, ACT, OUT_F32>, g, 3 * 32768, stream);
     case 3: return launch_kernel(gemm_nt_bf16_v2<32, 3, ACT, OUT_F32>, g, 3 * 16384, stream);
     case 4: return launch_kernel(gemm_nt_bf16_v2<32, 4, ACT, OUT_F32>, g, 4 * 16384, stream);
+    case 5: return launch_kernel(gemm_nt_bf16_v3<64, ACT, OUT_F32>, g, 2 * 32768, stream);
+    case 6: return launch_kernel(gemm_nt_bf16_v3<32, ACT, OUT_F32>, g, 2 * 16384, stream);
+    case 9: return launch_kernel_v4(gemm_nt_bf16_v4<192, ACT, OUT_F32>, g, 192, stream);
+    case 10: return launch_kernel_v4(gemm_nt_bf16_v4<256, ACT, OUT_F32>, g, 256, stream);
+    case 7: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32, 1>, g, 2 * 32768, stream);  // timing experiment: no DMA in the loop
+    case 8: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32, 2>, g, 2 * 32768, stream);  // timing experiment: no MFMA
     default: return VT_ERR_UNSUPPORTED;
   }
 }

@@ -28,6 +28,26 @@ def all_reduce_flat(flat, bucket_elems, group=None, async_handles=None):
         w.wait()
 
 
+def all_reduce_ranges(flat, ranges, bucket_elems, group=None, async_handles=None):
+    """all_reduce_flat over a list of [start, end) element ranges of `flat` (e.g. the gradient slab
+    regions of the encoder layers whose backward has just been enqueued)."""
+    for s, e in ranges:
+        if e > s:
+            all_reduce_flat(flat[s:e], bucket_elems, group=group, async_handles=async_handles)
+
+
+def complement_ranges(n, ranges):
+    """[0, n) minus the given disjoint ranges, as a sorted list of ranges."""
+    out, cur = [], 0
+    for s, e in sorted(ranges):
+        if s > cur:
+            out.append((cur, s))
+        cur = max(cur, e)
+    if cur < n:
+        out.append((cur, n))
+    return out
+
+
 def all_reduce_metrics(values, group=None):
     """The reference's 7x (x /= world; all_reduce(SUM)) of pretrain.py:169-189 as one message."""
     world = dist.get_world_size(group)

@@ -164,8 +164,14 @@ class PretrainEngine(object):
         self.wt_tab = (_lib.LayerWeightsT * L)()
         self.g_tab = (_lib.LayerGrads * L)()
         self._keep, self.wt = [], []
+        self.layer_ranges = []   # per layer: [(start, end) in the decay region, (start, end) in the no-decay region]
         for i in range(L):
             pre = "bert.encoder.layer.%d." % i
+            offs = [(o, o + c) for n_, _, o, c, _ in f.entries if n_.startswith(pre)]
+            dec = [r_ for r_ in offs if r_[0] < f.n_decay]
+            nod = [r_ for r_ in offs if r_[0] >= f.n_decay]
+            self.layer_ranges.append([(min(a_ for a_, _ in dec), max(b_ for _, b_ in dec)),
+                                      (min(a_ for a_, _ in nod), max(b_ for _, b_ in nod))])
             qw, qb = pre + "attention.self.query.weight", pre + "attention.self.query.bias"
             names = dict(
                 w_ao=pre + "attention.output.dense.weight", b_ao=pre + "attention.output.dense.bias",
@@ -267,7 +273,7 @@ class PretrainEngine(object):
         return max(0.0, float(self.t_total - s) / float(max(1.0, self.t_total - self.warmup_steps)))
 
     # ------------------------------------------------------------------------------ forward + backward
-    def forward_backward(self, batch, grad_scale=1.0, accumulate=False):
+    def forward_backward(self, batch, grad_scale=1.0, accumulate=False, comm=None):
         """One forward + backward; gradients of `grad_scale * loss` land in the flat slab (p.grad).
         Returns the reference's 7-tuple (0-d fp32 tensors)."""
         m, cfg, f = self.model, self.cfg, self.flat
@@ -376,6 +382,8 @@ class PretrainEngine(object):
         if not acc:
             # gradients that receive scatter-adds start from zero; the rest is overwritten by the kernels
             word_grad.zero_()
+            if dec_w_is_tied:
+                self._grad(pr.bias).zero_()  # shares the accumulate flag of the tied decoder weight below
         if Ml > 0:
             dl = torch.zeros((Ml, self.Vp), dtype=BF16, device=dev)
             sm = torch.exp(logp)
@@ -422,9 +430,27 @@ class PretrainEngine(object):
         g.copy_(g32)
         if ops.profiling():
             self._encoder_backward_unrolled(bufs, x0, mask, g, B, S, acc)
-        else:
+        elif comm is None:
             ops.encoder_backward(self.w_tab, self.wt_tab, bufs.acts, self.g_tab, x0, mask, False, g, bufs.ws, B, S, H, nh,
                                  I, cfg.layer_norm_eps, accumulate=acc)
+        else:
+            # data-parallel: backward in layer chunks (last layers first); as soon as a chunk's kernels are
+            # enqueued its gradient ranges are all-reduced on the communicator's stream, under the backward
+            # of the earlier layers
+            step = max(1, int(comm["layers_per_chunk"]))
+            hi = L
+            while hi > 0:
+                lo = max(0, hi - step)
+                n = hi - lo
+                sub = lambda arr, typ: (typ * n).from_address(ctypes.addressof(arr) + lo * ctypes.sizeof(typ))
+                x_in = x0 if lo == 0 else bufs.layers[lo - 1]["out"]
+                ops.encoder_backward(sub(self.w_tab, _lib.LayerWeights), sub(self.wt_tab, _lib.LayerWeightsT),
+                                     sub(bufs.acts, _lib.LayerActs), sub(self.g_tab, _lib.LayerGrads), x_in, mask, False, g,
+                                     bufs.ws, B, S, H, nh, I, cfg.layer_norm_eps, accumulate=acc)
+                rng = [(self.layer_ranges[lo][k][0], self.layer_ranges[hi - 1][k][1]) for k in (0, 1)]
+                comm["launch"](rng)
+                comm["done"].extend(rng)
+                hi = lo
         # embeddings: text rows
         de = ops.embed_layernorm_bwd(ids, tt, pos_ids, emb.word_embeddings.weight.detach(),
                                      emb.position_embeddings.weight.detach(), emb.token_type_embeddings.weight.detach(),
@@ -520,21 +546,33 @@ class PretrainEngine(object):
         self._wt_dirty = True
 
     def all_reduce_grads(self):
-        """Sum the flat gradient slab over the data-parallel group in fixed-size buckets."""
+        """Sum the flat gradient slab over the data-parallel group in fixed-size buckets (no overlap)."""
         if self.world == 1:
             return
         from .distributed import all_reduce_flat
 
         all_reduce_flat(self.flat.g, self.bucket_elems, self.pg)
 
-    def train_step(self, batch):
+    def train_step(self, batch, overlap=True, layers_per_chunk=3, _force_comm=None):
         """zero_grad -> forward -> backward -> gradient all-reduce -> AdamW -> schedule, as pretrain.py:150-193.
         The reference divides the loss by world_size before backward AND lets DDP average (SURVEY 3.1);
-        loss_scale_by_world reproduces that extra 1/world factor."""
+        loss_scale_by_world reproduces that extra 1/world factor.  With overlap, the all-reduce of the
+        encoder layers' gradients runs under the backward of the earlier layers."""
         ws = self.world
         scale = (1.0 / ws) if (ws > 1 and self.loss_scale_by_world) else 1.0
-        out = self.forward_backward(batch, grad_scale=scale)
-        self.all_reduce_grads()
+        if (ws == 1 and _force_comm is None) or not overlap:
+            out = self.forward_backward(batch, grad_scale=scale)
+            self.all_reduce_grads()
+        else:
+            from .distributed import all_reduce_ranges, complement_ranges
+
+            handles = []
+            launch = _force_comm or (lambda rng: all_reduce_ranges(self.flat.g, rng, self.bucket_elems, self.pg, handles))
+            comm = dict(layers_per_chunk=layers_per_chunk, launch=launch, done=[])
+            out = self.forward_backward(batch, grad_scale=scale, comm=comm)
+            launch(complement_ranges(self.flat.total, comm["done"]))  # embeddings, region projection, heads
+            for h in handles:
+                h.wait()
         self.optimizer_step(grad_scale=1.0 / ws)  # DDP's mean over ranks
         return out
 
