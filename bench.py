@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
     ap.add_argument("--text", type=int, default=128)
     ap.add_argument("--regions", type=int, default=100)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -52,6 +54,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -59,7 +63,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if a.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=a.backend)
     assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (a.gpus, world)
 
     from visitron_amd import ops

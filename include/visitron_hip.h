@@ -40,6 +40,9 @@ const char* vt_error_string(int code);
 int vt_abi_version(void);
 /* Tuning hook (benchmarks only): force the GEMM kernel variant, -1 = built-in choice.  Process-global. */
 void vt_debug_set_gemm_variant(int variant);
+/* Autotuner result: use kernel `variant` for linear layers of exactly this shape and activation (filled by
+ * the host before the shape is used; process-global, read-only afterwards). */
+void vt_gemm_tune(int M, int N, int K, int act, int variant);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R[M,N]);  A, W, R bf16; C bf16 (out_f32 == 0) or
  * fp32.  Replaces every nn.Linear call on the path -- query/key/value oscar/modeling_bert.py:43-45

@@ -786,8 +786,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v4(GemmArgs g) {
 //          3 = v2 BK32 x 3 stages (3 workgroups / CU); 4 = v2 BK32 x 4 stages;
 //          5 = v3 BK64 (register-pipelined fragments); 6 = v3 BK32; 9 = v4 256x192; 10 = v4 256x256;
 //          7, 8 = timing experiments (no DMA / no MFMA in the loop; wrong results).
-static int g_gemm_variant = -1;  // -1: heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
+static int g_gemm_variant = -1;  // -1: table / heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
 void vt_gemm_set_variant(int v) { g_gemm_variant = v; }
+
+// Shape -> variant table filled by the host-side autotuner (visitron_amd.ops.autotune_linear) before
+// the shapes are used; read-only afterwards.  Exact-match lookup; misses fall back to the heuristic.
+struct TuneEntry { int M, N, K, act, variant; };
+static TuneEntry g_tune[256];
+static int g_ntune = 0;
+void vt_gemm_tune_set(int M, int N, int K, int act, int variant) {
+  for (int i = 0; i < g_ntune; ++i)
+    if (g_tune[i].M == M && g_tune[i].N == N && g_tune[i].K == K && g_tune[i].act == act) { g_tune[i].variant = variant; return; }
+  if (g_ntune < 256) g_tune[g_ntune++] = TuneEntry{M, N, K, act, variant};
+}
+static int gemm_pick_variant(int M, int N, int K, int act) {
+  for (int i = 0; i < g_ntune; ++i)
+    if (g_tune[i].M == M && g_tune[i].N == N && g_tune[i].K == K && g_tune[i].act == act) return g_tune[i].variant;
+  // heuristic: wave-quantisation efficiency x measured relative rate of each tile
+  auto eff = [](long tiles, int slots) { const double w = (double)tiles / slots; return w / (double)((long)(w + 0.999)); };
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const long t192 = (long)((M + 255) / 256) * ((N + 191) / 192);
+  const double gelu_pen = (act == ACT_GELU) ? 0.84 : 1.0;
+  const double s1 = eff(t128, 512) * 1.0;
+  const double s9 = (N >= 192 && M >= 256) ? eff(t192, 256) * 1.12 * gelu_pen : 0.0;
+  return s9 > s1 ? 9 : GEMM_DEFAULT_VARIANT;
+}
 
 template <typename K>
 static int launch_kernel_v4(K kern, GemmArgs g, int bn, hipStream_t stream) {
@@ -845,7 +868,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   g.grp_rows = grp_rows; g.grp_stride = grp_stride;
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-  const int variant = g_gemm_variant >= 0 ? g_gemm_variant : GEMM_DEFAULT_VARIANT;
+  const int variant = g_gemm_variant >= 0 ? g_gemm_variant : gemm_pick_variant(M, N, K, act);
   switch (act * 2 + (out_f32 ? 1 : 0)) {
     case 0: return launch_gemm<ACT_NONE, false>(g, variant, stream);
     case 1: return launch_gemm<ACT_NONE, true>(g, variant, stream);

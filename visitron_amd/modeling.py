@@ -473,6 +473,7 @@ class CaptionBertEncoder(nn.Module):
                 setattr(table[i], k, v.data_ptr())
             table[i].out = outs[i].data_ptr()
         ws = dict(shared=shared, outs=outs, table=table)
+        ops.autotune_encoder_shapes(M, H, I, training=False, device=device)  # once per token count
         if len(self._ws) > 4:
             self._ws.clear()
         self._ws[key] = ws

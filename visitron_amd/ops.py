@@ -106,6 +106,60 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
     return out
 
 
+GEMM_CANDIDATES = (1, 9, 10)   # 128x128, 256x192, 256x256 tiles
+_tuned = {}
+
+
+def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device="cuda", reps=8):
+    """Time the GEMM kernel variants on one shape (random data, HIP events) and register the fastest in the
+    library's shape table.  Synchronises; call it before the timed region / graph capture."""
+    key = (M, N, K, act)
+    if key in _tuned:
+        return _tuned[key]
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(device, BF16)
+    w = (torch.randn(N, K, generator=g) * 0.03).to(device, BF16)
+    b = torch.zeros(N, device=device)
+    r = torch.randn(M, N, generator=g).to(device, BF16) if (residual or act == ACT_MUL) else None
+    out = torch.empty((M, N), dtype=BF16, device=device)
+    pre = torch.empty((M, N), dtype=BF16, device=device) if pre_act else None
+    best, best_t = GEMM_CANDIDATES[0], float("inf")
+    for v in GEMM_CANDIDATES:
+        lib.vt_debug_set_gemm_variant(v)
+        try:
+            for _ in range(2):
+                linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1)
+        except RuntimeError:
+            t = float("inf")
+        if t < best_t:
+            best, best_t = v, t
+    lib.vt_debug_set_gemm_variant(-1)
+    lib.vt_gemm_tune(M, N, K, act, best)
+    _tuned[key] = best
+    return best
+
+
+def autotune_encoder_shapes(M, H, I, training=False, device="cuda"):
+    """Tune every GEMM shape of one encoder layer at M token rows (forward; plus the dgrads when training)."""
+    res = {}
+    res["qkv"] = autotune_linear(M, 3 * H, H, device=device)
+    res["attn_out"] = autotune_linear(M, H, H, residual=True, device=device)
+    res["ffn_up"] = autotune_linear(M, I, H, act=ACT_GELU, pre_act=training, device=device)
+    res["ffn_down"] = autotune_linear(M, H, I, residual=True, device=device)
+    if training:
+        res["d_ffn_down"] = autotune_linear(M, I, H, act=ACT_MUL, device=device)
+        res["d_qkv"] = autotune_linear(M, H, 3 * H, residual=True, device=device)
+    return res
+
+
 def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None, out=None, lse=None):
     """qkv [B*S, 3*nh*64] bf16, mask fp32 [B,S] -> context [B*S, nh*64] bf16."""
     _require_hip(qkv, mask, head_scale, out, lse)
