@@ -781,10 +781,167 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v4(GemmArgs g) {
   }
 }
 
+// ================================================================================================
+// v5: 256x256 tile, BK = 32, 4-stage LDS ring, 8 waves as 2(M) x 4(N), wave tile 128 x 64, two phases
+// per K-step.  LDS traffic (DMA writes + fragment reads) is what bounds the kernels above, so here the
+// fragment reads of the NEXT phase and the DMA issue are placed in front of each phase's 16 MFMAs and
+// retired by counted waits only:
+//   phase 0: read A(rows 64..127 of the wave) of tile k | issue X pieces of tile k+3 | lgkmcnt(4) | 16 MFMA (rows 0..63)
+//   phase 1: vmcnt(6): tile k+1 landed | lgkmcnt(0) | barrier | read A(rows 0..63) + W of tile k+1 |
+//            issue W pieces of tile k+3 | 16 MFMA (rows 64..127)
+// One barrier per K-step; every wave has retired all its LDS reads before it, so the DMA of tile k+3
+// may overwrite the stage of tile k-1.  Fragment reads are inline asm (hipcc would drain the ring in
+// front of compiler-visible LDS reads); DMA past the last tile re-loads the last tile so the vmcnt
+// arithmetic is uniform.
+#define V5_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
+
+template <int ACT, bool OUT_F32, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BN = 256, BK = 32, STAGE = 32768, XT = 16384;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int nwg = gridDim.x;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int band_tiles = 4 * g.tiles_n;
+  const int band = t_id / band_tiles;
+  const int within = t_id - band * band_tiles;
+  const int rows_left = g.tiles_m - band * 4;
+  const int band_h = rows_left < 4 ? rows_left : 4;
+  const int bn = within / band_h;
+  const int bm = band * 4 + (within - bn * band_h);
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  // DMA pieces: 1 KiB = 16 rows x 64 B; wave w moves pieces 2w, 2w+1 of each operand tile
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 16 * (2 * wave + i) + (lane >> 2);
+    const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
+    int am = m0 + row;
+    am = am < g.M ? am : g.M - 1;
+    a_src[i] = g.A + (long)am * g.lda + c * 8;
+    int wnrow = n0 + (row & 192) + 16 * ((row >> 2) & 3) + 4 * ((row >> 4) & 3) + (row & 3);
+    wnrow = wnrow < g.N ? wnrow : g.N - 1;
+    w_src[i] = g.W + (long)wnrow * g.ldw + c * 8;
+  }
+  const int nk = g.K / BK;
+  auto dma_x = [&](int kt, int st) {
+    const int kk = (kt < nk ? kt : nk - 1) * BK;
+    glds16(a_src[0] + kk, smem + st * STAGE + (2 * wave) * 1024);
+    glds16(a_src[1] + kk, smem + st * STAGE + (2 * wave + 1) * 1024);
+  };
+  auto dma_w = [&](int kt, int st) {
+    const int kk = (kt < nk ? kt : nk - 1) * BK;
+    glds16(w_src[0] + kk, smem + st * STAGE + XT + (2 * wave) * 1024);
+    glds16(w_src[1] + kk, smem + st * STAGE + XT + (2 * wave + 1) * 1024);
+  };
+
+  // fragment addresses (stage 0): the swizzle depends on (lane&15)>>2 only, so sub-tiles are immediates
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int i16 = lane & 15;
+  const unsigned fsw = (unsigned)((((lane >> 4) ^ ((-(i16 >> 2)) & 3)) << 4));
+  const unsigned a_addr0 = lds0 + (128 * wm + i16) * 64 + fsw;        // + 1024 * mt
+  const unsigned w_addr0 = lds0 + XT + (64 * wn + i16) * 64 + fsw;    // + 1024 * t
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 A0[4], A1[4], Wa[4], Wb[4];
+
+  // prologue: tiles 0,1,2 in flight; tile 0 landed; first fragments read
+  dma_x(0, 0); dma_w(0, 0);
+  dma_x(1, 1); dma_w(1, 1);
+  dma_x(2, 2); dma_w(2, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  V5_DSR(A0[0], a_addr0, 0); V5_DSR(A0[1], a_addr0, 1024); V5_DSR(A0[2], a_addr0, 2048); V5_DSR(A0[3], a_addr0, 3072);
+  V5_DSR(Wa[0], w_addr0, 0); V5_DSR(Wa[1], w_addr0, 1024); V5_DSR(Wa[2], w_addr0, 2048); V5_DSR(Wa[3], w_addr0, 3072);
+
+  auto kstep = [&](int kt, u32x4 (&Wc)[4], u32x4 (&Wn)[4]) {
+    const unsigned so = (unsigned)(kt & 3) * STAGE;
+    // ---- phase 0 ----
+    {
+      const unsigned aa = a_addr0 + so;
+      V5_DSR(A1[0], aa, 4096); V5_DSR(A1[1], aa, 5120); V5_DSR(A1[2], aa, 6144); V5_DSR(A1[3], aa, 7168);
+    }
+    if (DBG != 1) dma_x(kt + 3, (kt + 3) & 3);
+    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG != 2) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wc[t]),
+                                                             __builtin_bit_cast(bf16x8, A0[mt]), acc[mt][t], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(Wc[i]), "v"(A0[i]), "v"(A1[i]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 1 ----
+    if (DBG != 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) {
+      const unsigned sn = (unsigned)((kt + 1) & 3) * STAGE;
+      const unsigned aa = a_addr0 + sn, ww = w_addr0 + sn;
+      V5_DSR(A0[0], aa, 0); V5_DSR(A0[1], aa, 1024); V5_DSR(A0[2], aa, 2048); V5_DSR(A0[3], aa, 3072);
+      V5_DSR(Wn[0], ww, 0); V5_DSR(Wn[1], ww, 1024); V5_DSR(Wn[2], ww, 2048); V5_DSR(Wn[3], ww, 3072);
+    } else {
+      // keep the LDS-op count of the step uniform for the next (non-existent) lgkmcnt(4): nothing to do
+    }
+    if (DBG != 1) dma_w(kt + 3, (kt + 3) & 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (DBG != 2)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[4 + mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wc[t]),
+                                                                 __builtin_bit_cast(bf16x8, A1[mt]), acc[4 + mt][t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(kt, Wa, Wb);
+    if (kt + 1 < nk) kstep(kt + 1, Wb, Wa);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the tail DMAs before the LDS goes away
+
+  {
+    f32x4 lo[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) lo[mt][t] = acc[mt][t];
+    gemm_epilogue<ACT, OUT_F32>(g, lo, lane, m0 + 128 * wm, n0 + 64 * wn);
+  }
+  {
+    f32x4 hi[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) hi[mt][t] = acc[4 + mt][t];
+    gemm_epilogue<ACT, OUT_F32>(g, hi, lane, m0 + 128 * wm + 64, n0 + 64 * wn);
+  }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------
 // variant: 0 = v1 (BK64, 2 buffers, row-major tiles); 1 = v2 BK64 x 2 stages; 2 = v2 BK64 x 3 stages;
 //          3 = v2 BK32 x 3 stages (3 workgroups / CU); 4 = v2 BK32 x 4 stages;
-//          5 = v3 BK64 (register-pipelined fragments); 6 = v3 BK32; 9 = v4 256x192; 10 = v4 256x256;
+//          5 = v3 BK64 (register-pipelined fragments); 6 = v3 BK32; 9 = v4 256x192; 10 = v4 256x256; 11 = v5 256x256 BK32 4-stage phased;
 //          7, 8 = timing experiments (no DMA / no MFMA in the loop; wrong results).
 static int g_gemm_variant = -1;  // -1: table / heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
 void vt_gemm_set_variant(int v) { g_gemm_variant = v; }
@@ -845,6 +1002,30 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
     case 6: return launch_kernel(gemm_nt_bf16_v3<32, ACT, OUT_F32>, g, 2 * 16384, stream);
     case 9: return launch_kernel_v4(gemm_nt_bf16_v4<192, ACT, OUT_F32>, g, 192, stream);
     case 10: return launch_kernel_v4(gemm_nt_bf16_v4<256, ACT, OUT_F32>, g, 256, stream);
+    case 11: {
+      GemmArgs g5 = g;
+      g5.tiles_m = (g.M + 255) / 256;
+      g5.tiles_n = (g.N + 255) / 256;
+      auto kern = gemm_nt_bf16_v5<ACT, OUT_F32>;
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return VT_ERR_HIP;
+      hipLaunchKernelGGL(kern, dim3(g5.tiles_m * g5.tiles_n), dim3(512), 4 * 32768, stream, g5);
+      return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+    }
+    case 12: case 13: {
+      GemmArgs g5 = g;
+      g5.tiles_m = (g.M + 255) / 256;
+      g5.tiles_n = (g.N + 255) / 256;
+      if (variant == 12) {
+        auto kern = gemm_nt_bf16_v5<ACT, OUT_F32, 1>;
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+        hipLaunchKernelGGL(kern, dim3(g5.tiles_m * g5.tiles_n), dim3(512), 4 * 32768, stream, g5);
+      } else {
+        auto kern = gemm_nt_bf16_v5<ACT, OUT_F32, 2>;
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+        hipLaunchKernelGGL(kern, dim3(g5.tiles_m * g5.tiles_n), dim3(512), 4 * 32768, stream, g5);
+      }
+      return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+    }
     case 7: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32, 1>, g, 2 * 32768, stream);  // timing experiment: no DMA in the loop
     case 8: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32, 2>, g, 2 * 32768, stream);  // timing experiment: no MFMA
     default: return VT_ERR_UNSUPPORTED;
