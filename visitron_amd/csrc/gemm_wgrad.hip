@@ -60,13 +60,21 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tn_bf16(WgradArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
 
+  // XCD-contiguous remap: blocks b and b+8 share an XCD (and its L2); give every XCD one contiguous
+  // range of the tile list, whose order is problem-major then n-tile-major, so the workgroups that
+  // share a dY column panel (same n-tile, every k-tile) stream it through ONE L2 instead of eight.
+  // (PMC: 1.65 GB fetched per layer launch before the remap vs 0.36 GB of operands.)
+  const int nwg = gridDim.x;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   // which problem / tile (wave-uniform scan over <= 8 problems)
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < WG_MAX_PROBLEMS; ++i)
-    if (i < a.nprob && (int)blockIdx.x >= a.p[i].tile_begin) pi = i;
+    if (i < a.nprob && t_id >= a.p[i].tile_begin) pi = i;
   const WgradProblem& P = a.p[pi];
-  const int lt = blockIdx.x - P.tile_begin;
+  const int lt = t_id - P.tile_begin;
   const int bn = lt / P.tiles_k, bk = lt - bn * P.tiles_k;
   const int n0 = bn * 128, k0 = bk * 128;
   const int M = a.M;
