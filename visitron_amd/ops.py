@@ -97,7 +97,7 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
     if ldc is None:
         ldc = out.stride(0)
     ldr = residual.stride(0) if residual is not None else 0
-    with _timed("gemm_nt_bf16_128x128", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
+    with _timed("gemm_nt_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
         rc = _lib.load().vt_linear_bf16_ex(
             _ptr(a), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(residual), ldr, _ptr(out), ldc,
             _ptr(pre_act_out), 0 if pre_act_out is None else pre_act_out.stride(0),
