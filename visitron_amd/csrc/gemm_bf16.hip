@@ -938,10 +938,129 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5(GemmArgs g) {
   }
 }
 
+// ================================================================================================
+// v6: the v2 structure (128x128 tile, BK 64, 2-stage ring) with EIGHT waves of 32x64 each: <= 128 VGPRs,
+// so two workgroups put 4 waves on every SIMD.  PMC showed the MFMA pipes only 35-41 % busy with two
+// waves per SIMD (LDS 10 % busy, no bank conflicts): more, smaller waves cover each other's barrier and
+// DMA-issue time at the price of 0.75 instead of 0.5 LDS fragment reads per MFMA.
+template <int ACT, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue_m2(const GemmArgs& g, f32x4 (&acc)[2][4], int lane, int row0, int col0) {
+  // same as gemm_epilogue for a 32-row wave tile: pad to 4 row-subtiles with rows >= M masked off
+  f32x4 a4[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { a4[0][t] = acc[0][t]; a4[1][t] = acc[1][t]; a4[2][t] = acc[0][t]; a4[3][t] = acc[0][t]; }
+  GemmArgs g2 = g;
+  const int lim = row0 + 32;
+  g2.M = g.M < lim ? g.M : lim;   // rows row0+32.. (the two padding subtiles) fall outside and are skipped
+  gemm_epilogue<ACT, OUT_F32>(g2, a4, lane, row0, col0);
+}
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(512, 4) void gemm_nt_bf16_v6(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE = 128 * 128, STAGE = 2 * TILE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;   // 4 x 2 waves, wave tile 32 x 64
+
+  const int nwg = gridDim.x;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int band_tiles = 8 * g.tiles_n;
+  const int band = t_id / band_tiles;
+  const int within = t_id - band * band_tiles;
+  const int rows_left = g.tiles_m - band * 8;
+  const int band_h = rows_left < 8 ? rows_left : 8;
+  const int bn = within / band_h;
+  const int bm = band * 8 + (within - bn * band_h);
+  const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
+
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = (wave * 2 + i) * 64 + lane;
+    const int row = p >> 3;
+    const int c = (p & 7) ^ ((row >> 1) & 7);
+    int am = m0 + row;
+    am = am < g.M ? am : g.M - 1;
+    a_src[i] = g.A + (long)am * g.lda + c * 8;
+    int wnrow = n0 + (row & 64) + 16 * ((row >> 2) & 3) + 4 * ((row >> 4) & 3) + (row & 3);
+    wnrow = wnrow < g.N ? wnrow : g.N - 1;
+    w_src[i] = g.W + (long)wnrow * g.ldw + c * 8;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned x_off[2], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int xr = 32 * wm + 16 * i + (lane & 15);
+    x_off[i] = lds0 + xr * 128 + (((lane >> 4) ^ ((xr >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int wr = 64 * wn + 16 * i + (lane & 15);
+    w_off[i] = lds0 + TILE + wr * 128 + (((lane >> 4) ^ ((wr >> 1) & 7)) << 4);
+  }
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    glds16(a_src[i], smem + (wave * 2 + i) * 1024);
+    glds16(w_src[i], smem + TILE + (wave * 2 + i) * 1024);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned so = (kt & 1) * STAGE;
+    u32x4 xf[2][2], wf[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[0][i] = lds_read_b128(w_off[i] + so);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xf[0][i] = lds_read_b128(x_off[i] + so);
+    if (kt + 1 < nk) {
+      char* nX = smem + ((kt + 1) & 1) * STAGE;
+      const int koff = (kt + 1) * 64;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        glds16(a_src[i] + koff, nX + (wave * 2 + i) * 1024);
+        glds16(w_src[i] + koff, nX + TILE + (wave * 2 + i) * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[1][i] = lds_read_b128((w_off[i] + so) ^ 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xf[1][i] = lds_read_b128((x_off[i] + so) ^ 64);
+    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0][t]),
+                                                             __builtin_bit_cast(bf16x8, xf[0][mt]), acc[mt][t], 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[1][t]),
+                                                             __builtin_bit_cast(bf16x8, xf[1][mt]), acc[mt][t], 0, 0, 0);
+  }
+  gemm_epilogue_m2<ACT, OUT_F32>(g, acc, lane, m0 + 32 * wm, n0 + 64 * wn);
+}
+
 // ---- launchers ---------------------------------------------------------------------------------
 // variant: 0 = v1 (BK64, 2 buffers, row-major tiles); 1 = v2 BK64 x 2 stages; 2 = v2 BK64 x 3 stages;
 //          3 = v2 BK32 x 3 stages (3 workgroups / CU); 4 = v2 BK32 x 4 stages;
-//          5 = v3 BK64 (register-pipelined fragments); 6 = v3 BK32; 9 = v4 256x192; 10 = v4 256x256; 11 = v5 256x256 BK32 4-stage phased;
+//          5 = v3 BK64 (register-pipelined fragments); 6 = v3 BK32; 9 = v4 256x192; 10 = v4 256x256; 11 = v5 256x256 BK32 4-stage phased; 14 = v6 128x128 with 8 waves of 32x64;
 //          7, 8 = timing experiments (no DMA / no MFMA in the loop; wrong results).
 static int g_gemm_variant = -1;  // -1: table / heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
 void vt_gemm_set_variant(int v) { g_gemm_variant = v; }
@@ -1009,6 +1128,11 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
       auto kern = gemm_nt_bf16_v5<ACT, OUT_F32>;
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768) != hipSuccess) return VT_ERR_HIP;
       hipLaunchKernelGGL(kern, dim3(g5.tiles_m * g5.tiles_n), dim3(512), 4 * 32768, stream, g5);
+      return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+    }
+    case 14: {
+      auto kern = gemm_nt_bf16_v6<ACT, OUT_F32>;
+      hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), 2 * 32768, stream, g);
       return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
     }
     case 12: case 13: {

@@ -106,7 +106,7 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
     return out
 
 
-GEMM_CANDIDATES = (1, 9, 10, 11)   # 128x128, 256x192, 256x256, 256x256 phased (BK32, 4-stage ring)
+GEMM_CANDIDATES = (1, 14, 9, 10, 11)   # 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring)
 _tuned = {}
 
 

@@ -289,6 +289,13 @@ class PretrainEngine(object):
         S, H, I, nh, L = T + R, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
         M = B * S
         labels, token_labels, next_action = batch["labels"], batch["token_labels"], batch.get("next_action")
+        # supervised-row compaction first: torch.nonzero synchronises with the host, and here the GPU is
+        # idle anyway (start of the step) instead of between the encoder and the heads
+        lab = labels.reshape(-1)
+        idx_w = torch.nonzero(lab != -1).flatten()
+        tl = token_labels.reshape(-1)
+        idx_t = torch.nonzero(tl != -1).flatten()
+        Ml, Mt = int(idx_w.numel()), int(idx_t.numel())
         am = batch.get("attention_mask")
         mask = None if am is None else am.to(torch.float32).contiguous()
         if mask is not None and mask.shape != (B, S):
@@ -320,9 +327,6 @@ class PretrainEngine(object):
 
         # heads on supervised rows only
         V, C, A = cfg.vocab_size, cfg.detector_classes, cfg.action_space
-        lab = labels.reshape(-1)
-        idx_w = torch.nonzero(lab != -1).flatten()
-        Ml = int(idx_w.numel())
         pr = m.mlmhead.predictions
         zero = torch.zeros((), dtype=torch.float32, device=dev)
         if Ml > 0:
@@ -342,9 +346,6 @@ class PretrainEngine(object):
         else:
             mask_loss = zero / zero  # CrossEntropyLoss over no valid target is nan, as in the reference
             words_acc = zero / zero
-        tl = token_labels.reshape(-1)
-        idx_t = torch.nonzero(tl != -1).flatten()
-        Mt = int(idx_t.numel())
         lin_tok = m.token_head[0]
         if Mt > 0:
             seq_t = seq.index_select(0, idx_t)
