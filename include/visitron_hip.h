@@ -75,14 +75,16 @@ int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, in
                           const float* head_scale, void* ctx, int64_t ld_ctx, float* lse, int B, int S,
                           int nh, int head_size, vt_stream_t stream);
 
-/* Backward of vt_attention_fwd_bf16 (S <= 256): dqkv = dq | dk | dv packed like qkv.  ctx is the
- * forward output, lse its saved log-sum-exp, delta_ws a [B,nh,S] fp32 scratch (rowsum(dctx*ctx) is
- * computed into it).  Autograd of oscar/modeling_bert.py:47-72 inside loss.backward()
- * (tasks/viewpoint_select/pretrain.py:191).  No atomics: bitwise reproducible. */
+/* Backward of vt_attention_fwd_bf16: dqkv = dq | dk | dv packed like qkv.  ctx is the forward output,
+ * lse its saved log-sum-exp, delta_ws a [B,nh,S] fp32 scratch (rowsum(dctx*ctx) is computed into it).
+ * Autograd of oscar/modeling_bert.py:47-72 inside loss.backward() (tasks/viewpoint_select/
+ * pretrain.py:191).  S <= 256: no atomics, bitwise reproducible, dq32_ws may be NULL.  S > 256: the
+ * keys are processed in blocks of 256 and dq is accumulated with fp32 atomics in dq32_ws, an fp32
+ * [B*S, nh*64] scratch slab (zeroed here), then rounded to bf16. */
 int vt_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
                           int64_t ld_ctx, const float* mask, int mask_additive, const float* lse,
-                          float* delta_ws, void* dqkv, int64_t ld_dqkv, int B, int S, int nh, int head_size,
-                          vt_stream_t stream);
+                          float* delta_ws, void* dqkv, int64_t ld_dqkv, float* dq32_ws, int B, int S, int nh,
+                          int head_size, vt_stream_t stream);
 
 /* y = BertLayerNorm(x) over rows of H (biased variance, eps inside the sqrt); x already holds
  * dense(h) + bias + residual.  BertSelfOutput / BertOutput LayerNorm (called at
@@ -205,6 +207,7 @@ typedef struct vt_bwd_workspace {
   void* g_qkv;   /* [M,3H] bf16 */
   float* delta;      /* [B,nh,S] */
   float* ln_partial; /* [512*2*H] */
+  float* dq32;       /* [M,H] fp32, required when S > 256 (else may be NULL) */
 } vt_bwd_workspace;
 
 /* g: [M,H] bf16, IN dL/d(last layer output), OUT dL/d(x) (layer-0 input).  acts must come from a

@@ -267,7 +267,7 @@ def test_wgrad_asymmetric_identity(dev):
     assert torch.equal(dw.cpu(), x)
 
 
-@pytest.mark.parametrize("B,S,nh", [(2, 228, 3), (1, 37, 2), (2, 256, 1), (3, 64, 2), (1, 5, 1)])
+@pytest.mark.parametrize("B,S,nh", [(2, 228, 3), (1, 37, 2), (2, 256, 1), (3, 64, 2), (1, 5, 1), (2, 300, 2), (1, 656, 2), (1, 767, 1)])
 def test_attention_bwd_matches_autograd(dev, B, S, nh):
     from visitron_amd import ops
 

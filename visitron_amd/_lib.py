@@ -34,7 +34,7 @@ class LayerGrads(ctypes.Structure):  # vt_layer_grads
 
 
 class BwdWorkspace(ctypes.Structure):  # vt_bwd_workspace
-    _fields_ = [(n, c_void_p) for n in ("g_pre", "g_pre2", "g_mid", "g_ctx", "g_qkv", "delta", "ln_partial")]
+    _fields_ = [(n, c_void_p) for n in ("g_pre", "g_pre2", "g_mid", "g_ctx", "g_qkv", "delta", "ln_partial", "dq32")]
 
 
 class WgradProblem(ctypes.Structure):  # vt_wgrad_problem
@@ -53,7 +53,8 @@ SIGNATURES = {
     "vt_linear_bf16_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_attention_bwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
-                                      c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
     "vt_layernorm_bwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "vt_embed_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

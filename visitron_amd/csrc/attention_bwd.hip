@@ -1,4 +1,4 @@
-// Backward of the fused self-attention (head size 64, S <= 256): given dCtx, recompute P from Q, K and
+// Backward of the fused self-attention (head size 64): given dCtx, recompute P from Q, K and
 // the forward's log-sum-exp and produce dQ | dK | dV in the packed [B*S, 3H] layout.  This is the
 // autograd of oscar/modeling_bert.py:47-72 inside `loss.backward()` (tasks/viewpoint_select/
 // pretrain.py:191):
@@ -16,8 +16,12 @@
 //   dV^T[d][key] += dO^T . P   dK^T[d][key] += Q^T . dS     (A = ds_read_b64_tr_b16 of the slices)
 // Only dS crosses LDS, once per slice, as a [4-query group][key] image that every wave then reads
 // (transposed) to form dQ^T[d][q] = K^T . dS^T over ALL keys -- wave w produces d rows 16w..16w+15
-// with v_mfma_f32_16x16x32_bf16 -- so dQ needs no reduction either.  Everything is bitwise
-// reproducible (no atomics).
+// with v_mfma_f32_16x16x32_bf16 -- so dQ needs no reduction either, and for S <= 256 everything is
+// bitwise reproducible (no atomics).  For S > 256 the keys are split into blocks of 256 with one
+// workgroup each (grid.z); dK/dV stay private, and the dQ partials of the key blocks are combined by
+// fp32 atomics into a scratch [B*S,H] slab: each slice's dQ^T is transposed through LDS so that a
+// wave-instruction adds 256 contiguous bytes of one row (the full-rate atomic shape), then a small
+// kernel rounds the slab to bf16.
 #include "common.hpp"
 
 #define LOG2E 1.4426950408889634f
@@ -30,6 +34,7 @@ struct AttnBwdArgs {
   const float* lse;     // [B, nh, S] natural-log LSE from the forward
   const float* delta;   // [B, nh, S] rowsum(dO * O)
   bf16_t* dqkv;         // [B*S, ld_dqkv]  dq | dk | dv
+  float* dq32;          // [B*S, nh*64] fp32 accumulation slab (zeroed) when S > 256, else null
   long ld_qkv, ld_d, ld_dqkv;
   int B, S, nh;
   float scale;          // 1 / sqrt(head_size)
@@ -41,7 +46,8 @@ struct AttnBwdArgs {
 #define AB_DO (AB_Q + 2 * 4096)     // 2 x [32 q][128 B], same
 #define AB_DS (AB_DO + 2 * 4096)    // 2 x [8 q-groups][256 keys][8 B]
 #define AB_ROW (AB_DS + 2 * 16384)  // 2 x (lse[32] | delta[32]) fp32
-#define AB_LDS_BYTES (AB_ROW + 2 * 256)
+#define AB_DQ (AB_ROW + 2 * 256)     // [32 q][64 d] fp32 staging for the atomic dQ path
+#define AB_LDS_BYTES (AB_DQ + 8192)
 
 typedef __attribute__((ext_vector_type(8))) short short8v;
 
@@ -66,6 +72,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h2 = lane >> 5;
   const int b = blockIdx.y, head = blockIdx.x;
+  const int kb0 = blockIdx.z * 256;   // first key of this workgroup's key block
   const int S = a.S, H = a.nh * 64;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -74,12 +81,13 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   const float* lse_p = a.lse + ((long)b * a.nh + head) * S;
   const float* del_p = a.delta + ((long)b * a.nh + head) * S;
   const int nslices = (S + 31) >> 5;
-  const int nkt = (S + 31) >> 5;  // 32-key steps for dQ
+  const int kcount = (S - kb0) < 256 ? (S - kb0) : 256;
+  const int nkt = (kcount + 31) >> 5;  // 32-key steps of this key block for dQ
 
   // ---- K tile (all keys) -> LDS for the dQ product ----
   for (int j = wave; j < nkt * 4; j += 4) {  // 8-row pieces
     const int row = 8 * j + (lane >> 3);
-    int kr = row < S ? row : S - 1;
+    int kr = (kb0 + row) < S ? (kb0 + row) : S - 1;
     const int cs = lane & 7;
     const int sw = (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;  // 32-B group XOR, in 16-B chunk units
     glds16(base + (long)kr * a.ld_qkv + H + ((cs ^ sw) << 3), smem + AB_K + j * 1024);
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   float kbias[2];
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
-    const int key = 64 * wave + 32 * kt + r;
+    const int key = kb0 + 64 * wave + 32 * kt + r;
     const int kr = key < S ? key : S - 1;
     const bf16_t* kp = base + (long)kr * a.ld_qkv + H + 8 * h2;
     const bf16_t* vp = base + (long)kr * a.ld_qkv + 2 * H + 8 * h2;
@@ -293,16 +301,33 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
       }
     }
     // store dQ: lane (q_local = lane&15, g): d = 16w + 4g .. +3
+    if (a.dq32 == nullptr) {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int q = sl * 32 + 16 * qt + (lane & 15);
-      if (q < S) {
-        const f32x4 v = qt == 0 ? dq0 : dq1;
-        u32x2 w;
-        w[0] = pack_bf16x2(v[0], v[1]);
-        w[1] = pack_bf16x2(v[2], v[3]);
-        *(u32x2*)(a.dqkv + ((long)b * S + q) * a.ld_dqkv + head * 64 + 16 * wave + 4 * g) = w;
+      for (int qt = 0; qt < 2; ++qt) {
+        const int q = sl * 32 + 16 * qt + (lane & 15);
+        if (q < S) {
+          const f32x4 v = qt == 0 ? dq0 : dq1;
+          u32x2 w;
+          w[0] = pack_bf16x2(v[0], v[1]);
+          w[1] = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)(a.dqkv + ((long)b * S + q) * a.ld_dqkv + head * 64 + 16 * wave + 4 * g) = w;
+        }
       }
+    } else {
+      // several key blocks: transpose the slice's dQ^T through LDS, then add whole 256-byte row
+      // segments atomically (lane = d) -- the atomic shape that runs at the full chip-wide rate
+      float* st = (float*)(smem + AB_DQ);
+      *(f32x4*)(st + (lane & 15) * 64 + 16 * wave + 4 * g) = dq0;
+      *(f32x4*)(st + (16 + (lane & 15)) * 64 + 16 * wave + 4 * g) = dq1;
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int ql = 8 * wave + rr;
+        const int q = sl * 32 + ql;
+        if (q < S) atomicAdd(a.dq32 + ((long)b * S + q) * H + head * 64 + lane, st[ql * 64 + lane]);
+      }
+      // the staging tile is rewritten only after the next slice's barrier, which every wave reaches
+      // after these reads
     }
     // no barrier needed here: the next slice writes the OTHER dS image / reads the other Q,dO buffers,
     // and the barrier inside the next slice orders this slice's dQ reads before the image is reused.
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   // ---- dK, dV of this wave's keys: lane = key, reg <-> d = 32dt + 16h2 + reg ----
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
-    const int key = 64 * wave + 32 * kt + r;
+    const int key = kb0 + 64 * wave + 32 * kt + r;
     if (key >= S) continue;
     bf16_t* orow = a.dqkv + ((long)b * S + key) * a.ld_dqkv + head * 64 + 16 * h2;
 #pragma unroll
@@ -354,11 +379,29 @@ __global__ __launch_bounds__(256) void attn_delta_rows(const bf16_t* __restrict_
   }
 }
 
+// dq (bf16, columns 0..H-1 of the packed dqkv rows) = round(dq32)
+__global__ __launch_bounds__(256) void attn_dq_round(const float* __restrict__ dq32, bf16_t* __restrict__ dqkv, long ld_dqkv,
+                                                     long rows, int H) {
+  const int cpr = H >> 3;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cpr) return;
+  const long row = i / cpr;
+  const int col = (int)(i - row * cpr) * 8;
+  const f32x4 x0 = *(const f32x4*)(dq32 + row * H + col), x1 = *(const f32x4*)(dq32 + row * H + col + 4);
+  u32x4 o;
+  o[0] = pack_bf16x2(x0[0], x0[1]); o[1] = pack_bf16x2(x0[2], x0[3]);
+  o[2] = pack_bf16x2(x1[0], x1[1]); o[3] = pack_bf16x2(x1[2], x1[3]);
+  *(u32x4*)(dqkv + row * ld_dqkv + col) = o;
+}
+
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
-                              long ld_dqkv, int B, int S, int nh, int head_size, hipStream_t stream) {
+                              long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream) {
   if (!qkv || !dctx || !ctx || !lse || !delta_ws || !dqkv) return VT_ERR_NULL;
-  if (head_size != 64 || S > 256) return VT_ERR_UNSUPPORTED;
+  if (head_size != 64) return VT_ERR_UNSUPPORTED;
+  const int nkb = (S + 255) / 256;
+  if (nkb > 1 && !dq32_ws) return VT_ERR_NULL;
+  if (nkb > 65535) return VT_ERR_BAD_SHAPE;
   if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
   if ((ld_qkv % 8) || (ld_d % 8) || (ld_ctx % 8) || (ld_dqkv % 8)) return VT_ERR_BAD_ALIGN;
   if (((uintptr_t)qkv | (uintptr_t)dctx | (uintptr_t)ctx | (uintptr_t)dqkv) & 15) return VT_ERR_BAD_ALIGN;
@@ -374,8 +417,15 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   AttnBwdArgs a;
   a.qkv = (const bf16_t*)qkv; a.dctx = (const bf16_t*)dctx; a.mask = mask; a.mask_additive = mask_additive;
   a.lse = lse; a.delta = delta_ws; a.dqkv = (bf16_t*)dqkv;
+  a.dq32 = nkb > 1 ? dq32_ws : nullptr;
+  if (nkb > 1 && hipMemsetAsync(dq32_ws, 0, (size_t)rows * nh * 64 * sizeof(float), stream) != hipSuccess) return VT_ERR_HIP;
   a.ld_qkv = ld_qkv; a.ld_d = ld_d; a.ld_dqkv = ld_dqkv; a.B = B; a.S = S; a.nh = nh;
   a.scale = 1.0f / sqrtf((float)head_size);
-  hipLaunchKernelGGL(attention_bwd_d64, dim3(nh, B), dim3(256), AB_LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(attention_bwd_d64, dim3(nh, B, nkb), dim3(256), AB_LDS_BYTES, stream, a);
+  if (nkb > 1) {
+    const long n = rows * (nh * 8);
+    hipLaunchKernelGGL(attn_dq_round, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dq32_ws, (bf16_t*)dqkv, ld_dqkv,
+                       rows, nh * 64);
+  }
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }

@@ -8,7 +8,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
                      hipStream_t stream, void* C2 = nullptr, long ldc2 = 0);
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
-                              long ld_dqkv, int B, int S, int nh, int head_size, hipStream_t stream);
+                              long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream);
 int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
                               hipStream_t stream);
@@ -88,9 +88,10 @@ int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, co
 
 int vt_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
                           int64_t ld_ctx, const float* mask, int mask_additive, const float* lse, float* delta_ws,
-                          void* dqkv, int64_t ld_dqkv, int B, int S, int nh, int head_size, vt_stream_t stream) {
+                          void* dqkv, int64_t ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size,
+                          vt_stream_t stream) {
   return vt_attention_bwd_dispatch(qkv, ld_qkv, dctx, ld_d, ctx, ld_ctx, mask, mask_additive, lse, delta_ws, dqkv,
-                                   ld_dqkv, B, S, nh, head_size, (hipStream_t)stream);
+                                   ld_dqkv, dq32_ws, B, S, nh, head_size, (hipStream_t)stream);
 }
 
 int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* gamma, void* dx,
@@ -241,7 +242,7 @@ int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weig
     rc = vt_gemm_dispatch(ws->g_pre2, H, wt.wt_ao, H, nullptr, nullptr, 0, ws->g_ctx, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream);
     if (rc) return rc;
     rc = vt_attention_bwd_dispatch(a.qkv, 3L * H, ws->g_ctx, H, a.ctx, H, mask, mask_additive, a.lse, ws->delta, ws->g_qkv,
-                                   3L * H, B, S, nh, 64, stream);
+                                   3L * H, ws->dq32, B, S, nh, 64, stream);
     if (rc) return rc;
     // through the packed q|k|v projection, plus the residual branch: dL/d(layer input) -> g
     rc = vt_gemm_dispatch(ws->g_qkv, 3L * H, wt.wt_qkv, 3L * H, nullptr, ws->g_pre2, H, g, H, M, H, 3 * H, VT_ACT_NONE, 0, 0, 0, stream);

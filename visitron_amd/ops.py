@@ -228,7 +228,7 @@ def pack_concat(s0, s1, kpad, out=None):
     return out
 
 
-def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False, out=None, delta_ws=None):
+def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False, out=None, delta_ws=None, dq32_ws=None):
     """Gradient of attention_fwd w.r.t. the packed qkv: returns dqkv [B*S, 3*nh*64] bf16."""
     _require_hip(qkv, dctx, ctx, lse, mask, out)
     H = nh * 64
@@ -236,10 +236,13 @@ def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False,
         out = torch.empty((B * S, 3 * H), dtype=BF16, device=qkv.device)
     if delta_ws is None:
         delta_ws = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
+    if dq32_ws is None and S > 256:
+        dq32_ws = torch.empty((B * S, H), dtype=torch.float32, device=qkv.device)
     with _timed("attention_bwd_d64", 10.0 * B * nh * S * S * 64, 2.0 * B * S * 9 * H):
         rc = _lib.load().vt_attention_bwd_bf16(
             _ptr(qkv), qkv.stride(0), _ptr(dctx), dctx.stride(0), _ptr(ctx), ctx.stride(0), _ptr(mask),
-            1 if mask_additive else 0, _ptr(lse), _ptr(delta_ws), _ptr(out), out.stride(0), B, S, nh, 64, _stream())
+            1 if mask_additive else 0, _ptr(lse), _ptr(delta_ws), _ptr(out), out.stride(0), _ptr(dq32_ws), B, S, nh, 64,
+            _stream())
     _lib.check(rc, "vt_attention_bwd_bf16")
     return out
 

@@ -119,6 +119,8 @@ class _TrainBuffers(object):
         self.ws_t = dict(g_pre=mk(H), g_pre2=mk(H), g_mid=mk(I), g_ctx=mk(H), g_qkv=mk(3 * H),
                          delta=torch.empty((B, nh, S), dtype=torch.float32, device=dev),
                          ln_partial=torch.empty(ops.LN_BWD_WS_ROWS * 2 * H, dtype=torch.float32, device=dev))
+        if S > 256:  # attention backward over several key blocks accumulates dQ in fp32
+            self.ws_t["dq32"] = torch.empty((M, H), dtype=torch.float32, device=dev)
         self.ws = _lib.BwdWorkspace()
         for k, v in self.ws_t.items():
             setattr(self.ws, k, v.data_ptr())
@@ -519,7 +521,7 @@ class PretrainEngine(object):
                               ws=w["ln_partial"], accumulate=acc)
             ops.linear(w["g_pre2"], wt["wt_ao"], out=w["g_ctx"])
             ops.attention_bwd(a["qkv"], w["g_ctx"], a["ctx"], a["lse"], B, S, nh, mask=mask, out=w["g_qkv"],
-                              delta_ws=w["delta"])
+                              delta_ws=w["delta"], dq32_ws=w.get("dq32"))
             ops.linear(w["g_qkv"], wt["wt_qkv"], residual=w["g_pre2"], out=g)
             ops.wgrad([dict(dy=w["g_mid"], x=a["attn_out"], dw=gr["d_w_in"], db=gr["d_b_in"], accumulate=acc),
                        dict(dy=w["g_pre"], x=a["mid"], dw=gr["d_w_out"], db=gr["d_b_out"], accumulate=acc),
