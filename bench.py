@@ -7,7 +7,7 @@ A step = one pass of the hot path over one synthetic batch that is already resid
   --mode train  (default) the pretrain step of tasks/viewpoint_select/pretrain.py:150-193 on
                 PreTrainOscar: forward (trunk + MLM / region-token / action heads + losses), backward,
                 gradient all-reduce over the data-parallel group (RCCL), fused AdamW, LR schedule;
-                bf16 compute, B=64 x (128 text + 100 region) per GPU, weak scaling
+                bf16 compute, B=256 x (128 text + 100 region) per GPU [BASELINE configs[2]], weak scaling
   --mode fwd    BertImgModelwithLocationEmbeds.forward (embeddings + region projection + 12-layer
                 encoder + pooler), same shapes   [BASELINE configs[1]]
 The train-mode line also carries the forward-only rate measured in the same process.
@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
-    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="sequences per GPU (default: 256 in train mode = BASELINE configs[2], 64 in fwd mode = configs[1])")
     ap.add_argument("--text", type=int, default=128)
     ap.add_argument("--regions", type=int, default=100)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse)")
@@ -48,6 +49,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 256 if a.mode == "train" else 64
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -194,7 +197,7 @@ def main():
             "config": {
                 "workload": ("oscar base (12L/768d/12h), %d text + %d region tokens, batch %d per GPU; " % (a.text, a.regions, a.batch))
                             + ("pretrain step = PreTrainOscar fwd (trunk + MLM/region-token/action heads, losses) + bwd + "
-                               "gradient all-reduce + fused AdamW [BASELINE configs[1] shape, configs[2] step]" if train else
+                               "gradient all-reduce + fused AdamW [BASELINE configs[2]: pretrain step, batch 256 per GPU]" if train else
                                "trunk forward (embeddings + region projection + encoder + pooler) [BASELINE configs[1]]"),
                 "global_batch": world * a.batch, "seq_len": S,
                 "parallelism": ("dp%d (flat-slab gradient all-reduce over RCCL)" if train else "dp%d (replicas, no collective)") % world,
