@@ -43,6 +43,8 @@ void vt_debug_set_gemm_variant(int variant);
 /* Autotuner result: use kernel `variant` for linear layers of exactly this shape and activation (filled by
  * the host before the shape is used; process-global, read-only afterwards). */
 void vt_gemm_tune(int M, int N, int K, int act, int variant);
+/* Tuning hook: 4 or 8 waves per workgroup in the attention backward (default 8). Process-global. */
+void vt_debug_set_attn_bwd_waves(int waves);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R[M,N]);  A, W, R bf16; C bf16 (out_f32 == 0) or
  * fp32.  Replaces every nn.Linear call on the path -- query/key/value oscar/modeling_bert.py:43-45

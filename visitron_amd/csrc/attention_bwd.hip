@@ -357,6 +357,295 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   }
 }
 
+// 8-wave form: wave w owns keys 32w..32w+31 (one key tile), <= 256 VGPRs, two waves per SIMD.
+__global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h2 = lane >> 5;
+  const int b = blockIdx.y, head = blockIdx.x;
+  const int kb0 = blockIdx.z * 256;   // first key of this workgroup's key block
+  const int S = a.S, H = a.nh * 64;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  const bf16_t* base = a.qkv + (long)b * S * a.ld_qkv + head * 64;
+  const bf16_t* dobase = a.dctx + (long)b * S * a.ld_d + head * 64;
+  const float* lse_p = a.lse + ((long)b * a.nh + head) * S;
+  const float* del_p = a.delta + ((long)b * a.nh + head) * S;
+  const int nslices = (S + 31) >> 5;
+  const int kcount = (S - kb0) < 256 ? (S - kb0) : 256;
+  const int nkt = (kcount + 31) >> 5;  // 32-key steps of this key block for dQ
+
+  // ---- K tile (all keys) -> LDS for the dQ product ----
+  for (int j = wave; j < nkt * 4; j += 8) {  // 8-row pieces
+    const int row = 8 * j + (lane >> 3);
+    int kr = (kb0 + row) < S ? (kb0 + row) : S - 1;
+    const int cs = lane & 7;
+    const int sw = (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;  // 32-B group XOR, in 16-B chunk units
+    glds16(base + (long)kr * a.ld_qkv + H + ((cs ^ sw) << 3), smem + AB_K + j * 1024);
+  }
+  // ---- slice loader: Q and dO rows q0..q0+31 (one 1-KiB piece = 8 rows; waves 0..3 take rows 8w..8w+7) ----
+  // The row constants (lse | delta) are fetched BEFORE the DMA is issued (vmcnt retires in order: a
+  // later register load would make the wave wait for the DMA too) and written to LDS by store_rows().
+  auto load_rows = [&](int sl) -> float {
+    float v = 0.f;
+    if (tid < 64) {
+      const int qq = sl * 32 + (tid & 31);
+      if (tid < 32) v = qq < S ? lse_p[qq] : INFINITY;  // +inf => P = 0 for padded queries
+      else v = qq < S ? del_p[qq] : 0.f;
+    }
+    return v;
+  };
+  auto store_rows = [&](float v, int buf) {
+    if (tid < 64) ((float*)(smem + AB_ROW + buf * 256))[tid] = v;
+  };
+  auto load_slice = [&](int sl, int buf) {
+    const int pw = wave & 3;
+    const int row = 8 * pw + (lane >> 3);
+    int q = sl * 32 + row;
+    q = q < S ? q : S - 1;
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    if (wave < 4) glds16(base + (long)q * a.ld_qkv + (c << 3), smem + AB_Q + buf * 4096 + pw * 1024);
+    else glds16(dobase + (long)q * a.ld_d + (c << 3), smem + AB_DO + buf * 4096 + pw * 1024);
+  };
+  store_rows(load_rows(0), 0);
+  load_slice(0, 0);
+
+  // ---- this wave's K and V fragments (B operands; lane = key) and its key biases ----
+  bf16x8 kf[1][4], vf[1][4];
+  float kbias[1];
+#pragma unroll
+  for (int kt = 0; kt < 1; ++kt) {
+    const int key = kb0 + 32 * wave + r;
+    const int kr = key < S ? key : S - 1;
+    const bf16_t* kp = base + (long)kr * a.ld_qkv + H + 8 * h2;
+    const bf16_t* vp = base + (long)kr * a.ld_qkv + 2 * H + 8 * h2;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      kf[kt][ds] = *(const bf16x8*)(kp + 16 * ds);
+      vf[kt][ds] = *(const bf16x8*)(vp + 16 * ds);
+    }
+    float add = -INFINITY;
+    if (key < S) {
+      add = 0.f;
+      if (a.mask) {
+        const float mval = a.mask[(long)b * S + key];
+        add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
+      }
+    }
+    kbias[kt] = add;
+  }
+
+  f32x16 dv[2][1], dk[2][1];  // [d-tile][key-tile]: lane = key, reg <-> d = 32dt + 16h2 + reg
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 1; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dv[i][j][e] = 0.f; dk[i][j][e] = 0.f; }
+
+  // lane-constant addressing
+  const int a_row = r * 128;                                  // Q / dO row read (A operand of S, dP)
+  const int a_swz = (r >> 1) & 7;
+  const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, dhalf = (lane >> 4) & 1, g = lane >> 4;
+  // transposed slice reads (A operand of dV^T / dK^T): rows q = 16*s2 + 4*h2 + q4 (+8), cols d-perm
+  const int t_row = 4 * h2 + q4;
+  const int t_col = 2 * (16 * (p4 & 1) + 8 * dhalf + 4 * (p4 >> 1));  // + 64*dt, within the 128-B row
+  // slices use the 16-B chunk swizzle (row>>1)&7: as a byte XOR on bits 4..6
+  const int t_sw0 = (((t_row) >> 1) & 7) << 4;          // rows 4h2+q4        (s2 = 0)
+  const int t_sw1 = (((t_row + 8) >> 1) & 7) << 4;      // rows +8
+  const int t_sw2 = (((t_row + 16) >> 1) & 7) << 4;     // s2 = 1
+  const int t_sw3 = (((t_row + 24) >> 1) & 7) << 4;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int sl = 0; sl < nslices; ++sl) {
+    const int buf = sl & 1;
+
+    const char* sQ = smem + AB_Q + buf * 4096;
+    const char* sDO = smem + AB_DO + buf * 4096;
+    const float* rowv = (const float*)(smem + AB_ROW + buf * 256);
+    char* sDS = smem + AB_DS + buf * 16384;
+
+    // A fragments of this slice: Q and dO rows (lane (r, h2): row r, d = 16ds + 8h2 ..)
+    bf16x8 qa[4], da[4];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      qa[ds] = *(const bf16x8*)(sQ + a_row + (((2 * ds + h2) ^ a_swz) << 4));
+      da[ds] = *(const bf16x8*)(sDO + a_row + (((2 * ds + h2) ^ a_swz) << 4));
+    }
+    // per-register row constants: q = (reg&3) + 8(reg>>2) + 4h2
+    f32x4 lse4[4], del4[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      lse4[g4] = *(const f32x4*)(rowv + 8 * g4 + 4 * h2);
+      del4[g4] = *(const f32x4*)(rowv + 32 + 8 * g4 + 4 * h2);
+    }
+    // transposed A operands of the slice: [s2][dt] for dO^T (dV) and Q^T (dK)
+    bf16x8 doT[2][2], qT[2][2];
+    {
+      const unsigned bq = lds0 + AB_Q + buf * 4096 + t_row * 128;
+      const unsigned bd = lds0 + AB_DO + buf * 4096 + t_row * 128;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int cb = t_col + 64 * dt;
+        // rows +8 => +1024 bytes, but the swizzle differs between the two blocks: two explicit reads
+        short4v q0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(bq + (cb ^ t_sw0)));
+        short4v q1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(bq + 1024 + (cb ^ t_sw1)));
+        short4v q2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(bq + 2048 + (cb ^ t_sw2)));
+        short4v q3 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(bq + 3072 + (cb ^ t_sw3)));
+        qT[0][dt] = __builtin_bit_cast(bf16x8, (short8v){q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]});
+        qT[1][dt] = __builtin_bit_cast(bf16x8, (short8v){q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]});
+        short4v d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(bd + (cb ^ t_sw0)));
+        short4v d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(bd + 1024 + (cb ^ t_sw1)));
+        short4v d2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(bd + 2048 + (cb ^ t_sw2)));
+        short4v d3 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(bd + 3072 + (cb ^ t_sw3)));
+        doT[0][dt] = __builtin_bit_cast(bf16x8, (short8v){d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]});
+        doT[1][dt] = __builtin_bit_cast(bf16x8, (short8v){d2[0], d2[1], d2[2], d2[3], d3[0], d3[1], d3[2], d3[3]});
+      }
+    }
+
+    // prefetch the next slice now that this slice's operands are in registers (issuing the DMA before
+    // those LDS reads would make hipcc wait for it first); buffer buf^1 was last read in slice sl-1,
+    // which every wave left through the barrier below
+    float next_rowv = 0.f;
+    if (sl + 1 < nslices) {
+      next_rowv = load_rows(sl + 1);
+      load_slice(sl + 1, buf ^ 1);
+    }
+
+#pragma unroll
+    for (int kt = 0; kt < 1; ++kt) {
+      // S = Q K^T and dP = dO V^T for keys 32w .. 32w+31 (lane = key)
+      f32x16 sacc, dpacc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { sacc[e] = 0.f; dpacc[e] = 0.f; }
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ds], kf[kt][ds], sacc, 0, 0, 0);
+        dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ds], vf[kt][ds], dpacc, 0, 0, 0);
+      }
+      // P = exp(s/8 + mask - lse);  dS = P (dP - delta) / 8
+      f32x16 pacc;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g4 + e;
+          const float s = fmaf(sacc[i], a.scale, kbias[kt]);
+          const float p = __builtin_amdgcn_exp2f((s - lse4[g4][e]) * LOG2E);
+          pacc[i] = p;
+          sacc[i] = p * (dpacc[i] - del4[g4][e]) * a.scale;  // dS' (scale folded in)
+        }
+      // dV^T += dO^T P ; dK^T += Q^T dS'   (k = q, 2 steps of 16)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pb = pack8(pacc, s2);
+        const bf16x8 sb = pack8(sacc, s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[s2][dt], pb, dv[dt][kt], 0, 0, 0);
+          dk[dt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[s2][dt], sb, dk[dt][kt], 0, 0, 0);
+        }
+      }
+      // dS' -> LDS image [q-group G][key][4 q] (8 B per (G,key)), key index XOR-swizzled by G
+      {
+        const int key = 32 * wave + r;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int G = 2 * g4 + h2;
+          const int kx = key ^ (((G >> 1) & 1) << 2) ^ ((G & 1) << 4);
+          u32x2 w;
+          w[0] = pack_bf16x2(sacc[4 * g4 + 0], sacc[4 * g4 + 1]);
+          w[1] = pack_bf16x2(sacc[4 * g4 + 2], sacc[4 * g4 + 3]);
+          *(u32x2*)(sDS + (G * 256 + kx) * 8) = w;
+        }
+      }
+    }
+
+    if (sl + 1 < nslices) store_rows(next_rowv, buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next slice's DMA (issued above) has landed
+    __syncthreads();                                   // ... and every wave's dS' is in the image
+
+    // ---- dQ^T[d][q] = sum_key K^T[d][key] dS'^T[key][q]; wave w: d = 16w .. 16w+15, both 16-q tiles ----
+    f32x4 dq0 = {0.f, 0.f, 0.f, 0.f};
+    const int dqd = wave >> 1, dqq = wave & 1;   // this wave's 16(d) x 16(q) tile of dQ^T
+    {
+      const unsigned kbase = lds0 + AB_K;
+      const unsigned dsb = lds0 + AB_DS + buf * 16384;
+      for (int ks = 0; ks < nkt; ++ks) {
+        const int krow = 32 * ks + 8 * g + q4;  // first block row; second block = +4
+        const int ksw = ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 5);
+        const int ksw2 = (((((krow + 4) >> 1) & 1) | ((((krow + 4) >> 3) & 1) << 1)) << 5);
+        const int kcol = 2 * (16 * dqd) + 8 * p4;
+        short4v k0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(kbase + krow * 128 + (kcol ^ ksw)));
+        short4v k1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(kbase + (krow + 4) * 128 + (kcol ^ ksw2)));
+        const bf16x8 ka = __builtin_bit_cast(bf16x8, (short8v){k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]});
+        {
+          const int qt = dqq;
+          const int G = 4 * qt + p4;
+          const int gsw = (((G >> 1) & 1) << 2) ^ ((G & 1) << 4);
+          short4v s0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(dsb + (G * 256 + (krow ^ gsw)) * 8));
+          short4v s1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(dsb + (G * 256 + ((krow + 4) ^ gsw)) * 8));
+          const bf16x8 sbq = __builtin_bit_cast(bf16x8, (short8v){s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]});
+          dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, sbq, dq0, 0, 0, 0);
+        }
+      }
+    }
+    // store dQ: lane (q_local = lane&15, g): d = 16w + 4g .. +3
+    if (a.dq32 == nullptr) {
+      const int q = sl * 32 + 16 * dqq + (lane & 15);
+      if (q < S) {
+        u32x2 w;
+        w[0] = pack_bf16x2(dq0[0], dq0[1]);
+        w[1] = pack_bf16x2(dq0[2], dq0[3]);
+        *(u32x2*)(a.dqkv + ((long)b * S + q) * a.ld_dqkv + head * 64 + 16 * dqd + 4 * g) = w;
+      }
+    } else {
+      // several key blocks: transpose the slice's dQ^T through LDS, then add whole 256-byte row
+      // segments atomically (lane = d) -- the atomic shape that runs at the full chip-wide rate
+      float* st = (float*)(smem + AB_DQ);
+      *(f32x4*)(st + (16 * dqq + (lane & 15)) * 64 + 16 * dqd + 4 * g) = dq0;
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int ql = 4 * wave + rr;
+        const int q = sl * 32 + ql;
+        if (q < S) atomicAdd(a.dq32 + ((long)b * S + q) * H + head * 64 + lane, st[ql * 64 + lane]);
+      }
+      // the staging tile is rewritten only after the next slice's barrier, which every wave reaches
+      // after these reads
+    }
+    // no barrier needed here: the next slice writes the OTHER dS image / reads the other Q,dO buffers,
+    // and the barrier inside the next slice orders this slice's dQ reads before the image is reused.
+  }
+
+  // ---- dK, dV of this wave's keys: lane = key, reg <-> d = 32dt + 16h2 + reg ----
+#pragma unroll
+  for (int kt = 0; kt < 1; ++kt) {
+    const int key = kb0 + 32 * wave + r;
+    if (key >= S) continue;
+    bf16_t* orow = a.dqkv + ((long)b * S + key) * a.ld_dqkv + head * 64 + 16 * h2;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      u32x4 k0, k1, v0, v1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        k0[i] = pack_bf16x2(dk[dt][kt][2 * i], dk[dt][kt][2 * i + 1]);
+        k1[i] = pack_bf16x2(dk[dt][kt][8 + 2 * i], dk[dt][kt][8 + 2 * i + 1]);
+        v0[i] = pack_bf16x2(dv[dt][kt][2 * i], dv[dt][kt][2 * i + 1]);
+        v1[i] = pack_bf16x2(dv[dt][kt][8 + 2 * i], dv[dt][kt][8 + 2 * i + 1]);
+      }
+      ((u32x4*)(orow + H + 32 * dt))[0] = k0;
+      ((u32x4*)(orow + H + 32 * dt))[1] = k1;
+      ((u32x4*)(orow + 2 * H + 32 * dt))[0] = v0;
+      ((u32x4*)(orow + 2 * H + 32 * dt))[1] = v1;
+    }
+  }
+}
+
 // delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]   (one wave per token row; 64 d per head = 8 lanes x 8)
 __global__ __launch_bounds__(256) void attn_delta_rows(const bf16_t* __restrict__ d_o, long ld_d, const bf16_t* __restrict__ o,
                                                        long ld_o, float* __restrict__ delta, int B, int S, int nh) {
@@ -394,6 +683,9 @@ __global__ __launch_bounds__(256) void attn_dq_round(const float* __restrict__ d
   *(u32x4*)(dqkv + row * ld_dqkv + col) = o;
 }
 
+static int g_attn_bwd_waves = 8;
+void vt_attn_bwd_set_waves(int w) { g_attn_bwd_waves = (w == 4) ? 4 : 8; }
+
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
                               long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream) {
@@ -421,7 +713,17 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   if (nkb > 1 && hipMemsetAsync(dq32_ws, 0, (size_t)rows * nh * 64 * sizeof(float), stream) != hipSuccess) return VT_ERR_HIP;
   a.ld_qkv = ld_qkv; a.ld_d = ld_d; a.ld_dqkv = ld_dqkv; a.B = B; a.S = S; a.nh = nh;
   a.scale = 1.0f / sqrtf((float)head_size);
-  hipLaunchKernelGGL(attention_bwd_d64, dim3(nh, B, nkb), dim3(256), AB_LDS_BYTES, stream, a);
+  if (g_attn_bwd_waves == 4) {
+    hipLaunchKernelGGL(attention_bwd_d64, dim3(nh, B, nkb), dim3(256), AB_LDS_BYTES, stream, a);
+  } else {
+    static bool attr8 = false;
+    if (!attr8) {
+      if (hipFuncSetAttribute((const void*)attention_bwd_d64_w8, hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_BYTES) != hipSuccess)
+        return VT_ERR_HIP;
+      attr8 = true;
+    }
+    hipLaunchKernelGGL(attention_bwd_d64_w8, dim3(nh, B, nkb), dim3(512), AB_LDS_BYTES, stream, a);
+  }
   if (nkb > 1) {
     const long n = rows * (nh * 8);
     hipLaunchKernelGGL(attn_dq_round, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dq32_ws, (bf16_t*)dqkv, ld_dqkv,

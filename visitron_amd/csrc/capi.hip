@@ -34,6 +34,7 @@ int vt_pack_concat_dispatch(const float* s0, int d0, const float* s1, int d1, vo
 
 void vt_gemm_set_variant(int v);
 void vt_gemm_tune_set(int M, int N, int K, int act, int variant);
+void vt_attn_bwd_set_waves(int w);
 
 #define WG_MAX_PROBLEMS 8
 struct WgradProblem {
@@ -71,6 +72,7 @@ int vt_abi_version(void) { return 1; }
 
 void vt_debug_set_gemm_variant(int variant) { vt_gemm_set_variant(variant); }
 void vt_gemm_tune(int M, int N, int K, int act, int variant) { vt_gemm_tune_set(M, N, K, act, variant); }
+void vt_debug_set_attn_bwd_waves(int waves) { vt_attn_bwd_set_waves(waves); }
 
 int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* R,
                    int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int act, int out_f32, int grp_rows,
