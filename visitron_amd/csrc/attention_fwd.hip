@@ -7,7 +7,8 @@
 // The additive mask is computed here from the caller's raw mask exactly as
 // tasks/viewpoint_select/encoder.py:238-241 does: (1.0 - mask) * -10000.0 (any numeric mask).
 //
-// gfx950 design.  One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32
+// gfx950 design.  One workgroup = 8 waves = 256 queries of one (batch, head) (the whole sequence at
+// S = 228, so K and V are staged once per head); each wave owns 32
 // queries and keeps the QUERY on the MFMA lane for both products (v_mfma_f32_32x32x16_bf16):
 //   S^T[key][query]  = K . Q^T        A = K rows (ds_read_b128 from a swizzled LDS tile), B = Q (registers)
 //   O^T[d][query]   += V^T . P^T      B = P^T taken straight from the S^T accumulators (no LDS,
@@ -48,7 +49,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 2) void attention_fwd_d64(AttnArgs a) {
+__global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_d64(AttnArgs a) {
   const int r = lane & 31, h2 = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int S = a.S, H = a.nh * 64;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * 256 + wave * 32;
   const bool wave_active = q0 < S;  // wave-uniform
 
   const bf16_t* base = a.qkv + (long)b * S * a.ld_qkv + head * 64;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_d64(AttnArgs a) {
     if (kc > 0) __syncthreads();  // previous chunk fully consumed
 
     // ---- stage K, V (8-row pieces, one 1-KiB DMA each) and the additive bias ----
-    for (int j = wave; j < ntiles * 4; j += 4) {
+    for (int j = wave; j < ntiles * 4; j += 8) {
       const int row = 8 * j + (lane >> 3);
       int kr = kc + row;
       kr = kr < S ? kr : S - 1;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_d64(AttnArgs a) {
       glds16(src + H + ((cs ^ ((row >> 1) & 7)) << 3), smem + ATT_SK + j * 1024);
       glds16(src + 2 * H + ((cs ^ (((row >> 1) & 1) << 2)) << 3), smem + ATT_SV + j * 1024);
     }
-    {
+    if (tid < ATT_KCHUNK) {
       const int key = kc + tid;
       float bias = -INFINITY;
       if (key < S) {
@@ -213,7 +214,7 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = (bf16_t*)ctx; a.lse = lse;
   a.ld_qkv = ld_qkv; a.ld_ctx = ld_ctx; a.B = B; a.S = S; a.nh = nh;
   a.scale = 1.0f / sqrtf((float)head_size);
-  dim3 grid((S + 127) / 128, nh, B);
-  hipLaunchKernelGGL(attention_fwd_d64, grid, dim3(256), ATT_LDS_BYTES, stream, a);
+  dim3 grid((S + 255) / 256, nh, B);
+  hipLaunchKernelGGL(attention_fwd_d64, grid, dim3(512), ATT_LDS_BYTES, stream, a);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
