@@ -97,7 +97,7 @@ int vt_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
                       int grp_rows, int grp_stride, vt_stream_t stream);
 
 /* Backward of vt_layernorm_bf16: dx, and dgamma / dbeta (fp32, overwritten or accumulated).  x is the
- * pre-LayerNorm input (statistics are recomputed).  partial_ws: fp32 scratch of 512 * 2 * H floats. */
+ * pre-LayerNorm input (statistics are recomputed).  partial_ws: fp32 scratch of 1024 * 2 * H floats. */
 int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* gamma,
                           void* dx, int64_t lddx, float* dgamma, float* dbeta, float* partial_ws, int M, int H,
                           float eps, int accumulate, vt_stream_t stream);
@@ -117,7 +117,7 @@ int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_
 
 /* Backward of vt_embed_layernorm: de[B*T,H] fp32 = gradient w.r.t. (word + pos + type) per token (for
  * the three table scatter-adds), dgamma / dbeta of the embedding LayerNorm.  g: gradient rows b*S+t
- * of the [B,S,H] bf16 buffer.  partial_ws: 512 * 2 * H floats. */
+ * of the [B,S,H] bf16 buffer.  partial_ws: 1024 * 2 * H floats. */
 int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
                            const float* word, const float* pos, const float* type, const float* gamma,
                            const void* g, int64_t ldg, float* de, float* dgamma, float* dbeta, float* partial_ws,
@@ -208,7 +208,7 @@ typedef struct vt_bwd_workspace {
   void* g_ctx;   /* [M,H]  bf16 */
   void* g_qkv;   /* [M,3H] bf16 */
   float* delta;      /* [B,nh,S] */
-  float* ln_partial; /* [512*2*H] */
+  float* ln_partial; /* [1024*2*H] */
   float* dq32;       /* [M,H] fp32, required when S > 256 (else may be NULL) */
 } vt_bwd_workspace;
 

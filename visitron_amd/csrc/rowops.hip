@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ p
   }
 }
 
-#define LN_BWD_MAX_BLOCKS 512
+#define LN_BWD_MAX_BLOCKS 1024
 int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
                               hipStream_t stream) {

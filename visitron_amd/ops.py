@@ -11,7 +11,7 @@ from . import _lib
 
 BF16 = torch.bfloat16
 ACT_NONE, ACT_GELU, ACT_TANH, ACT_MUL = 0, 1, 2, 3
-LN_BWD_WS_ROWS = 512  # vt_layernorm_bwd_bf16 scratch = LN_BWD_WS_ROWS * 2 * H floats
+LN_BWD_WS_ROWS = 1024  # vt_layernorm_bwd_bf16 scratch = LN_BWD_WS_ROWS * 2 * H floats
 
 
 # ---- optional per-launch timing (HIP events on the launch stream); used by bench.py only ----------
