@@ -132,6 +132,13 @@ int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, in
                   float step_size, float b1, float b2, float eps, float wd, float grad_scale,
                   vt_stream_t stream);
 
+/* Fused softmax cross-entropy rows for the MLM head (tasks/viewpoint_select/encoder.py:387-389, argmax
+ * :399, and the criterion's backward): loss_row[r] = logsumexp(z[r, :V]) - z[r, y[r]], amax[r] =
+ * argmax(z[r, :V]) (first index on ties), dz[r, :Vpad] = bf16((softmax(z[r]) - onehot(y[r])) * scale),
+ * columns V..Vpad-1 zero.  z fp32 [rows, ldz], labels must be valid (0 <= y < V). */
+int vt_ce_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz,
+                       int64_t lddz, int64_t rows, int V, int Vpad, float scale, vt_stream_t stream);
+
 /* out[c, r] = in[r, c] (bf16; R, C multiples of 8): refreshes the transposed weight copies that the
  * dgrad GEMMs consume (vt_layer_weights_t). */
 int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream);

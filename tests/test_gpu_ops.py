@@ -353,3 +353,26 @@ def test_transpose(dev, R, C):
     out = torch.zeros((C, R), dtype=BF16, device=dev)
     ops.transpose(xd, out)
     assert torch.equal(out, xd.t().contiguous())
+
+
+@pytest.mark.parametrize("rows,V", [(37, 30522), (5, 97), (3, 8), (64, 1601)])
+def test_fused_ce_rows(dev, rows, V):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(V)
+    Vp = (V + 63) // 64 * 64
+    z = torch.zeros(rows, Vp)
+    z[:, :V] = _rand((rows, V), g, 3.0)
+    z[0, min(5, V - 1)] = z[0, :V].max() + 1  # a clear argmax
+    y = torch.randint(0, V, (rows,), generator=g)
+    zr = z[:, :V].clone().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(zr, y, reduction="none")
+    (loss.sum() * 0.25).backward()
+    dz = torch.full((rows, Vp), 7.0, dtype=BF16, device=dev)
+    lr, am = ops.ce_softmax_rows(z.to(dev), y.to(dev), V, dz, 0.25)
+    torch.cuda.synchronize()
+    assert maxabs(lr, loss) < 1e-4 * (1 + float(loss.abs().max()))
+    assert torch.equal(am.cpu(), z[:, :V].argmax(1))
+    assert maxabs(dz[:, :V], zr.grad) < 4e-3 * float(zr.grad.abs().max()) + 1e-6
+    if Vp > V:
+        assert float(dz[:, V:].float().abs().max()) == 0.0

@@ -17,6 +17,8 @@ int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids,
                                     const float* pos, const float* type, const float* gamma, const void* g, long ldg,
                                     float* de, float* dgamma, float* dbeta, float* partial_ws, int B, int T, int S, int H,
                                     int n_word, int n_pos, int n_type, float eps, int accumulate, hipStream_t stream);
+int vt_ce_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, long lddz,
+                           long rows, int V, int Vpad, float scale, hipStream_t stream);
 int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, int C, hipStream_t stream);
 int vt_adamw_dispatch(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float step_size, float b1,
                       float b2, float eps, float wd, float grad_scale, hipStream_t stream);
@@ -114,6 +116,11 @@ int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const in
 int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float step_size, float b1,
                   float b2, float eps, float wd, float grad_scale, vt_stream_t stream) {
   return vt_adamw_dispatch(p, g, m, v, p_bf16, n, lr, step_size, b1, b2, eps, wd, grad_scale, (hipStream_t)stream);
+}
+
+int vt_ce_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, int64_t lddz,
+                       int64_t rows, int V, int Vpad, float scale, vt_stream_t stream) {
+  return vt_ce_softmax_dispatch(z, ldz, y, loss_row, amax, dz, lddz, rows, V, Vpad, scale, (hipStream_t)stream);
 }
 
 int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream) {

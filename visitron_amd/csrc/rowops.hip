@@ -659,3 +659,96 @@ int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, 
                      (bf16_t*)out, ldo, R, C);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Fused softmax cross-entropy over the MLM logits (tasks/viewpoint_select/encoder.py:387-389 + the
+// argmax of :399 + the backward of the criterion): per supervised row, ONE kernel produces
+//   loss_row = logsumexp(z) - z[y],  argmax(z),  dz = (softmax(z) - onehot(y)) * scale   (bf16, zero-padded)
+// instead of torch's log_softmax / exp / scatter / mul / cast passes over a [rows, 30522] fp32 tensor.
+// One 256-thread workgroup per row; the row (<= 122 KB) is read twice (second pass from L2).
+__global__ __launch_bounds__(256) void ce_softmax_rows(const float* __restrict__ z, long ldz, const int64_t* __restrict__ y,
+                                                       float* __restrict__ loss_row, int64_t* __restrict__ amax,
+                                                       bf16_t* __restrict__ dz, long lddz, int V, int Vpad, float scale) {
+  __shared__ float red_m[4], red_s[4], red_bv[4];
+  __shared__ int red_bi[4];
+  const long row = blockIdx.x;
+  const float* zp = z + row * ldz;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // pass 1: online max / sum-exp, and argmax (first index on ties, as torch.argmax)
+  float m = -INFINITY, s = 0.f, bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = tid * 4; c < V; c += 1024) {
+    float v[4];
+    if (c + 4 <= V) {
+      const f32x4 t = *(const f32x4*)(zp + c);
+      v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = (c + i < V) ? zp[c + i] : -INFINITY;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (v[i] > bv) { bv = v[i]; bi = c + i; }
+      const float mn = fmaxf(m, v[i]);
+      s = s * __expf(m - mn) + __expf(v[i] - mn);
+      m = mn;
+    }
+  }
+  // wave reduce (m, s) and (bv, bi)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mn = fmaxf(m, m2);
+    s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+    const float bv2 = __shfl_xor(bv, o, 64);
+    const int bi2 = __shfl_xor(bi, o, 64);
+    if (bv2 > bv || (bv2 == bv && bi2 < bi)) { bv = bv2; bi = bi2; }
+  }
+  if (lane == 0) { red_m[wave] = m; red_s[wave] = s; red_bv[wave] = bv; red_bi[wave] = bi; }
+  __syncthreads();
+  m = red_m[0]; s = red_s[0]; bv = red_bv[0]; bi = red_bi[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const float mn = fmaxf(m, red_m[w]);
+    s = s * __expf(m - mn) + red_s[w] * __expf(red_m[w] - mn);
+    m = mn;
+    if (red_bv[w] > bv || (red_bv[w] == bv && red_bi[w] < bi)) { bv = red_bv[w]; bi = red_bi[w]; }
+  }
+  const float lse = m + __logf(s);
+  const int64_t label = y[row];
+  if (tid == 0) {
+    loss_row[row] = lse - zp[label];
+    amax[row] = bi;
+  }
+  // pass 2: gradient row
+  bf16_t* dp = dz + row * lddz;
+  for (int c = tid * 8; c < Vpad; c += 2048) {
+    float g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int col = c + i;
+      float p = 0.f;
+      if (col < V) {
+        p = __expf(zp[col] - lse);
+        if (col == (int)label) p -= 1.0f;
+        p *= scale;
+      }
+      g[i] = p;
+    }
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(g[2 * i], g[2 * i + 1]);
+    *(u32x4*)(dp + c) = o;
+  }
+}
+
+int vt_ce_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, long lddz,
+                           long rows, int V, int Vpad, float scale, hipStream_t stream) {
+  if (!z || !y || !loss_row || !amax || !dz) return VT_ERR_NULL;
+  if (rows <= 0 || V <= 0 || Vpad < V || (Vpad % 8) || lddz < Vpad) return VT_ERR_BAD_SHAPE;
+  if ((ldz % 4) || (lddz % 8) || (((uintptr_t)z | (uintptr_t)dz) & 15)) return VT_ERR_BAD_ALIGN;
+  hipLaunchKernelGGL(ce_softmax_rows, dim3((unsigned)rows), dim3(256), 0, stream, z, ldz, y, loss_row, amax, (bf16_t*)dz, lddz,
+                     V, Vpad, scale);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

@@ -292,6 +292,20 @@ def adamw_flat(p, g, m, v, p_bf16, lr, step_size, b1, b2, eps, wd, grad_scale=1.
     _lib.check(rc, "vt_adamw_flat")
 
 
+def ce_softmax_rows(z, y, V, dz, scale):
+    """Fused CE over logits z fp32 [rows, >=V] with labels y: returns (loss_row fp32 [rows], argmax int64 [rows])
+    and fills dz bf16 [rows, Vpad] with (softmax - onehot) * scale."""
+    _require_hip(z, y, dz)
+    rows = z.shape[0]
+    loss = torch.empty(rows, dtype=torch.float32, device=z.device)
+    amax = torch.empty(rows, dtype=torch.int64, device=z.device)
+    with _timed("ce_softmax_rows", 0.0, rows * (8.0 * V + 2.0 * dz.shape[1])):
+        rc = _lib.load().vt_ce_softmax_rows(_ptr(z), z.stride(0), _ptr(y), _ptr(loss), _ptr(amax), _ptr(dz), dz.stride(0),
+                                            rows, V, dz.shape[1], float(scale), _stream())
+    _lib.check(rc, "vt_ce_softmax_rows")
+    return loss, amax
+
+
 def transpose(src, out):
     """out[c, r] = src[r, c] (bf16 2-D, row strides allowed)."""
     _require_hip(src, out)

@@ -341,10 +341,11 @@ class PretrainEngine(object):
                                pr.transform.LayerNorm.variance_epsilon)
             logits = torch.empty((Ml, self.Vp), dtype=torch.float32, device=dev)
             ops.linear(t2, self._mirror(pr.decoder.weight), pr.bias.detach(), out=logits, out_f32=True)
-            lw = logits[:, :V]
-            logp = torch.log_softmax(lw, dim=-1)
-            mask_loss = -logp.gather(1, y_w[:, None]).mean()
-            words_acc = (lw.argmax(1) == y_w).sum().float() / Ml
+            # fused CE: per-row loss, argmax and the gradient (softmax - onehot) * grad_scale / Ml in one kernel
+            dl = torch.empty((Ml, self.Vp), dtype=BF16, device=dev)
+            loss_rows, amax_w = ops.ce_softmax_rows(logits, y_w, V, dl, float(grad_scale) / Ml)
+            mask_loss = loss_rows.mean()
+            words_acc = (amax_w == y_w).sum().float() / Ml
         else:
             mask_loss = zero / zero  # CrossEntropyLoss over no valid target is nan, as in the reference
             words_acc = zero / zero
@@ -390,10 +391,6 @@ class PretrainEngine(object):
             if dec_w_is_tied:
                 self._grad(pr.bias).zero_()  # shares the accumulate flag of the tied decoder weight below
         if Ml > 0:
-            dl = torch.zeros((Ml, self.Vp), dtype=BF16, device=dev)
-            sm = torch.exp(logp)
-            sm.scatter_add_(1, y_w[:, None], torch.full((Ml, 1), -1.0, device=dev))
-            dl[:, :V] = (sm * (gs / Ml)).to(BF16)
             dec_grad = self._grad(pr.decoder.weight)
             ops.wgrad([dict(dy=dl[:, :V], x=t2, dw=dec_grad, db=self._grad(pr.bias), accumulate=acc or dec_w_is_tied)], Ml)
             g_t2 = ops.linear(dl, self.head_t["dec"])
