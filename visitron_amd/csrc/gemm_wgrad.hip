@@ -38,22 +38,33 @@ struct WgradArgs {
   int M;
 };
 
-#define WG_TILE_BYTES (64 * 256)
-#define WG_STAGE_BYTES (2 * WG_TILE_BYTES)
-#define WG_LDS_BYTES (2 * WG_STAGE_BYTES)
+#define WG_TILE_BYTES (64 * 256)   // X tile: 64 rows x 128 columns
+// TN = width of the dY tile (n-range of the output tile): 128 (4 waves) or 256 (8 waves, 85 instead of 64
+// FLOP per staged byte; a layer's four matrices are then 216 tiles = one round on 256 CUs)
+template <int TN> struct WgCfg {
+  static constexpr int PITCH_Y = TN * 2;               // bytes per dY tile row
+  static constexpr int TILE_Y = 64 * PITCH_Y;
+  static constexpr int STAGE = TILE_Y + WG_TILE_BYTES; // dY tile then X tile
+  static constexpr int LDS = 2 * STAGE;
+  static constexpr int WAVES = TN / 32;                // (TN/64) x 2
+  static constexpr int NPY = (TILE_Y / 1024) / WAVES;  // dY DMA pieces per wave per stage (4)
+  static constexpr int NPX = 16 / WAVES;               // X DMA pieces per wave per stage (4 or 2)
+};
 
 __device__ __forceinline__ int wg_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-__device__ __forceinline__ bf16x8 tr_frag(unsigned addr) {
+__device__ __forceinline__ bf16x8 tr_frag(unsigned addr, int pitch) {
   // rows m..m+3 and m+4..m+7 of a 16-column block, delivered column-major: 8 bf16 along m per lane
   short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)addr);
-  short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(addr + 4 * 256));
+  short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(uintptr_t)(addr + 4 * pitch));
   typedef __attribute__((ext_vector_type(8))) short short8v;
   short8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_wgrad_tn_bf16(WgradArgs a) {
+template <int TN>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
+  using C = WgCfg<TN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -76,12 +87,12 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tn_bf16(WgradArgs a) {
   const WgradProblem& P = a.p[pi];
   const int lt = t_id - P.tile_begin;
   const int bn = lt / P.tiles_k, bk = lt - bn * P.tiles_k;
-  const int n0 = bn * 128, k0 = bk * 128;
+  const int n0 = bn * TN, k0 = bk * 128;
   const int M = a.M;
 
   // buffer descriptors: base at the tile's first column; rows >= M (and columns past the row end of
   // the last row) fall outside num_records and read as zero
-  const int ncols_y = (P.N - n0) < 128 ? (P.N - n0) : 128;
+  const int ncols_y = (P.N - n0) < TN ? (P.N - n0) : TN;
   const int ncols_x = (P.K - k0) < 128 ? (P.K - k0) : 128;
   // whole 16-B chunks must be in range (a partially out-of-range dwordx4 reads as zero): round the
   // column count up to 8; ld % 8 == 0 keeps that inside the last row's storage
@@ -90,16 +101,24 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tn_bf16(WgradArgs a) {
   __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dY + n0), 0, (int)bytes_y, 0x00020000);
   __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(P.X + k0), 0, (int)bytes_x, 0x00020000);
 
-  // DMA pieces: a 64x256B tile = 16 pieces of 1 KiB (4 rows each); wave w moves pieces 4w..4w+3.
-  // LDS slot (row, cs) holds logical 16-B chunk c = cs ^ (swz(row) << 1).  Columns past the matrix
-  // edge are redirected out of range (zero fill).
-  int voff_y[4], voff_x[4];
+  // DMA pieces of 1 KiB: the X tile (256-B rows) in 16 pieces of 4 rows; the dY tile in pieces of
+  // 1024 / PITCH_Y rows.  LDS slot (row, cs) holds logical 16-B chunk c = cs ^ (swz(row) << 1) (the XOR
+  // stays inside a 256-B window).  Columns past the matrix edge are redirected out of range (zero fill).
+  int voff_y[C::NPY], voff_x[C::NPX];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pce = wave * 4 + i;
+  for (int i = 0; i < C::NPY; ++i) {
+    const int pce = wave * C::NPY + i;
+    constexpr int RPP = 1024 / C::PITCH_Y;        // rows per piece (4 or 2)
+    constexpr int CPR = C::PITCH_Y / 16;          // chunks per row (16 or 32)
+    const int row = pce * RPP + lane / CPR;
+    const int c = (lane % CPR) ^ (wg_swz(row) << 1);
+    voff_y[i] = (c * 8 < ncols_y) ? (int)(row * P.ldy * 2 + c * 16) : 0x7fffffff;
+  }
+#pragma unroll
+  for (int i = 0; i < C::NPX; ++i) {
+    const int pce = wave * C::NPX + i;
     const int row = pce * 4 + (lane >> 4);
     const int c = (lane & 15) ^ (wg_swz(row) << 1);
-    voff_y[i] = (c * 8 < ncols_y) ? (int)(row * P.ldy * 2 + c * 16) : 0x7fffffff;
     voff_x[i] = (c * 8 < ncols_x) ? (int)(row * P.ldx * 2 + c * 16) : 0x7fffffff;
   }
   const int step_y = (int)(64 * P.ldy * 2), step_x = (int)(64 * P.ldx * 2);
@@ -113,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tn_bf16(WgradArgs a) {
   unsigned y_addr[4], x_addr[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    y_addr[t] = lds0 + frow * 256 + ((((64 * wn + 16 * t) * 2) + 8 * p4) ^ fsw);
-    x_addr[t] = lds0 + WG_TILE_BYTES + frow * 256 + ((((64 * wk + 16 * t) * 2) + 8 * p4) ^ fsw);
+    y_addr[t] = lds0 + frow * C::PITCH_Y + ((((64 * wn + 16 * t) * 2) + 8 * p4) ^ fsw);
+    x_addr[t] = lds0 + C::TILE_Y + frow * 256 + ((((64 * wk + 16 * t) * 2) + 8 * p4) ^ fsw);
   }
 
   f32x4 acc[4][4];
@@ -132,33 +151,35 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tn_bf16(WgradArgs a) {
 
   const int nk = (M + 63) >> 6;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, LDS_PTR(smem + (wave * 4 + i) * 1024), 16, voff_y[i], 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + WG_TILE_BYTES + (wave * 4 + i) * 1024), 16, voff_x[i], 0, 0, 0);
-  }
+  for (int i = 0; i < C::NPY; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, LDS_PTR(smem + (wave * C::NPY + i) * 1024), 16, voff_y[i], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < C::NPX; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + C::TILE_Y + (wave * C::NPX + i) * 1024), 16, voff_x[i], 0, 0, 0);
 
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const unsigned so = (kt & 1) * WG_STAGE_BYTES;
+    const unsigned so = (kt & 1) * C::STAGE;
 
     bf16x8 yf[2][4], xf[2][4];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        yf[ks][t] = tr_frag(y_addr[t] + so + ks * (32 * 256));
-        xf[ks][t] = tr_frag(x_addr[t] + so + ks * (32 * 256));
+        yf[ks][t] = tr_frag(y_addr[t] + so + ks * (32 * C::PITCH_Y), C::PITCH_Y);
+        xf[ks][t] = tr_frag(x_addr[t] + so + ks * (32 * 256), 256);
       }
 
     if (kt + 1 < nk) {
-      char* nb = smem + ((kt + 1) & 1) * WG_STAGE_BYTES;
+      char* nb = smem + ((kt + 1) & 1) * C::STAGE;
       const int sy = (kt + 1) * step_y, sx = (kt + 1) * step_x;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, LDS_PTR(nb + (wave * 4 + i) * 1024), 16, voff_y[i], sy, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(nb + WG_TILE_BYTES + (wave * 4 + i) * 1024), 16, voff_x[i], sx, 0, 0);
-      }
+      for (int i = 0; i < C::NPY; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, LDS_PTR(nb + (wave * C::NPY + i) * 1024), 16, voff_y[i], sy, 0, 0);
+#pragma unroll
+      for (int i = 0; i < C::NPX; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(nb + C::TILE_Y + (wave * C::NPX + i) * 1024), 16, voff_x[i], sx, 0, 0);
     }
 
 #pragma unroll
@@ -205,9 +226,31 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tn_bf16(WgradArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_tn_bf16(WgradArgs a) { wgrad_body<128>(a); }
+__global__ __launch_bounds__(512, 2) void gemm_wgrad_tn_bf16_w256(WgradArgs a) { wgrad_body<256>(a); }
+
 // Host entry.  problems: array of `nprob` WgradProblem-like records filled by capi.hip.
+static int g_wgrad_tn = 0;  // 0: choose; 128 / 256: forced (tuning hook)
+void vt_wgrad_set_tile(int tn) { g_wgrad_tn = tn; }
+
+template <int TN>
+static int wgrad_launch(WgradArgs& a, int total, hipStream_t stream) {
+  if (TN == 256) {
+    if (hipFuncSetAttribute((const void*)gemm_wgrad_tn_bf16_w256, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<256>::LDS) != hipSuccess) return VT_ERR_HIP;
+    hipLaunchKernelGGL(gemm_wgrad_tn_bf16_w256, dim3(total), dim3(512), WgCfg<256>::LDS, stream, a);
+  } else {
+    if (hipFuncSetAttribute((const void*)gemm_wgrad_tn_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg<128>::LDS) != hipSuccess) return VT_ERR_HIP;
+    hipLaunchKernelGGL(gemm_wgrad_tn_bf16, dim3(total), dim3(256), WgCfg<128>::LDS, stream, a);
+  }
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
 int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream) {
   if (a.nprob <= 0 || a.nprob > WG_MAX_PROBLEMS || a.M <= 0) return VT_ERR_BAD_SHAPE;
+  // 128-wide n-tiles by default: the 256-wide form (8 waves, one workgroup per CU) measured 24 % SLOWER on
+  // the encoder layer group (15.2 vs 12.2 ms per step at B=256) and is kept only behind the tuning hook
+  int tn = 128;
+  if (g_wgrad_tn == 128 || g_wgrad_tn == 256) tn = g_wgrad_tn;
   int total = 0;
   for (int i = 0; i < a.nprob; ++i) {
     WgradProblem& P = a.p[i];
@@ -218,14 +261,7 @@ int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream) {
     if ((long)a.M * P.ldy * 2 >= (1L << 31) || (long)a.M * P.ldx * 2 >= (1L << 31)) return VT_ERR_UNSUPPORTED;
     P.tiles_k = (P.K + 127) / 128;
     P.tile_begin = total;
-    total += ((P.N + 127) / 128) * P.tiles_k;
+    total += ((P.N + tn - 1) / tn) * P.tiles_k;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_wgrad_tn_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES) != hipSuccess)
-      return VT_ERR_HIP;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_wgrad_tn_bf16, dim3(total), dim3(256), WG_LDS_BYTES, stream, a);
-  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+  return tn == 256 ? wgrad_launch<256>(a, total, stream) : wgrad_launch<128>(a, total, stream);
 }
