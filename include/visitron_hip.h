@@ -64,7 +64,22 @@ int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const
  * and act == VT_ACT_MUL (out = acc * R). */
 int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                       const void* R, int64_t ldr, void* C, int64_t ldc, void* C2, int64_t ldc2, int M, int N,
-                      int K, int act, int out_f32, int grp_rows, int grp_stride, vt_stream_t stream);
+                      int K, int act, int out_f32, int grp_rows, int grp_stride, float drop_p, uint64_t drop_seed,
+                      uint32_t drop_site, vt_stream_t stream);
+
+/* ---- dropout (nn.Dropout of BertEmbeddings / BertSelfOutput / BertOutput / the image embedding,
+ * tasks/viewpoint_select/encoder.py:284, and the attention-probability dropout oscar/modeling_bert.py:62).
+ * Every kernel that applies dropout takes (p, step seed, site): keep(element) is a counter-based hash of
+ * (seed, site, element index), kept values are scaled by 1/(1-p), and the backward kernels recompute the
+ * mask instead of storing it.  p = 0 disables it.  Sites: 8*layer + {0 attention probabilities,
+ * 1 attention.output, 2 output}; 0xE0 embeddings; 0xE1 image embedding.  In vt_linear_bf16_ex the
+ * dropout is applied to act(acc + bias) BEFORE the residual add, element index m * N + n. */
+int vt_apply_dropout_bf16(void* x, int64_t ld, int64_t rows, int cols, float drop_p, uint64_t drop_seed,
+                          uint32_t drop_site, vt_stream_t stream);
+/* Test hook: out[i] = 1 if element i of the site is kept (head_index = b*nh + h for attention sites where
+ * element i = q * S + key, else -1). */
+int vt_debug_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, uint32_t drop_site,
+                          int head_index, vt_stream_t stream);
 
 /* Fused scaled-dot-product attention, head size 64 (oscar/modeling_bert.py:47-72):
  * ctx[b,s,h*64:(h+1)*64] = softmax_k(q.k / 8 + (1 - mask[b,k]) * -10000) . v  [* head_scale[h]].
@@ -75,7 +90,8 @@ int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, co
  * the natural-log log-sum-exp of the masked scores for the backward pass. */
 int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive,
                           const float* head_scale, void* ctx, int64_t ld_ctx, float* lse, int B, int S,
-                          int nh, int head_size, vt_stream_t stream);
+                          int nh, int head_size, float drop_p, uint64_t drop_seed, uint32_t drop_site,
+                          vt_stream_t stream);
 
 /* Backward of vt_attention_fwd_bf16: dqkv = dq | dk | dv packed like qkv.  ctx is the forward output,
  * lse its saved log-sum-exp, delta_ws a [B,nh,S] fp32 scratch (rowsum(dctx*ctx) is computed into it).
@@ -86,7 +102,7 @@ int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, in
 int vt_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
                           int64_t ld_ctx, const float* mask, int mask_additive, const float* lse,
                           float* delta_ws, void* dqkv, int64_t ld_dqkv, float* dq32_ws, int B, int S, int nh,
-                          int head_size, vt_stream_t stream);
+                          int head_size, float drop_p, uint64_t drop_seed, uint32_t drop_site, vt_stream_t stream);
 
 /* y = BertLayerNorm(x) over rows of H (biased variance, eps inside the sqrt); x already holds
  * dense(h) + bias + residual.  BertSelfOutput / BertOutput LayerNorm (called at
@@ -100,7 +116,10 @@ int vt_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
  * pre-LayerNorm input (statistics are recomputed).  partial_ws: fp32 scratch of 1024 * 2 * H floats. */
 int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* gamma,
                           void* dx, int64_t lddx, float* dgamma, float* dbeta, float* partial_ws, int M, int H,
-                          float eps, int accumulate, vt_stream_t stream);
+                          float eps, int accumulate, void* dx_dropped, int64_t lddxd, float drop_p,
+                          uint64_t drop_seed, uint32_t drop_site, vt_stream_t stream);
+/* (dx_dropped, optional: dx * mask / (1-p) of the given site = the gradient of the dense output that was
+ * dropped out before the residual add.) */
 
 /* out = g * d, bf16, n elements (n % 8 == 0), d = saved gelu' values: the dGELU of the MLM-head transform. */
 int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_stream_t stream);
@@ -112,8 +131,8 @@ int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_str
 int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
                        const float* word, const float* pos, const float* type, const float* gamma,
                        const float* beta, void* y, int64_t ldy, int B, int T, int S, int H,
-                       int n_word, int n_pos, int n_type, float eps, int* err_flag,
-                       vt_stream_t stream);
+                       int n_word, int n_pos, int n_type, float eps, int* err_flag, float drop_p,
+                       uint64_t drop_seed, vt_stream_t stream);
 
 /* Backward of vt_embed_layernorm: de[B*T,H] fp32 = gradient w.r.t. (word + pos + type) per token (for
  * the three table scatter-adds), dgamma / dbeta of the embedding LayerNorm.  g: gradient rows b*S+t
@@ -122,7 +141,7 @@ int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const in
                            const float* word, const float* pos, const float* type, const float* gamma,
                            const void* g, int64_t ldg, float* de, float* dgamma, float* dbeta, float* partial_ws,
                            int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
-                           int accumulate, vt_stream_t stream);
+                           int accumulate, float drop_p, uint64_t drop_seed, vt_stream_t stream);
 
 /* Fused AdamW over a flat fp32 slab of n parameters (n % 4 == 0), the pytorch-transformers rule of
  * tasks/viewpoint_select/pretrain.py:128-130: m,v moments; p -= step_size * m / (sqrt(v) + eps) with
@@ -193,7 +212,8 @@ typedef struct vt_layer_acts {
  * The output of the last layer is acts[L-1].out. */
 int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers,
                             const void* x, const float* mask, int mask_additive, const float* head_scale,
-                            int B, int S, int H, int nh, int I, float ln_eps, vt_stream_t stream);
+                            int B, int S, int H, int nh, int I, float ln_eps, float p_hidden, float p_attn,
+                            uint64_t drop_seed, vt_stream_t stream);
 
 /* ---- backward of the encoder stack (the encoder part of loss.backward(), pretrain.py:191) ------ */
 typedef struct vt_layer_weights_t { /* transposed bf16 copies consumed by the dgrad GEMMs */
@@ -217,6 +237,8 @@ typedef struct vt_bwd_workspace {
   float* delta;      /* [B,nh,S] */
   float* ln_partial; /* [1024*2*H] */
   float* dq32;       /* [M,H] fp32, required when S > 256 (else may be NULL) */
+  void* g_pre_d;     /* [M,H] bf16, required when p_hidden > 0 */
+  void* g_pre2_d;    /* [M,H] bf16, required when p_hidden > 0 */
 } vt_bwd_workspace;
 
 /* g: [M,H] bf16, IN dL/d(last layer output), OUT dL/d(x) (layer-0 input).  acts must come from a
@@ -226,7 +248,10 @@ int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weig
                              const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers,
                              const void* x, const float* mask, int mask_additive, void* g,
                              const vt_bwd_workspace* ws, int B, int S, int H, int nh, int I, float ln_eps,
-                             int accumulate, vt_stream_t stream);
+                             int accumulate, float p_hidden, float p_attn, uint64_t drop_seed, int layer0,
+                             vt_stream_t stream);
+/* (p_hidden, p_attn, drop_seed: the values the forward used; layer0 = index of layers[0] in the full
+ * stack when the backward is run over a sub-range of layers.) */
 
 #ifdef __cplusplus
 }

@@ -20,3 +20,45 @@ def model_pair(oracle_cls, product_cls, cfg, seed=0, device="cuda:0", weight_std
 
 def maxabs(a, b):
     return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
+
+
+class FixedMaskDropout(torch.nn.Module):
+    """nn.Dropout with the keep-mask given instead of drawn: x * keep / (1 - p)."""
+
+    def __init__(self, keep, p):
+        super().__init__()
+        self.keep, self.p = keep.float(), float(p)
+
+    def forward(self, x):
+        return x * self.keep.view_as(x) / (1.0 - self.p)
+
+
+def inject_dropout_masks(ref, p_hidden, p_attn, seed, B, T, R, device="cuda:0"):
+    """Replace every nn.Dropout of the oracle model by a FixedMaskDropout holding the keep-mask the HIP
+    kernels derive from (seed, site, element index) — read back through vt_debug_dropout_mask."""
+    from visitron_amd import ops
+
+    cfg = ref.config
+    H, nh, S = cfg.hidden_size, cfg.num_attention_heads, T + R
+
+    def keep(n, p, site, head=-1):
+        return ops.dropout_mask(n, (p, seed, site), head_index=head, device=device).cpu()
+
+    def setmod(name, mod):
+        parent = ref
+        parts = name.split(".")
+        for q in parts[:-1]:
+            parent = getattr(parent, q)
+        setattr(parent, parts[-1], mod)
+
+    setmod("bert.embeddings.dropout", FixedMaskDropout(keep(B * T * H, p_hidden, ops.SITE_EMB).view(B, T, H), p_hidden))
+    if R:
+        setmod("bert.dropout", FixedMaskDropout(keep(B * R * H, p_hidden, ops.SITE_IMG).view(B, R, H), p_hidden))
+    for l in range(cfg.num_hidden_layers):
+        pre = "bert.encoder.layer.%d." % l
+        att = torch.stack([keep(S * S, p_attn, ops.site_attn(l), head=i).view(S, S) for i in range(B * nh)])
+        setmod(pre + "attention.self.dropout", FixedMaskDropout(att.view(B, nh, S, S), p_attn))
+        setmod(pre + "attention.output.dropout",
+               FixedMaskDropout(keep(B * S * H, p_hidden, ops.site_selfout(l)).view(B, S, H), p_hidden))
+        setmod(pre + "output.dropout", FixedMaskDropout(keep(B * S * H, p_hidden, ops.site_out(l)).view(B, S, H), p_hidden))
+    return ref

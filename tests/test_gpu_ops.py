@@ -376,3 +376,131 @@ def test_fused_ce_rows(dev, rows, V):
     assert maxabs(dz[:, :V], zr.grad) < 4e-3 * float(zr.grad.abs().max()) + 1e-6
     if Vp > V:
         assert float(dz[:, V:].float().abs().max()) == 0.0
+
+
+# ---- dropout (counter-based hash masks; the backward kernels recompute them) ------------------------------
+def test_dropout_mask_is_bernoulli_and_site_keyed(dev):
+    from visitron_amd import ops
+
+    n = 1 << 20
+    for p in (0.1, 0.5):
+        k = ops.dropout_mask(n, (p, 1234, 3), device=dev).float()
+        assert abs(float(k.mean()) - (1.0 - p)) < 4.0 * math.sqrt(p * (1 - p) / n) + 1e-4
+        # neighbouring elements are uncorrelated
+        c = float(((k[1:] - k.mean()) * (k[:-1] - k.mean())).mean() / k.var())
+        assert abs(c) < 5e-3
+    a = ops.dropout_mask(n, (0.5, 1234, 3), device=dev)
+    assert torch.equal(a, ops.dropout_mask(n, (0.5, 1234, 3), device=dev))         # deterministic
+    for other in ((0.5, 1235, 3), (0.5, 1234, 4)):                                  # seed / site change the stream
+        b = ops.dropout_mask(n, other, device=dev)
+        assert abs(float((a == b).float().mean()) - 0.5) < 5e-3
+    h0 = ops.dropout_mask(n, (0.5, 1234, 3), head_index=0, device=dev)
+    h1 = ops.dropout_mask(n, (0.5, 1234, 3), head_index=1, device=dev)
+    assert abs(float((h0 == h1).float().mean()) - 0.5) < 5e-3
+    assert int(ops.dropout_mask(4096, (0.0, 7, 0), device=dev).sum()) == 4096       # p = 0 keeps everything
+
+
+@pytest.mark.parametrize("M,N,K,res", [(456, 768, 768, True), (300, 768, 3072, True), (130, 200, 128, False)])
+def test_linear_dropout_before_residual(dev, M, N, K, res):
+    """BertSelfOutput / BertOutput: LN(dropout(dense(h)) + residual) (oscar/modeling_bert.py:94,120)."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(M + N)
+    a, w, b = bf16_round(_rand((M, K), g)), bf16_round(_rand((N, K), g, 0.05)), _rand((N,), g, 0.1)
+    r = bf16_round(_rand((M, N), g)) if res else None
+    drop = (0.2, 99, 5)
+    keep = ops.dropout_mask(M * N, drop, device=dev).view(M, N).float().cpu()
+    want = (a @ w.t() + b) * keep / 0.8
+    if res:
+        want = want + r
+    got = ops.linear(a.to(dev, BF16), w.to(dev, BF16), b.to(dev), residual=None if r is None else r.to(dev, BF16), drop=drop)
+    torch.cuda.synchronize()
+    assert maxabs(got, want) < 2e-2 * (1 + float(want.abs().max()))
+    # dropped elements are exactly the residual (or zero)
+    base = r if res else torch.zeros(M, N)
+    assert torch.equal(got.float().cpu()[keep == 0], bf16_round(base)[keep == 0])
+
+
+def test_apply_dropout_and_layernorm_bwd_dropped_copy(dev):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(8)
+    M, H = 300, 768
+    x, dy, gamma = bf16_round(_rand((M, H), g)), bf16_round(_rand((M, H), g)), _rand((H,), g).abs() + 0.5
+    drop = (0.3, 5, 17)
+    keep = ops.dropout_mask(M * H, drop, device=dev).view(M, H)
+    dg, db = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    dxd = torch.empty((M, H), dtype=BF16, device=dev)
+    dx = ops.layernorm_bwd(x.to(dev, BF16), dy.to(dev, BF16), gamma.to(dev), 1e-12, dg, db, dx_dropped=dxd, drop=drop)
+    dg2, db2 = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    dx_plain = ops.layernorm_bwd(x.to(dev, BF16), dy.to(dev, BF16), gamma.to(dev), 1e-12, dg2, db2)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_plain) and torch.equal(dg, dg2)       # the unmasked gradient is unchanged
+    assert maxabs(dxd, dx.float() * keep / 0.7) < 2e-2 * (1 + float(dx.float().abs().max()))
+    assert int((dxd[keep == 0] != 0).sum()) == 0
+    y = dx.clone()
+    ops.apply_dropout(y, drop)
+    assert maxabs(y, dxd) < 2e-2 * (1 + float(dx.float().abs().max()))
+
+
+def _attn_keep(ops, B, nh, S, drop, dev):
+    return torch.stack([ops.dropout_mask(S * S, drop, head_index=i, device=dev).view(S, S)
+                        for i in range(B * nh)]).view(B, nh, S, S).float().cpu()
+
+
+@pytest.mark.parametrize("B,S,nh,waves", [(2, 228, 3, 8), (1, 37, 2, 8), (2, 300, 2, 8), (1, 656, 1, 8), (2, 228, 2, 4),
+                                          (1, 300, 1, 4)])
+def test_attention_dropout_fwd_bwd_match_autograd(dev, B, S, nh, waves):
+    """attention_probs dropout (oscar/modeling_bert.py:62) with the kernel's own keep-mask fed to torch."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(S * 3 + nh)
+    H, p = nh * 64, 0.2
+    drop = (p, 4242, 16)
+    qkv = bf16_round(_rand((B * S, 3 * H), g, 1.2)).requires_grad_(True)
+    dctx = bf16_round(_rand((B * S, H), g, 0.7))
+    mask = (torch.rand(B, S, generator=g) > 0.25).float()
+    mask[:, 0] = 1.0
+    keep = _attn_keep(ops, B, nh, S, drop, dev)
+    t = qkv.view(B, S, 3, nh, 64).permute(2, 0, 3, 1, 4)
+    s = t[0] @ t[1].transpose(-1, -2) / 8.0 + ((1.0 - mask) * -10000.0)[:, None, None, :]
+    ctx_ref = ((torch.softmax(s, dim=-1) * keep / (1 - p)) @ t[2]).permute(0, 2, 1, 3).reshape(B * S, H)
+    ctx_ref.backward(dctx)
+    want = qkv.grad
+    qd = qkv.detach().to(dev, BF16)
+    lse = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
+    ctx = ops.attention_fwd(qd, B, S, nh, mask=mask.to(dev), lse=lse, drop=drop)
+    ops.set_attn_bwd_waves(waves)
+    try:
+        got = ops.attention_bwd(qd, dctx.to(dev, BF16), ctx, lse, B, S, nh, mask=mask.to(dev), drop=drop)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_attn_bwd_waves(8)
+    assert maxabs(ctx, ctx_ref) < 4e-2
+    got = got.float().cpu()
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        w = want[:, sl]
+        err = float((got[:, sl] - w).abs().max())
+        assert err < 2.5e-2 * (1.0 + float(w.abs().max())), (name, err, float(w.abs().max()))
+
+
+def test_embed_layernorm_dropout(dev):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    B, T, S, H, V = 2, 9, 12, 128, 50
+    ids = torch.randint(0, V, (B, T), generator=g)
+    word, pos, typ = _rand((V, H), g), _rand((64, H), g), _rand((2, H), g)
+    gamma, beta = _rand((H,), g).abs() + 0.5, _rand((H,), g)
+    p = 0.25
+    out = torch.zeros((B * S, H), dtype=BF16, device=dev)
+    ops.embed_layernorm(ids.to(dev), None, None, word.to(dev), pos.to(dev), typ.to(dev), gamma.to(dev), beta.to(dev),
+                        1e-12, out, S, drop=(p, 77, 0))
+    plain = torch.zeros((B * S, H), dtype=BF16, device=dev)
+    ops.embed_layernorm(ids.to(dev), None, None, word.to(dev), pos.to(dev), typ.to(dev), gamma.to(dev), beta.to(dev),
+                        1e-12, plain, S)
+    keep = ops.dropout_mask(B * T * H, (p, 77, ops.SITE_EMB), device=dev).view(B, T, H).float()
+    torch.cuda.synchronize()
+    o = out.view(B, S, H)[:, :T].float()
+    pl = plain.view(B, S, H)[:, :T].float()
+    assert maxabs(o, pl * keep / (1 - p)) < 2e-2 * (1 + float(pl.abs().max()))

@@ -10,6 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvisitron_hip.so")
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+c_uint64, c_uint32 = ctypes.c_uint64, ctypes.c_uint32
+DROP = [c_float, c_uint64, c_uint32]  # (p, step seed, site)
 
 
 class LayerWeights(ctypes.Structure):  # vt_layer_weights
@@ -34,7 +36,8 @@ class LayerGrads(ctypes.Structure):  # vt_layer_grads
 
 
 class BwdWorkspace(ctypes.Structure):  # vt_bwd_workspace
-    _fields_ = [(n, c_void_p) for n in ("g_pre", "g_pre2", "g_mid", "g_ctx", "g_qkv", "delta", "ln_partial", "dq32")]
+    _fields_ = [(n, c_void_p) for n in ("g_pre", "g_pre2", "g_mid", "g_ctx", "g_qkv", "delta", "ln_partial", "dq32",
+                                        "g_pre_d", "g_pre2_d")]
 
 
 class WgradProblem(ctypes.Structure):  # vt_wgrad_problem
@@ -52,14 +55,17 @@ SIGNATURES = {
     "vt_linear_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_linear_bf16_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                                  c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                  c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int] + DROP + [c_void_p]),
+    "vt_apply_dropout_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int] + DROP + [c_void_p]),
+    "vt_debug_dropout_mask": (c_int, [c_void_p, c_int64] + DROP + [c_int, c_void_p]),
     "vt_attention_bwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
-                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int,
-                                      c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int]
+                              + DROP + [c_void_p]),
     "vt_layernorm_bwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
-                                      c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
+                                      c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_int64] + DROP
+                              + [c_void_p]),
     "vt_embed_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                        c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+                                        c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_uint64, c_void_p]),
     "vt_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                               c_float, c_float, c_float, c_float, c_void_p]),
     "vt_ce_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
@@ -69,19 +75,19 @@ SIGNATURES = {
     "vt_encoder_backward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerWeightsT),
                                          ctypes.POINTER(LayerActs), ctypes.POINTER(LayerGrads), c_int, c_void_p,
                                          c_void_p, c_int, c_void_p, ctypes.POINTER(BwdWorkspace), c_int, c_int, c_int,
-                                         c_int, c_int, c_float, c_int, c_void_p]),
+                                         c_int, c_int, c_float, c_int, c_float, c_float, c_uint64, c_int, c_void_p]),
     "vt_attention_fwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p,
-                                      c_int, c_int, c_int, c_int, c_void_p]),
+                                      c_int, c_int, c_int, c_int] + DROP + [c_void_p]),
     "vt_layernorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vt_embed_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                                   c_void_p, c_void_p]),
+                                   c_void_p, c_float, c_uint64, c_void_p]),
     "vt_pack_concat_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "vt_wgrad_bf16": (c_int, [ctypes.POINTER(WgradProblem), c_int, c_int, c_void_p]),
     "vt_encoder_forward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerActs), c_int, c_void_p,
                                         c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
-                                        c_void_p]),
+                                        c_float, c_float, c_uint64, c_void_p]),
 }
 
 _lib = None

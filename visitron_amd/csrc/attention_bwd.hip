@@ -38,6 +38,7 @@ struct AttnBwdArgs {
   long ld_qkv, ld_d, ld_dqkv;
   int B, S, nh;
   float scale;          // 1 / sqrt(head_size)
+  DropCfg drop;         // the forward's attention-probability dropout (same seed / indexing)
 };
 
 // LDS map (bytes)
@@ -81,6 +82,8 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   const float* lse_p = a.lse + ((long)b * a.nh + head) * S;
   const float* del_p = a.delta + ((long)b * a.nh + head) * S;
   const int nslices = (S + 31) >> 5;
+  DropCfg dr = a.drop;
+  dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
   const int kcount = (S - kb0) < 256 ? (S - kb0) : 256;
   const int nkt = (kcount + 31) >> 5;  // 32-key steps of this key block for dQ
 
@@ -242,8 +245,15 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
           const int i = 4 * g4 + e;
           const float s = fmaf(sacc[i], a.scale, kbias[kt]);
           const float p = __builtin_amdgcn_exp2f((s - lse4[g4][e]) * LOG2E);
-          pacc[i] = p;
-          sacc[i] = p * (dpacc[i] - del4[g4][e]) * a.scale;  // dS' (scale folded in)
+          float dpv = dpacc[i], pv = p;
+          if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
+            const uint32_t q = (uint32_t)(sl * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2);
+            const bool keep = vt_keep(dr, q * (uint32_t)S + (uint32_t)(kb0 + 64 * wave + 32 * kt + r));
+            dpv = keep ? dpv * dr.scale : 0.f;
+            pv = keep ? p * dr.scale : 0.f;
+          }
+          pacc[i] = pv;
+          sacc[i] = p * (dpv - del4[g4][e]) * a.scale;  // dS' (scale folded in)
         }
       // dV^T += dO^T P ; dK^T += Q^T dS'   (k = q, 2 steps of 16)
 #pragma unroll
@@ -374,6 +384,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   const float* lse_p = a.lse + ((long)b * a.nh + head) * S;
   const float* del_p = a.delta + ((long)b * a.nh + head) * S;
   const int nslices = (S + 31) >> 5;
+  DropCfg dr = a.drop;
+  dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
   const int kcount = (S - kb0) < 256 ? (S - kb0) : 256;
   const int nkt = (kcount + 31) >> 5;  // 32-key steps of this key block for dQ
 
@@ -476,13 +488,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       qa[ds] = *(const bf16x8*)(sQ + a_row + (((2 * ds + h2) ^ a_swz) << 4));
       da[ds] = *(const bf16x8*)(sDO + a_row + (((2 * ds + h2) ^ a_swz) << 4));
     }
-    // per-register row constants: q = (reg&3) + 8(reg>>2) + 4h2
-    f32x4 lse4[4], del4[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      lse4[g4] = *(const f32x4*)(rowv + 8 * g4 + 4 * h2);
-      del4[g4] = *(const f32x4*)(rowv + 32 + 8 * g4 + 4 * h2);
-    }
+    // per-register row constants (q = (reg&3) + 8(reg>>2) + 4h2) are read from LDS where they are used:
+    // holding them across the MFMA chains costs 32 registers this kernel does not have
     // transposed A operands of the slice: [s2][dt] for dO^T (dV) and Q^T (dK)
     bf16x8 doT[2][2], qT[2][2];
     {
@@ -530,15 +537,25 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       // P = exp(s/8 + mask - lse);  dS = P (dP - delta) / 8
       f32x16 pacc;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4)
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 lse4_g = *(const f32x4*)(rowv + 8 * g4 + 4 * h2);
+        const f32x4 del4_g = *(const f32x4*)(rowv + 32 + 8 * g4 + 4 * h2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g4 + e;
           const float s = fmaf(sacc[i], a.scale, kbias[kt]);
-          const float p = __builtin_amdgcn_exp2f((s - lse4[g4][e]) * LOG2E);
-          pacc[i] = p;
-          sacc[i] = p * (dpacc[i] - del4[g4][e]) * a.scale;  // dS' (scale folded in)
+          const float p = __builtin_amdgcn_exp2f((s - lse4_g[e]) * LOG2E);
+          float dpv = dpacc[i], pv = p;
+          if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
+            const uint32_t q = (uint32_t)(sl * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2);
+            const bool keep = vt_keep(dr, q * (uint32_t)S + (uint32_t)(kb0 + 32 * wave + r));
+            dpv = keep ? dpv * dr.scale : 0.f;
+            pv = keep ? p * dr.scale : 0.f;
+          }
+          pacc[i] = pv;
+          sacc[i] = p * (dpv - del4_g[e]) * a.scale;  // dS' (scale folded in)
         }
+      }
       // dV^T += dO^T P ; dK^T += Q^T dS'   (k = q, 2 steps of 16)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -688,7 +705,8 @@ void vt_attn_bwd_set_waves(int w) { g_attn_bwd_waves = (w == 4) ? 4 : 8; }
 
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
-                              long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream) {
+                              long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream,
+                              const DropCfg* drop = nullptr) {
   if (!qkv || !dctx || !ctx || !lse || !delta_ws || !dqkv) return VT_ERR_NULL;
   if (head_size != 64) return VT_ERR_UNSUPPORTED;
   const int nkb = (S + 255) / 256;
@@ -713,6 +731,7 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   if (nkb > 1 && hipMemsetAsync(dq32_ws, 0, (size_t)rows * nh * 64 * sizeof(float), stream) != hipSuccess) return VT_ERR_HIP;
   a.ld_qkv = ld_qkv; a.ld_d = ld_d; a.ld_dqkv = ld_dqkv; a.B = B; a.S = S; a.nh = nh;
   a.scale = 1.0f / sqrtf((float)head_size);
+  if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
   if (g_attn_bwd_waves == 4) {
     hipLaunchKernelGGL(attention_bwd_d64, dim3(nh, B, nkb), dim3(256), AB_LDS_BYTES, stream, a);
   } else {

@@ -31,6 +31,8 @@ struct AttnArgs {
   long ld_qkv, ld_ctx;
   int B, S, nh;
   float scale;              // 1 / sqrt(head_size)
+  DropCfg drop;             // dropout on the attention probabilities (oscar/modeling_bert.py:62); per (b,h) the
+                            // seed is hash32(drop.seed, b*nh+h) and the element index is q * S + key
 };
 
 #define LOG2E 1.4426950408889634f
@@ -76,6 +78,9 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
+  DropCfg dr = a.drop;
+  dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
+  const uint32_t q_elem = (uint32_t)(q0 + r) * (uint32_t)S;
 
   // lane-constant LDS offsets
   const int k_row_off = r * 128;                       // + kt*4096
@@ -162,6 +167,14 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
         for (int s2 = 0; s2 < 2; ++s2) {
           typedef __attribute__((ext_vector_type(8))) short short8v;
           short8v pbs;
+          if (dr.thresh) {  // drop probabilities AFTER the row sum was taken (the normaliser uses all of them)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int i = 8 * s2 + j;
+              const uint32_t key = (uint32_t)(kc + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2);
+              sacc[i] = vt_keep(dr, q_elem + key) ? sacc[i] * dr.scale : 0.f;
+            }
+          }
 #pragma unroll
           for (int j = 0; j < 8; ++j) pbs[j] = (short)f32_to_bf16(sacc[8 * s2 + j]);
           const bf16x8 pb = __builtin_bit_cast(bf16x8, pbs);
@@ -198,7 +211,8 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
 }
 
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
-                              long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream) {
+                              long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream,
+                              const DropCfg* drop = nullptr) {
   if (!qkv || !ctx) return VT_ERR_NULL;
   if (head_size != 64) return VT_ERR_UNSUPPORTED;
   if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
@@ -214,6 +228,7 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = (bf16_t*)ctx; a.lse = lse;
   a.ld_qkv = ld_qkv; a.ld_ctx = ld_ctx; a.B = B; a.S = S; a.nh = nh;
   a.scale = 1.0f / sqrtf((float)head_size);
+  if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
   dim3 grid((S + 255) / 256, nh, B);
   hipLaunchKernelGGL(attention_fwd_d64, grid, dim3(512), ATT_LDS_BYTES, stream, a);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;

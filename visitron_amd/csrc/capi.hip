@@ -5,32 +5,37 @@
 
 int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const void* R, long ldr,
                      void* C, long ldc, int M, int N, int K, int act, int out_f32, int grp_rows, int grp_stride,
-                     hipStream_t stream, void* C2 = nullptr, long ldc2 = 0);
+                     hipStream_t stream, void* C2 = nullptr, long ldc2 = 0, const DropCfg* drop = nullptr);
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
-                              long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream);
+                              long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream,
+                              const DropCfg* drop = nullptr);
 int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
-                              hipStream_t stream);
+                              hipStream_t stream, void* dx2 = nullptr, long lddx2 = 0, const DropCfg* drop = nullptr);
+int vt_apply_dropout_dispatch(void* x, long ld, long rows, int cols, const DropCfg& d, hipStream_t stream);
+int vt_dropout_mask_dispatch(uint8_t* out, long n, const DropCfg& d, hipStream_t stream);
 int vt_dgelu_mul_dispatch(const void* g, const void* h, void* out, long n, hipStream_t stream);
 int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                                     const float* pos, const float* type, const float* gamma, const void* g, long ldg,
                                     float* de, float* dgamma, float* dbeta, float* partial_ws, int B, int T, int S, int H,
-                                    int n_word, int n_pos, int n_type, float eps, int accumulate, hipStream_t stream);
+                                    int n_word, int n_pos, int n_type, float eps, int accumulate, hipStream_t stream,
+                                    const DropCfg* drop = nullptr);
 int vt_ce_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, long lddz,
                            long rows, int V, int Vpad, float scale, hipStream_t stream);
 int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, int C, hipStream_t stream);
 int vt_adamw_dispatch(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float step_size, float b1,
                       float b2, float eps, float wd, float grad_scale, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
-                              long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream);
+                              long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream,
+                              const DropCfg* drop = nullptr);
 int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
                           float* mean, float* rstd, int M, int H, float eps, int grp_rows, int grp_stride,
                           hipStream_t stream);
 int vt_embed_layernorm_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                                 const float* pos, const float* type, const float* gamma, const float* beta, void* y,
                                 long ldy, int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
-                                int* err_flag, hipStream_t stream);
+                                int* err_flag, hipStream_t stream, const DropCfg* drop = nullptr);
 int vt_pack_concat_dispatch(const float* s0, int d0, const float* s1, int d1, void* out, int kpad, long rows,
                             hipStream_t stream);
 
@@ -70,7 +75,7 @@ const char* vt_error_string(int code) {
   }
 }
 
-int vt_abi_version(void) { return 1; }
+int vt_abi_version(void) { return 2; }
 
 void vt_debug_set_gemm_variant(int variant) { vt_gemm_set_variant(variant); }
 void vt_gemm_tune(int M, int N, int K, int act, int variant) { vt_gemm_tune_set(M, N, K, act, variant); }
@@ -85,32 +90,50 @@ int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const
 
 int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* R,
                       int64_t ldr, void* C, int64_t ldc, void* C2, int64_t ldc2, int M, int N, int K, int act,
-                      int out_f32, int grp_rows, int grp_stride, vt_stream_t stream) {
+                      int out_f32, int grp_rows, int grp_stride, float drop_p, uint64_t drop_seed, uint32_t drop_site,
+                      vt_stream_t stream) {
+  const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_gemm_dispatch(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, out_f32, grp_rows, grp_stride,
-                          (hipStream_t)stream, C2, ldc2);
+                          (hipStream_t)stream, C2, ldc2, &d);
+}
+
+int vt_apply_dropout_bf16(void* x, int64_t ld, int64_t rows, int cols, float drop_p, uint64_t drop_seed, uint32_t drop_site,
+                          vt_stream_t stream) {
+  return vt_apply_dropout_dispatch(x, ld, rows, cols, vt_make_drop(drop_p, drop_seed, drop_site), (hipStream_t)stream);
+}
+
+int vt_debug_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, uint32_t drop_site, int head_index,
+                          vt_stream_t stream) {
+  DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
+  if (head_index >= 0) d.seed = vt_hash32(d.seed, (uint32_t)head_index);  // attention sites: one stream per (b, h)
+  return vt_dropout_mask_dispatch(out, n, d, (hipStream_t)stream);
 }
 
 int vt_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
                           int64_t ld_ctx, const float* mask, int mask_additive, const float* lse, float* delta_ws,
                           void* dqkv, int64_t ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size,
-                          vt_stream_t stream) {
+                          float drop_p, uint64_t drop_seed, uint32_t drop_site, vt_stream_t stream) {
+  const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_attention_bwd_dispatch(qkv, ld_qkv, dctx, ld_d, ctx, ld_ctx, mask, mask_additive, lse, delta_ws, dqkv,
-                                   ld_dqkv, dq32_ws, B, S, nh, head_size, (hipStream_t)stream);
+                                   ld_dqkv, dq32_ws, B, S, nh, head_size, (hipStream_t)stream, &d);
 }
 
 int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* gamma, void* dx,
                           int64_t lddx, float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps,
-                          int accumulate, vt_stream_t stream) {
+                          int accumulate, void* dx_dropped, int64_t lddxd, float drop_p, uint64_t drop_seed,
+                          uint32_t drop_site, vt_stream_t stream) {
+  const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_layernorm_bwd_dispatch(x, ldx, dy, ldy, gamma, dx, lddx, dgamma, dbeta, partial_ws, M, H, eps, accumulate,
-                                   (hipStream_t)stream);
+                                   (hipStream_t)stream, dx_dropped, lddxd, &d);
 }
 
 int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                            const float* pos, const float* type, const float* gamma, const void* g, int64_t ldg, float* de,
                            float* dgamma, float* dbeta, float* partial_ws, int B, int T, int S, int H, int n_word, int n_pos,
-                           int n_type, float eps, int accumulate, vt_stream_t stream) {
+                           int n_type, float eps, int accumulate, float drop_p, uint64_t drop_seed, vt_stream_t stream) {
+  const DropCfg d = vt_make_drop(drop_p, drop_seed, VT_SITE_EMB);
   return vt_embed_layernorm_bwd_dispatch(ids, type_ids, pos_ids, word, pos, type, gamma, g, ldg, de, dgamma, dbeta, partial_ws,
-                                         B, T, S, H, n_word, n_pos, n_type, eps, accumulate, (hipStream_t)stream);
+                                         B, T, S, H, n_word, n_pos, n_type, eps, accumulate, (hipStream_t)stream, &d);
 }
 
 int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float step_size, float b1,
@@ -132,9 +155,11 @@ int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_str
 }
 
 int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
-                          int64_t ld_ctx, float* lse, int B, int S, int nh, int head_size, vt_stream_t stream) {
+                          int64_t ld_ctx, float* lse, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
+                          uint32_t drop_site, vt_stream_t stream) {
+  const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_attention_fwd_dispatch(qkv, ld_qkv, mask, mask_additive, head_scale, ctx, ld_ctx, lse, B, S, nh, head_size,
-                                   (hipStream_t)stream);
+                                   (hipStream_t)stream, &d);
 }
 
 int vt_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
@@ -147,9 +172,10 @@ int vt_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
 int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                        const float* pos, const float* type, const float* gamma, const float* beta, void* y,
                        int64_t ldy, int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
-                       int* err_flag, vt_stream_t stream) {
+                       int* err_flag, float drop_p, uint64_t drop_seed, vt_stream_t stream) {
+  const DropCfg d = vt_make_drop(drop_p, drop_seed, VT_SITE_EMB);
   return vt_embed_layernorm_dispatch(ids, type_ids, pos_ids, word, pos, type, gamma, beta, y, ldy, B, T, S, H, n_word,
-                                     n_pos, n_type, eps, err_flag, (hipStream_t)stream);
+                                     n_pos, n_type, eps, err_flag, (hipStream_t)stream, &d);
 }
 
 int vt_pack_concat_bf16(const float* s0, int d0, const float* s1, int d1, void* out, int kpad, int64_t rows,
@@ -180,7 +206,7 @@ int vt_wgrad_bf16(const vt_wgrad_problem* problems, int nprob, int M, vt_stream_
 //   -> FFN-up GEMM(+bias+GELU) -> FFN-down GEMM(+bias+residual) -> LayerNorm
 int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers, const void* x,
                             const float* mask, int mask_additive, const float* head_scale, int B, int S, int H, int nh,
-                            int I, float ln_eps, vt_stream_t stream_) {
+                            int I, float ln_eps, float p_hidden, float p_attn, uint64_t drop_seed, vt_stream_t stream_) {
   if (!layers || !acts || !x) return VT_ERR_NULL;
   if (num_layers <= 0 || B <= 0 || S <= 0 || nh <= 0 || H != nh * 64 || (H % 64) || (I % 64)) return VT_ERR_BAD_SHAPE;
   hipStream_t stream = (hipStream_t)stream_;
@@ -193,17 +219,20 @@ int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts*
     int rc;
     rc = vt_gemm_dispatch(cur, H, w.w_qkv, H, w.b_qkv, nullptr, 0, a.qkv, 3L * H, M, 3 * H, H, VT_ACT_NONE, 0, 0, 0, stream);
     if (rc) return rc;
+    const DropCfg d_att = vt_make_drop(p_attn, drop_seed, VT_SITE_ATTN(l));
+    const DropCfg d_so = vt_make_drop(p_hidden, drop_seed, VT_SITE_SELFOUT(l));
+    const DropCfg d_out = vt_make_drop(p_hidden, drop_seed, VT_SITE_OUT(l));
     rc = vt_attention_fwd_dispatch(a.qkv, 3L * H, mask, mask_additive, head_scale ? head_scale + (long)l * nh : nullptr, a.ctx, H,
-                                   a.lse, B, S, nh, 64, stream);
+                                   a.lse, B, S, nh, 64, stream, &d_att);
     if (rc) return rc;
-    rc = vt_gemm_dispatch(a.ctx, H, w.w_ao, H, w.b_ao, cur, H, a.attn_pre, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream);
+    rc = vt_gemm_dispatch(a.ctx, H, w.w_ao, H, w.b_ao, cur, H, a.attn_pre, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream, nullptr, 0, &d_so);
     if (rc) return rc;
     rc = vt_layernorm_dispatch(a.attn_pre, H, a.attn_out, H, w.ln1_g, w.ln1_b, a.ln1_mean, a.ln1_rstd, M, H, ln_eps, 0, 0, stream);
     if (rc) return rc;
     rc = vt_gemm_dispatch(a.attn_out, H, w.w_in, H, w.b_in, nullptr, 0, a.mid, I, M, I, H, VT_ACT_GELU, 0, 0, 0, stream,
                           a.mid_pre, I);
     if (rc) return rc;
-    rc = vt_gemm_dispatch(a.mid, I, w.w_out, I, w.b_out, a.attn_out, H, a.out_pre, H, M, H, I, VT_ACT_NONE, 0, 0, 0, stream);
+    rc = vt_gemm_dispatch(a.mid, I, w.w_out, I, w.b_out, a.attn_out, H, a.out_pre, H, M, H, I, VT_ACT_NONE, 0, 0, 0, stream, nullptr, 0, &d_out);
     if (rc) return rc;
     rc = vt_layernorm_dispatch(a.out_pre, H, a.out, H, w.ln2_g, w.ln2_b, a.ln2_mean, a.ln2_rstd, M, H, ln_eps, 0, 0, stream);
     if (rc) return rc;
@@ -219,8 +248,10 @@ int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts*
 int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weights_t* layers_t,
                              const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers, const void* x,
                              const float* mask, int mask_additive, void* g, const vt_bwd_workspace* ws, int B, int S,
-                             int H, int nh, int I, float ln_eps, int accumulate, vt_stream_t stream_) {
+                             int H, int nh, int I, float ln_eps, int accumulate, float p_hidden, float p_attn,
+                             uint64_t drop_seed, int layer0, vt_stream_t stream_) {
   if (!layers || !layers_t || !acts || !grads || !x || !g || !ws) return VT_ERR_NULL;
+  if (p_hidden > 0.f && (!ws->g_pre_d || !ws->g_pre2_d)) return VT_ERR_NULL;
   if (num_layers <= 0 || B <= 0 || S <= 0 || nh <= 0 || H != nh * 64 || (I % 64)) return VT_ERR_BAD_SHAPE;
   if (!ws->g_pre || !ws->g_pre2 || !ws->g_mid || !ws->g_ctx || !ws->g_qkv || !ws->delta || !ws->ln_partial) return VT_ERR_NULL;
   hipStream_t stream = (hipStream_t)stream_;
@@ -233,25 +264,32 @@ int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weig
     if (!a.mid_pre || !a.lse) return VT_ERR_NULL;
     const void* x_in = l == 0 ? x : acts[l - 1].out;
     int rc;
+    // dropout sites of this layer (the forward used layer index layer0 + l)
+    const DropCfg d_att = vt_make_drop(p_attn, drop_seed, VT_SITE_ATTN(layer0 + l));
+    const DropCfg d_so = vt_make_drop(p_hidden, drop_seed, VT_SITE_SELFOUT(layer0 + l));
+    const DropCfg d_out = vt_make_drop(p_hidden, drop_seed, VT_SITE_OUT(layer0 + l));
+    // with hidden dropout the gradient of a dense output is the pre-LayerNorm gradient times the mask
+    void* g_pre_dn = p_hidden > 0.f ? ws->g_pre_d : ws->g_pre;
+    void* g_pre2_dn = p_hidden > 0.f ? ws->g_pre2_d : ws->g_pre2;
     // LayerNorm 2 backward: dL/d(out_pre)
     rc = vt_layernorm_bwd_dispatch(a.out_pre, H, g, H, w.ln2_g, ws->g_pre, H, d.d_ln2_g, d.d_ln2_b, ws->ln_partial, M, H,
-                                   ln_eps, accumulate, stream);
+                                   ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre_d : nullptr, H, &d_out);
     if (rc) return rc;
     // through output.dense and the GELU: g_mid = (g_pre . W_out) * gelu'(pre-activation) (saved in mid_pre)
-    rc = vt_gemm_dispatch(ws->g_pre, H, wt.wt_out, H, nullptr, a.mid_pre, I, ws->g_mid, I, M, I, H, VT_ACT_MUL, 0, 0, 0, stream);
+    rc = vt_gemm_dispatch(g_pre_dn, H, wt.wt_out, H, nullptr, a.mid_pre, I, ws->g_mid, I, M, I, H, VT_ACT_MUL, 0, 0, 0, stream);
     if (rc) return rc;
     // through intermediate.dense, plus the residual branch: dL/d(attn_out) -> g
     rc = vt_gemm_dispatch(ws->g_mid, I, wt.wt_in, I, nullptr, ws->g_pre, H, g, H, M, H, I, VT_ACT_NONE, 0, 0, 0, stream);
     if (rc) return rc;
     // LayerNorm 1 backward: dL/d(attn_pre)
     rc = vt_layernorm_bwd_dispatch(a.attn_pre, H, g, H, w.ln1_g, ws->g_pre2, H, d.d_ln1_g, d.d_ln1_b, ws->ln_partial, M, H,
-                                   ln_eps, accumulate, stream);
+                                   ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre2_d : nullptr, H, &d_so);
     if (rc) return rc;
     // through attention.output.dense: dL/d(ctx)
-    rc = vt_gemm_dispatch(ws->g_pre2, H, wt.wt_ao, H, nullptr, nullptr, 0, ws->g_ctx, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream);
+    rc = vt_gemm_dispatch(g_pre2_dn, H, wt.wt_ao, H, nullptr, nullptr, 0, ws->g_ctx, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream);
     if (rc) return rc;
     rc = vt_attention_bwd_dispatch(a.qkv, 3L * H, ws->g_ctx, H, a.ctx, H, mask, mask_additive, a.lse, ws->delta, ws->g_qkv,
-                                   3L * H, ws->dq32, B, S, nh, 64, stream);
+                                   3L * H, ws->dq32, B, S, nh, 64, stream, &d_att);
     if (rc) return rc;
     // through the packed q|k|v projection, plus the residual branch: dL/d(layer input) -> g
     rc = vt_gemm_dispatch(ws->g_qkv, 3L * H, wt.wt_qkv, 3L * H, nullptr, ws->g_pre2, H, g, H, M, H, 3 * H, VT_ACT_NONE, 0, 0, 0, stream);
@@ -266,9 +304,9 @@ int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weig
       P.N = N; P.K = K; P.accumulate = accumulate; P.tiles_k = 0; P.tile_begin = 0;
     };
     set(0, ws->g_mid, I, a.attn_out, H, d.d_w_in, d.d_b_in, I, H);
-    set(1, ws->g_pre, H, a.mid, I, d.d_w_out, d.d_b_out, H, I);
+    set(1, g_pre_dn, H, a.mid, I, d.d_w_out, d.d_b_out, H, I);
     set(2, ws->g_qkv, 3L * H, x_in, H, d.d_w_qkv, d.d_b_qkv, 3 * H, H);
-    set(3, ws->g_pre2, H, a.ctx, H, d.d_w_ao, d.d_b_ao, H, H);
+    set(3, g_pre2_dn, H, a.ctx, H, d.d_w_ao, d.d_b_ao, H, H);
     for (int i = 4; i < WG_MAX_PROBLEMS; ++i) wa.p[i] = wa.p[0];
     rc = vt_wgrad_dispatch(wa, stream);
     if (rc) return rc;

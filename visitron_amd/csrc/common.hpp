@@ -72,6 +72,41 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- dropout: counter-based hash RNG --------------------------------------------------------------
+// keep(element) = hash32(site_seed, element index) >> 8 >= p * 2^24; kept values are scaled by 1/(1-p).
+// Nothing is stored: the backward kernels recompute the same mask from (seed, index).  site_seed mixes
+// the step seed with a site id (layer, which dropout), see vt_site_seed.
+struct DropCfg {
+  uint32_t thresh;   // p * 2^24, 0 = no dropout
+  uint32_t seed;     // site seed
+  float scale;       // 1 / (1 - p)
+};
+__host__ __device__ __forceinline__ uint32_t vt_hash32(uint32_t seed, uint32_t idx) {
+  uint32_t x = idx * 0x9E3779B1u ^ seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ bool vt_keep(const DropCfg& d, uint32_t idx) { return (vt_hash32(d.seed, idx) >> 8) >= d.thresh; }
+__host__ __device__ __forceinline__ uint32_t vt_site_seed(uint64_t step_seed, uint32_t site) {
+  uint64_t x = step_seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+__host__ __forceinline__ DropCfg vt_make_drop(float p, uint64_t step_seed, uint32_t site) {
+  DropCfg d;
+  d.thresh = p > 0.f ? (uint32_t)(p * 16777216.0f) : 0u;
+  d.seed = vt_site_seed(step_seed, site);
+  d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  return d;
+}
+// dropout sites: layer l uses 8*l + {0: attention probs, 1: attention.output dropout, 2: output dropout};
+// 0xE0 = embeddings, 0xE1 = image embedding
+#define VT_SITE_ATTN(l) (8u * (l) + 0u)
+#define VT_SITE_SELFOUT(l) (8u * (l) + 1u)
+#define VT_SITE_OUT(l) (8u * (l) + 2u)
+#define VT_SITE_EMB 0xE0u
+#define VT_SITE_IMG 0xE1u
+
 // error codes of the C ABI (include/visitron_hip.h)
 #define VT_OK 0
 #define VT_ERR_BAD_SHAPE (-1)

@@ -36,6 +36,8 @@ struct GemmArgs {
   int M, N, K;
   int grp_rows, grp_stride;  // output row = (m / grp_rows) * grp_stride + m % grp_rows  (0: identity)
   int tiles_m, tiles_n;
+  DropCfg drop;              // dropout on act(acc + bias) BEFORE the residual add (BertSelfOutput / BertOutput /
+                             // image embedding); element index = m * N + n
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_MUL = 3 };  // MUL: out = acc * R (R = saved gelu'(pre-activation))
@@ -109,6 +111,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);
+      if (g.drop.thresh) {
+        const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)nb;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f;
+      }
       if (g.R) {
         const u32x4* rp = (const u32x4*)(g.R + orow * g.ldr + nb);
         const u32x4 r0 = rp[0], r1 = rp[1];
@@ -144,6 +151,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
         if (nb + i < g.N) {
           if (g.C2) g.C2[orow * g.ldc2 + nb + i] = f32_to_bf16((ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i]);
           float x = apply_act<ACT>(v[i]);
+          if (g.drop.thresh) x = vt_keep(g.drop, (uint32_t)m * (uint32_t)g.N + (uint32_t)(nb + i)) ? x * g.drop.scale : 0.f;
           if (g.R) {
             const float rr = bf16_to_f32(g.R[orow * g.ldr + nb + i]);
             x = (ACT == ACT_MUL) ? x * rr : x + rr;
@@ -604,6 +612,11 @@ __device__ __forceinline__ void gemm_epilogue_grp(const GemmArgs& g, f32x4 (&acc
       }
 #pragma unroll
       for (int i = 0; i < W; ++i) v[i] = apply_act<ACT>(v[i]);
+      if (g.drop.thresh) {
+        const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)nb;
+#pragma unroll
+        for (int i = 0; i < W; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f;
+      }
       if (g.R) {
 #pragma unroll
         for (int h = 0; h < W / 8; ++h) {
@@ -635,6 +648,7 @@ __device__ __forceinline__ void gemm_epilogue_grp(const GemmArgs& g, f32x4 (&acc
         if (nb + i < g.N) {
           if (g.C2) g.C2[orow * g.ldc2 + nb + i] = f32_to_bf16((ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i]);
           float x = apply_act<ACT>(v[i]);
+          if (g.drop.thresh) x = vt_keep(g.drop, (uint32_t)m * (uint32_t)g.N + (uint32_t)(nb + i)) ? x * g.drop.scale : 0.f;
           if (g.R) {
             const float rr = bf16_to_f32(g.R[orow * g.ldr + nb + i]);
             x = (ACT == ACT_MUL) ? x * rr : x + rr;
@@ -1159,7 +1173,7 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
 // Host entry used by the C ABI (capi.hip).  Returns a VT_* code; never synchronises.
 int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const void* R, long ldr,
                      void* C, long ldc, int M, int N, int K, int act, int out_f32, int grp_rows, int grp_stride,
-                     hipStream_t stream, void* C2 = nullptr, long ldc2 = 0) {
+                     hipStream_t stream, void* C2 = nullptr, long ldc2 = 0, const DropCfg* drop = nullptr) {
   if (!A || !W || !C) return VT_ERR_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K % GEMM_BK) != 0) return VT_ERR_BAD_SHAPE;
   if ((lda % 8) || (ldw % 8) || (R && (ldr % 8)) || (ldc % (out_f32 ? 4 : 8)) || (C2 && (ldc2 % 8))) return VT_ERR_BAD_ALIGN;
@@ -1171,6 +1185,8 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc; g.C2 = (bf16_t*)C2; g.ldc2 = ldc2;
   g.M = M; g.N = N; g.K = K;
   g.grp_rows = grp_rows; g.grp_stride = grp_stride;
+  if (drop) g.drop = *drop; else { g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f; }
+  if (g.drop.thresh && (long)M * N >= (1L << 32)) return VT_ERR_UNSUPPORTED;
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   const int variant = g_gemm_variant >= 0 ? g_gemm_variant : gemm_pick_variant(M, N, K, act);

@@ -110,6 +110,7 @@ struct EmbArgs {
   int n_word, n_pos, n_type;
   float eps;
   int* err;  // set to 1 when an index is out of range (the torch reference would raise)
+  DropCfg drop;  // BertEmbeddings.dropout after the LayerNorm; element index = token * H + col
 };
 
 template <int CH>
@@ -174,6 +175,11 @@ __global__ __launch_bounds__(256) void embed_layernorm(EmbArgs a) {
         o[i] = (v[c][i] - u) * rs * g0[i] + b0[i];
         o[4 + i] = (v[c][4 + i] - u) * rs * g1[i] + b1[i];
       }
+      if (a.drop.thresh) {
+        const uint32_t e0 = (uint32_t)tok * (uint32_t)a.H + (uint32_t)col;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = vt_keep(a.drop, e0 + i) ? o[i] * a.drop.scale : 0.f;
+      }
       u32x4 w;
 #pragma unroll
       for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256) void embed_layernorm(EmbArgs a) {
 int vt_embed_layernorm_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                                 const float* pos, const float* type, const float* gamma, const float* beta, void* y,
                                 long ldy, int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
-                                int* err_flag, hipStream_t stream) {
+                                int* err_flag, hipStream_t stream, const DropCfg* drop = nullptr) {
   if (!ids || !word || !pos || !type || !gamma || !beta || !y) return VT_ERR_NULL;
   if (B <= 0 || T <= 0 || S < T || H <= 0 || (H % 8) || H > 2048) return VT_ERR_BAD_SHAPE;
   if ((ldy % 8) || (((uintptr_t)word | (uintptr_t)pos | (uintptr_t)type | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15))
@@ -194,6 +200,7 @@ int vt_embed_layernorm_dispatch(const int64_t* ids, const int64_t* type_ids, con
   a.ids = ids; a.type_ids = type_ids; a.pos_ids = pos_ids; a.word = word; a.pos = pos; a.type = type;
   a.gamma = gamma; a.beta = beta; a.y = (bf16_t*)y; a.ldy = ldy; a.B = B; a.T = T; a.S = S; a.H = H;
   a.n_word = n_word; a.n_pos = n_pos; a.n_type = n_type; a.eps = eps; a.err = err_flag;
+  if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
   const dim3 grid((B * T + 3) / 4), block(256);
   const int ch = (H + 511) / 512;
   if (ch == 1) hipLaunchKernelGGL(embed_layernorm<1>, grid, block, 0, stream, a);
@@ -251,6 +258,8 @@ struct LnBwdArgs {
   const bf16_t* dy; long ldy;
   const float* gamma;
   bf16_t* dx; long lddx;
+  bf16_t* dx2; long lddx2;   // optional: dx * dropout mask * scale (gradient of the dense output that was dropped
+  DropCfg drop;              // out before the residual add); element index = row * H + col
   float* partial;  // [gridDim.x][2][H]
   int M, H;
   float eps;
@@ -334,6 +343,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows(LnBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
         *(u32x4*)(a.dx + row * a.lddx + col) = w;
+        if (a.dx2) {
+          const uint32_t e0 = (uint32_t)row * (uint32_t)a.H + (uint32_t)col;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (!a.drop.thresh || vt_keep(a.drop, e0 + i)) ? o[i] * a.drop.scale : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
+          *(u32x4*)(a.dx2 + row * a.lddx2 + col) = w;
+        }
       }
     }
   }
@@ -385,13 +402,16 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ p
 #define LN_BWD_MAX_BLOCKS 1024
 int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
-                              hipStream_t stream) {
+                              hipStream_t stream, void* dx2 = nullptr, long lddx2 = 0, const DropCfg* drop = nullptr) {
   if (!x || !dy || !gamma || !dx || !dgamma || !dbeta || !partial_ws) return VT_ERR_NULL;
   if (M <= 0 || H <= 0 || (H % 8) || H > 1024) return VT_ERR_BAD_SHAPE;
   if ((ldx % 8) || (ldy % 8) || (lddx % 8) || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15)) return VT_ERR_BAD_ALIGN;
   LnBwdArgs a;
   a.x = (const bf16_t*)x; a.ldx = ldx; a.dy = (const bf16_t*)dy; a.ldy = ldy; a.gamma = gamma;
   a.dx = (bf16_t*)dx; a.lddx = lddx; a.partial = partial_ws; a.M = M; a.H = H; a.eps = eps;
+  a.dx2 = (bf16_t*)dx2; a.lddx2 = lddx2;
+  if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
+  if (dx2 && ((lddx2 % 8) || ((uintptr_t)dx2 & 15))) return VT_ERR_BAD_ALIGN;
   int nblocks = (M + 3) / 4;
   if (nblocks > LN_BWD_MAX_BLOCKS) nblocks = LN_BWD_MAX_BLOCKS;
   if (H <= 512) hipLaunchKernelGGL(layernorm_bwd_rows<1>, dim3(nblocks), dim3(256), 0, stream, a);
@@ -440,6 +460,7 @@ struct EmbBwdArgs {
   int B, T, S, H;
   int n_word, n_pos, n_type;
   float eps;
+  DropCfg drop;  // same mask as the forward: the incoming gradient is masked and scaled first
 };
 
 template <int CH>
@@ -487,6 +508,11 @@ __global__ __launch_bounds__(256) void embed_layernorm_bwd(EmbBwdArgs a) {
         const u32x4 d = *(const u32x4*)(gp + col);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { gv[c][2 * i] = bf16lo(d[i]); gv[c][2 * i + 1] = bf16hi(d[i]); }
+        if (a.drop.thresh) {
+          const uint32_t e0 = (uint32_t)tok * (uint32_t)a.H + (uint32_t)col;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) gv[c][i] = vt_keep(a.drop, e0 + i) ? gv[c][i] * a.drop.scale : 0.f;
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { xv[c][i] = 0.f; gv[c][i] = 0.f; }
@@ -557,7 +583,8 @@ __global__ __launch_bounds__(256) void embed_layernorm_bwd(EmbBwdArgs a) {
 int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                                     const float* pos, const float* type, const float* gamma, const void* g, long ldg,
                                     float* de, float* dgamma, float* dbeta, float* partial_ws, int B, int T, int S, int H,
-                                    int n_word, int n_pos, int n_type, float eps, int accumulate, hipStream_t stream) {
+                                    int n_word, int n_pos, int n_type, float eps, int accumulate, hipStream_t stream,
+                                    const DropCfg* drop = nullptr) {
   if (!ids || !word || !pos || !type || !gamma || !g || !de || !dgamma || !dbeta || !partial_ws) return VT_ERR_NULL;
   if (B <= 0 || T <= 0 || S < T || H <= 0 || (H % 8) || H > 1024) return VT_ERR_BAD_SHAPE;
   if ((ldg % 8) || (((uintptr_t)word | (uintptr_t)pos | (uintptr_t)type | (uintptr_t)g | (uintptr_t)de) & 15)) return VT_ERR_BAD_ALIGN;
@@ -565,6 +592,7 @@ int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids,
   a.ids = ids; a.type_ids = type_ids; a.pos_ids = pos_ids; a.word = word; a.pos = pos; a.type = type; a.gamma = gamma;
   a.g = (const bf16_t*)g; a.ldg = ldg; a.de = de; a.partial = partial_ws; a.B = B; a.T = T; a.S = S; a.H = H;
   a.n_word = n_word; a.n_pos = n_pos; a.n_type = n_type; a.eps = eps;
+  if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
   long nb = ((long)B * T + 3) / 4;
   const int nblocks = (int)(nb > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : nb);
   if (H <= 512) hipLaunchKernelGGL(embed_layernorm_bwd<1>, dim3(nblocks), dim3(256), 0, stream, a);
@@ -750,5 +778,47 @@ int vt_ce_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* lo
   if ((ldz % 4) || (lddz % 8) || (((uintptr_t)z | (uintptr_t)dz) & 15)) return VT_ERR_BAD_ALIGN;
   hipLaunchKernelGGL(ce_softmax_rows, dim3((unsigned)rows), dim3(256), 0, stream, z, ldz, y, loss_row, amax, (bf16_t*)dz, lddz,
                      V, Vpad, scale);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// x *= dropout mask * scale in place (bf16 [rows, cols], element index = row * cols + col): masks the
+// compacted image-row gradient with the mask the region-projection epilogue used.
+__global__ __launch_bounds__(256) void apply_dropout_bf16(bf16_t* __restrict__ x, long ld, long rows, int cols, DropCfg d) {
+  const int cpr = cols >> 3;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cpr) return;
+  const long row = i / cpr;
+  const int col = (int)(i - row * cpr) * 8;
+  u32x4 w = *(u32x4*)(x + row * ld + col);
+  const uint32_t e0 = (uint32_t)row * (uint32_t)cols + (uint32_t)col;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { v[2 * k] = bf16lo(w[k]); v[2 * k + 1] = bf16hi(w[k]); }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = vt_keep(d, e0 + k) ? v[k] * d.scale : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+  *(u32x4*)(x + row * ld + col) = w;
+}
+
+int vt_apply_dropout_dispatch(void* x, long ld, long rows, int cols, const DropCfg& d, hipStream_t stream) {
+  if (!x) return VT_ERR_NULL;
+  if (rows <= 0 || cols <= 0 || (cols % 8) || (ld % 8) || rows * cols >= (1L << 32)) return VT_ERR_BAD_SHAPE;
+  if (!d.thresh) return VT_OK;
+  const long n = rows * (cols >> 3);
+  hipLaunchKernelGGL(apply_dropout_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (bf16_t*)x, ld, rows, cols, d);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// out[i] = 1 if element i of the site is kept (tests: lets the CPU oracle run with the SAME masks)
+__global__ __launch_bounds__(256) void dropout_mask_dump(uint8_t* __restrict__ out, long n, DropCfg d) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = vt_keep(d, (uint32_t)i) ? 1 : 0;
+}
+
+int vt_dropout_mask_dispatch(uint8_t* out, long n, const DropCfg& d, hipStream_t stream) {
+  if (!out) return VT_ERR_NULL;
+  if (n <= 0 || n >= (1L << 32)) return VT_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(dropout_mask_dump, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, n, d);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }

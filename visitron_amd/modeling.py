@@ -276,8 +276,8 @@ def _as_bf16_2d(x):
 def _no_train_dropout(module, p):
     if module.training and p > 0.0:
         raise NotImplementedError(
-            "dropout p=%g in training mode is not implemented in the HIP path yet; "
-            "use model.eval() or set the dropout probabilities to 0" % p
+            "dropout p=%g in training mode is served by the fused training path only (PreTrainOscar.forward with "
+            "grad enabled, or PretrainEngine); use model.eval() for module-level / no-grad calls" % p
         )
 
 

@@ -11,6 +11,22 @@ from . import _lib
 
 BF16 = torch.bfloat16
 ACT_NONE, ACT_GELU, ACT_TANH, ACT_MUL = 0, 1, 2, 3
+NO_DROP = (0.0, 0, 0)      # (p, step seed, site): dropout disabled
+SITE_EMB, SITE_IMG = 0xE0, 0xE1
+
+
+def site_attn(layer):
+    return 8 * layer
+
+
+def site_selfout(layer):
+    return 8 * layer + 1
+
+
+def site_out(layer):
+    return 8 * layer + 2
+
+
 LN_BWD_WS_ROWS = 1024  # vt_layernorm_bwd_bf16 scratch = LN_BWD_WS_ROWS * 2 * H floats
 
 
@@ -80,7 +96,7 @@ def round_up(x, m):
 
 
 def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False, grp_rows=0, grp_stride=0,
-           M=None, lda=None, ldc=None, pre_act_out=None):
+           M=None, lda=None, ldc=None, pre_act_out=None, drop=NO_DROP):
     """out = act(a @ w.T + bias) (+ residual).  a [M,K] bf16 (row stride lda), w [N,K] bf16.
     pre_act_out: optional bf16 [M,N] buffer saved for backward: gelu'(a @ w.T + bias) when act == ACT_GELU,
     else a @ w.T + bias.  act == ACT_MUL: out = (a @ w.T) * residual."""
@@ -101,7 +117,7 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
         rc = _lib.load().vt_linear_bf16_ex(
             _ptr(a), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(residual), ldr, _ptr(out), ldc,
             _ptr(pre_act_out), 0 if pre_act_out is None else pre_act_out.stride(0),
-            M, N, K, act, 1 if out_f32 else 0, grp_rows, grp_stride, _stream())
+            M, N, K, act, 1 if out_f32 else 0, grp_rows, grp_stride, float(drop[0]), int(drop[1]), int(drop[2]), _stream())
     _lib.check(rc, "vt_linear_bf16_ex")
     return out
 
@@ -160,7 +176,7 @@ def autotune_encoder_shapes(M, H, I, training=False, device="cuda"):
     return res
 
 
-def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None, out=None, lse=None):
+def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None, out=None, lse=None, drop=NO_DROP):
     """qkv [B*S, 3*nh*64] bf16, mask fp32 [B,S] -> context [B*S, nh*64] bf16."""
     _require_hip(qkv, mask, head_scale, out, lse)
     assert qkv.dtype == BF16
@@ -172,7 +188,7 @@ def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None
     with _timed("attention_fwd_d64", 4.0 * B * nh * S * S * 64, 2.0 * B * S * 4 * H):
         rc = _lib.load().vt_attention_fwd_bf16(
             _ptr(qkv), qkv.stride(0), _ptr(mask), 1 if mask_additive else 0, _ptr(head_scale), _ptr(out),
-            out.stride(0), _ptr(lse), B, S, nh, 64, _stream())
+            out.stride(0), _ptr(lse), B, S, nh, 64, float(drop[0]), int(drop[1]), int(drop[2]), _stream())
     _lib.check(rc, "vt_attention_fwd_bf16")
     return out
 
@@ -193,7 +209,7 @@ def layernorm(x, gamma, beta, eps, out=None, mean=None, rstd=None, M=None, grp_r
     return out
 
 
-def embed_layernorm(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, eps, out, S, err_flag=None):
+def embed_layernorm(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, eps, out, S, err_flag=None, drop=NO_DROP):
     """Writes rows b*S + t (t < T) of ``out`` [B*S, H] bf16."""
     _require_hip(ids, word, out)
     B, T = ids.shape
@@ -206,7 +222,7 @@ def embed_layernorm(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, eps, ou
         rc = _lib.load().vt_embed_layernorm(
             _ptr(ids), _ptr(type_ids), _ptr(pos_ids), _ptr(word), _ptr(pos), _ptr(typ), _ptr(gamma), _ptr(beta),
             _ptr(out), out.stride(0), B, T, S, H, word.shape[0], pos.shape[0], typ.shape[0], float(eps),
-            _ptr(err_flag), _stream())
+            _ptr(err_flag), float(drop[0]), int(drop[1]), _stream())
     _lib.check(rc, "vt_embed_layernorm")
     return out
 
@@ -228,7 +244,8 @@ def pack_concat(s0, s1, kpad, out=None):
     return out
 
 
-def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False, out=None, delta_ws=None, dq32_ws=None):
+def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False, out=None, delta_ws=None, dq32_ws=None,
+                  drop=NO_DROP):
     """Gradient of attention_fwd w.r.t. the packed qkv: returns dqkv [B*S, 3*nh*64] bf16."""
     _require_hip(qkv, dctx, ctx, lse, mask, out)
     H = nh * 64
@@ -242,13 +259,15 @@ def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False,
         rc = _lib.load().vt_attention_bwd_bf16(
             _ptr(qkv), qkv.stride(0), _ptr(dctx), dctx.stride(0), _ptr(ctx), ctx.stride(0), _ptr(mask),
             1 if mask_additive else 0, _ptr(lse), _ptr(delta_ws), _ptr(out), out.stride(0), _ptr(dq32_ws), B, S, nh, 64,
-            _stream())
+            float(drop[0]), int(drop[1]), int(drop[2]), _stream())
     _lib.check(rc, "vt_attention_bwd_bf16")
     return out
 
 
-def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta, dx=None, ws=None, accumulate=False, M=None):
-    """dx (bf16) and dgamma/dbeta (fp32, in place) of BertLayerNorm; x = pre-LayerNorm input."""
+def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta, dx=None, ws=None, accumulate=False, M=None, dx_dropped=None,
+                  drop=NO_DROP):
+    """dx (bf16) and dgamma/dbeta (fp32, in place) of BertLayerNorm; x = pre-LayerNorm input.
+    dx_dropped (optional bf16 [M,H]) receives dx * dropout mask / (1-p) of site `drop`."""
     _require_hip(x, dy, gamma, dgamma, dbeta, dx)
     H = gamma.numel()
     if M is None:
@@ -260,13 +279,14 @@ def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta, dx=None, ws=None, accumulate
     with _timed("layernorm_bwd_rows", 0.0, 6.0 * M * H):
         rc = _lib.load().vt_layernorm_bwd_bf16(
             _ptr(x), x.stride(0), _ptr(dy), dy.stride(0), _ptr(gamma), _ptr(dx), dx.stride(0), _ptr(dgamma),
-            _ptr(dbeta), _ptr(ws), M, H, float(eps), 1 if accumulate else 0, _stream())
+            _ptr(dbeta), _ptr(ws), M, H, float(eps), 1 if accumulate else 0, _ptr(dx_dropped),
+            0 if dx_dropped is None else dx_dropped.stride(0), float(drop[0]), int(drop[1]), int(drop[2]), _stream())
     _lib.check(rc, "vt_layernorm_bwd_bf16")
     return dx
 
 
 def embed_layernorm_bwd(ids, type_ids, pos_ids, word, pos, typ, gamma, eps, g, S, dgamma, dbeta, ws=None,
-                        accumulate=False):
+                        accumulate=False, drop=NO_DROP):
     """-> de fp32 [B*T, H]: gradient w.r.t. the summed embedding of every text token."""
     _require_hip(ids, word, g)
     B, T = ids.shape
@@ -277,7 +297,7 @@ def embed_layernorm_bwd(ids, type_ids, pos_ids, word, pos, typ, gamma, eps, g, S
     rc = _lib.load().vt_embed_layernorm_bwd(
         _ptr(ids), _ptr(type_ids), _ptr(pos_ids), _ptr(word), _ptr(pos), _ptr(typ), _ptr(gamma), _ptr(g), g.stride(0),
         _ptr(de), _ptr(dgamma), _ptr(dbeta), _ptr(ws), B, T, S, H, word.shape[0], pos.shape[0], typ.shape[0],
-        float(eps), 1 if accumulate else 0, _stream())
+        float(eps), 1 if accumulate else 0, float(drop[0]), int(drop[1]), _stream())
     _lib.check(rc, "vt_embed_layernorm_bwd")
     return de
 
@@ -306,6 +326,30 @@ def ce_softmax_rows(z, y, V, dz, scale):
     return loss, amax
 
 
+def set_attn_bwd_waves(waves):
+    """Tuning/test hook: 4- or 8-wave attention backward kernel (8 is the default)."""
+    _lib.load().vt_debug_set_attn_bwd_waves(int(waves))
+
+
+def apply_dropout(x, drop):
+    """x *= mask / (1-p) in place (bf16 [rows, cols], element index row * cols + col)."""
+    _require_hip(x)
+    assert x.dtype == BF16 and x.stride(1) == 1
+    rc = _lib.load().vt_apply_dropout_bf16(_ptr(x), x.stride(0), x.shape[0], x.shape[1], float(drop[0]), int(drop[1]),
+                                           int(drop[2]), _stream())
+    _lib.check(rc, "vt_apply_dropout_bf16")
+    return x
+
+
+def dropout_mask(n, drop, head_index=-1, device="cuda"):
+    """uint8 [n]: 1 where element i of the site is kept (test hook: feed the oracle the same masks)."""
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    rc = _lib.load().vt_debug_dropout_mask(_ptr(out), n, float(drop[0]), int(drop[1]), int(drop[2]), int(head_index),
+                                           _stream())
+    _lib.check(rc, "vt_debug_dropout_mask")
+    return out
+
+
 def transpose(src, out):
     """out[c, r] = src[r, c] (bf16 2-D, row strides allowed)."""
     _require_hip(src, out)
@@ -328,13 +372,13 @@ def dgelu_mul(g, h, out=None):
 
 
 def encoder_backward(layer_weights, layer_weights_t, layer_acts, layer_grads, x, mask, mask_additive, g, ws,
-                     B, S, H, nh, I, eps, accumulate=False):
+                     B, S, H, nh, I, eps, accumulate=False, p_hidden=0.0, p_attn=0.0, drop_seed=0, layer0=0):
     """Reverse layer loop in C; g [B*S,H] bf16 is updated in place to dL/dx."""
     _require_hip(x, mask, g)
     rc = _lib.load().vt_encoder_backward_bf16(
         layer_weights, layer_weights_t, layer_acts, layer_grads, len(layer_weights), _ptr(x), _ptr(mask),
         1 if mask_additive else 0, _ptr(g), ctypes.byref(ws), B, S, H, nh, I, float(eps), 1 if accumulate else 0,
-        _stream())
+        float(p_hidden), float(p_attn), int(drop_seed), int(layer0), _stream())
     _lib.check(rc, "vt_encoder_backward_bf16")
 
 
@@ -360,12 +404,13 @@ def wgrad(problems, M):
     _lib.check(rc, "vt_wgrad_bf16")
 
 
-def encoder_forward(layer_weights, layer_acts, x, mask, mask_additive, head_scale, B, S, H, nh, I, eps):
+def encoder_forward(layer_weights, layer_acts, x, mask, mask_additive, head_scale, B, S, H, nh, I, eps,
+                    p_hidden=0.0, p_attn=0.0, drop_seed=0):
     """Run the layer loop in C.  layer_weights / layer_acts: ctypes arrays built by the caller
     (``visitron_amd.modeling`` keeps them alive together with the tensors they point into)."""
     _require_hip(x, mask, head_scale)
     L = len(layer_weights)
     rc = _lib.load().vt_encoder_forward_bf16(
         layer_weights, layer_acts, L, _ptr(x), _ptr(mask), 1 if mask_additive else 0, _ptr(head_scale),
-        B, S, H, nh, I, float(eps), _stream())
+        B, S, H, nh, I, float(eps), float(p_hidden), float(p_attn), int(drop_seed), _stream())
     _lib.check(rc, "vt_encoder_forward_bf16")

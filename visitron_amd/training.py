@@ -117,6 +117,7 @@ class _TrainBuffers(object):
         self.g = mk(H)
         self.g_seq32 = torch.empty((M, H), dtype=torch.float32, device=dev)
         self.ws_t = dict(g_pre=mk(H), g_pre2=mk(H), g_mid=mk(I), g_ctx=mk(H), g_qkv=mk(3 * H),
+                         g_pre_d=mk(H), g_pre2_d=mk(H),   # dropout-masked copies (hidden dropout > 0)
                          delta=torch.empty((B, nh, S), dtype=torch.float32, device=dev),
                          ln_partial=torch.empty(ops.LN_BWD_WS_ROWS * 2 * H, dtype=torch.float32, device=dev))
         if S > 256:  # attention backward over several key blocks accumulates dQ in fp32
@@ -137,10 +138,8 @@ class PretrainEngine(object):
         if getattr(model.bert, "use_img_layernorm", None):
             raise NotImplementedError("use_img_layernorm is not implemented in the HIP training path yet")
         for p_ in (cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob):
-            if p_ > 0.0:
-                raise NotImplementedError(
-                    "dropout > 0 is not implemented in the HIP training path yet; set hidden_dropout_prob and "
-                    "attention_probs_dropout_prob to 0")
+            if not 0.0 <= p_ < 1.0:
+                raise ValueError("dropout probability must be in [0, 1)")
         self.model, self.cfg = model, cfg
         self.flat = FlatParams(model, attach_grads=attach_grads)
         self.lr, self.wd, self.eps, self.betas, self.correct_bias = lr, weight_decay, eps, betas, correct_bias
@@ -155,6 +154,12 @@ class PretrainEngine(object):
         self.loss_scale_by_world = loss_scale_by_world
         self._bufs = {}
         self._tables = None
+        # dropout: masks come from a counter-based hash of (seed, site, element); the seed of a
+        # forward/backward pair = base (torch's seed, decorrelated per rank) + number of pairs so far
+        rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
+        self.drop_seed_base = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * (rank + 1)) & 0xFFFFFFFFFFFFFFFF
+        self.fb_count = 0
+        self.last_drop_seed = 0
         self._wt_dirty = True
         self._build_tables()
 
@@ -306,22 +311,30 @@ class PretrainEngine(object):
         bufs = self._buffers(B, S)
         emb = m.bert.embeddings
         eps = emb.LayerNorm.variance_epsilon
+        # dropout (nn.Dropout follows the module's training flag): same (p, seed) in forward and backward
+        p_h = float(cfg.hidden_dropout_prob) if m.training else 0.0
+        p_a = float(cfg.attention_probs_dropout_prob) if m.training else 0.0
+        seed = (self.drop_seed_base + self.fb_count) & 0xFFFFFFFFFFFFFFFF
+        self.fb_count += 1
+        self.last_drop_seed = seed
+        dp_kw = dict(p_hidden=p_h, p_attn=p_a, drop_seed=seed)
 
         # ---------------- forward ----------------
         x0 = bufs.x0
         err = torch.zeros(1, dtype=torch.int32, device=dev)
         ops.embed_layernorm(ids, tt, pos_ids, emb.word_embeddings.weight.detach(), emb.position_embeddings.weight.detach(),
                             emb.token_type_embeddings.weight.detach(), emb.LayerNorm.weight.detach(),
-                            emb.LayerNorm.bias.detach(), eps, x0, S, err_flag=err)
+                            emb.LayerNorm.bias.detach(), eps, x0, S, err_flag=err, drop=(p_h, seed, ops.SITE_EMB))
         a_img = None
         if img is not None:
             a_img = ops.pack_concat(img.reshape(B * R, -1).float().contiguous(),
                                     batch["img_location_embeddings"].reshape(B * R, -1).float().contiguous(), self.kpad)
-            ops.linear(a_img, self.w_img, self.b_img, out=x0[T:], ldc=H, grp_rows=R, grp_stride=S)
+            ops.linear(a_img, self.w_img, self.b_img, out=x0[T:], ldc=H, grp_rows=R, grp_stride=S,
+                       drop=(p_h, seed, ops.SITE_IMG))
         if ops.profiling():
-            self._encoder_forward_unrolled(bufs, x0, mask, B, S)
+            self._encoder_forward_unrolled(bufs, x0, mask, B, S, p_h, p_a, seed)
         else:
-            ops.encoder_forward(self.w_tab, bufs.acts, x0, mask, False, None, B, S, H, nh, I, cfg.layer_norm_eps)
+            ops.encoder_forward(self.w_tab, bufs.acts, x0, mask, False, None, B, S, H, nh, I, cfg.layer_norm_eps, **dp_kw)
         seq = bufs.layers[-1]["out"]
         pooled = ops.linear(seq, self._mirror(m.bert.pooler.dense.weight), m.bert.pooler.dense.bias.detach(),
                             act=ACT_TANH, out_f32=True, M=B, lda=S * H)
@@ -431,10 +444,10 @@ class PretrainEngine(object):
         g = bufs.g
         g.copy_(g32)
         if ops.profiling():
-            self._encoder_backward_unrolled(bufs, x0, mask, g, B, S, acc)
+            self._encoder_backward_unrolled(bufs, x0, mask, g, B, S, acc, p_h, p_a, seed)
         elif comm is None:
             ops.encoder_backward(self.w_tab, self.wt_tab, bufs.acts, self.g_tab, x0, mask, False, g, bufs.ws, B, S, H, nh,
-                                 I, cfg.layer_norm_eps, accumulate=acc)
+                                 I, cfg.layer_norm_eps, accumulate=acc, **dp_kw)
         else:
             # data-parallel: backward in layer chunks (last layers first); as soon as a chunk's kernels are
             # enqueued its gradient ranges are all-reduced on the communicator's stream, under the backward
@@ -448,7 +461,7 @@ class PretrainEngine(object):
                 x_in = x0 if lo == 0 else bufs.layers[lo - 1]["out"]
                 ops.encoder_backward(sub(self.w_tab, _lib.LayerWeights), sub(self.wt_tab, _lib.LayerWeightsT),
                                      sub(bufs.acts, _lib.LayerActs), sub(self.g_tab, _lib.LayerGrads), x_in, mask, False, g,
-                                     bufs.ws, B, S, H, nh, I, cfg.layer_norm_eps, accumulate=acc)
+                                     bufs.ws, B, S, H, nh, I, cfg.layer_norm_eps, accumulate=acc, layer0=lo, **dp_kw)
                 rng = [(self.layer_ranges[lo][k][0], self.layer_ranges[hi - 1][k][1]) for k in (0, 1)]
                 comm["launch"](rng)
                 comm["done"].extend(rng)
@@ -457,7 +470,8 @@ class PretrainEngine(object):
         de = ops.embed_layernorm_bwd(ids, tt, pos_ids, emb.word_embeddings.weight.detach(),
                                      emb.position_embeddings.weight.detach(), emb.token_type_embeddings.weight.detach(),
                                      emb.LayerNorm.weight.detach(), eps, g, S, self._grad(emb.LayerNorm.weight),
-                                     self._grad(emb.LayerNorm.bias), ws=bufs.ws_t["ln_partial"], accumulate=acc)
+                                     self._grad(emb.LayerNorm.bias), ws=bufs.ws_t["ln_partial"], accumulate=acc,
+                                     drop=(p_h, seed, ops.SITE_EMB))
         pos_grad, type_grad = self._grad(emb.position_embeddings.weight), self._grad(emb.token_type_embeddings.weight)
         if not acc:
             pos_grad.zero_()
@@ -477,6 +491,8 @@ class PretrainEngine(object):
         # region projection
         if img is not None:
             g_img = g.view(B, S, H)[:, T:].reshape(B * R, H)
+            if p_h > 0.0:
+                ops.apply_dropout(g_img, (p_h, seed, ops.SITE_IMG))   # g is not read again after this point
             ops.wgrad([dict(dy=g_img, x=a_img, dw=self.dw_img, db=self.db_img)], B * R)
             D = m.bert.img_dim
             gi, gl = self._grad(m.bert.img_embedding.weight), self._grad(m.bert.location_embeds.weight)
@@ -489,41 +505,46 @@ class PretrainEngine(object):
         return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
 
     # ---- the launch sequences of vt_encoder_forward/backward_bf16 issued op by op (bench.py's per-kernel timing)
-    def _encoder_forward_unrolled(self, bufs, x0, mask, B, S):
+    def _encoder_forward_unrolled(self, bufs, x0, mask, B, S, p_h=0.0, p_a=0.0, seed=0):
         cfg = self.cfg
         nh, eps = cfg.num_attention_heads, cfg.layer_norm_eps
         cur = x0
-        for (t, _), a in zip(self._keep, bufs.layers):
+        for l, ((t, _), a) in enumerate(zip(self._keep, bufs.layers)):
             ops.linear(cur, t["w_qkv"], t["b_qkv"], out=a["qkv"])
-            ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, out=a["ctx"], lse=a["lse"])
-            ops.linear(a["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=a["attn_pre"])
+            ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, out=a["ctx"], lse=a["lse"], drop=(p_a, seed, ops.site_attn(l)))
+            ops.linear(a["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=a["attn_pre"], drop=(p_h, seed, ops.site_selfout(l)))
             ops.layernorm(a["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=a["attn_out"])
             ops.linear(a["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=a["mid"], pre_act_out=a["mid_pre"])
-            ops.linear(a["mid"], t["w_out"], t["b_out"], residual=a["attn_out"], out=a["out_pre"])
+            ops.linear(a["mid"], t["w_out"], t["b_out"], residual=a["attn_out"], out=a["out_pre"],
+                       drop=(p_h, seed, ops.site_out(l)))
             ops.layernorm(a["out_pre"], t["ln2_g"], t["ln2_b"], eps, out=a["out"])
             cur = a["out"]
 
-    def _encoder_backward_unrolled(self, bufs, x0, mask, g, B, S, acc):
+    def _encoder_backward_unrolled(self, bufs, x0, mask, g, B, S, acc, p_h=0.0, p_a=0.0, seed=0):
         cfg = self.cfg
         nh, eps, M = cfg.num_attention_heads, cfg.layer_norm_eps, B * S
         w = bufs.ws_t
         for l in range(cfg.num_hidden_layers - 1, -1, -1):
             (t, gr), a, (_, wt) = self._keep[l], bufs.layers[l], self.wt[l]
             x_in = x0 if l == 0 else bufs.layers[l - 1]["out"]
+            hd = p_h > 0.0   # with hidden dropout the dense outputs' gradients are the masked copies
+            g_pre_dn, g_pre2_dn = (w["g_pre_d"], w["g_pre2_d"]) if hd else (w["g_pre"], w["g_pre2"])
             ops.layernorm_bwd(a["out_pre"], g, t["ln2_g"], eps, gr["d_ln2_g"], gr["d_ln2_b"], dx=w["g_pre"],
-                              ws=w["ln_partial"], accumulate=acc)
-            ops.linear(w["g_pre"], wt["wt_out"], residual=a["mid_pre"], act=ACT_MUL, out=w["g_mid"])
+                              ws=w["ln_partial"], accumulate=acc, dx_dropped=w["g_pre_d"] if hd else None,
+                              drop=(p_h, seed, ops.site_out(l)))
+            ops.linear(g_pre_dn, wt["wt_out"], residual=a["mid_pre"], act=ACT_MUL, out=w["g_mid"])
             ops.linear(w["g_mid"], wt["wt_in"], residual=w["g_pre"], out=g)
             ops.layernorm_bwd(a["attn_pre"], g, t["ln1_g"], eps, gr["d_ln1_g"], gr["d_ln1_b"], dx=w["g_pre2"],
-                              ws=w["ln_partial"], accumulate=acc)
-            ops.linear(w["g_pre2"], wt["wt_ao"], out=w["g_ctx"])
+                              ws=w["ln_partial"], accumulate=acc, dx_dropped=w["g_pre2_d"] if hd else None,
+                              drop=(p_h, seed, ops.site_selfout(l)))
+            ops.linear(g_pre2_dn, wt["wt_ao"], out=w["g_ctx"])
             ops.attention_bwd(a["qkv"], w["g_ctx"], a["ctx"], a["lse"], B, S, nh, mask=mask, out=w["g_qkv"],
-                              delta_ws=w["delta"], dq32_ws=w.get("dq32"))
+                              delta_ws=w["delta"], dq32_ws=w.get("dq32"), drop=(p_a, seed, ops.site_attn(l)))
             ops.linear(w["g_qkv"], wt["wt_qkv"], residual=w["g_pre2"], out=g)
             ops.wgrad([dict(dy=w["g_mid"], x=a["attn_out"], dw=gr["d_w_in"], db=gr["d_b_in"], accumulate=acc),
-                       dict(dy=w["g_pre"], x=a["mid"], dw=gr["d_w_out"], db=gr["d_b_out"], accumulate=acc),
+                       dict(dy=g_pre_dn, x=a["mid"], dw=gr["d_w_out"], db=gr["d_b_out"], accumulate=acc),
                        dict(dy=w["g_qkv"], x=x_in, dw=gr["d_w_qkv"], db=gr["d_b_qkv"], accumulate=acc),
-                       dict(dy=w["g_pre2"], x=a["ctx"], dw=gr["d_w_ao"], db=gr["d_b_ao"], accumulate=acc)], M)
+                       dict(dy=g_pre2_dn, x=a["ctx"], dw=gr["d_w_ao"], db=gr["d_b_ao"], accumulate=acc)], M)
 
     # ------------------------------------------------------------------------------ optimizer
     def optimizer_step(self, grad_scale=1.0):
