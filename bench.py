@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--regions", type=int, default=100)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: all ranks use cuda:0")
+    ap.add_argument("--dropout", type=float, default=0.1,
+                    help="hidden / attention-probs dropout in the train step (reference defaults: --drop_out 0.1, "
+                         "params.py:299, and BERT-base attention_probs_dropout_prob 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -78,7 +81,7 @@ def main():
     from visitron_amd.synth import make_batch
     from visitron_amd.training import PretrainEngine
 
-    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg = BertConfig(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout)
     torch.manual_seed(0)  # reference init N(0, 0.02) (BertPreTrainedModel.init_weights), identical on every rank
     S = a.text + a.regions
     train = a.mode == "train"
@@ -202,6 +205,7 @@ def main():
                 "global_batch": world * a.batch, "seq_len": S,
                 "parallelism": ("dp%d (flat-slab gradient all-reduce over RCCL)" if train else "dp%d (replicas, no collective)") % world,
                 "weights": "random init N(0,0.02), seed 0",
+                "dropout": a.dropout if train else 0.0,
             },
             "encoder_flops_per_seq_fwd": f_enc,
             "mfma_frac_whole_step": round((3 if train else 1) * f_enc * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),

@@ -62,6 +62,45 @@ def test_linear_matches_fp32(dev, M, N, K, act, res, f32out):
         assert bool((out[:, N:].float() == 7.0).all())
 
 
+@pytest.mark.parametrize(
+    "M,N,K,act,res,f32out",
+    [
+        (512, 512, 128, 0, False, False),     # 2x2 tiles, two K-steps
+        (256, 256, 64, 0, False, True),       # a single K-step (prologue-only pipeline)
+        (700, 768, 192, 0, True, False),      # M tail, odd number of K-steps
+        (456, 2304, 768, 0, False, False),
+        (300, 3072, 768, 1, False, False),    # GELU epilogue
+        (1000, 768, 3072, 0, True, False),    # long K
+        (130, 36, 128, 0, False, True),       # N tail inside the first 64-column block
+        (520, 1601, 768, 0, False, True),     # N tail not a multiple of 16
+        (64, 768, 768, 2, False, True),       # tanh
+        (9000, 1024, 256, 0, True, False),    # 144 tiles: several tiles per workgroup on some XCDs only
+        (70000, 768, 64, 0, False, False),    # 822 tiles of one K-step each (every step crosses a tile boundary)
+    ],
+)
+@pytest.mark.parametrize("variant", [15, 16])
+def test_linear_variant_256x256_agpr(dev, M, N, K, act, res, f32out, variant):
+    """The 256x256-tile kernels with 128x128 wave tiles (15: one tile per workgroup, 16: persistent with the K
+    pipeline running across tiles) on their own: tails, odd K-step counts, epilogues."""
+    from visitron_amd import ops
+
+    ops.set_gemm_variant(variant)
+    try:
+        test_linear_matches_fp32(dev, M, N, K, act, res, f32out)
+        # row remap + dropout + saved pre-activation through the same kernel
+        g = torch.Generator().manual_seed(M + K)
+        a, w = bf16_round(_rand((M, K), g)), bf16_round(_rand((N, K), g, 0.05))
+        if not f32out and act == 0:
+            drop = (0.2, 11, 3)
+            keep = ops.dropout_mask(M * N, drop, device=dev).view(M, N).float().cpu()
+            got = ops.linear(a.to(dev, BF16), w.to(dev, BF16), drop=drop)
+            torch.cuda.synchronize()
+            want = (a @ w.t()) * keep / 0.8
+            assert maxabs(got, want) < 2e-2 * (1 + float(want.abs().max()))
+    finally:
+        ops.set_gemm_variant(-1)
+
+
 def test_linear_asymmetric_identity(dev):
     """A = I against an ASYMMETRIC W catches a transposed or permuted accumulator write-out."""
     from visitron_amd import ops

@@ -1,0 +1,143 @@
+// Shared by the NT GEMM kernels (gemm_bf16.hip, gemm_v7.hip): argument block and the register epilogue.
+#pragma once
+#include "common.hpp"
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* W;
+  const float* bias;
+  const bf16_t* R;   // residual added after the activation; for ACT_MUL: the factor (saved gelu')
+  void* C;
+  bf16_t* C2;        // optional second output for backward: gelu'(acc + bias) if ACT_GELU, else acc + bias
+  long lda, ldw, ldr, ldc, ldc2;
+  int M, N, K;
+  int grp_rows, grp_stride;  // output row = (m / grp_rows) * grp_stride + m % grp_rows  (0: identity)
+  int tiles_m, tiles_n;
+  DropCfg drop;              // dropout on act(acc + bias) BEFORE the residual add (BertSelfOutput / BertOutput /
+                             // image embedding); element index = m * N + n
+};
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_MUL = 3 };  // MUL: out = acc * R (R = saved gelu'(pre-activation))
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 64
+#define GEMM_TILE_BYTES (128 * 64 * 2)
+#define GEMM_LDS_BYTES (4 * GEMM_TILE_BYTES)
+#define GEMM_DEFAULT_VARIANT 1
+
+template <int ACT>
+__device__ __forceinline__ float apply_act(float x) {
+  if (ACT == ACT_GELU) return gelu_erf(x);
+  if (ACT == ACT_TANH) return tanh_fast(x);
+  return x;  // ACT_NONE and ACT_MUL (the latter multiplies by R where R is read)
+}
+
+// Epilogue shared by the GEMM kernels: lane (j = lane&15, gq = lane>>4) owns output rows
+// row0+16mt+j (mt = 0..3) and the 16 consecutive columns col0+16gq .. +15; bias, activation and
+// residual are applied in registers and each lane stores 32 (bf16) or 64 (fp32) contiguous bytes.
+template <int ACT, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int lane, int row0, int col0) {
+  const int gq = lane >> 4;
+  const int nb = col0 + 16 * gq;
+  if (nb >= g.N) return;
+  const bool full = (nb + 16 <= g.N);
+
+  float bv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bv[i] = 0.f;
+  if (g.bias) {
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 t4 = *(const f32x4*)(g.bias + nb + 4 * i);
+        bv[4 * i + 0] = t4[0]; bv[4 * i + 1] = t4[1]; bv[4 * i + 2] = t4[2]; bv[4 * i + 3] = t4[3];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (nb + i < g.N) bv[i] = g.bias[nb + i];
+    }
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = row0 + 16 * mt + (lane & 15);
+    if (m >= g.M) continue;
+    const long orow = g.grp_rows ? (long)(m / g.grp_rows) * g.grp_stride + (m % g.grp_rows) : (long)m;
+    float v[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * t + e] = acc[mt][t][e] + bv[4 * t + e];
+
+    if (full) {
+      if (g.C2) {  // saved for the backward pass: the activation's derivative (GELU) or the pre-activation
+        float s2[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s2[i] = (ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i];
+        u32x4* cp2 = (u32x4*)(g.C2 + orow * g.ldc2 + nb);
+        u32x4 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o0[i] = pack_bf16x2(s2[2 * i], s2[2 * i + 1]);
+          o1[i] = pack_bf16x2(s2[8 + 2 * i], s2[8 + 2 * i + 1]);
+        }
+        cp2[0] = o0;
+        cp2[1] = o1;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);
+      if (g.drop.thresh) {
+        const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)nb;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f;
+      }
+      if (g.R) {
+        const u32x4* rp = (const u32x4*)(g.R + orow * g.ldr + nb);
+        const u32x4 r0 = rp[0], r1 = rp[1];
+        float rv[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          rv[2 * i] = bf16lo(r0[i]);
+          rv[2 * i + 1] = bf16hi(r0[i]);
+          rv[8 + 2 * i] = bf16lo(r1[i]);
+          rv[8 + 2 * i + 1] = bf16hi(r1[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (ACT == ACT_MUL) ? v[i] * rv[i] : v[i] + rv[i];
+      }
+      if (OUT_F32) {
+        f32x4* cp = (f32x4*)((float*)g.C + orow * g.ldc + nb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cp[i] = (f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+      } else {
+        u32x4* cp = (u32x4*)((bf16_t*)g.C + orow * g.ldc + nb);
+        u32x4 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+          o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+        }
+        cp[0] = o0;
+        cp[1] = o1;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (nb + i < g.N) {
+          if (g.C2) g.C2[orow * g.ldc2 + nb + i] = f32_to_bf16((ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i]);
+          float x = apply_act<ACT>(v[i]);
+          if (g.drop.thresh) x = vt_keep(g.drop, (uint32_t)m * (uint32_t)g.N + (uint32_t)(nb + i)) ? x * g.drop.scale : 0.f;
+          if (g.R) {
+            const float rr = bf16_to_f32(g.R[orow * g.ldr + nb + i]);
+            x = (ACT == ACT_MUL) ? x * rr : x + rr;
+          }
+          if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;
+          else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = f32_to_bf16(x);
+        }
+      }
+    }
+  }
+}
+

@@ -1,0 +1,410 @@
+// NT GEMM, 256x256 tile with 128x128 wave tiles and AGPR accumulators (variant 15 of vt_gemm_dispatch).
+#include "gemm_common.hpp"
+
+// ================================================================================================
+// v7: 256x256 tile, BK = 64, FOUR waves as 2(M) x 2(N), wave tile 128 x 128 = 8x8 MFMA tiles whose 256
+// accumulator registers live in AGPRs; one wave per SIMD, 512 registers each.  A wave reads 16 fragments
+// per 64 MFMAs (0.25 LDS fragment reads per MFMA, half of the 128x128 kernels above), which is what the
+// measurements above said bounds them.  With a single wave per SIMD nothing hides a stall, so the K loop
+// is one hand-ordered instruction stream (inline asm MFMAs / LDS reads, at most two other instructions
+// between consecutive MFMAs):
+//   tile kt sits in LDS stage s = kt & 1 (X image 32 KiB, then W image 32 KiB; same row images and XOR
+//   swizzle as above), its k-substep-0 fragments are already in register set 0;
+//   phase A (64 MFMAs, set 0): read X fragments of substep 1 -> set 1 | lgkmcnt(0) + barrier: every wave
+//            is done with the X image of stage s | issue the 8 X DMA pieces of tile kt+2 into it,
+//            alternating with the W fragment reads of substep 1 | lgkmcnt(0) + barrier: W image free |
+//            first W DMA pieces of tile kt+2;
+//   phase B (64 MFMAs, set 1): more W pieces | vmcnt(13): the 16 pieces of tile kt+1 (issued one
+//            iteration ago) have landed | barrier | read substep-0 fragments of tile kt+1 from stage s^1
+//            -> set 0, alternating with the last W pieces | lgkmcnt(0).
+// Operands come through buffer_load ... lds with per-piece scalar offsets and two per-lane offsets (the
+// swizzle depends on the piece parity only); rows past M / N and tiles past K read as zeros through
+// num_records, so no clamping and no tail code.
+#define V7_STAGE 65536
+#define V7_WOFF 32768
+#define V7_MFMA(S, i)                                                                                             \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(i) & 7][(i) >> 3]) : "v"(wf[S][(i) >> 3]), \
+               "v"(xf[S][(i) & 7]))
+#define V7_LDSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+// One K-step: the current stage holds the K-tile whose substep-0 fragments are in set 0; (rx, rw) describe the
+// K-tile two steps ahead.  VMW is the vmcnt that proves the NEXT K-tile has landed: 13 in steady state (the 13
+// pieces issued so far in this step may stay in flight), 0 right after an epilogue (its stores share the counter).
+#define V7_STEP(VMW)                                                                                       \
+  {                                                                                                        \
+    const unsigned xn0 = xa0 ^ V7_STAGE, wn0 = wa0 ^ V7_STAGE; /* substep-0 addresses of the other stage */ \
+    _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
+      V7_MFMA(0, i);                                                                                       \
+      if (i < 16 && (i & 1)) V7_LDSR(xf[1][i >> 1], xa1, (i >> 1) * 2048);                                 \
+      if (i == 20) {                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        __builtin_amdgcn_s_barrier();                                                                      \
+      }                                                                                                    \
+      if (i >= 22 && i < 38 && !(i & 1)) V7_DMA_X(rx, dst, (i - 22) >> 1);                                 \
+      if (i >= 22 && i < 38 && (i & 1)) V7_LDSR(wf[1][(i - 22) >> 1], wa1, ((i - 22) >> 1) * 2048);        \
+      if (i == 50) {                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        __builtin_amdgcn_s_barrier();                                                                      \
+      }                                                                                                    \
+      if (i >= 52 && !(i & 3)) V7_DMA_W(rw, dst, (i - 52) >> 2);                                           \
+    }                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
+      V7_MFMA(1, i);                                                                                       \
+      if (i == 4) V7_DMA_W(rw, dst, 3);                                                                    \
+      if (i == 10) V7_DMA_W(rw, dst, 4);                                                                   \
+      if (i == 24) {                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");                                         \
+        __builtin_amdgcn_s_barrier();                                                                      \
+      }                                                                                                    \
+      if (i >= 26 && i < 58 && !(i & 1)) {                                                                 \
+        const int j = (i - 26) >> 1;                                                                       \
+        if (j < 8) V7_LDSR(xf[0][j], xn0, j * 2048);                                                       \
+        else V7_LDSR(wf[0][j - 8], wn0, (j - 8) * 2048);                                                   \
+      }                                                                                                    \
+      if (i == 31) V7_DMA_W(rw, dst, 5);                                                                   \
+      if (i == 39) V7_DMA_W(rw, dst, 6);                                                                   \
+      if (i == 47) V7_DMA_W(rw, dst, 7);                                                                   \
+    }                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    xa0 ^= V7_STAGE; xa1 ^= V7_STAGE; wa0 ^= V7_STAGE; wa1 ^= V7_STAGE; dst ^= V7_STAGE;                   \
+  }
+
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-contiguous chunk of the grouped tile order (bands of 8 row-tiles, column-tile major inside)
+  const int nwg = gridDim.x;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  const int band_tiles = 8 * g.tiles_n;
+  const int band = t_id / band_tiles;
+  const int within = t_id - band * band_tiles;
+  const int rows_left = g.tiles_m - band * 8;
+  const int band_h = rows_left < 8 ? rows_left : 8;
+  const int bn = within / band_h;
+  const int bm = band * 8 + (within - bn * band_h);
+  const int m0 = bm * 256, n0 = bn * 256;
+
+  // ---- DMA addressing.  Piece p = wave*8 + i covers LDS rows 8p .. 8p+7 of an operand image (128 B per row);
+  // lane -> row 8p + (lane>>3), 16-B chunk (lane&7) ^ swz(row), swz(row) = (4*(i&1) + (lane>>4)) & 7.
+  const int rows_x = g.M - m0 < 256 ? g.M - m0 : 256;
+  const int rows_w = g.N - n0 < 256 ? g.N - n0 : 256;
+  const bf16_t* xbase = g.A + (long)m0 * g.lda;
+  const bf16_t* wbase = g.W + (long)n0 * g.ldw;
+  // bytes of the tile's row panel that may be read: full rows except the last one, which holds K elements
+  const unsigned xbytes = (unsigned)(((long)(rows_x - 1) * g.lda + g.K) * 2);
+  const unsigned wbytes = (unsigned)(((long)(rows_w - 1) * g.ldw + g.K) * 2);
+  int vx[2], vw[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int c = (lane & 7) ^ ((4 * par + (lane >> 4)) & 7);
+    vx[par] = (lane >> 3) * (int)g.lda * 2 + c * 16;
+    // W rows are permuted inside each 64-row block so that a lane's 4 N-subtiles interleave to 16
+    // consecutive output columns: image row r <- W row 16*((r>>2)&3) + 4*((r>>4)&3) + (r&3)
+    vw[par] = (16 * (lane >> 5) + ((lane >> 3) & 3)) * (int)g.ldw * 2 + c * 16;
+  }
+  int sx[8], sw[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sx[i] = (wave * 8 + i) * 8 * (int)g.lda * 2;
+    sw[i] = (64 * wave + 32 * (i & 1) + 4 * (i >> 1)) * (int)g.ldw * 2;
+  }
+  const int nk = g.K >> 6;
+
+  // ---- fragment addresses: X image row 128*wm + 16*mt + (lane&15), W image row 128*wn + 16*nt + (lane&15);
+  // chunk (lane>>4) ^ swz(row) for k-substep 0, the same ^ 4 (address ^ 64) for substep 1
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned fr = (lane & 15) * 128 + ((((unsigned)lane >> 4) ^ (((unsigned)lane & 15) >> 1)) << 4);
+  // current-stage addresses of the two k-substeps; toggled (^ V7_STAGE) every K-step.  They are loop-carried on
+  // purpose: as long-lived loop invariants the register allocator would park them in scratch.
+  unsigned xa0 = lds0 + wm * 16384 + fr, xa1 = xa0 ^ 64;
+  unsigned wa0 = lds0 + V7_WOFF + wn * 16384 + fr, wa1 = wa0 ^ 64;
+  unsigned dst = wave * 8192;   // byte offset of this wave's first DMA piece inside the current stage's X image
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  u32x4 xf[2][8], wf[2][8];
+
+  auto rsrc_x = [&](int kt) {
+    const unsigned kb = (unsigned)kt * 128u;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)xbase + kb), 0, kt < nk ? (int)(xbytes - kb) : 0, 0x00020000);
+  };
+  auto rsrc_w = [&](int kt) {
+    const unsigned kb = (unsigned)kt * 128u;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)wbase + kb), 0, kt < nk ? (int)(wbytes - kb) : 0, 0x00020000);
+  };
+#define V7_DMA_X(rs, d, i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(smem + (d) + (i) * 1024), 16, vx[(i) & 1], sx[i], 0, 0)
+#define V7_DMA_W(rs, d, i) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(smem + (d) + V7_WOFF + (i) * 1024), 16, vw[(i) & 1], sw[i], 0, 0)
+
+  // prologue: tiles 0 and 1 in flight, substep-0 fragments of tile 0 in set 0
+  {
+    __amdgpu_buffer_rsrc_t rx0 = rsrc_x(0), rw0 = rsrc_w(0), rx1 = rsrc_x(1), rw1 = rsrc_w(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) V7_DMA_X(rx0, dst, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) V7_DMA_W(rw0, dst, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) V7_DMA_X(rx1, dst + V7_STAGE, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) V7_DMA_W(rw1, dst + V7_STAGE, i);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      V7_LDSR(xf[0][i], xa0, i * 2048);
+      V7_LDSR(wf[0][i], wa0, i * 2048);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // one K-step per iteration: tile kt in the current stage; MFMA i = 8*nt + mt
+  for (int kt = 0; kt < nk; ++kt) {
+    __amdgpu_buffer_rsrc_t rx = rsrc_x(kt + 2), rw = rsrc_w(kt + 2);
+    V7_STEP(13)
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+  // epilogue: four 64x64 quadrants of the wave tile through the shared register epilogue (spelled out:
+  // a rolled loop would index the accumulators dynamically and push them to scratch)
+#define V7_EPI(mh, nh)                                                                                  \
+  {                                                                                                     \
+    f32x4 sub[4][4];                                                                                    \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+        /* keeps the accumulators in AGPRs until their quadrant is stored */                            \
+        asm volatile("" : "+a"(acc[4 * (mh) + mt][4 * (nh) + t]));                                      \
+        sub[mt][t] = acc[4 * (mh) + mt][4 * (nh) + t];                                                  \
+      }                                                                                                 \
+    gemm_epilogue<ACT, OUT_F32>(g, sub, lane, m0 + 128 * wm + 64 * (mh), n0 + 128 * wn + 64 * (nh));    \
+  }
+#ifdef V7_DIAG
+  {
+    float t = 0.f;
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) _Pragma("unroll") for (int j = 0; j < 8; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    ((float*)g.C)[blockIdx.x * 256 + tid] = t;
+  }
+#else
+  V7_EPI(0, 0)
+  V7_EPI(0, 1)
+  V7_EPI(1, 0)
+  V7_EPI(1, 1)
+#endif
+}
+
+
+// ================================================================================================
+// v8: v7 made persistent.  One workgroup per CU walks its share of the output tiles and the K-step pipeline
+// runs straight across tile boundaries: while tile t is in its last two K-steps the DMA already fetches the
+// first two K-tiles of tile t+1, so the epilogue of t is the only time the MFMA pipes idle (v7 pays launch +
+// first-fetch latency per tile on top: ~11 us of a ~28 us tile at K = 768).  Each XCD owns a contiguous
+// chunk of the grouped tile order; its workgroups take tiles of the chunk round-robin, so the tiles in flight
+// on one L2 are neighbours.
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int T = g.tiles_m * g.tiles_n;
+  const int nwg = gridDim.x, b = blockIdx.x;
+  const int xcd = b & 7;
+  const int nx = (nwg - xcd + 7) >> 3;                 // workgroups on this XCD
+  const int ng = nwg < 8 ? nwg : 8;                    // XCD groups that have a workgroup
+  const int c0 = (int)((long)T * xcd / ng), c1 = (int)((long)T * (xcd + 1) / ng);
+  const int first = c0 + (b >> 3);
+  const int band_tiles = 8 * g.tiles_n;
+  const int nk = g.K >> 6;
+
+  auto tile_origin = [&](int t, int& m0, int& n0) {   // grouped order: bands of 8 row-tiles, column-tile major inside
+    const int band = t / band_tiles;
+    const int within = t - band * band_tiles;
+    const int rows_left = g.tiles_m - band * 8;
+    const int band_h = rows_left < 8 ? rows_left : 8;
+    const int bn = within / band_h;
+    m0 = (band * 8 + (within - bn * band_h)) * 256;
+    n0 = bn * 256;
+  };
+
+  int vx[2], vw[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int c = (lane & 7) ^ ((4 * par + (lane >> 4)) & 7);
+    vx[par] = (lane >> 3) * (int)g.lda * 2 + c * 16;
+    vw[par] = (16 * (lane >> 5) + ((lane >> 3) & 3)) * (int)g.ldw * 2 + c * 16;
+  }
+  int sx[8], sw[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sx[i] = (wave * 8 + i) * 8 * (int)g.lda * 2;
+    sw[i] = (64 * wave + 32 * (i & 1) + 4 * (i >> 1)) * (int)g.ldw * 2;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned fr = (lane & 15) * 128 + ((((unsigned)lane >> 4) ^ (((unsigned)lane & 15) >> 1)) << 4);
+  unsigned xa0 = lds0 + wm * 16384 + fr, xa1 = xa0 ^ 64;
+  unsigned wa0 = lds0 + V7_WOFF + wn * 16384 + fr, wa1 = wa0 ^ 64;
+  unsigned dst = wave * 8192;
+
+  // ---- DMA cursor: the K-tile the next 16 pieces fetch (runs two K-tiles ahead of the MFMAs, across tiles)
+  int cur_t = first, cur_kt = 0;
+  const char* cur_x = nullptr;
+  const char* cur_w = nullptr;
+  unsigned cur_xb = 0, cur_wb = 0;
+  auto cursor_tile = [&]() {
+    if (cur_t < c1) {
+      int m0, n0;
+      tile_origin(cur_t, m0, n0);
+      const int rows_x = g.M - m0 < 256 ? g.M - m0 : 256;
+      const int rows_w = g.N - n0 < 256 ? g.N - n0 : 256;
+      cur_x = (const char*)(g.A + (long)m0 * g.lda);
+      cur_w = (const char*)(g.W + (long)n0 * g.ldw);
+      cur_xb = (unsigned)(((long)(rows_x - 1) * g.lda + g.K) * 2);
+      cur_wb = (unsigned)(((long)(rows_w - 1) * g.ldw + g.K) * 2);
+    } else {
+      cur_xb = 0; cur_wb = 0;   // past the last tile: null descriptors, the pieces read nothing
+    }
+  };
+  auto cursor_next = [&]() {
+    if (++cur_kt == nk) { cur_kt = 0; cur_t += nx; cursor_tile(); }
+  };
+#define V8_RSRC_X() __builtin_amdgcn_make_buffer_rsrc((void*)(cur_x + cur_kt * 128), 0, cur_xb ? (int)(cur_xb - cur_kt * 128) : 0, 0x00020000)
+#define V8_RSRC_W() __builtin_amdgcn_make_buffer_rsrc((void*)(cur_w + cur_kt * 128), 0, cur_wb ? (int)(cur_wb - cur_kt * 128) : 0, 0x00020000)
+
+  f32x4 acc[8][8];
+  u32x4 xf[2][8], wf[2][8];
+
+  if (first >= c1) return;   // uniform: more workgroups than tiles on this XCD
+  cursor_tile();
+  {
+    __amdgpu_buffer_rsrc_t rx0 = V8_RSRC_X(), rw0 = V8_RSRC_W();
+    cursor_next();
+    __amdgpu_buffer_rsrc_t rx1 = V8_RSRC_X(), rw1 = V8_RSRC_W();
+    cursor_next();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) V7_DMA_X(rx0, dst, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) V7_DMA_W(rw0, dst, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) V7_DMA_X(rx1, dst + V7_STAGE, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) V7_DMA_W(rw1, dst + V7_STAGE, i);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      V7_LDSR(xf[0][i], xa0, i * 2048);
+      V7_LDSR(wf[0][i], wa0, i * 2048);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  for (int t = first; t < c1; t += nx) {
+    int m0, n0;
+    tile_origin(t, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {  // first K-step of the tile: the epilogue's stores may still be outstanding, so the landing wait is vmcnt(0)
+      __amdgpu_buffer_rsrc_t rx = V8_RSRC_X(), rw = V8_RSRC_W();
+      cursor_next();
+      V7_STEP(0)
+    }
+    for (int kt = 1; kt < nk; ++kt) {
+      __amdgpu_buffer_rsrc_t rx = V8_RSRC_X(), rw = V8_RSRC_W();
+      cursor_next();
+      V7_STEP(13)
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    V7_EPI(0, 0)
+    V7_EPI(0, 1)
+    V7_EPI(1, 0)
+    V7_EPI(1, 1)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static int v8_grid(int tiles) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
+    cus = p.multiProcessorCount;
+  }
+  return tiles < cus ? tiles : cus;
+}
+
+template <int ACT, bool OUT_F32>
+static int launch_v8(const GemmArgs& g, hipStream_t stream) {
+  GemmArgs g8 = g;
+  g8.tiles_m = (g.M + 255) / 256;
+  g8.tiles_n = (g.N + 255) / 256;
+  if ((g.K & 63) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31)) return VT_ERR_UNSUPPORTED;
+  const int grid = v8_grid(g8.tiles_m * g8.tiles_n);
+  if (grid <= 0) return VT_ERR_HIP;
+  auto kern = gemm_nt_bf16_v8<ACT, OUT_F32>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V7_STAGE) != hipSuccess) return VT_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 2 * V7_STAGE, stream, g8);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+template <int ACT, bool OUT_F32>
+static int launch_v7(const GemmArgs& g, hipStream_t stream) {
+  GemmArgs g7 = g;
+  g7.tiles_m = (g.M + 255) / 256;
+  g7.tiles_n = (g.N + 255) / 256;
+  // operand panels are addressed with 32-bit byte offsets inside a tile's row panel
+  if ((g.K & 63) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31)) return VT_ERR_UNSUPPORTED;
+  auto kern = gemm_nt_bf16_v7<ACT, OUT_F32>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V7_STAGE) != hipSuccess) return VT_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(g7.tiles_m * g7.tiles_n), dim3(256), 2 * V7_STAGE, stream, g7);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream) {
+#ifdef V7_ONE
+  return launch_v8<ACT_NONE, false>(g, stream);
+#else
+  switch (act * 2 + (out_f32 ? 1 : 0)) {
+    case 0: return launch_v8<ACT_NONE, false>(g, stream);
+    case 1: return launch_v8<ACT_NONE, true>(g, stream);
+    case 2: return launch_v8<ACT_GELU, false>(g, stream);
+    case 3: return launch_v8<ACT_GELU, true>(g, stream);
+    case 4: return launch_v8<ACT_TANH, false>(g, stream);
+    case 5: return launch_v8<ACT_TANH, true>(g, stream);
+    case 6: return launch_v8<ACT_MUL, false>(g, stream);
+    case 7: return launch_v8<ACT_MUL, true>(g, stream);
+    default: return VT_ERR_UNSUPPORTED;
+  }
+#endif
+}
+
+int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream) {
+#ifdef V7_ONE
+  return launch_v7<ACT_NONE, false>(g, stream);
+#else
+  switch (act * 2 + (out_f32 ? 1 : 0)) {
+    case 0: return launch_v7<ACT_NONE, false>(g, stream);
+    case 1: return launch_v7<ACT_NONE, true>(g, stream);
+    case 2: return launch_v7<ACT_GELU, false>(g, stream);
+    case 3: return launch_v7<ACT_GELU, true>(g, stream);
+    case 4: return launch_v7<ACT_TANH, false>(g, stream);
+    case 5: return launch_v7<ACT_TANH, true>(g, stream);
+    case 6: return launch_v7<ACT_MUL, false>(g, stream);
+    case 7: return launch_v7<ACT_MUL, true>(g, stream);
+    default: return VT_ERR_UNSUPPORTED;
+  }
+#endif
+}

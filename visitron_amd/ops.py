@@ -122,7 +122,13 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
     return out
 
 
-GEMM_CANDIDATES = (1, 14, 9, 10, 11)   # 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring)
+# 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring), 256x256 with 128x128 wave tiles (AGPR)
+GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15)
+
+
+def set_gemm_variant(v):
+    """Tuning/test hook: force one GEMM kernel variant (-1: shape table / heuristic)."""
+    _lib.load().vt_debug_set_gemm_variant(int(v))
 _tuned = {}
 
 
