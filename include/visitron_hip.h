@@ -40,6 +40,8 @@ const char* vt_error_string(int code);
 int vt_abi_version(void);
 /* Tuning hook (benchmarks only): force the GEMM kernel variant, -1 = built-in choice.  Process-global. */
 void vt_debug_set_gemm_variant(int variant);
+/* Debug: device buffer (>= 64 * 8 B per workgroup) that the persistent GEMM fills with phase timestamps; NULL = off. */
+void vt_debug_set_gemm_trace(void* buf);
 /* Autotuner result: use kernel `variant` for linear layers of exactly this shape and activation (filled by
  * the host before the shape is used; process-global, read-only afterwards). */
 void vt_gemm_tune(int M, int N, int K, int act, int variant);

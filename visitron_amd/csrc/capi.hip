@@ -40,6 +40,7 @@ int vt_pack_concat_dispatch(const float* s0, int d0, const float* s1, int d1, vo
                             hipStream_t stream);
 
 void vt_gemm_set_variant(int v);
+void vt_gemm_set_trace(void* p);
 void vt_gemm_tune_set(int M, int N, int K, int act, int variant);
 void vt_attn_bwd_set_waves(int w);
 
@@ -78,6 +79,7 @@ const char* vt_error_string(int code) {
 int vt_abi_version(void) { return 2; }
 
 void vt_debug_set_gemm_variant(int variant) { vt_gemm_set_variant(variant); }
+void vt_debug_set_gemm_trace(void* buf) { vt_gemm_set_trace(buf); }
 void vt_gemm_tune(int M, int N, int K, int act, int variant) { vt_gemm_tune_set(M, N, K, act, variant); }
 void vt_debug_set_attn_bwd_waves(int waves) { vt_attn_bwd_set_waves(waves); }
 

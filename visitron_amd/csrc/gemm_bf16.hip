@@ -939,6 +939,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_bf16_v6(GemmArgs g) {
 //          7, 8 = timing experiments (no DMA / no MFMA in the loop; wrong results).
 int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip
 int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip (persistent)
+static void* g_gemm_trace = nullptr;
+void vt_gemm_set_trace(void* p) { g_gemm_trace = p; }
 static int g_gemm_variant = -1;  // -1: table / heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
 void vt_gemm_set_variant(int v) { g_gemm_variant = v; }
 
@@ -1051,6 +1053,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   g.M = M; g.N = N; g.K = K;
   g.grp_rows = grp_rows; g.grp_stride = grp_stride;
   if (drop) g.drop = *drop; else { g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f; }
+  g.trace = (unsigned long long*)g_gemm_trace;
   if (g.drop.thresh && (long)M * N >= (1L << 32)) return VT_ERR_UNSUPPORTED;
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;

@@ -13,6 +13,7 @@ struct GemmArgs {
   int M, N, K;
   int grp_rows, grp_stride;  // output row = (m / grp_rows) * grp_stride + m % grp_rows  (0: identity)
   int tiles_m, tiles_n;
+  unsigned long long* trace; // debug: per-workgroup phase timestamps of the persistent kernel (vt_debug_set_gemm_trace)
   DropCfg drop;              // dropout on act(acc + bias) BEFORE the residual add (BertSelfOutput / BertOutput /
                              // image embedding); element index = m * N + n
 };
@@ -33,17 +34,12 @@ __device__ __forceinline__ float apply_act(float x) {
   return x;  // ACT_NONE and ACT_MUL (the latter multiplies by R where R is read)
 }
 
-// Epilogue shared by the GEMM kernels: lane (j = lane&15, gq = lane>>4) owns output rows
-// row0+16mt+j (mt = 0..3) and the 16 consecutive columns col0+16gq .. +15; bias, activation and
-// residual are applied in registers and each lane stores 32 (bf16) or 64 (fp32) contiguous bytes.
-template <int ACT, bool OUT_F32>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int lane, int row0, int col0) {
-  const int gq = lane >> 4;
-  const int nb = col0 + 16 * gq;
-  if (nb >= g.N) return;
-  const bool full = (nb + 16 <= g.N);
-
-  float bv[16];
+// ---- register epilogue pieces ----------------------------------------------------------------------------------
+// Lane (j = lane&15, gq = lane>>4) owns output rows row0+16mt+j (mt = 0..3) and the 16 consecutive columns
+// nb = col0+16gq .. +15 (accumulators a[t][e] -> column 4t+e); bias, activation, dropout and residual are applied
+// in registers.  The pieces work on ONE 16-row block so that callers holding many accumulators (the 256x256-tile
+// kernels) keep only 16 of them in VGPRs at a time.
+__device__ __forceinline__ void epi_load_bias(const GemmArgs& g, int nb, bool full, float (&bv)[16]) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) bv[i] = 0.f;
   if (g.bias) {
@@ -59,85 +55,148 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
         if (nb + i < g.N) bv[i] = g.bias[nb + i];
     }
   }
+}
 
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = row0 + 16 * mt + (lane & 15);
-    if (m >= g.M) continue;
-    const long orow = g.grp_rows ? (long)(m / g.grp_rows) * g.grp_stride + (m % g.grp_rows) : (long)m;
-    float v[16];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[4 * t + e] = acc[mt][t][e] + bv[4 * t + e];
+__device__ __forceinline__ long epi_out_row(const GemmArgs& g, int m) {
+  return g.grp_rows ? (long)(m / g.grp_rows) * g.grp_stride + (m % g.grp_rows) : (long)m;
+}
 
-    if (full) {
-      if (g.C2) {  // saved for the backward pass: the activation's derivative (GELU) or the pre-activation
-        float s2[16];
+// v = act(a + bias) [dropout] [+|* residual] for one row (all 16 columns valid); s2 = what C2 stores
+template <int ACT, bool WANT_S2>
+__device__ __forceinline__ void epi_row_values(const GemmArgs& g, const f32x4 (&a)[4], const float (&bv)[16], int m, long orow, int nb,
+                                               float (&v)[16], float (&s2)[16]) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s2[i] = (ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i];
-        u32x4* cp2 = (u32x4*)(g.C2 + orow * g.ldc2 + nb);
-        u32x4 o0, o1;
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          o0[i] = pack_bf16x2(s2[2 * i], s2[2 * i + 1]);
-          o1[i] = pack_bf16x2(s2[8 + 2 * i], s2[8 + 2 * i + 1]);
-        }
-        cp2[0] = o0;
-        cp2[1] = o1;
+    for (int e = 0; e < 4; ++e) v[4 * t + e] = a[t][e] + bv[4 * t + e];
+  if (WANT_S2) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s2[i] = (ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);
+  if (g.drop.thresh) {
+    const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)nb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f;
+  }
+  if (g.R) {
+    const u32x4* rp = (const u32x4*)(g.R + orow * g.ldr + nb);
+    const u32x4 r0 = rp[0], r1 = rp[1];
+    float rv[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rv[2 * i] = bf16lo(r0[i]);
+      rv[2 * i + 1] = bf16hi(r0[i]);
+      rv[8 + 2 * i] = bf16lo(r1[i]);
+      rv[8 + 2 * i + 1] = bf16hi(r1[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (ACT == ACT_MUL) ? v[i] * rv[i] : v[i] + rv[i];
+  }
+}
+
+// one 16-row block, stored straight from registers: 32 (bf16) or 64 (fp32) contiguous bytes per lane
+template <int ACT, bool OUT_F32>
+__device__ __forceinline__ void epi_row_direct(const GemmArgs& g, const f32x4 (&a)[4], const float (&bv)[16], int m, int nb, bool full) {
+  if (m >= g.M) return;
+  const long orow = epi_out_row(g, m);
+  if (full) {
+    float v[16], s2[16];
+    if (g.C2) {
+      epi_row_values<ACT, true>(g, a, bv, m, orow, nb, v, s2);
+      u32x4* cp2 = (u32x4*)(g.C2 + orow * g.ldc2 + nb);
+      u32x4 o0, o1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o0[i] = pack_bf16x2(s2[2 * i], s2[2 * i + 1]);
+        o1[i] = pack_bf16x2(s2[8 + 2 * i], s2[8 + 2 * i + 1]);
       }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);
-      if (g.drop.thresh) {
-        const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)nb;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f;
-      }
-      if (g.R) {
-        const u32x4* rp = (const u32x4*)(g.R + orow * g.ldr + nb);
-        const u32x4 r0 = rp[0], r1 = rp[1];
-        float rv[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          rv[2 * i] = bf16lo(r0[i]);
-          rv[2 * i + 1] = bf16hi(r0[i]);
-          rv[8 + 2 * i] = bf16lo(r1[i]);
-          rv[8 + 2 * i + 1] = bf16hi(r1[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (ACT == ACT_MUL) ? v[i] * rv[i] : v[i] + rv[i];
-      }
-      if (OUT_F32) {
-        f32x4* cp = (f32x4*)((float*)g.C + orow * g.ldc + nb);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cp[i] = (f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-      } else {
-        u32x4* cp = (u32x4*)((bf16_t*)g.C + orow * g.ldc + nb);
-        u32x4 o0, o1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-          o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
-        }
-        cp[0] = o0;
-        cp[1] = o1;
-      }
+      cp2[0] = o0;
+      cp2[1] = o1;
     } else {
+      epi_row_values<ACT, false>(g, a, bv, m, orow, nb, v, s2);
+    }
+    if (OUT_F32) {
+      f32x4* cp = (f32x4*)((float*)g.C + orow * g.ldc + nb);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (nb + i < g.N) {
-          if (g.C2) g.C2[orow * g.ldc2 + nb + i] = f32_to_bf16((ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i]);
-          float x = apply_act<ACT>(v[i]);
-          if (g.drop.thresh) x = vt_keep(g.drop, (uint32_t)m * (uint32_t)g.N + (uint32_t)(nb + i)) ? x * g.drop.scale : 0.f;
-          if (g.R) {
-            const float rr = bf16_to_f32(g.R[orow * g.ldr + nb + i]);
-            x = (ACT == ACT_MUL) ? x * rr : x + rr;
-          }
-          if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;
-          else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = f32_to_bf16(x);
+      for (int i = 0; i < 4; ++i) cp[i] = (f32x4){v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+    } else {
+      u32x4* cp = (u32x4*)((bf16_t*)g.C + orow * g.ldc + nb);
+      u32x4 o0, o1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+      }
+      cp[0] = o0;
+      cp[1] = o1;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (nb + i < g.N) {
+        const float pre = a[i >> 2][i & 3] + bv[i];
+        if (g.C2) g.C2[orow * g.ldc2 + nb + i] = f32_to_bf16((ACT == ACT_GELU) ? gelu_erf_grad(pre) : pre);
+        float x = apply_act<ACT>(pre);
+        if (g.drop.thresh) x = vt_keep(g.drop, (uint32_t)m * (uint32_t)g.N + (uint32_t)(nb + i)) ? x * g.drop.scale : 0.f;
+        if (g.R) {
+          const float rr = bf16_to_f32(g.R[orow * g.ldr + nb + i]);
+          x = (ACT == ACT_MUL) ? x * rr : x + rr;
         }
+        if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;
+        else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = f32_to_bf16(x);
       }
     }
   }
 }
 
+// Epilogue of the 128x128-tile kernels: a 64x64 wave tile held as acc[mt][t].
+template <int ACT, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int lane, int row0, int col0) {
+  const int nb = col0 + 16 * (lane >> 4);
+  if (nb >= g.N) return;
+  const bool full = (nb + 16 <= g.N);
+  float bv[16];
+  epi_load_bias(g, nb, full, bv);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) epi_row_direct<ACT, OUT_F32>(g, acc[mt], bv, row0 + 16 * mt + (lane & 15), nb, full);
+}
+
+// ---- bf16 epilogue with an LDS transpose (256x256-tile kernels) -------------------------------------------------
+// The register path stores 2 x 16 B per lane and row: one store instruction scatters 64 16-byte pieces over 16
+// rows.  Here a wave parks a 64x64 quadrant in 8 KiB of LDS (same XOR swizzle as the operand images: conflict-free
+// both ways) and stores it back row-major, 8 full 128-byte lines per store instruction.  LDS traffic is inline asm
+// with hand-placed lgkmcnt waits: the compiler would drain the in-flight LDS-DMA of the next tile (vmcnt(0)) in
+// front of compiler-visible LDS accesses.
+__device__ __forceinline__ unsigned epi_lds_addr(unsigned base, int row, int chunk) {
+  return base + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+__device__ __forceinline__ void epi_lds_put(unsigned lds_wave, int lane, int mt, const float (&v)[16]) {
+  u32x4 o0, o1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+    o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+  }
+  const int row = 16 * mt + (lane & 15), gq = lane >> 4;
+  asm volatile("ds_write_b128 %0, %1" ::"v"(epi_lds_addr(lds_wave, row, 2 * gq)), "v"(o0) : "memory");
+  asm volatile("ds_write_b128 %0, %1" ::"v"(epi_lds_addr(lds_wave, row, 2 * gq + 1)), "v"(o1) : "memory");
+}
+// the parked 32x64 bf16 slab -> C[row0 .. row0+31, col0 .. col0+63], rows past M masked
+__device__ __forceinline__ void epi_store_slab(const GemmArgs& g, bf16_t* C, long ldc, unsigned lds_wave, int lane, int row0, int col0) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  u32x4 rv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned a = epi_lds_addr(lds_wave, 8 * i + (lane >> 3), lane & 7);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(rv[i]) : "v"(a));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = row0 + 8 * i + (lane >> 3);
+    asm volatile("" : "+v"(rv[i]));   // the value is final only after the wait above
+    if (m < g.M) *(u32x4*)(C + epi_out_row(g, m) * ldc + col0 + 8 * (lane & 7)) = rv[i];
+  }
+}

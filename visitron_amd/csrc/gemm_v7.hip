@@ -21,11 +21,164 @@
 // swizzle depends on the piece parity only); rows past M / N and tiles past K read as zeros through
 // num_records, so no clamping and no tail code.
 #define V7_STAGE 65536
+#define V7_LDS_BYTES (2 * V7_STAGE + 4096)   // two operand stages + 1 KiB per wave: the tile's bias values
 #define V7_WOFF 32768
 #define V7_MFMA(S, i)                                                                                             \
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(i) & 7][(i) >> 3]) : "v"(wf[S][(i) >> 3]), \
                "v"(xf[S][(i) & 7]))
 #define V7_LDSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+// ---- epilogue of the 256x256-tile kernels (bf16 output, whole 64-column slabs: EPI_LDS) ---------------------------
+// No compiler-visible VMEM loads and no conditional VMEM instructions: hipcc puts s_waitcnt vmcnt(0) at the joins
+// behind conditional loads (bias / residual), and with one wave per SIMD every such wait drains the stores of the
+// previous slab and the next tile's LDS-DMA (measured: 1.5 us per slab, 10-13 us per tile, against a 17 us K loop).
+//   * bias: fetched with one LDS-DMA piece per wave into a private 1 KiB slot in the tile's first K-step (null
+//     bias = zero-length descriptor = zeros), read back with ds_read in the epilogue;
+//   * residual / GELU' factor R: buffer loads in inline asm, prefetched one slab ahead and retired by a counted
+//     vmcnt (the stores of the current slab may stay in flight);
+//   * C / C2: buffer stores from the LDS-transposed slab, unconditional (rows past M fall outside num_records).
+__device__ __forceinline__ u32x4 v7_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xffffu);
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void v7_buf_load16(u32x4& d, u32x4 rs, int voff, int soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void v7_buf_load16_o16(u32x4& d, u32x4 rs, int voff, int soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(d) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void v7_buf_store16(u32x4 d, u32x4 rs, int voff, int soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(d), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, int soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:16" ::"v"(d), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+// slab = 16 rows x 64 columns of the 128x128 wave tile: accumulator row block MT, column half NH.  Spelled out 16
+// times (about 50 instructions each): one wave per SIMD has nothing to hide a taken branch or an LDS round trip
+// behind, so the epilogue is straight-line code with the stores going out directly from the accumulator layout
+// (2 x 16 B per lane and row).
+#define V7_SLAB(MT, NH)                                                                                   \
+  {                                                                                                       \
+    float v[16];                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                       \
+      asm volatile("" : "+a"(acc[MT][4 * (NH) + t]));   /* stays in AGPRs until its slab's turn */         \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) v[4 * t + e] = acc[MT][4 * (NH) + t][e] + bv[4 * t + e]; \
+    }                                                                                                     \
+    const int so_row = 128 * wm + 16 * (MT);                                                              \
+    if (has_c2) {   /* saved for the backward pass: the activation's derivative (GELU) or the pre-activation */ \
+      u32x4 p0, p1;                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        p0[i] = pack_bf16x2(ACT == ACT_GELU ? gelu_erf_grad(v[2 * i]) : v[2 * i],                         \
+                            ACT == ACT_GELU ? gelu_erf_grad(v[2 * i + 1]) : v[2 * i + 1]);                \
+        p1[i] = pack_bf16x2(ACT == ACT_GELU ? gelu_erf_grad(v[8 + 2 * i]) : v[8 + 2 * i],                 \
+                            ACT == ACT_GELU ? gelu_erf_grad(v[8 + 2 * i + 1]) : v[8 + 2 * i + 1]);        \
+      }                                                                                                   \
+      v7_buf_store16(p0, rs_c2, vo_c2, so_row * ldc2_b + ec * 2);                                         \
+      v7_buf_store16_o16(p1, rs_c2, vo_c2, so_row * ldc2_b + ec * 2);                                     \
+    }                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);                           \
+    if (g.drop.thresh) {                                                                                  \
+      const uint32_t e0 = (uint32_t)(m0 + so_row + j) * (uint32_t)g.N + (uint32_t)(ec + 16 * gq);         \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f; \
+    }                                                                                                     \
+    if (HAS_R) {                                                                                          \
+      /* this slab's residual was issued one slab ago, before that slab's stores (2, or 4 with C2) */     \
+      if ((MT) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+      else if (has_c2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                   \
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                               \
+      asm volatile("" : "+v"(rr0), "+v"(rr1));                                                            \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        const float r0 = bf16lo(rr0[i]), r1 = bf16hi(rr0[i]), r2 = bf16lo(rr1[i]), r3 = bf16hi(rr1[i]);   \
+        if (ACT == ACT_MUL) { v[2 * i] *= r0; v[2 * i + 1] *= r1; v[8 + 2 * i] *= r2; v[8 + 2 * i + 1] *= r3; } \
+        else { v[2 * i] += r0; v[2 * i + 1] += r1; v[8 + 2 * i] += r2; v[8 + 2 * i + 1] += r3; }          \
+      }                                                                                                   \
+      if ((MT) < 7) {                                                                                     \
+        v7_buf_load16(rr0, rs_r, vo_r, (so_row + 16) * ldr_b + ec * 2);                                   \
+        v7_buf_load16_o16(rr1, rs_r, vo_r, (so_row + 16) * ldr_b + ec * 2);                               \
+      }                                                                                                   \
+    }                                                                                                     \
+    u32x4 o0, o1;                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+      o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);                                                        \
+      o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);                                                \
+    }                                                                                                     \
+    v7_buf_store16(o0, rs_c, vo_c, so_row * ldc_b + ec * 2);                                              \
+    v7_buf_store16_o16(o1, rs_c, vo_c, so_row * ldc_b + ec * 2);                                          \
+  }
+
+template <int ACT, bool HAS_R>
+__device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)[8][8], int lane, int wave, int m0, int n0, unsigned lds0) {
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned bias_slot = lds0 + 2 * V7_STAGE + wave * 1024;   // this wave's copy of the tile's 256 bias values
+  const int rows = g.M - m0 < 256 ? g.M - m0 : 256;
+  const int ldc_b = (int)g.ldc * 2, ldc2_b = (int)g.ldc2 * 2, ldr_b = (int)g.ldr * 2;
+  // rows past M fall outside num_records: their loads read zeros, their stores are dropped
+  const u32x4 rs_c = v7_rsrc((const bf16_t*)g.C + (long)m0 * g.ldc, (unsigned)rows * ldc_b);
+  const u32x4 rs_c2 = v7_rsrc(g.C2 ? g.C2 + (long)m0 * g.ldc2 : nullptr, g.C2 ? (unsigned)rows * ldc2_b : 0u);
+  const u32x4 rs_r = v7_rsrc(g.R ? g.R + (long)m0 * g.ldr : nullptr, g.R ? (unsigned)rows * ldr_b : 0u);
+  const int gq = lane >> 4, j = lane & 15;
+  const int vo_c = j * ldc_b + gq * 32, vo_c2 = j * ldc2_b + gq * 32, vo_r = j * ldr_b + gq * 32;
+  const bool has_c2 = g.C2 != nullptr;
+  u32x4 rr0, rr1;   // residual of the next slab, two 8-column halves
+  // the two 64-column halves spelled out: a rolled (or not fully unrolled) loop would index the accumulators
+  // dynamically and demote them to scratch
+#define V7_HALF(NH)                                                                                       \
+  {                                                                                                       \
+    const int ecr = 128 * wn + 64 * (NH);   /* tile-relative first column */                              \
+    const int ec = n0 + ecr;                                                                              \
+    if (ec < g.N) {   /* N % 64 == 0 (host-checked): the 64 columns are all valid */                      \
+      if (HAS_R) {                                                                                        \
+        v7_buf_load16(rr0, rs_r, vo_r, (128 * wm) * ldr_b + ec * 2);                                      \
+        v7_buf_load16_o16(rr1, rs_r, vo_r, (128 * wm) * ldr_b + ec * 2);                                  \
+      }                                                                                                   \
+      u32x4 bq[4];                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        const unsigned ba = bias_slot + 4 * (ecr + 16 * gq) + 16 * i;                                     \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(bq[i]) : "v"(ba));                                      \
+      }                                                                                                   \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                  \
+      float bv[16];                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        asm volatile("" : "+v"(bq[i]));                                                                   \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) bv[4 * i + e] = __uint_as_float(bq[i][e]);          \
+      }                                                                                                   \
+      V7_SLAB(0, NH) V7_SLAB(1, NH) V7_SLAB(2, NH) V7_SLAB(3, NH)                                         \
+      V7_SLAB(4, NH) V7_SLAB(5, NH) V7_SLAB(6, NH) V7_SLAB(7, NH)                                         \
+    }                                                                                                     \
+  }
+  V7_HALF(0)
+  V7_HALF(1)
+}
+
+// slab h of the plain register epilogue (fp32 output, N not a multiple of 64, row remap): a switch moves the slab's
+// 16 accumulator registers to VGPRs (AGPRs cannot be indexed dynamically) inside a rolled loop
+#define V7_SLAB_CASE(h)                                                                                   \
+  case h:                                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                       \
+      asm volatile("" : "+a"(acc[(h) >> 1][4 * ((h) & 1) + t]));                                          \
+      a[t] = acc[(h) >> 1][4 * ((h) & 1) + t];                                                            \
+    }                                                                                                     \
+    break;
+#define V7_SLAB_SWITCH(h)                                                                                 \
+  switch (h) {                                                                                            \
+    V7_SLAB_CASE(0) V7_SLAB_CASE(1) V7_SLAB_CASE(2) V7_SLAB_CASE(3)                                       \
+    V7_SLAB_CASE(4) V7_SLAB_CASE(5) V7_SLAB_CASE(6) V7_SLAB_CASE(7)                                       \
+    V7_SLAB_CASE(8) V7_SLAB_CASE(9) V7_SLAB_CASE(10) V7_SLAB_CASE(11)                                     \
+    V7_SLAB_CASE(12) V7_SLAB_CASE(13) V7_SLAB_CASE(14) V7_SLAB_CASE(15)                                   \
+  }
+
+// bias of the tile's 256 columns -> this wave's LDS slot, as one more LDS-DMA piece (null bias: zero-length)
+#define V7_DMA_BIAS()                                                                                     \
+  if (EPI_LDS) {                                                                                          \
+    const int bn_ = g.N - n0 < 256 ? g.N - n0 : 256;                                                      \
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.bias ? g.bias + n0 : nullptr), 0, g.bias ? bn_ * 4 : 0, 0x00020000); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(smem + 2 * V7_STAGE + wave * 1024), 16, lane * 16, 0, 0, 0); \
+  }
 
 // One K-step: the current stage holds the K-tile whose substep-0 fragments are in set 0; (rx, rw) describe the
 // K-tile two steps ahead.  VMW is the vmcnt that proves the NEXT K-tile has landed: 13 in steady state (the 13
@@ -33,6 +186,8 @@
 #define V7_STEP(VMW)                                                                                       \
   {                                                                                                        \
     const unsigned xn0 = xa0 ^ V7_STAGE, wn0 = wa0 ^ V7_STAGE; /* substep-0 addresses of the other stage */ \
+    /* re-defined every step: as plain loop invariants the allocator parks them in scratch (reload + vmcnt(0)) */ \
+    asm volatile("" : "+v"(vx[0]), "+v"(vx[1]), "+v"(vw[0]), "+v"(vw[1]));                                \
     _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
       V7_MFMA(0, i);                                                                                       \
       if (i < 16 && (i & 1)) V7_LDSR(xf[1][i >> 1], xa1, (i >> 1) * 2048);                                 \
@@ -69,7 +224,8 @@
     xa0 ^= V7_STAGE; xa1 ^= V7_STAGE; wa0 ^= V7_STAGE; wa1 ^= V7_STAGE; dst ^= V7_STAGE;                   \
   }
 
-template <int ACT, bool OUT_F32>
+#define V7_TR nullptr
+template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R>
 __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -149,6 +305,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   // prologue: tiles 0 and 1 in flight, substep-0 fragments of tile 0 in set 0
   {
     __amdgpu_buffer_rsrc_t rx0 = rsrc_x(0), rw0 = rsrc_w(0), rx1 = rsrc_x(1), rw1 = rsrc_w(1);
+    V7_DMA_BIAS()
 #pragma unroll
     for (int i = 0; i < 8; ++i) V7_DMA_X(rx0, dst, i);
 #pragma unroll
@@ -174,18 +331,24 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   }
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
-  // epilogue: four 64x64 quadrants of the wave tile through the shared register epilogue (spelled out:
-  // a rolled loop would index the accumulators dynamically and push them to scratch)
-#define V7_EPI(mh, nh)                                                                                  \
-  {                                                                                                     \
-    f32x4 sub[4][4];                                                                                    \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
-      _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
-        /* keeps the accumulators in AGPRs until their quadrant is stored */                            \
-        asm volatile("" : "+a"(acc[4 * (mh) + mt][4 * (nh) + t]));                                      \
-        sub[mt][t] = acc[4 * (mh) + mt][4 * (nh) + t];                                                  \
-      }                                                                                                 \
-    gemm_epilogue<ACT, OUT_F32>(g, sub, lane, m0 + 128 * wm + 64 * (mh), n0 + 128 * wn + 64 * (nh));    \
+  // epilogue: EPI_LDS -> v7_epilogue_lds (above); otherwise (fp32 output, N not a multiple of 64, row remap) the
+  // plain register epilogue, slab by slab
+#define V7_EPILOGUE()                                                                                     \
+  if (EPI_LDS) {                                                                                          \
+    v7_epilogue_fast<ACT, HAS_R>(g, acc, lane, wave, m0, n0, lds0);                                       \
+  } else {                                                                                                \
+    _Pragma("unroll 1") for (int h = 0; h < 16; ++h) {                                                    \
+      f32x4 a[4];                                                                                         \
+      V7_SLAB_SWITCH(h)                                                                                   \
+      const int er0 = m0 + 128 * wm + 16 * (h >> 1), ec0 = n0 + 128 * wn + 64 * (h & 1);                  \
+      const int nb = ec0 + 16 * (lane >> 4);                                                              \
+      if (nb < g.N) {                                                                                     \
+        const bool full = nb + 16 <= g.N;                                                                 \
+        float bv[16];                                                                                     \
+        epi_load_bias(g, nb, full, bv);                                                                   \
+        epi_row_direct<ACT, OUT_F32>(g, a, bv, er0 + (lane & 15), nb, full);                              \
+      }                                                                                                   \
+    }                                                                                                     \
   }
 #ifdef V7_DIAG
   {
@@ -194,10 +357,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
     ((float*)g.C)[blockIdx.x * 256 + tid] = t;
   }
 #else
-  V7_EPI(0, 0)
-  V7_EPI(0, 1)
-  V7_EPI(1, 0)
-  V7_EPI(1, 1)
+  V7_EPILOGUE()
 #endif
 }
 
@@ -209,7 +369,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
 // first-fetch latency per tile on top: ~11 us of a ~28 us tile at K = 768).  Each XCD owns a contiguous
 // chunk of the grouped tile order; its workgroups take tiles of the chunk round-robin, so the tiles in flight
 // on one L2 are neighbours.
-template <int ACT, bool OUT_F32>
+#undef V7_TR
+#define V7_TR tr
+template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R>
 __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -285,6 +447,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   u32x4 xf[2][8], wf[2][8];
 
   if (first >= c1) return;   // uniform: more workgroups than tiles on this XCD
+  // debug trace: slot 0 = realtime (100 MHz) at entry, 1 = shader clock at entry, then per tile (realtime): K loop
+  // start, K loop end, epilogue end; last two slots repeat (realtime, shader clock) at exit
+  unsigned long long* tr = g.trace ? g.trace + (long)b * 64 : nullptr;
+  int tri = 2;
+#define V8_TRACE_RT() if (tr && tid == 0 && tri < 40) tr[tri++] = __builtin_amdgcn_s_memrealtime()
+  if (tr && tid == 0) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[1] = __builtin_amdgcn_s_memtime(); }
+  if (tr && g.trace[256 * 64]) {   // experiment: staggered start, delay = (b * 37 % 64) / 64 * trace[256*64] * 10 ns
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long d = (unsigned long long)((b * 37) & 63) * g.trace[256 * 64] / 64;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
   cursor_tile();
   {
     __amdgpu_buffer_rsrc_t rx0 = V8_RSRC_X(), rw0 = V8_RSRC_W();
@@ -316,10 +489,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    {  // first K-step of the tile: the epilogue's stores may still be outstanding, so the landing wait is vmcnt(0)
+    V8_TRACE_RT();
+    {  // first K-step of the tile; the bias piece goes first, so the step's landing wait covers it too
       __amdgpu_buffer_rsrc_t rx = V8_RSRC_X(), rw = V8_RSRC_W();
       cursor_next();
-      V7_STEP(0)
+      V7_DMA_BIAS()
+      V7_STEP(13)
     }
     for (int kt = 1; kt < nk; ++kt) {
       __amdgpu_buffer_rsrc_t rx = V8_RSRC_X(), rw = V8_RSRC_W();
@@ -327,12 +502,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
       V7_STEP(13)
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    V7_EPI(0, 0)
-    V7_EPI(0, 1)
-    V7_EPI(1, 0)
-    V7_EPI(1, 1)
+    V8_TRACE_RT();
+    V7_EPILOGUE()
+    V8_TRACE_RT();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tr && tid == 0) { tr[62] = __builtin_amdgcn_s_memrealtime(); tr[63] = __builtin_amdgcn_s_memtime(); }
 }
 
 static int v8_grid(int tiles) {
@@ -354,9 +529,14 @@ static int launch_v8(const GemmArgs& g, hipStream_t stream) {
   if ((g.K & 63) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31)) return VT_ERR_UNSUPPORTED;
   const int grid = v8_grid(g8.tiles_m * g8.tiles_n);
   if (grid <= 0) return VT_ERR_HIP;
-  auto kern = gemm_nt_bf16_v8<ACT, OUT_F32>;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V7_STAGE) != hipSuccess) return VT_ERR_HIP;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 2 * V7_STAGE, stream, g8);
+  // bf16 output with whole 64-column slabs goes through the LDS-transposed (coalesced) epilogue
+  // bf16 output in whole 64-column slabs without row remap: the straight-line epilogue, specialised on the residual
+  const bool fast = !OUT_F32 && (g.N & 63) == 0 && g.grp_rows == 0;
+  if (ACT == ACT_MUL && !g.R) return VT_ERR_NULL;
+  auto kern = !fast ? gemm_nt_bf16_v8<ACT, OUT_F32, false, false>
+                    : ((g.R || ACT == ACT_MUL) ? gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, true> : gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL>);
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES) != hipSuccess) return VT_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), V7_LDS_BYTES, stream, g8);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
@@ -367,9 +547,12 @@ static int launch_v7(const GemmArgs& g, hipStream_t stream) {
   g7.tiles_n = (g.N + 255) / 256;
   // operand panels are addressed with 32-bit byte offsets inside a tile's row panel
   if ((g.K & 63) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31)) return VT_ERR_UNSUPPORTED;
-  auto kern = gemm_nt_bf16_v7<ACT, OUT_F32>;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V7_STAGE) != hipSuccess) return VT_ERR_HIP;
-  hipLaunchKernelGGL(kern, dim3(g7.tiles_m * g7.tiles_n), dim3(256), 2 * V7_STAGE, stream, g7);
+  const bool fast = !OUT_F32 && (g.N & 63) == 0 && g.grp_rows == 0;
+  if (ACT == ACT_MUL && !g.R) return VT_ERR_NULL;
+  auto kern = !fast ? gemm_nt_bf16_v7<ACT, OUT_F32, false, false>
+                    : ((g.R || ACT == ACT_MUL) ? gemm_nt_bf16_v7<ACT, OUT_F32, !OUT_F32, true> : gemm_nt_bf16_v7<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL>);
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES) != hipSuccess) return VT_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(g7.tiles_m * g7.tiles_n), dim3(256), V7_LDS_BYTES, stream, g7);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 

@@ -122,8 +122,9 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
     return out
 
 
-# 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring), 256x256 with 128x128 wave tiles (AGPR)
-GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15)
+# 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring), 256x256 with 128x128 wave tiles
+# and AGPR accumulators (15: one tile per workgroup, 16: persistent)
+GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16)
 
 
 def set_gemm_variant(v):
