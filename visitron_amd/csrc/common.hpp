@@ -55,6 +55,23 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+// erf-GELU and its derivative in one go (training forward saves the derivative): they share the reciprocal, the
+// polynomial and the exponential (exp(-x^2/2) is both erf's tail factor and the normal pdf); same values as
+// gelu_erf / gelu_erf_grad
+__device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float y = 1.061405429f;
+  y = y * t - 1.453152027f;
+  y = y * t + 1.421413741f;
+  y = y * t - 0.284496736f;
+  y = y * t + 0.254829592f;
+  const float e = __expf(-ax * ax);
+  const float erf_x = copysignf(1.0f - y * t * e, x);
+  const float cdf = 0.5f * (1.0f + erf_x);
+  g = x * cdf;
+  dg = cdf + x * (0.3989422804014327f * e);
+}
 __device__ __forceinline__ float tanh_fast(float x) {
   // tanh(x) = 1 - 2/(exp(2x)+1); saturates cleanly for |x| large
   const float e = __expf(2.0f * x);

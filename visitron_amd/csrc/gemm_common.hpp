@@ -69,12 +69,17 @@ __device__ __forceinline__ void epi_row_values(const GemmArgs& g, const f32x4 (&
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[4 * t + e] = a[t][e] + bv[4 * t + e];
-  if (WANT_S2) {
+  if (WANT_S2 && ACT == ACT_GELU) {   // value and derivative share the reciprocal / polynomial / exponential
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s2[i] = (ACT == ACT_GELU) ? gelu_erf_grad(v[i]) : v[i];
+    for (int i = 0; i < 16; ++i) gelu_erf_both(v[i], v[i], s2[i]);
+  } else {
+    if (WANT_S2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s2[i] = v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);
   }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);
   if (g.drop.thresh) {
     const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)nb;
 #pragma unroll

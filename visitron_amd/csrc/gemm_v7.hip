@@ -71,35 +71,41 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
     }                                                                                                     \
     const int so_row = 128 * wm + 16 * (MT);                                                              \
     if (has_c2) {   /* saved for the backward pass: the activation's derivative (GELU) or the pre-activation */ \
+      float d2[16];                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                    \
+        if (ACT == ACT_GELU) gelu_erf_both(v[i], v[i], d2[i]);                                            \
+        else { d2[i] = v[i]; v[i] = apply_act<ACT>(v[i]); }                                               \
+      }                                                                                                   \
       u32x4 p0, p1;                                                                                       \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
-        p0[i] = pack_bf16x2(ACT == ACT_GELU ? gelu_erf_grad(v[2 * i]) : v[2 * i],                         \
-                            ACT == ACT_GELU ? gelu_erf_grad(v[2 * i + 1]) : v[2 * i + 1]);                \
-        p1[i] = pack_bf16x2(ACT == ACT_GELU ? gelu_erf_grad(v[8 + 2 * i]) : v[8 + 2 * i],                 \
-                            ACT == ACT_GELU ? gelu_erf_grad(v[8 + 2 * i + 1]) : v[8 + 2 * i + 1]);        \
+        p0[i] = pack_bf16x2(d2[2 * i], d2[2 * i + 1]);                                                    \
+        p1[i] = pack_bf16x2(d2[8 + 2 * i], d2[8 + 2 * i + 1]);                                            \
       }                                                                                                   \
       v7_buf_store16(p0, rs_c2, vo_c2, so_row * ldc2_b + ec * 2);                                         \
       v7_buf_store16_o16(p1, rs_c2, vo_c2, so_row * ldc2_b + ec * 2);                                     \
+    } else {                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);                         \
     }                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);                           \
     if (g.drop.thresh) {                                                                                  \
       const uint32_t e0 = (uint32_t)(m0 + so_row + j) * (uint32_t)g.N + (uint32_t)(ec + 16 * gq);         \
       _Pragma("unroll") for (int i = 0; i < 16; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f; \
     }                                                                                                     \
     if (HAS_R) {                                                                                          \
-      /* this slab's residual was issued one slab ago, before that slab's stores (2, or 4 with C2) */     \
-      if ((MT) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
-      else if (has_c2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                   \
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                               \
-      asm volatile("" : "+v"(rr0), "+v"(rr1));                                                            \
+      /* this slab's residual was issued 4 slabs ago (the first four before slab 0); behind it in the queue: the  \
+         younger residual loads and the stores issued since -> counted wait (VMEM retires in order).  With C2      \
+         stores in the stream as well (not a combination the encoder uses) simply drain. */                        \
+      if (has_c2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((MT) < 4 ? 6 + 2 * (MT) : 22 - 2 * (MT)) : "memory"); \
+      asm volatile("" : "+v"(rq[(MT) & 3][0]), "+v"(rq[(MT) & 3][1]));                                    \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
-        const float r0 = bf16lo(rr0[i]), r1 = bf16hi(rr0[i]), r2 = bf16lo(rr1[i]), r3 = bf16hi(rr1[i]);   \
+        const u32x4 q0 = rq[(MT) & 3][0], q1 = rq[(MT) & 3][1];                                           \
+        const float r0 = bf16lo(q0[i]), r1 = bf16hi(q0[i]), r2 = bf16lo(q1[i]), r3 = bf16hi(q1[i]);       \
         if (ACT == ACT_MUL) { v[2 * i] *= r0; v[2 * i + 1] *= r1; v[8 + 2 * i] *= r2; v[8 + 2 * i + 1] *= r3; } \
         else { v[2 * i] += r0; v[2 * i + 1] += r1; v[8 + 2 * i] += r2; v[8 + 2 * i + 1] += r3; }          \
       }                                                                                                   \
-      if ((MT) < 7) {                                                                                     \
-        v7_buf_load16(rr0, rs_r, vo_r, (so_row + 16) * ldr_b + ec * 2);                                   \
-        v7_buf_load16_o16(rr1, rs_r, vo_r, (so_row + 16) * ldr_b + ec * 2);                               \
+      if ((MT) < 4) {                                                                                     \
+        v7_buf_load16(rq[(MT) & 3][0], rs_r, vo_r, (so_row + 64) * ldr_b + ec * 2);                       \
+        v7_buf_load16_o16(rq[(MT) & 3][1], rs_r, vo_r, (so_row + 64) * ldr_b + ec * 2);                   \
       }                                                                                                   \
     }                                                                                                     \
     u32x4 o0, o1;                                                                                         \
@@ -124,7 +130,7 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
   const int gq = lane >> 4, j = lane & 15;
   const int vo_c = j * ldc_b + gq * 32, vo_c2 = j * ldc2_b + gq * 32, vo_r = j * ldr_b + gq * 32;
   const bool has_c2 = g.C2 != nullptr;
-  u32x4 rr0, rr1;   // residual of the next slab, two 8-column halves
+  u32x4 rq[4][2];   // residual ring: the next four slabs, two 8-column halves each
   // the two 64-column halves spelled out: a rolled (or not fully unrolled) loop would index the accumulators
   // dynamically and demote them to scratch
 #define V7_HALF(NH)                                                                                       \
@@ -133,8 +139,10 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
     const int ec = n0 + ecr;                                                                              \
     if (ec < g.N) {   /* N % 64 == 0 (host-checked): the 64 columns are all valid */                      \
       if (HAS_R) {                                                                                        \
-        v7_buf_load16(rr0, rs_r, vo_r, (128 * wm) * ldr_b + ec * 2);                                      \
-        v7_buf_load16_o16(rr1, rs_r, vo_r, (128 * wm) * ldr_b + ec * 2);                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+          v7_buf_load16(rq[q][0], rs_r, vo_r, (128 * wm + 16 * q) * ldr_b + ec * 2);                      \
+          v7_buf_load16_o16(rq[q][1], rs_r, vo_r, (128 * wm + 16 * q) * ldr_b + ec * 2);                  \
+        }                                                                                                 \
       }                                                                                                   \
       u32x4 bq[4];                                                                                        \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \

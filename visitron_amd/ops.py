@@ -4,6 +4,7 @@ torch is plumbing here (device memory + the current HIP stream); all arithmetic 
 hot path runs in ``libvisitron_hip.so``.  Every function raises on CPU tensors.
 """
 import ctypes
+import os
 
 import torch
 
@@ -162,6 +163,9 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
             t = e0.elapsed_time(e1)
         except RuntimeError:
             t = float("inf")
+        if os.environ.get("VT_TUNE_VERBOSE"):
+            print("  tune M=%d N=%d K=%d act=%d res=%d pre=%d variant %2d: %8.1f us %6.0f TF" % (
+                M, N, K, act, int(r is not None), int(pre_act), v, t / reps * 1e3, 2.0 * M * N * K / (t / reps * 1e-3) * 1e-12))
         if t < best_t:
             best, best_t = v, t
     lib.vt_debug_set_gemm_variant(-1)
