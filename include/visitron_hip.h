@@ -42,6 +42,9 @@ int vt_abi_version(void);
 void vt_debug_set_gemm_variant(int variant);
 /* Debug: device buffer (>= 64 * 8 B per workgroup) that the persistent GEMM fills with phase timestamps; NULL = off. */
 void vt_debug_set_gemm_trace(void* buf);
+/* Tuning/test hook for vt_wgrad_bf16: 0 automatic (persistent stream-K kernel where N, K are multiples of 256),
+   128 / 256 force the one-tile-per-workgroup kernel with that n-tile width, -8 never the persistent kernel. */
+void vt_debug_set_wgrad_kernel(int mode);
 /* Autotuner result: use kernel `variant` for linear layers of exactly this shape and activation (filled by
  * the host before the shape is used; process-global, read-only afterwards). */
 void vt_gemm_tune(int M, int N, int K, int act, int variant);

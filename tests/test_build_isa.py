@@ -1,0 +1,62 @@
+"""CPU: properties of the generated gfx950 code that the hand-scheduled GEMM kernels rely on and that a compiler
+change could silently break (checked on the device assembly, no GPU needed)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "visitron_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _device_asm(src, tmp_path):
+    out = os.path.join(str(tmp_path), os.path.basename(src) + ".s")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", out],
+                   check=True, cwd=CSRC, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernels(asm):
+    """name -> text of each kernel (label .. .end_amdhsa_kernel)."""
+    res = {}
+    for m in re.finditer(r"^(_Z\w+):.*?\.end_amdhsa_kernel", asm, re.S | re.M):
+        res[m.group(1)] = m.group(0)
+    return res
+
+
+def test_agpr_gemm_kernels_have_no_scratch(tmp_path):
+    """The 256x256-tile kernels keep 256 accumulators in AGPRs through inline-asm MFMAs; an accumulator array that
+    falls to scratch (a loop left rolled, a dynamic index) is both slow and WRONG (the asm MFMAs are asynchronous)."""
+    ks = _kernels(_device_asm(os.path.join(CSRC, "gemm_v7.hip"), tmp_path))
+    assert len(ks) >= 30
+    for name, text in ks.items():
+        m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", text)
+        assert m and int(m.group(1)) == 0, name
+        assert "scratch_" not in text, name
+
+
+def test_wgrad_v8_fragment_registers_are_left_alone(tmp_path):
+    """gemm_wgrad_tn_v8 names v[96:227] in its instruction text (transposing-read fragments, the bias ones operand);
+    nothing the compiler emits may touch them, and the code object's register count must cover them."""
+    ks = _kernels(_device_asm(os.path.join(CSRC, "gemm_wgrad_v8.hip"), tmp_path))
+    text = [t for n, t in ks.items() if "gemm_wgrad_tn_v8" in n][0]
+    assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", text).group(1)) == 0
+    assert int(re.search(r"\.amdhsa_accum_offset (\d+)", text).group(1)) >= 228
+    assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", text).group(1)) >= 228 + 256
+    for line in text.splitlines():
+        t = line.strip()
+        if not t or t[0] in ";." or t.startswith("ds_read_b64_tr_b16") or t.startswith("v_mfma"):
+            continue
+        regs = set()
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", t):
+            regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", t):
+            regs.add(int(m.group(1)))
+        hit = [r for r in regs if 96 <= r <= 227]
+        if hit:
+            assert t.startswith("v_mov_b32 v22") and "0x3f803f80" in t, t   # the ones operand, set once at entry

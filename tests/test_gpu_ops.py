@@ -294,6 +294,45 @@ def test_wgrad_grouped_matches_fp32(dev, M):
         assert float((p["dw"].cpu().double() - 2 * w_dw).abs().max()) < 4e-4 * float(w_dw.abs().max()) + 2e-3
 
 
+@pytest.mark.parametrize("M,specs", [
+    (1000, [(256, 256, True), (512, 768, True)]),                        # M tail inside the last row block; 8 tiles on 8 workgroups
+    (14592, [(2304, 768, True), (768, 768, True), (3072, 768, True), (768, 3072, True)]),   # an encoder layer's group (B = 64)
+    (4100, [(768, 768, False), (256, 1024, True)]),
+])
+def test_wgrad_persistent_streamk_matches_plain_kernel_and_fp32(dev, M, specs):
+    """The persistent stream-K weight-gradient kernel (fp32 atomics of partial tiles) against fp64 and against the
+    one-tile-per-workgroup kernel on the same operands; overwrite and accumulate modes."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(M + 1)
+    data = []
+    for N, K, bias in specs:
+        dy, x = bf16_round(_rand((M, N), g, 0.5)), bf16_round(_rand((M, K), g))
+        data.append((dy, x, bias, dy.double().t() @ x.double(), dy.double().sum(0)))
+
+    def run(mode, accumulate):
+        ops.set_wgrad_kernel(mode)
+        try:
+            probs = [dict(dy=dy.to(dev, BF16), x=x.to(dev, BF16), dw=torch.full((dy.shape[1], x.shape[1]), 3.0, device=dev),
+                          db=torch.full((dy.shape[1],), 3.0, device=dev) if bias else None, accumulate=accumulate)
+                     for dy, x, bias, _, _ in data]
+            ops.wgrad(probs, M)
+            torch.cuda.synchronize()
+            return probs
+        finally:
+            ops.set_wgrad_kernel(0)
+
+    for accumulate in (False, True):
+        new, old = run(0, accumulate), run(-8, accumulate)
+        for pn, po, (_, _, bias, w_dw, w_db) in zip(new, old, data):
+            off = 3.0 if accumulate else 0.0
+            scale = float(w_dw.abs().max())
+            assert float((pn["dw"].cpu().double() - off - w_dw).abs().max()) < 2e-4 * scale + 1e-3
+            assert float((pn["dw"] - po["dw"]).abs().max()) < 1e-4 * scale + 1e-4      # fp32 summation order only
+            if bias:
+                assert float((pn["db"].cpu().double() - off - w_db).abs().max()) < 2e-4 * float(w_db.abs().max()) + 1e-3
+
+
 def test_wgrad_asymmetric_identity(dev):
     """dY = I (M = N) against an asymmetric X: dW must equal X exactly (catches transposed writes)."""
     from visitron_amd import ops

@@ -41,25 +41,12 @@ int vt_pack_concat_dispatch(const float* s0, int d0, const float* s1, int d1, vo
 
 void vt_gemm_set_variant(int v);
 void vt_gemm_set_trace(void* p);
+void vt_wgrad_set_tile(int tn);
+void vt_wgrad_v8_enable(int on);
 void vt_gemm_tune_set(int M, int N, int K, int act, int variant);
 void vt_attn_bwd_set_waves(int w);
 
-#define WG_MAX_PROBLEMS 8
-struct WgradProblem {
-  const bf16_t* dY; long ldy;
-  const bf16_t* X; long ldx;
-  float* dW; long ldw;
-  float* db;
-  int N, K;
-  int tiles_k;
-  int tile_begin;
-  int accumulate;
-};
-struct WgradArgs {
-  WgradProblem p[WG_MAX_PROBLEMS];
-  int nprob;
-  int M;
-};
+#include "wgrad_common.hpp"
 int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream);
 
 extern "C" {
@@ -80,6 +67,11 @@ int vt_abi_version(void) { return 2; }
 
 void vt_debug_set_gemm_variant(int variant) { vt_gemm_set_variant(variant); }
 void vt_debug_set_gemm_trace(void* buf) { vt_gemm_set_trace(buf); }
+void vt_debug_set_wgrad_kernel(int mode) {
+  // 0: automatic; 128 / 256: the 128(k)-tile kernel with that n-tile width; 8: automatic (alias); -8: never the persistent kernel
+  vt_wgrad_set_tile(mode == 128 || mode == 256 ? mode : 0);
+  vt_wgrad_v8_enable(mode == -8 ? 0 : 1);
+}
 void vt_gemm_tune(int M, int N, int K, int act, int variant) { vt_gemm_tune_set(M, N, K, act, variant); }
 void vt_debug_set_attn_bwd_waves(int waves) { vt_attn_bwd_set_waves(waves); }
 

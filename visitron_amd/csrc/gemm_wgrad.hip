@@ -19,24 +19,7 @@
 // an extra MFMA against an all-ones A fragment in the k-tile-0 workgroups.
 #include "common.hpp"
 
-#define WG_MAX_PROBLEMS 8
-
-struct WgradProblem {
-  const bf16_t* dY; long ldy;   // [M, N]
-  const bf16_t* X; long ldx;    // [M, K]
-  float* dW; long ldw;          // [N, K] fp32
-  float* db;                    // [N] fp32 or null
-  int N, K;
-  int tiles_k;                  // ceil(K / 128)
-  int tile_begin;               // first linear tile id of this problem
-  int accumulate;               // 0: overwrite dW/db, 1: add to them
-};
-
-struct WgradArgs {
-  WgradProblem p[WG_MAX_PROBLEMS];
-  int nprob;
-  int M;
-};
+#include "wgrad_common.hpp"
 
 #define WG_TILE_BYTES (64 * 256)   // X tile: 64 rows x 128 columns
 // TN = width of the dY tile (n-range of the output tile): 128 (4 waves) or 256 (8 waves, 85 instead of 64
@@ -245,6 +228,8 @@ static int wgrad_launch(WgradArgs& a, int total, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
+int vt_wgrad_v8_dispatch(WgradArgs& a, hipStream_t stream);   // gemm_wgrad_v8.hip
+
 int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream) {
   if (a.nprob <= 0 || a.nprob > WG_MAX_PROBLEMS || a.M <= 0) return VT_ERR_BAD_SHAPE;
   // 128-wide n-tiles by default: the 256-wide form (8 waves, one workgroup per CU) measured 24 % SLOWER on
@@ -259,6 +244,14 @@ int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream) {
     if ((P.ldy % 8) || (P.ldx % 8) || (P.ldw % 4) || (P.K % 4)) return VT_ERR_BAD_ALIGN;
     if (((uintptr_t)P.dY | (uintptr_t)P.X | (uintptr_t)P.dW) & 15) return VT_ERR_BAD_ALIGN;
     if ((long)a.M * P.ldy * 2 >= (1L << 31) || (long)a.M * P.ldx * 2 >= (1L << 31)) return VT_ERR_UNSUPPORTED;
+  }
+  // groups whose matrices are whole 256x256 tiles: the persistent stream-K kernel (long reductions, every CU busy)
+  if (g_wgrad_tn == 0) {
+    const int rc8 = vt_wgrad_v8_dispatch(a, stream);
+    if (rc8 != VT_ERR_UNSUPPORTED) return rc8;
+  }
+  for (int i = 0; i < a.nprob; ++i) {
+    WgradProblem& P = a.p[i];
     P.tiles_k = (P.K + 127) / 128;
     P.tile_begin = total;
     total += ((P.N + tn - 1) / tn) * P.tiles_k;

@@ -393,6 +393,11 @@ def encoder_backward(layer_weights, layer_weights_t, layer_acts, layer_grads, x,
     _lib.check(rc, "vt_encoder_backward_bf16")
 
 
+def set_wgrad_kernel(mode):
+    """Tuning/test hook: 0 automatic, 128 / 256 the one-tile-per-workgroup kernel, -8 never the persistent kernel."""
+    _lib.load().vt_debug_set_wgrad_kernel(int(mode))
+
+
 def wgrad(problems, M):
     """Grouped weight gradients.  problems: list of dicts(dy, x, dw, db=None, accumulate=False) with
     dy [M,N] bf16, x [M,K] bf16, dw [N,K] fp32, db [N] fp32; one launch for up to 8 problems."""
