@@ -171,11 +171,20 @@ def main():
         gemm = kernels.get("gemm_nt_bf16")
         if gemm and gemm["ms"] > 0:
             achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+            # HBM bytes per launch of the same kernels: not measurable from inside this process; taken from the
+            # committed PMC passes of this command (profiles/README.md), null when that file is absent
+            traffic, traffic_src = None, None
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "train_b256_pmc_hbm_traffic_v3.json")
+            if train and a.batch == 256 and os.path.exists(tp):
+                tj = json.load(open(tp))
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01/train_b256_pmc_hbm_traffic_v3.json"
             roofline = {
-                "kernel": "gemm_nt_bf16 (NT GEMM family: 128x128 / 256x192 / 256x256 tiles chosen per shape by the autotuner)",
+                "kernel": "gemm_nt_bf16 (NT GEMM family; per shape the autotuner picks among the persistent 256x256-tile "
+                          "kernel with 128x128 wave tiles / AGPR accumulators and the older 128x128 .. 256x256 tiles)",
                 "bound": "mfma", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": None, "launches": gemm["n"], "avg_us": round(gemm["ms"] * 1e3 / gemm["n"], 2),
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                "launches": gemm["n"], "avg_us": round(gemm["ms"] * 1e3 / gemm["n"], 2),
                 "flops_per_launch": gemm["flops"] / gemm["n"],
             }
 

@@ -1,0 +1,41 @@
+"""profiles/: turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only, as the guide prescribes) into a
+per-kernel HBM traffic table and the per-launch figure bench.py reports as roofline.traffic for the NT GEMM family.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B, so it is doubled
+(MI355X_MICROARCH.md, HBM / rocprofv3 section).
+usage: python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_prefix>"""
+import collections
+import csv
+import json
+import sys
+
+
+def agg(path, ctr):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == ctr:
+            d[r["Kernel_Name"]][0] += 1
+            d[r["Kernel_Name"]][1] += float(r["Counter_Value"])
+    return d
+
+
+fetch, write, prefix = sys.argv[1:4]
+f, w = agg(fetch, "FETCH_SIZE"), agg(write, "WRITE_SIZE")
+rows = []
+for name in set(f) | set(w):
+    nf, fv = f.get(name, [0, 0.0])
+    nw, wv = w.get(name, [0, 0.0])
+    n = max(nf, nw)
+    rows.append(dict(kernel=name, launches=n, read_MB_per_launch=round(2.0 * fv * 1024 / max(nf, 1) / 1e6, 2),
+                     write_MB_per_launch=round(wv * 1024 / max(nw, 1) / 1e6, 2)))
+rows.sort(key=lambda r: -(r["read_MB_per_launch"] + r["write_MB_per_launch"]) * r["launches"])
+with open(prefix + ".csv", "w", newline="") as fh:
+    wr = csv.DictWriter(fh, fieldnames=["kernel", "launches", "read_MB_per_launch", "write_MB_per_launch"])
+    wr.writeheader()
+    wr.writerows(rows)
+nt = [r for r in rows if "gemm_nt_bf16" in r["kernel"]]
+n = sum(r["launches"] for r in nt)
+tot = sum((r["read_MB_per_launch"] + r["write_MB_per_launch"]) * r["launches"] for r in nt) * 1e6
+json.dump({"kernel_family": "gemm_nt_bf16*", "launches": n, "hbm_bytes_per_launch": round(tot / n),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1, "
+                     "FETCH_SIZE doubled (gfx950)"}, open(prefix + ".json", "w"), indent=1)
+print("NT GEMM family: %d launches, %.1f MB per launch" % (n, tot / n / 1e6))
