@@ -10,14 +10,19 @@ N, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (768, 768)
 x = torch.randn(M, K, device=dev).to(torch.bfloat16)
 w = torch.randn(N, K, device=dev).to(torch.bfloat16)
 y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+MODE = sys.argv[4] if len(sys.argv) > 4 else "plain"      # plain | gelu_pre | res | bias
+bias = torch.zeros(N, device=dev) if MODE != "plain" else None
+pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if MODE == "gelu_pre" else None
+res = torch.randn(M, N, device=dev).to(torch.bfloat16) if MODE == "res" else None
+kw = dict(bias=bias, residual=res, act=1 if MODE == "gelu_pre" else 0, pre_act_out=pre)
 ops.set_gemm_variant(16)
 for _ in range(3):
-    ops.linear(x, w, out=y)
+    ops.linear(x, w, out=y, **kw)
 torch.cuda.synchronize()
 buf = torch.zeros(256 * 64 + 8, dtype=torch.int64, device=dev)
 buf[256 * 64] = int(float(sys.argv[3]) * 100) if len(sys.argv) > 3 else 0   # stagger window in us
 _lib.load().vt_debug_set_gemm_trace(buf.data_ptr())
-ops.linear(x, w, out=y)
+ops.linear(x, w, out=y, **kw)
 torch.cuda.synchronize()
 _lib.load().vt_debug_set_gemm_trace(None)
 t = buf[:256 * 64].view(256, 64).cpu()

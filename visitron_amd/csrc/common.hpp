@@ -38,7 +38,7 @@ __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w &
 // (1e-3) and far below bf16 resolution; ~12 VALU ops instead of libm's erff.
 __device__ __forceinline__ float fast_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
   float y = 1.061405429f;
   y = y * t - 1.453152027f;
   y = y * t + 1.421413741f;
@@ -60,7 +60,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // gelu_erf / gelu_erf_grad
 __device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
   const float ax = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
   float y = 1.061405429f;
   y = y * t - 1.453152027f;
   y = y * t + 1.421413741f;
@@ -72,10 +72,31 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
   g = x * cdf;
   dg = cdf + x * (0.3989422804014327f * e);
 }
+// The same for two elements with packed fp32 arithmetic (v_pk_mul/fma/add_f32: two lanes' worth per issue slot);
+// the reciprocal, the exponential and the sign transfer stay per element.  At one wave per SIMD the GEMM epilogue
+// has nothing to overlap its VALU work with, so the instruction count is its time.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ void gelu_erf_both2(f32x2 x, f32x2& g, f32x2& dg) {
+  const f32x2 ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
+  const f32x2 den = ax * 0.3275911f + 1.0f;
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 y = t * 0.5307027145f - 0.7265760135f;      // the erf polynomial with its coefficients halved
+  y = y * t + 0.7107068705f;
+  y = y * t - 0.142248368f;
+  y = y * t + 0.127414796f;
+  const f32x2 q = y * t;                              // 0.5 * (1 - |erf|) / exp(-x^2/2)
+  const f32x2 a2 = (ax * ax) * -1.4426950408889634f;  // -x^2/2 in base 2
+  const f32x2 e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+  const f32x2 h = 0.5f - q * e;                       // 0.5 * |erf|
+  const f32x2 hs = {copysignf(h[0], x[0]), copysignf(h[1], x[1])};
+  const f32x2 cdf = hs + 0.5f;
+  g = x * cdf;
+  dg = cdf + x * (e * 0.3989422804014327f);
+}
 __device__ __forceinline__ float tanh_fast(float x) {
   // tanh(x) = 1 - 2/(exp(2x)+1); saturates cleanly for |x| large
   const float e = __expf(2.0f * x);
-  return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

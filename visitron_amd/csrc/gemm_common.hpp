@@ -71,7 +71,11 @@ __device__ __forceinline__ void epi_row_values(const GemmArgs& g, const f32x4 (&
     for (int e = 0; e < 4; ++e) v[4 * t + e] = a[t][e] + bv[4 * t + e];
   if (WANT_S2 && ACT == ACT_GELU) {   // value and derivative share the reciprocal / polynomial / exponential
 #pragma unroll
-    for (int i = 0; i < 16; ++i) gelu_erf_both(v[i], v[i], s2[i]);
+    for (int i = 0; i < 16; i += 2) {
+      f32x2 gg, dd;
+      gelu_erf_both2((f32x2){v[i], v[i + 1]}, gg, dd);
+      v[i] = gg[0]; v[i + 1] = gg[1]; s2[i] = dd[0]; s2[i + 1] = dd[1];
+    }
   } else {
     if (WANT_S2) {
 #pragma unroll
