@@ -101,6 +101,38 @@ def test_linear_variant_256x256_agpr(dev, M, N, K, act, res, f32out, variant):
         ops.set_gemm_variant(-1)
 
 
+@pytest.mark.parametrize("N,K,act,res,pre", [(768, 768, 0, True, False), (3072, 768, 1, False, True), (3072, 768, 3, True, False),
+                                             (768, 3072, 0, True, False)])
+def test_linear_persistent_kernel_full_size_against_plain_kernel(dev, N, K, act, res, pre):
+    """BASELINE-size rows (B = 256 x 228 tokens): the persistent kernel's hand-counted vmcnt waits (residual ring,
+    bias through LDS-DMA, stores in flight) under a full chip's memory traffic.  The 128x128-tile kernel, whose waits
+    the compiler places, accumulates in the same order: outputs must agree to a bf16 ulp of the activation."""
+    from visitron_amd import ops
+
+    M = 58368
+    g = torch.Generator().manual_seed(N + K)
+    a = _rand((M, K), g).to(dev, BF16)
+    w = _rand((N, K), g, 0.05).to(dev, BF16)
+    b = _rand((N,), g, 0.1).to(dev)
+    r = _rand((M, N), g).to(dev, BF16) if res else None
+    outs = []
+    for variant in (1, 16):
+        ops.set_gemm_variant(variant)
+        try:
+            p_out = torch.empty((M, N), dtype=BF16, device=dev) if pre else None
+            y = ops.linear(a, w, b, residual=r, act=act, pre_act_out=p_out)
+            torch.cuda.synchronize()
+            outs.append((y.float(), None if p_out is None else p_out.float()))
+        finally:
+            ops.set_gemm_variant(-1)
+    (y1, p1), (y2, p2) = outs
+    scale = float(y1.abs().max())
+    assert float((y1 - y2).abs().max()) <= scale * 2 ** -7
+    assert float(((y1 - y2).abs() > 0).float().mean()) < 0.02      # rounding ties only
+    if pre:
+        assert float((p1 - p2).abs().max()) <= float(p1.abs().max()) * 2 ** -7
+
+
 def test_linear_asymmetric_identity(dev):
     """A = I against an ASYMMETRIC W catches a transposed or permuted accumulator write-out."""
     from visitron_amd import ops

@@ -26,6 +26,10 @@
 #define V7_MFMA(S, i)                                                                                             \
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(i) & 7][(i) >> 3]) : "v"(wf[S][(i) >> 3]), \
                "v"(xf[S][(i) & 7]))
+// first K-step of a tile: C = 0 (an inline constant), so the 256 accumulator registers need no zeroing pass
+#define V7_MFMA0(S, i)                                                                                            \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[(i) & 7][(i) >> 3]) : "v"(wf[S][(i) >> 3]), \
+               "v"(xf[S][(i) & 7]))
 #define V7_LDSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
 // ---- epilogue of the 256x256-tile kernels (bf16 output, whole 64-column slabs: EPI_LDS) ---------------------------
@@ -197,13 +201,15 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
 // One K-step: the current stage holds the K-tile whose substep-0 fragments are in set 0; (rx, rw) describe the
 // K-tile two steps ahead.  VMW is the vmcnt that proves the NEXT K-tile has landed: 13 in steady state (the 13
 // pieces issued so far in this step may stay in flight), 0 right after an epilogue (its stores share the counter).
-#define V7_STEP(VMW)                                                                                       \
+#define V7_STEP(VMW) V7_STEP_(VMW, V7_MFMA)
+#define V7_STEP_FIRST(VMW) V7_STEP_(VMW, V7_MFMA0)   /* first K-step of a tile: phase A starts from C = 0 */
+#define V7_STEP_(VMW, MFMA_A)                                                                                     \
   {                                                                                                        \
     const unsigned xn0 = xa0 ^ V7_STAGE, wn0 = wa0 ^ V7_STAGE; /* substep-0 addresses of the other stage */ \
     /* re-defined every step: as plain loop invariants the allocator parks them in scratch (reload + vmcnt(0)) */ \
     asm volatile("" : "+v"(vx[0]), "+v"(vx[1]), "+v"(vw[0]), "+v"(vw[1]));                                \
     _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
-      V7_MFMA(0, i);                                                                                       \
+      MFMA_A(0, i);                                                                                        \
       if (i < 16 && (i & 1)) V7_LDSR(xf[1][i >> 1], xa1, (i >> 1) * 2048);                                 \
       if (i == 20) {                                                                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
@@ -297,11 +303,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   unsigned wa0 = lds0 + V7_WOFF + wn * 16384 + fr, wa1 = wa0 ^ 64;
   unsigned dst = wave * 8192;   // byte offset of this wave's first DMA piece inside the current stage's X image
 
-  f32x4 acc[8][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[8][8];   // defined by the first K-step (C = 0)
   u32x4 xf[2][8], wf[2][8];
 
   auto rsrc_x = [&](int kt) {
@@ -339,7 +341,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   }
 
   // one K-step per iteration: tile kt in the current stage; MFMA i = 8*nt + mt
-  for (int kt = 0; kt < nk; ++kt) {
+  {
+    __amdgpu_buffer_rsrc_t rx = rsrc_x(2), rw = rsrc_w(2);
+    V7_STEP_FIRST(13)
+  }
+  for (int kt = 1; kt < nk; ++kt) {
     __amdgpu_buffer_rsrc_t rx = rsrc_x(kt + 2), rw = rsrc_w(kt + 2);
     V7_STEP(13)
   }
@@ -499,16 +505,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   for (int t = first; t < c1; t += nx) {
     int m0, n0;
     tile_origin(t, m0, n0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     V8_TRACE_RT();
     {  // first K-step of the tile; the bias piece goes first, so the step's landing wait covers it too
       __amdgpu_buffer_rsrc_t rx = V8_RSRC_X(), rw = V8_RSRC_W();
       cursor_next();
       V7_DMA_BIAS()
-      V7_STEP(13)
+      V7_STEP_FIRST(13)
     }
     for (int kt = 1; kt < nk; ++kt) {
       __amdgpu_buffer_rsrc_t rx = V8_RSRC_X(), rw = V8_RSRC_W();
