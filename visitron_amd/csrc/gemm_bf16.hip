@@ -939,6 +939,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_bf16_v6(GemmArgs g) {
 //          7, 8 = timing experiments (no DMA / no MFMA in the loop; wrong results).
 int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip
 int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip (persistent)
+int vt_gemm_v9_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v9.hip (persistent, 32x32x16 MFMAs)
 static void* g_gemm_trace = nullptr;
 void vt_gemm_set_trace(void* p) { g_gemm_trace = p; }
 static int g_gemm_variant = -1;  // -1: table / heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
@@ -1031,6 +1032,7 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
     }
     case 15: return vt_gemm_v7_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
     case 16: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
+    case 17: return vt_gemm_v9_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
     case 7: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32, 1>, g, 2 * 32768, stream);  // timing experiment: no DMA in the loop
     case 8: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32, 2>, g, 2 * 32768, stream);  // timing experiment: no MFMA
     default: return VT_ERR_UNSUPPORTED;

@@ -124,7 +124,8 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
 
 
 # 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring), 256x256 with 128x128 wave tiles
-# and AGPR accumulators (15: one tile per workgroup, 16: persistent)
+# and AGPR accumulators (15: one tile per workgroup, 16: persistent).  Variant 17 (the persistent kernel on 32x32x16
+# MFMAs, gemm_v9.hip) measured level with 16 on the plain shapes and slower with epilogues: not a candidate.
 GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16)
 
 
