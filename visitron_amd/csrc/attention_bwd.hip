@@ -60,9 +60,9 @@ __device__ __forceinline__ bf16x8 tr_pair_b(unsigned addr, int second_off) {
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
-  short8v r;
+  u32x4 r;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (short)f32_to_bf16(v[8 * s2 + j]);
+  for (int j = 0; j < 4; ++j) r[j] = pack_bf16x2(v[8 * s2 + 2 * j], v[8 * s2 + 2 * j + 1]);
   return __builtin_bit_cast(bf16x8, r);
 }
 

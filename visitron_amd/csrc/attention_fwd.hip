@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           typedef __attribute__((ext_vector_type(8))) short short8v;
-          short8v pbs;
+          u32x4 pbw;
           if (dr.thresh) {  // drop probabilities AFTER the row sum was taken (the normaliser uses all of them)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
             }
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pbs[j] = (short)f32_to_bf16(sacc[8 * s2 + j]);
-          const bf16x8 pb = __builtin_bit_cast(bf16x8, pbs);
+          for (int j = 0; j < 4; ++j) pbw[j] = pack_bf16x2(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1]);
+          const bf16x8 pb = __builtin_bit_cast(bf16x8, pbw);
           const char* vp = smem + ATT_SV + (kt * 32 + 16 * s2 + v_row) * 128;
           const bf16x8 vf0 = tr_pair(vp + ((v_colb) ^ v_swz));
           const bf16x8 vf1 = tr_pair(vp + ((v_colb + 64) ^ v_swz));

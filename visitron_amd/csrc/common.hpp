@@ -28,8 +28,13 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
+// two round-to-nearest-even conversions in ONE v_cvt_pk_bf16_f32 (converting the halves separately costs two
+// converts, a shift and an or: 4 instructions per output dword in every epilogue)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const bf16x2_t v = __builtin_convertvector((f32x2){lo, hi}, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
@@ -75,7 +80,6 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
 // The same for two elements with packed fp32 arithmetic (v_pk_mul/fma/add_f32: two lanes' worth per issue slot);
 // the reciprocal, the exponential and the sign transfer stay per element.  At one wave per SIMD the GEMM epilogue
 // has nothing to overlap its VALU work with, so the instruction count is its time.
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ void gelu_erf_both2(f32x2 x, f32x2& g, f32x2& dg) {
   const f32x2 ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
   const f32x2 den = ax * 0.3275911f + 1.0f;

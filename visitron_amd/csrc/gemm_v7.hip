@@ -101,21 +101,23 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
       _Pragma("unroll") for (int i = 0; i < 16; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f; \
     }                                                                                                     \
     if (HAS_R) {                                                                                          \
-      /* this slab's residual was issued 4 slabs ago (the first four before slab 0); behind it in the queue: the  \
-         younger residual loads and the stores issued since -> counted wait (VMEM retires in order).  With C2      \
-         stores in the stream as well (not a combination the encoder uses) simply drain. */                        \
+      /* slab s = 8*NH + MT; its residual was issued 8 slabs ago (the first eight before slab 0: a 4-deep ring left \
+         each slab waiting ~0.45 us on HBM latency).  Behind it in the queue: the younger residual loads and the    \
+         stores issued since -> counted wait (VMEM retires in order).  With C2 stores in the stream as well (not a  \
+         combination the encoder uses) simply drain. */                                                            \
       if (has_c2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((MT) < 4 ? 6 + 2 * (MT) : 22 - 2 * (MT)) : "memory"); \
-      asm volatile("" : "+v"(rq[(MT) & 3][0]), "+v"(rq[(MT) & 3][1]));                                    \
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NH) == 0 ? 14 + 2 * (MT) : 30 - 2 * (MT)) : "memory"); \
+      asm volatile("" : "+v"(rq[MT][0]), "+v"(rq[MT][1]));                                                \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
-        const u32x4 q0 = rq[(MT) & 3][0], q1 = rq[(MT) & 3][1];                                           \
+        const u32x4 q0 = rq[MT][0], q1 = rq[MT][1];                                                       \
         const float r0 = bf16lo(q0[i]), r1 = bf16hi(q0[i]), r2 = bf16lo(q1[i]), r3 = bf16hi(q1[i]);       \
         if (ACT == ACT_MUL) { v[2 * i] *= r0; v[2 * i + 1] *= r1; v[8 + 2 * i] *= r2; v[8 + 2 * i + 1] *= r3; } \
         else { v[2 * i] += r0; v[2 * i + 1] += r1; v[8 + 2 * i] += r2; v[8 + 2 * i + 1] += r3; }          \
       }                                                                                                   \
-      if ((MT) < 4) {                                                                                     \
-        v7_buf_load16(rq[(MT) & 3][0], rs_r, vo_r, (so_row + 64) * ldr_b + ec * 2);                       \
-        v7_buf_load16_o16(rq[(MT) & 3][1], rs_r, vo_r, (so_row + 64) * ldr_b + ec * 2);                   \
+      if ((NH) == 0) {   /* same rows of the other column half; issued unconditionally: the counts above rely on it \
+                            (columns past N are never used, rows past M read zeros) */                              \
+        v7_buf_load16(rq[MT][0], rs_r, vo_r, so_row * ldr_b + (ec + 64) * 2);                             \
+        v7_buf_load16_o16(rq[MT][1], rs_r, vo_r, so_row * ldr_b + (ec + 64) * 2);                         \
       }                                                                                                   \
     }                                                                                                     \
     u32x4 o0, o1;                                                                                         \
@@ -140,7 +142,7 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
   const int gq = lane >> 4, j = lane & 15;
   const int vo_c = j * ldc_b + gq * 32, vo_c2 = j * ldc2_b + gq * 32, vo_r = j * ldr_b + gq * 32;
   const bool has_c2 = g.C2 != nullptr;
-  u32x4 rq[4][2];   // residual ring: the next four slabs, two 8-column halves each
+  u32x4 rq[8][2];   // residual ring: the next eight slabs (one column half), two 8-column halves each
   // the two 64-column halves spelled out: a rolled (or not fully unrolled) loop would index the accumulators
   // dynamically and demote them to scratch
 #define V7_HALF(NH)                                                                                       \
@@ -148,8 +150,8 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
     const int ecr = 128 * wn + 64 * (NH);   /* tile-relative first column */                              \
     const int ec = n0 + ecr;                                                                              \
     if (ec < g.N) {   /* N % 64 == 0 (host-checked): the 64 columns are all valid */                      \
-      if (HAS_R) {                                                                                        \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+      if (HAS_R && (NH) == 0) {                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                   \
           v7_buf_load16(rq[q][0], rs_r, vo_r, (128 * wm + 16 * q) * ldr_b + ec * 2);                      \
           v7_buf_load16_o16(rq[q][1], rs_r, vo_r, (128 * wm + 16 * q) * ldr_b + ec * 2);                  \
         }                                                                                                 \
