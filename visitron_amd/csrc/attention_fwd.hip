@@ -169,10 +169,14 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
           u32x4 pbw;
           if (dr.thresh) {  // drop probabilities AFTER the row sum was taken (the normaliser uses all of them)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 8; j += 2) {   // elements i, i+1 are neighbouring keys: one hash for both (S even)
               const int i = 8 * s2 + j;
-              const uint32_t key = (uint32_t)(kc + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2);
-              sacc[i] = vt_keep(dr, q_elem + key) ? sacc[i] * dr.scale : 0.f;
+              const uint32_t e = q_elem + (uint32_t)(kc + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2);
+              bool k0, k1;
+              if ((S & 1) == 0) vt_keep2(dr, e, k0, k1);
+              else { k0 = vt_keep(dr, e); k1 = vt_keep(dr, e + 1); }
+              sacc[i] = k0 ? sacc[i] * dr.scale : 0.f;
+              sacc[i + 1] = k1 ? sacc[i + 1] * dr.scale : 0.f;
             }
           }
 #pragma unroll

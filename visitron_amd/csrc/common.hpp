@@ -115,20 +115,47 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- dropout: counter-based hash RNG --------------------------------------------------------------
-// keep(element) = hash32(site_seed, element index) >> 8 >= p * 2^24; kept values are scaled by 1/(1-p).
-// Nothing is stored: the backward kernels recompute the same mask from (seed, index).  site_seed mixes
-// the step seed with a site id (layer, which dropout), see vt_site_seed.
+// One 32-bit hash serves TWO neighbouring elements: keep(element i) = 16 bits of hash32(site_seed, i >> 1) (low half
+// for even i, high half for odd i) >= p * 2^16; kept values are scaled by 1/(1-p).  Nothing is stored: the backward
+// kernels recompute the same mask from (seed, index).  site_seed mixes the step seed with a site id (layer, which
+// dropout), see vt_site_seed.  The hash is two multiply / xor-shift rounds (v_mul_lo_u32 is a quarter-rate
+// instruction and the epilogues that apply dropout have nothing to overlap it with).
 struct DropCfg {
-  uint32_t thresh;   // p * 2^24, 0 = no dropout
+  uint32_t thresh;   // p * 2^16, 0 = no dropout
   uint32_t seed;     // site seed
   float scale;       // 1 / (1 - p)
 };
 __host__ __device__ __forceinline__ uint32_t vt_hash32(uint32_t seed, uint32_t idx) {
-  uint32_t x = idx * 0x9E3779B1u ^ seed;
-  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  uint32_t x = (idx ^ seed) * 0x9E3779B1u;
+  x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13; x ^= x << 7; x ^= x >> 17;
   return x;
 }
-__host__ __device__ __forceinline__ bool vt_keep(const DropCfg& d, uint32_t idx) { return (vt_hash32(d.seed, idx) >> 8) >= d.thresh; }
+__host__ __device__ __forceinline__ bool vt_keep(const DropCfg& d, uint32_t idx) {
+  const uint32_t h = vt_hash32(d.seed, idx >> 1);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= d.thresh;
+}
+// elements idx (even) and idx + 1 from one hash
+__host__ __device__ __forceinline__ void vt_keep2(const DropCfg& d, uint32_t idx_even, bool& k0, bool& k1) {
+  const uint32_t h = vt_hash32(d.seed, idx_even >> 1);
+  k0 = (h & 0xffffu) >= d.thresh;
+  k1 = (h >> 16) >= d.thresh;
+}
+// v[0..N) *= keep / (1-p) for N consecutive elements starting at e0 (N even); pairs share a hash when e0 is even
+template <int N>
+__device__ __forceinline__ void vt_drop_run(const DropCfg& d, uint32_t e0, float (&v)[N]) {
+  if ((e0 & 1u) == 0) {
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+      bool k0, k1;
+      vt_keep2(d, e0 + i, k0, k1);
+      v[i] = k0 ? v[i] * d.scale : 0.f;
+      v[i + 1] = k1 ? v[i + 1] * d.scale : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = vt_keep(d, e0 + i) ? v[i] * d.scale : 0.f;
+  }
+}
 __host__ __device__ __forceinline__ uint32_t vt_site_seed(uint64_t step_seed, uint32_t site) {
   uint64_t x = step_seed + 0x9E3779B97F4A7C15ull * (uint64_t)(site + 1);
   x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
@@ -136,7 +163,7 @@ __host__ __device__ __forceinline__ uint32_t vt_site_seed(uint64_t step_seed, ui
 }
 __host__ __forceinline__ DropCfg vt_make_drop(float p, uint64_t step_seed, uint32_t site) {
   DropCfg d;
-  d.thresh = p > 0.f ? (uint32_t)(p * 16777216.0f) : 0u;
+  d.thresh = p > 0.f ? (uint32_t)(p * 65536.0f) : 0u;
   d.seed = vt_site_seed(step_seed, site);
   d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   return d;

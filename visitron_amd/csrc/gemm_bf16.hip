@@ -475,8 +475,7 @@ __device__ __forceinline__ void gemm_epilogue_grp(const GemmArgs& g, f32x4 (&acc
       for (int i = 0; i < W; ++i) v[i] = apply_act<ACT>(v[i]);
       if (g.drop.thresh) {
         const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)nb;
-#pragma unroll
-        for (int i = 0; i < W; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f;
+        vt_drop_run<W>(g.drop, e0, v);
       }
       if (g.R) {
 #pragma unroll

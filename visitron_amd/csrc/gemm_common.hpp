@@ -86,8 +86,7 @@ __device__ __forceinline__ void epi_row_values(const GemmArgs& g, const f32x4 (&
   }
   if (g.drop.thresh) {
     const uint32_t e0 = (uint32_t)m * (uint32_t)g.N + (uint32_t)nb;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f;
+    vt_drop_run<16>(g.drop, e0, v);
   }
   if (g.R) {
     const u32x4* rp = (const u32x4*)(g.R + orow * g.ldr + nb);

@@ -98,7 +98,7 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
     }                                                                                                     \
     if (g.drop.thresh) {                                                                                  \
       const uint32_t e0 = (uint32_t)(m0 + so_row + j) * (uint32_t)g.N + (uint32_t)(ec + 16 * gq);         \
-      _Pragma("unroll") for (int i = 0; i < 16; ++i) v[i] = vt_keep(g.drop, e0 + i) ? v[i] * g.drop.scale : 0.f; \
+      vt_drop_run<16>(g.drop, e0, v);                                                                     \
     }                                                                                                     \
     if (HAS_R) {                                                                                          \
       /* slab s = 8*NH + MT; its residual was issued 8 slabs ago (the first eight before slab 0: a 4-deep ring left \

@@ -177,8 +177,7 @@ __global__ __launch_bounds__(256) void embed_layernorm(EmbArgs a) {
       }
       if (a.drop.thresh) {
         const uint32_t e0 = (uint32_t)tok * (uint32_t)a.H + (uint32_t)col;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = vt_keep(a.drop, e0 + i) ? o[i] * a.drop.scale : 0.f;
+        vt_drop_run<8>(a.drop, e0, o);
       }
       u32x4 w;
 #pragma unroll
@@ -345,8 +344,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows(LnBwdArgs a) {
         *(u32x4*)(a.dx + row * a.lddx + col) = w;
         if (a.dx2) {
           const uint32_t e0 = (uint32_t)row * (uint32_t)a.H + (uint32_t)col;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = (!a.drop.thresh || vt_keep(a.drop, e0 + i)) ? o[i] * a.drop.scale : 0.f;
+          vt_drop_run<8>(a.drop, e0, o);   // thresh 0: everything kept, scale 1
 #pragma unroll
           for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
           *(u32x4*)(a.dx2 + row * a.lddx2 + col) = w;
@@ -510,8 +508,7 @@ __global__ __launch_bounds__(256) void embed_layernorm_bwd(EmbBwdArgs a) {
         for (int i = 0; i < 4; ++i) { gv[c][2 * i] = bf16lo(d[i]); gv[c][2 * i + 1] = bf16hi(d[i]); }
         if (a.drop.thresh) {
           const uint32_t e0 = (uint32_t)tok * (uint32_t)a.H + (uint32_t)col;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) gv[c][i] = vt_keep(a.drop, e0 + i) ? gv[c][i] * a.drop.scale : 0.f;
+          vt_drop_run<8>(a.drop, e0, gv[c]);
         }
       } else {
 #pragma unroll
@@ -794,8 +791,7 @@ __global__ __launch_bounds__(256) void apply_dropout_bf16(bf16_t* __restrict__ x
   float v[8];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { v[2 * k] = bf16lo(w[k]); v[2 * k + 1] = bf16hi(w[k]); }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = vt_keep(d, e0 + k) ? v[k] * d.scale : 0.f;
+  vt_drop_run<8>(d, e0, v);
 #pragma unroll
   for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
   *(u32x4*)(x + row * ld + col) = w;
