@@ -132,6 +132,11 @@ GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16)
 def set_gemm_variant(v):
     """Tuning/test hook: force one GEMM kernel variant (-1: shape table / heuristic)."""
     _lib.load().vt_debug_set_gemm_variant(int(v))
+# The persistent kernel (16) launches one workgroup per CU and needs every CU to itself (512 registers per wave, 132 KiB
+# of LDS): a collective running beside it on a few CUs makes the workgroups mapped to those CUs wait for a whole kernel
+# time.  Data-parallel training (gradient all-reduce overlapped with the backward) therefore tunes without it; the
+# one-tile-per-workgroup form of the same kernel (15) is within 3-5 % and simply queues its tiles.
+PERSISTENT_GEMM_OK = True
 _tuned = {}
 
 
@@ -151,6 +156,8 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
     pre = torch.empty((M, N), dtype=BF16, device=device) if pre_act else None
     best, best_t = GEMM_CANDIDATES[0], float("inf")
     for v in GEMM_CANDIDATES:
+        if v == 16 and not PERSISTENT_GEMM_OK:
+            continue
         lib.vt_debug_set_gemm_variant(v)
         try:
             for _ in range(2):

@@ -267,6 +267,8 @@ class PretrainEngine(object):
                 self._bufs.clear()
             b = _TrainBuffers(cfg.num_hidden_layers, B * S, B, S, cfg.hidden_size, cfg.intermediate_size,
                               cfg.num_attention_heads, self.flat.p.device)
+            if self.world > 1:
+                ops.PERSISTENT_GEMM_OK = False   # collectives share the CUs with the backward (see ops.py)
             ops.autotune_encoder_shapes(B * S, cfg.hidden_size, cfg.intermediate_size, training=True,
                                         device=self.flat.p.device)
             self._bufs[key] = b
