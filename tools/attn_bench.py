@@ -1,0 +1,39 @@
+"""Stand-alone timing of the fused attention kernels at the bench shape (B x 12 heads x S, head size 64)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from visitron_amd import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 228
+p = float(sys.argv[3]) if len(sys.argv) > 3 else 0.1
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+nh, dev = 12, "cuda:0"
+H = nh * 64
+qkv = (torch.randn(B * S, 3 * H, device=dev) * 0.8).to(torch.bfloat16)
+dctx = torch.randn(B * S, H, device=dev).to(torch.bfloat16)
+mask = torch.ones(B, S, device=dev)
+lse = torch.zeros(B, nh, S, device=dev)
+drop = (p, 1234, 0) if p > 0 else ops.NO_DROP
+delta = torch.empty(B, nh, S, device=dev)
+out = torch.empty(B * S, 3 * H, device=dev, dtype=torch.bfloat16)
+ctx = ops.attention_fwd(qkv, B, S, nh, mask=mask, lse=lse, drop=drop)
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+tf = timeit(lambda: ops.attention_fwd(qkv, B, S, nh, mask=mask, lse=lse, drop=drop))
+tb = timeit(lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=mask, out=out, delta_ws=delta, drop=drop))
+fl = 4.0 * B * nh * S * S * 64
+print("B=%d S=%d p=%.2f: fwd %.1f us (%.0f TF/s)  bwd %.1f us (%.0f TF/s)" % (B, S, p, tf, fl / tf * 1e-6, tb, 2.5 * fl / tb * 1e-6))
