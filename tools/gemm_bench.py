@@ -14,7 +14,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seq", type=int, default=228)
-    ap.add_argument("--variants", default="0,1,2,3,4")
+    ap.add_argument("--variants", default="1,14,9,10,11,15,16")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=20)
     a = ap.parse_args()

@@ -23,107 +23,9 @@
 //     bias / GELU / residual are applied in registers, no LDS round trip;
 //   * block ids are remapped so that the tiles sharing an activation row-panel run on one XCD
 //     (one L2).
+// This file holds the 2-waves-per-SIMD kernels (v2, v4, v5, v6 below) and the dispatcher / shape table; the
+// one-wave-per-SIMD 256x256 kernels with AGPR accumulators are in gemm_v7.hip (variants 15, 16) and gemm_v9.hip (17).
 #include "gemm_common.hpp"
-
-template <int ACT, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_128x128(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware bijective remap: blocks b and b+8 share an XCD; give each XCD a contiguous tile range.
-  const int nwg = gridDim.x;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  const int bm = t_id / g.tiles_n, bn = t_id - bm * g.tiles_n;
-  const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
-
-  // ---- per-lane DMA source pointers (4 pieces of A, 4 of W per K-step) ----
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = (wave * 4 + i) * 64 + lane;  // 16-B chunk index inside the 128x64 tile
-    const int row = p >> 3;
-    const int c = (p & 7) ^ ((row >> 1) & 7);  // logical chunk stored at this LDS slot
-    int am = m0 + row;
-    am = am < g.M ? am : g.M - 1;
-    a_src[i] = g.A + (long)am * g.lda + c * 8;
-    // LDS row -> output column permutation (see header): lane ends up with 16 consecutive columns
-    int wnrow = n0 + (row & 64) + 16 * ((row >> 2) & 3) + 4 * ((row >> 4) & 3) + (row & 3);
-    wnrow = wnrow < g.N ? wnrow : g.N - 1;
-    w_src[i] = g.W + (long)wnrow * g.ldw + c * 8;
-  }
-
-  // ---- per-lane fragment read offsets (bytes inside a tile), k-substep 0; substep 1 = ^64 ----
-  int x_off[4], w_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int xr = 64 * wm + 16 * i + (lane & 15);
-    x_off[i] = xr * 128 + (((lane >> 4) ^ ((xr >> 1) & 7)) << 4);
-    const int wr = 64 * wn + 16 * i + (lane & 15);
-    w_off[i] = wr * 128 + (((lane >> 4) ^ ((wr >> 1) & 7)) << 4);
-  }
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = g.K / GEMM_BK;
-
-  // prologue: tile 0 -> buffer 0
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    glds16(a_src[i], smem + (wave * 4 + i) * 1024);
-    glds16(w_src[i], smem + GEMM_TILE_BYTES + (wave * 4 + i) * 1024);
-  }
-
-  for (int kt = 0; kt < nk; ++kt) {
-    // my pieces of tile kt have landed; after the barrier everybody's have, and everybody has
-    // finished reading the other buffer (its fragments were consumed by the previous MFMAs).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    char* sX = smem + (kt & 1) * (2 * GEMM_TILE_BYTES);
-    char* sW = sX + GEMM_TILE_BYTES;
-
-    bf16x8 xf[2][4], wf[2][4];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        wf[ks][i] = *(const bf16x8*)(sW + (w_off[i] ^ (ks * 64)));
-        xf[ks][i] = *(const bf16x8*)(sX + (x_off[i] ^ (ks * 64)));
-      }
-    }
-
-    if (kt + 1 < nk) {  // DMA of the next tile into the other buffer, in flight during the MFMAs
-      char* nX = smem + ((kt + 1) & 1) * (2 * GEMM_TILE_BYTES);
-      const int koff = (kt + 1) * GEMM_BK;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        glds16(a_src[i] + koff, nX + (wave * 4 + i) * 1024);
-        glds16(w_src[i] + koff, nX + GEMM_TILE_BYTES + (wave * 4 + i) * 1024);
-      }
-    }
-
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][t], xf[ks][mt], acc[mt][t], 0, 0, 0);
-  }
-
-  gemm_epilogue<ACT, OUT_F32>(g, acc, lane, m0 + 64 * wm, n0 + 64 * wn);
-}
 
 // ================================================================================================
 // v2: the same tile / fragment / epilogue design with
@@ -146,7 +48,7 @@ __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
   return v;
 }
 
-template <int BK, int NSTAGE, int ACT, bool OUT_F32, int DBG = 0>
+template <int BK, int NSTAGE, int ACT, bool OUT_F32>
 __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_nt_bf16_v2(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CH = BK / 8;             // 16-B chunks per tile row
@@ -240,7 +142,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_nt_bf16_v2(GemmA
       xf[0][i] = lds_read_b128(x_off[i] + so);
     }
 
-    if (DBG != 1 && kt + NSTAGE - 1 < nk) {
+    if (kt + NSTAGE - 1 < nk) {
       char* nX = smem + pslot * STAGE;
       const int koff = (kt + NSTAGE - 1) * BK;
 #pragma unroll
@@ -261,14 +163,6 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_nt_bf16_v2(GemmA
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG == 2) {  // timing experiment: keep the loads alive, skip the matrix work
-#pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wf[0][i]), "v"(xf[0][i]), "v"(wf[KS - 1][i]), "v"(xf[KS - 1][i]));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
-      pslot = (pslot + 1 == NSTAGE) ? 0 : pslot + 1;
-      continue;
-    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -287,139 +181,6 @@ __global__ __launch_bounds__(256, (BK == 32 ? 3 : 2)) void gemm_nt_bf16_v2(GemmA
     }
     slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
     pslot = (pslot + 1 == NSTAGE) ? 0 : pslot + 1;
-  }
-
-  gemm_epilogue<ACT, OUT_F32>(g, acc, lane, m0 + 64 * wm, n0 + 64 * wn);
-}
-
-// ================================================================================================
-// v3: register-level software pipelining.  Fragments of tile k+1 are read from LDS while the MFMAs of
-// tile k (already in registers) run, and the DMA of tile k+2 is issued right after those reads into
-// the buffer tile k just vacated: two LDS buffers, ONE barrier per K-step, no LDS read ever waits in
-// front of an MFMA of the same step, and no LDS-DMA is outstanding when hipcc sees an LDS read (so
-// plain loads are safe and the scheduler may interleave them with the MFMAs).
-template <int BK, int ACT, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_v3(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CH = BK / 8;
-  constexpr int ROWB = BK * 2;
-  constexpr int TILE = 128 * ROWB;
-  constexpr int STAGE = 2 * TILE;
-  constexpr int NP = BK / 16;
-  constexpr int KS = BK / 32;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int nwg = gridDim.x;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  const int band_tiles = 8 * g.tiles_n;
-  const int band = t_id / band_tiles;
-  const int within = t_id - band * band_tiles;
-  const int rows_left = g.tiles_m - band * 8;
-  const int band_h = rows_left < 8 ? rows_left : 8;
-  const int bn = within / band_h;
-  const int bm = band * 8 + (within - bn * band_h);
-  const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
-
-  const bf16_t* a_src[NP];
-  const bf16_t* w_src[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int p = (wave * NP + i) * 64 + lane;
-    const int row = p / CH;
-    const int c = (p % CH) ^ swz<BK>(row);
-    int am = m0 + row;
-    am = am < g.M ? am : g.M - 1;
-    a_src[i] = g.A + (long)am * g.lda + c * 8;
-    int wnrow = n0 + (row & 64) + 16 * ((row >> 2) & 3) + 4 * ((row >> 4) & 3) + (row & 3);
-    wnrow = wnrow < g.N ? wnrow : g.N - 1;
-    w_src[i] = g.W + (long)wnrow * g.ldw + c * 8;
-  }
-  int x_off[4], w_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int xr = 64 * wm + 16 * i + (lane & 15);
-    x_off[i] = xr * ROWB + (((lane >> 4) ^ swz<BK>(xr)) << 4);
-    const int wr = 64 * wn + 16 * i + (lane & 15);
-    w_off[i] = TILE + wr * ROWB + (((lane >> 4) ^ swz<BK>(wr)) << 4);
-  }
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = g.K / BK;
-  auto stage = [&](int kt, int buf) {
-    char* d = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      glds16(a_src[i] + kt * BK, d + (wave * NP + i) * 1024);
-      glds16(w_src[i] + kt * BK, d + TILE + (wave * NP + i) * 1024);
-    }
-  };
-
-  bf16x8 xa[KS][4], wa[KS][4];   // fragment set A
-  bf16x8 xb[KS][4], wb[KS][4];   // fragment set B (the loop is unrolled by two so the sets swap roles
-                                 // without register copies)
-
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      wa[ks][i] = *(const bf16x8*)(smem + (w_off[i] ^ (ks * 64)));
-      xa[ks][i] = *(const bf16x8*)(smem + (x_off[i] ^ (ks * 64)));
-    }
-  if (nk > 1) stage(1, 1);
-  // retire the prologue reads before the loop header: otherwise hipcc's wait-count merge at the loop
-  // entry keeps an lgkmcnt(0) in front of every step's MFMAs
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wa[ks][i]), "v"(xa[ks][i]));
-
-  // one K-step: multiply the `cur` fragments (tile kt) while the `nxt` fragments (tile kt+1) are read
-  auto kstep = [&](int kt, bf16x8 (&xc)[KS][4], bf16x8 (&wc)[KS][4], bf16x8 (&xn)[KS][4], bf16x8 (&wn_)[KS][4]) {
-    if (kt + 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt+1 landed (its DMA was issued one step ago)
-      __builtin_amdgcn_s_barrier();                      // ... for every wave; and tile kt's buffer is free
-      // pin the (long finished) reads of the current set here, so that the only LDS wait of the step sits
-      // BEFORE the new reads are issued and never between them and the MFMAs
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wc[ks][i]), "v"(xc[ks][i]));
-      const char* sb = smem + ((kt + 1) & 1) * STAGE;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          wn_[ks][i] = *(const bf16x8*)(sb + (w_off[i] ^ (ks * 64)));
-          xn[ks][i] = *(const bf16x8*)(sb + (x_off[i] ^ (ks * 64)));
-        }
-      if (kt + 2 < nk) stage(kt + 2, kt & 1);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ks][t], xc[ks][mt], acc[mt][t], 0, 0, 0);
-  };
-
-  for (int kt = 0; kt < nk; kt += 2) {
-    kstep(kt, xa, wa, xb, wb);
-    if (kt + 1 < nk) kstep(kt + 1, xb, wb, xa, wa);
   }
 
   gemm_epilogue<ACT, OUT_F32>(g, acc, lane, m0 + 64 * wm, n0 + 64 * wn);
@@ -669,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v4(GemmArgs g) {
 // arithmetic is uniform.
 #define V5_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF))
 
-template <int ACT, bool OUT_F32, int DBG = 0>
+template <int ACT, bool OUT_F32>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256, BN = 256, BK = 32, STAGE = 32768, XT = 16384;
@@ -749,23 +510,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5(GemmArgs g) {
       const unsigned aa = a_addr0 + so;
       V5_DSR(A1[0], aa, 4096); V5_DSR(A1[1], aa, 5120); V5_DSR(A1[2], aa, 6144); V5_DSR(A1[3], aa, 7168);
     }
-    if (DBG != 1) dma_x(kt + 3, (kt + 3) & 3);
+    dma_x(kt + 3, (kt + 3) & 3);
     asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG != 2) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Wc[t]),
                                                              __builtin_bit_cast(bf16x8, A0[mt]), acc[mt][t], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(Wc[i]), "v"(A0[i]), "v"(A1[i]));
-    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 1 ----
-    if (DBG != 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + 1 < nk) {
@@ -776,9 +532,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5(GemmArgs g) {
     } else {
       // keep the LDS-op count of the step uniform for the next (non-existent) lgkmcnt(4): nothing to do
     }
-    if (DBG != 1) dma_w(kt + 3, (kt + 3) & 3);
+    dma_w(kt + 3, (kt + 3) & 3);
     __builtin_amdgcn_sched_barrier(0);
-    if (DBG != 2)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -932,10 +687,10 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_bf16_v6(GemmArgs g) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
-// variant: 0 = v1 (BK64, 2 buffers, row-major tiles); 1 = v2 BK64 x 2 stages; 2 = v2 BK64 x 3 stages;
-//          3 = v2 BK32 x 3 stages (3 workgroups / CU); 4 = v2 BK32 x 4 stages;
-//          5 = v3 BK64 (register-pipelined fragments); 6 = v3 BK32; 9 = v4 256x192; 10 = v4 256x256; 11 = v5 256x256 BK32 4-stage phased; 14 = v6 128x128 with 8 waves of 32x64;
-//          7, 8 = timing experiments (no DMA / no MFMA in the loop; wrong results).
+// variant: 1 = 128x128 tile, 4 waves, BK 64, 2-stage ring (v2); 14 = the same tile with 8 waves of 32x64 (v6);
+//          9 / 10 = 256x192 / 256x256 tile, 8 waves (v4); 11 = 256x256, BK 32, 4-stage ring, phased (v5);
+//          15 / 16 = 256x256 tile, 4 waves of 128x128 with AGPR accumulators, one tile per workgroup / persistent
+//          (gemm_v7.hip); 17 = the persistent kernel on 32x32x16 MFMAs (gemm_v9.hip).
 int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip
 int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip (persistent)
 int vt_gemm_v9_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v9.hip (persistent, 32x32x16 MFMAs)
@@ -991,13 +746,7 @@ static int launch_kernel(K kern, const GemmArgs& g, int lds_bytes, hipStream_t s
 template <int ACT, bool OUT_F32>
 static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
   switch (variant) {
-    case 0: return launch_kernel(gemm_nt_bf16_128x128<ACT, OUT_F32>, g, GEMM_LDS_BYTES, stream);
     case 1: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32>, g, 2 * 32768, stream);
-    case 2: return launch_kernel(gemm_nt_bf16_v2<64, 3, ACT, OUT_F32>, g, 3 * 32768, stream);
-    case 3: return launch_kernel(gemm_nt_bf16_v2<32, 3, ACT, OUT_F32>, g, 3 * 16384, stream);
-    case 4: return launch_kernel(gemm_nt_bf16_v2<32, 4, ACT, OUT_F32>, g, 4 * 16384, stream);
-    case 5: return launch_kernel(gemm_nt_bf16_v3<64, ACT, OUT_F32>, g, 2 * 32768, stream);
-    case 6: return launch_kernel(gemm_nt_bf16_v3<32, ACT, OUT_F32>, g, 2 * 16384, stream);
     case 9: return launch_kernel_v4(gemm_nt_bf16_v4<192, ACT, OUT_F32>, g, 192, stream);
     case 10: return launch_kernel_v4(gemm_nt_bf16_v4<256, ACT, OUT_F32>, g, 256, stream);
     case 11: {
@@ -1014,26 +763,9 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
       hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), 2 * 32768, stream, g);
       return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
     }
-    case 12: case 13: {
-      GemmArgs g5 = g;
-      g5.tiles_m = (g.M + 255) / 256;
-      g5.tiles_n = (g.N + 255) / 256;
-      if (variant == 12) {
-        auto kern = gemm_nt_bf16_v5<ACT, OUT_F32, 1>;
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-        hipLaunchKernelGGL(kern, dim3(g5.tiles_m * g5.tiles_n), dim3(512), 4 * 32768, stream, g5);
-      } else {
-        auto kern = gemm_nt_bf16_v5<ACT, OUT_F32, 2>;
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-        hipLaunchKernelGGL(kern, dim3(g5.tiles_m * g5.tiles_n), dim3(512), 4 * 32768, stream, g5);
-      }
-      return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
-    }
     case 15: return vt_gemm_v7_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
     case 16: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
     case 17: return vt_gemm_v9_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
-    case 7: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32, 1>, g, 2 * 32768, stream);  // timing experiment: no DMA in the loop
-    case 8: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32, 2>, g, 2 * 32768, stream);  // timing experiment: no MFMA
     default: return VT_ERR_UNSUPPORTED;
   }
 }
