@@ -315,3 +315,29 @@ def test_dropout_chunked_backward_uses_the_layers_own_masks(dev):
     eng.forward_backward(b, comm=dict(layers_per_chunk=1, launch=lambda r: None, done=done))
     torch.cuda.synchronize()
     assert maxabs(eng.flat.g, g_one) < 1e-3 * float(g_one.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("p_h", [0.0, 0.2])
+def test_img_layernorm_training_matches_oracle(dev, p_h):
+    """use_img_layernorm (encoder.py:173-185, 280-284): LayerNorm on the summed image embedding, then dropout; losses
+    and every gradient (incl. bert.LayerNorm.*) against the oracle on the same weights / masks."""
+    from helpers import inject_dropout_masks
+    from visitron_amd.synth import make_batch
+
+    cfg = _dropout_cfg(p_h, 0.0)
+    cfg.use_img_layernorm, cfg.img_layer_norm_eps = 1, 1e-12
+    ref, prod, eng = _engine_pair(cfg, 9, dev)
+    assert "bert.LayerNorm.weight" in dict(prod.named_parameters())
+    B, T, R = 3, 20, 17
+    b = make_batch(cfg, B, text_len=T, region_len=R, seed=31)
+    got = eng.forward_backward({k: v.to(dev) for k, v in b.items()})
+    torch.cuda.synchronize()
+    ref.train()
+    inject_dropout_masks(ref, p_h, 0.0, eng.last_drop_seed, B, T, R, device=dev)
+    want = ref(**b)
+    want[0].backward()
+    for i in range(4):
+        assert abs(float(got[i]) - float(want[i])) < 5e-2, (i, float(got[i]), float(want[i]))
+    wg = dict(ref.named_parameters())
+    bad = {n: _rel(p.grad, wg[n].grad) for n, p in prod.named_parameters() if _rel(p.grad, wg[n].grad) > 0.08}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]

@@ -135,8 +135,6 @@ class PretrainEngine(object):
         cfg = model.config
         if cfg.hidden_size != 64 * cfg.num_attention_heads:
             raise NotImplementedError("the HIP training path serves head size 64")
-        if getattr(model.bert, "use_img_layernorm", None):
-            raise NotImplementedError("use_img_layernorm is not implemented in the HIP training path yet")
         for p_ in (cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob):
             if not 0.0 <= p_ < 1.0:
                 raise ValueError("dropout probability must be in [0, 1)")
@@ -331,8 +329,19 @@ class PretrainEngine(object):
         if img is not None:
             a_img = ops.pack_concat(img.reshape(B * R, -1).float().contiguous(),
                                     batch["img_location_embeddings"].reshape(B * R, -1).float().contiguous(), self.kpad)
-            ops.linear(a_img, self.w_img, self.b_img, out=x0[T:], ldc=H, grp_rows=R, grp_stride=S,
-                       drop=(p_h, seed, ops.SITE_IMG))
+            if getattr(m.bert, "use_img_layernorm", None):
+                # encoder.py:280-284: LayerNorm on the summed image embedding, THEN dropout; the pre-LayerNorm rows are
+                # kept (compact [B*R, H]) for the backward pass
+                ln = m.bert.LayerNorm
+                img_pre = ops.linear(a_img, self.w_img, self.b_img)
+                img_ln = ops.layernorm(img_pre, ln.weight.detach(), ln.bias.detach(), ln.variance_epsilon)
+                if p_h > 0.0:
+                    ops.apply_dropout(img_ln, (p_h, seed, ops.SITE_IMG))
+                x0.view(B, S, H)[:, T:].copy_(img_ln.view(B, R, H))
+            else:
+                img_pre = None
+                ops.linear(a_img, self.w_img, self.b_img, out=x0[T:], ldc=H, grp_rows=R, grp_stride=S,
+                           drop=(p_h, seed, ops.SITE_IMG))
         if ops.profiling():
             self._encoder_forward_unrolled(bufs, x0, mask, B, S, p_h, p_a, seed)
         else:
@@ -495,6 +504,11 @@ class PretrainEngine(object):
             g_img = g.view(B, S, H)[:, T:].reshape(B * R, H)
             if p_h > 0.0:
                 ops.apply_dropout(g_img, (p_h, seed, ops.SITE_IMG))   # g is not read again after this point
+            if img_pre is not None:   # back through the image LayerNorm
+                ln = m.bert.LayerNorm
+                g_img = ops.layernorm_bwd(img_pre, g_img.contiguous(), ln.weight.detach(), ln.variance_epsilon,
+                                          self._grad(ln.weight), self._grad(ln.bias), ws=bufs.ws_t["ln_partial"],
+                                          accumulate=acc)
             ops.wgrad([dict(dy=g_img, x=a_img, dw=self.dw_img, db=self.db_img)], B * R)
             D = m.bert.img_dim
             gi, gl = self._grad(m.bert.img_embedding.weight), self._grad(m.bert.location_embeds.weight)
