@@ -98,6 +98,13 @@ int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, in
                           int nh, int head_size, float drop_p, uint64_t drop_seed, uint32_t drop_site,
                           vt_stream_t stream);
 
+/* The attention probabilities the reference returns under config.output_attentions (oscar/modeling_bert.py:58-66,
+ * 74-79; eval mode): probs[b,h,q,k] = exp(q.k/8 + bias[k] - lse[b,h,q]) [* head_scale[h]], fp32 [B,nh,S,S], from qkv
+ * and the lse written by vt_attention_fwd_bf16 (same mask arguments). */
+int vt_attention_probs_f32(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive,
+                           const float* head_scale, const float* lse, float* probs, int B, int S, int nh,
+                           int head_size, vt_stream_t stream);
+
 /* Backward of vt_attention_fwd_bf16: dqkv = dq | dk | dv packed like qkv.  ctx is the forward output,
  * lse its saved log-sum-exp, delta_ws a [B,nh,S] fp32 scratch (rowsum(dctx*ctx) is computed into it).
  * Autograd of oscar/modeling_bert.py:47-72 inside loss.backward() (tasks/viewpoint_select/

@@ -163,3 +163,40 @@ def test_base_config_cfg1_matches_oracle(dev):
     assert float(rel) < TOL_BF16
     for i in range(4):
         assert abs(float(got[i]) - float(want[i])) < TOL_BF16 * max(1.0, abs(float(want[i])))
+
+
+def test_output_attentions_matches_oracle(dev):
+    """config.output_attentions (oscar/modeling_bert.py:74-79, 157-168; encoder.py:299-303): the per-layer attention
+    probabilities [B, heads, S, S] behind the hidden states in the encoder / trunk outputs, and as the second output of
+    the attention sub-modules (with head_mask applied)."""
+    from oracle.modeling import BertImgModelwithLocationEmbeds as OTrunk
+    from oracle.modeling import CaptionBertLayer as OLayer
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds, CaptionBertLayer
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config(output_attentions=True, output_hidden_states=True)
+    ref, prod = model_pair(OTrunk, BertImgModelwithLocationEmbeds, cfg, seed=6, device=dev)
+    b = make_batch(cfg, 3, text_len=21, region_len=13, seed=9, with_labels=False)
+    with torch.no_grad():
+        want = ref(**b)
+        got = prod(**_to(b, dev))
+    assert len(got) == len(want) == 4 and len(got[3]) == len(want[3]) == cfg.num_hidden_layers
+    assert maxabs(got[0], want[0]) < TOL_BF16
+    for pg, pw in zip(got[3], want[3]):
+        assert pg.shape == pw.shape == (3, cfg.num_attention_heads, 34, 34)
+        assert maxabs(pg, pw) < 2e-2                      # probabilities are <= 1
+        assert maxabs(pg.sum(-1), torch.ones(3, cfg.num_attention_heads, 34)) < 1e-2
+    # sub-module call with a head mask
+    refl, prodl = model_pair(OLayer, CaptionBertLayer, cfg, seed=7, device=dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 19, cfg.hidden_size, generator=g)
+    ext = torch.zeros(2, 1, 1, 19)
+    ext[1, 0, 0, 10:] = -10000.0
+    hm = torch.tensor([1.0, 0.5]).view(1, 2, 1, 1)
+    with torch.no_grad():
+        w = refl.attention.self(x, ext, hm)
+        o = prodl.attention.self(x.to(dev), ext.to(dev), hm.to(dev))
+        wl, ol = refl(x, ext), prodl(x.to(dev), ext.to(dev))
+    assert len(o) == len(w) == 2 and maxabs(o[1], w[1]) < 2e-2 and maxabs(o[0], w[0]) < TOL_BF16
+    assert len(ol) == len(wl) == 2 and maxabs(ol[1], wl[1]) < 2e-2

@@ -60,6 +60,8 @@ SIGNATURES = {
                                   c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int] + DROP + [c_void_p]),
     "vt_apply_dropout_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int] + DROP + [c_void_p]),
     "vt_debug_dropout_mask": (c_int, [c_void_p, c_int64] + DROP + [c_int, c_void_p]),
+    "vt_attention_probs_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_int, c_void_p]),
     "vt_attention_bwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int]
                               + DROP + [c_void_p]),

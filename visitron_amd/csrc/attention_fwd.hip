@@ -237,3 +237,55 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   hipLaunchKernelGGL(attention_fwd_d64, grid, dim3(512), ATT_LDS_BYTES, stream, a);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
+
+
+// ---- attention probabilities for `output_attentions` (oscar/modeling_bert.py:58-66, 74-79) ------------------------
+// probs[b,h,q,k] = exp(q.k / 8 + bias[k] - lse[b,h,q]) [* head_scale[h]] in fp32, from the packed projection output and
+// the log-sum-exp the fused forward kernel saved; eval mode (no dropout).  A diagnostic output: one workgroup per
+// (query, head, batch), plain VALU dot products, the row written contiguously.
+__global__ __launch_bounds__(256) void attention_probs_d64(AttnArgs a, float* __restrict__ probs) {
+  __shared__ float qs[64];
+  const int q = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int S = a.S, H = a.nh * 64;
+  const bf16_t* base = a.qkv + (long)b * S * a.ld_qkv + head * 64;
+  if (threadIdx.x < 64) qs[threadIdx.x] = bf16_to_f32(base[(long)q * a.ld_qkv + threadIdx.x]);
+  __syncthreads();
+  const float lse = a.lse[((long)b * a.nh + head) * S + q];
+  const float hs = a.head_scale ? a.head_scale[head] : 1.0f;
+  float* out = probs + (((long)b * a.nh + head) * S + q) * S;
+  for (int key = threadIdx.x; key < S; key += 256) {
+    const u32x4* kp = (const u32x4*)(base + (long)key * a.ld_qkv + H);
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const u32x4 w = kp[c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dot = fmaf(qs[8 * c + 2 * i], bf16lo(w[i]), dot);
+        dot = fmaf(qs[8 * c + 2 * i + 1], bf16hi(w[i]), dot);
+      }
+    }
+    float add = 0.f;
+    if (a.mask) {
+      const float mval = a.mask[(long)b * S + key];
+      add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
+    }
+    out[key] = __expf(fmaf(dot, a.scale, add) - lse) * hs;
+  }
+}
+
+int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale,
+                                const float* lse, float* probs, int B, int S, int nh, int head_size, hipStream_t stream) {
+  if (!qkv || !lse || !probs) return VT_ERR_NULL;
+  if (head_size != 64) return VT_ERR_UNSUPPORTED;
+  if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
+  if ((ld_qkv % 8) || ld_qkv < 3L * nh * 64 || ((uintptr_t)qkv & 15)) return VT_ERR_BAD_ALIGN;
+  AttnArgs a;
+  a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = nullptr;
+  a.lse = const_cast<float*>(lse);
+  a.ld_qkv = ld_qkv; a.ld_ctx = 0; a.B = B; a.S = S; a.nh = nh;
+  a.scale = 1.0f / sqrtf((float)head_size);
+  a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f;
+  hipLaunchKernelGGL(attention_probs_d64, dim3(S, nh, B), dim3(256), 0, stream, a, probs);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

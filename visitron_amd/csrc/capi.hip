@@ -26,6 +26,8 @@ int vt_ce_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* lo
 int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, int C, hipStream_t stream);
 int vt_adamw_dispatch(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float step_size, float b1,
                       float b2, float eps, float wd, float grad_scale, hipStream_t stream);
+int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale,
+                                const float* lse, float* probs, int B, int S, int nh, int head_size, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                               long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream,
                               const DropCfg* drop = nullptr);
@@ -154,6 +156,12 @@ int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, in
   const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_attention_fwd_dispatch(qkv, ld_qkv, mask, mask_additive, head_scale, ctx, ld_ctx, lse, B, S, nh, head_size,
                                    (hipStream_t)stream, &d);
+}
+
+int vt_attention_probs_f32(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive, const float* head_scale,
+                           const float* lse, float* probs, int B, int S, int nh, int head_size, vt_stream_t stream) {
+  return vt_attention_probs_dispatch(qkv, ld_qkv, mask, mask_additive, head_scale, lse, probs, B, S, nh, head_size,
+                                     (hipStream_t)stream);
 }
 
 int vt_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,

@@ -368,17 +368,22 @@ class CaptionBertSelfAttention(nn.Module):
             raise NotImplementedError("the fused attention kernel serves head size 64")
         if history_state is not None:
             raise NotImplementedError("history_state is not implemented in the HIP path yet")
-        if self.output_attentions:
-            raise NotImplementedError("output_attentions is not implemented in the HIP path yet")
         _no_train_dropout(self, self.dropout.p)
         B, S, H = hidden_states.shape
         w, b = self.packed_qkv()
         qkv = ops.linear(_as_bf16_2d(hidden_states), w, b)
         mask = _additive_mask_2d(attention_mask, B, S) if attention_mask is not None else None
         hs = _head_scale([head_mask], 1, self.num_attention_heads, hidden_states.device)
-        ctx = ops.attention_fwd(qkv, B, S, self.num_attention_heads, mask=mask, mask_additive=True,
-                                head_scale=None if hs is None else hs[0].contiguous())
-        return (ctx.view(B, S, H).to(hidden_states.dtype),)
+        hs0 = None if hs is None else hs[0].contiguous()
+        lse = None
+        if self.output_attentions:
+            lse = torch.empty((B, self.num_attention_heads, S), dtype=torch.float32, device=hidden_states.device)
+        ctx = ops.attention_fwd(qkv, B, S, self.num_attention_heads, mask=mask, mask_additive=True, head_scale=hs0, lse=lse)
+        outputs = (ctx.view(B, S, H).to(hidden_states.dtype),)
+        if self.output_attentions:   # :74-79: the probabilities after dropout (identity in eval) and head_mask
+            probs = ops.attention_probs(qkv, lse, B, S, self.num_attention_heads, mask=mask, mask_additive=True, head_scale=hs0)
+            outputs = outputs + (probs.to(hidden_states.dtype),)
+        return outputs
 
 
 class CaptionBertAttention(nn.Module):
@@ -484,28 +489,38 @@ class CaptionBertEncoder(nn.Module):
         """x_bf16 [B*S,H] -> list of per-layer outputs (len L if output_hidden_states else 1 shared)."""
         if self._hidden != self._heads * 64:
             raise NotImplementedError("the fused encoder serves head size 64 (hidden = 64 * heads)")
-        if self.output_attentions:
-            raise NotImplementedError("output_attentions is not implemented in the HIP path yet")
         for layer in self.layer:
             _no_train_dropout(layer, layer.attention.self.dropout.p)
             _no_train_dropout(layer, layer.output.dropout.p)
         pk = self.packed()
         ws = self._workspace(B * S, B, x_bf16.device, self.output_hidden_states)
+        self._last_attentions = None
+        if self.output_attentions:   # per-layer probabilities need each layer's qkv: the op-by-op launch sequence
+            probs = []
+            outs = self._run_unrolled(pk, ws, x_bf16, B, S, mask_f32, mask_additive, head_scale, probs)
+            self._last_attentions = probs
+            return outs
         if ops.profiling():  # bench.py's per-kernel timing: the same launches, issued one by one
             return self._run_unrolled(pk, ws, x_bf16, B, S, mask_f32, mask_additive, head_scale)
         ops.encoder_forward(pk.table, ws["table"], x_bf16, mask_f32, mask_additive, head_scale, B, S,
                             self._hidden, self._heads, self._inter, self._eps)
         return ws["outs"]
 
-    def _run_unrolled(self, pk, ws, x, B, S, mask, mask_additive, head_scale):
-        """The launch sequence of vt_encoder_forward_bf16 issued op by op (same kernels, same buffers)."""
+    def _run_unrolled(self, pk, ws, x, B, S, mask, mask_additive, head_scale, probs=None):
+        """The launch sequence of vt_encoder_forward_bf16 issued op by op (same kernels, same buffers); with `probs` (a
+        list) also each layer's attention probabilities (output_attentions)."""
         sh, nh, eps = ws["shared"], self._heads, self._eps
         cur = x
+        lse = torch.empty((B, nh, S), dtype=torch.float32, device=x.device) if probs is not None else None
         for i, t in enumerate(pk.tensors):
             out = ws["outs"][i]
+            hs_i = None if head_scale is None else head_scale[i].contiguous()
             ops.linear(cur, t["w_qkv"], t["b_qkv"], out=sh["qkv"])
-            ops.attention_fwd(sh["qkv"], B, S, nh, mask=mask, mask_additive=mask_additive,
-                              head_scale=None if head_scale is None else head_scale[i].contiguous(), out=sh["ctx"])
+            ops.attention_fwd(sh["qkv"], B, S, nh, mask=mask, mask_additive=mask_additive, head_scale=hs_i, out=sh["ctx"],
+                              lse=lse)
+            if probs is not None:
+                probs.append(ops.attention_probs(sh["qkv"], lse, B, S, nh, mask=mask, mask_additive=mask_additive,
+                                                 head_scale=hs_i))
             ops.linear(sh["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=sh["attn_pre"])
             ops.layernorm(sh["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=sh["attn_out"])
             ops.linear(sh["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=sh["mid"])
@@ -528,6 +543,8 @@ class CaptionBertEncoder(nn.Module):
         outputs = (last,)
         if self.output_hidden_states:
             outputs = outputs + ((hidden_states,) + tuple(o.view(B, S, H).to(dt) for o in outs[:-1]) + (last,),)
+        if self.output_attentions:
+            outputs = outputs + (tuple(p.to(dt) for p in self._last_attentions),)
         return outputs
 
 
@@ -650,6 +667,8 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
         if self.encoder.output_hidden_states:
             hidden = (x.view(B, S, H).to(dt),) + tuple(o.view(B, S, H).to(dt) for o in outs[:-1]) + (sequence_output,)
             outputs = outputs + (hidden,)
+        if self.encoder.output_attentions:
+            outputs = outputs + (tuple(p.to(dt) for p in self.encoder._last_attentions),)
         return outputs
 
 

@@ -212,6 +212,17 @@ def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None
     return out
 
 
+def attention_probs(qkv, lse, B, S, nh, mask=None, mask_additive=False, head_scale=None):
+    """fp32 [B, nh, S, S] attention probabilities (config.output_attentions) from qkv and attention_fwd's lse."""
+    _require_hip(qkv, lse, mask, head_scale)
+    assert qkv.dtype == BF16 and lse.dtype == torch.float32 and lse.numel() == B * nh * S
+    probs = torch.empty((B, nh, S, S), dtype=torch.float32, device=qkv.device)
+    rc = _lib.load().vt_attention_probs_f32(_ptr(qkv), qkv.stride(0), _ptr(mask), 1 if mask_additive else 0,
+                                            _ptr(head_scale), _ptr(lse), _ptr(probs), B, S, nh, 64, _stream())
+    _lib.check(rc, "vt_attention_probs_f32")
+    return probs
+
+
 def layernorm(x, gamma, beta, eps, out=None, mean=None, rstd=None, M=None, grp_rows=0, grp_stride=0):
     _require_hip(x, gamma, beta, out)
     assert x.dtype == BF16 and gamma.dtype == torch.float32
