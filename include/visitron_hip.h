@@ -170,6 +170,14 @@ int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, in
 int vt_ce_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz,
                        int64_t lddz, int64_t rows, int V, int Vpad, float scale, vt_stream_t stream);
 
+/* The masked-region-token head's loss (tasks/viewpoint_select/encoder.py:323-326, 380-385): token_head ends in a
+ * Softmax and the criterion applies log-softmax again.  Per supervised row of logits z [rows, V] (V <= 2048):
+ * loss_row = logsumexp(softmax(z)) - softmax(z)[y], amax = argmax, dz (bf16 [rows, Vpad], zero past V) =
+ * d(scale * loss_row)/dz. */
+int vt_ce_double_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* loss_row, int64_t* amax,
+                              void* dz, int64_t lddz, int64_t rows, int V, int Vpad, float scale,
+                              vt_stream_t stream);
+
 /* out[c, r] = in[r, c] (bf16; R, C multiples of 8): refreshes the transposed weight copies that the
  * dgrad GEMMs consume (vt_layer_weights_t). */
 int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream);

@@ -619,3 +619,27 @@ def test_embed_layernorm_dropout(dev):
     o = out.view(B, S, H)[:, :T].float()
     pl = plain.view(B, S, H)[:, :T].float()
     assert maxabs(o, pl * keep / (1 - p)) < 2e-2 * (1 + float(pl.abs().max()))
+
+
+@pytest.mark.parametrize("rows,V", [(37, 1601), (5, 11), (300, 40)])
+def test_fused_double_softmax_ce_rows(dev, rows, V):
+    """token_head = Linear + Softmax and CrossEntropyLoss on top (encoder.py:323-326, 380-385): loss, argmax and the
+    gradient through both softmaxes against autograd."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(rows + V)
+    Vp = (V + 63) // 64 * 64
+    z = torch.zeros(rows, Vp)
+    z[:, :V] = _rand((rows, V), g, 2.0)
+    y = torch.randint(0, V, (rows,), generator=g)
+    zr = z[:, :V].clone().requires_grad_(True)
+    p = torch.softmax(zr, dim=-1)
+    loss = torch.nn.functional.cross_entropy(p, y, reduction="none")
+    (loss.sum() * 0.37).backward()
+    dz = torch.full((rows, Vp), 9.0, dtype=BF16, device=dev)
+    lr, am = ops.ce_double_softmax_rows(z.to(dev), y.to(dev), V, dz, 0.37)
+    torch.cuda.synchronize()
+    assert maxabs(lr, loss.detach()) < 1e-4 * (1 + float(loss.abs().max()))
+    assert torch.equal(am.cpu(), p.argmax(1))
+    assert maxabs(dz[:, :V], zr.grad) < 1e-2 * float(zr.grad.abs().max()) + 1e-6
+    assert float(dz[:, V:].float().abs().max() if Vp > V else 0.0) == 0.0

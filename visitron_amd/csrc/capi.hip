@@ -21,6 +21,8 @@ int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids,
                                     float* de, float* dgamma, float* dbeta, float* partial_ws, int B, int T, int S, int H,
                                     int n_word, int n_pos, int n_type, float eps, int accumulate, hipStream_t stream,
                                     const DropCfg* drop = nullptr);
+int vt_ce_double_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, long lddz,
+                                  long rows, int V, int Vpad, float scale, hipStream_t stream);
 int vt_ce_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, long lddz,
                            long rows, int V, int Vpad, float scale, hipStream_t stream);
 int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, int C, hipStream_t stream);
@@ -140,6 +142,11 @@ int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, in
 int vt_ce_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, int64_t lddz,
                        int64_t rows, int V, int Vpad, float scale, vt_stream_t stream) {
   return vt_ce_softmax_dispatch(z, ldz, y, loss_row, amax, dz, lddz, rows, V, Vpad, scale, (hipStream_t)stream);
+}
+
+int vt_ce_double_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz,
+                              int64_t lddz, int64_t rows, int V, int Vpad, float scale, vt_stream_t stream) {
+  return vt_ce_double_softmax_dispatch(z, ldz, y, loss_row, amax, dz, lddz, rows, V, Vpad, scale, (hipStream_t)stream);
 }
 
 int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream) {

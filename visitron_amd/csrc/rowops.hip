@@ -778,6 +778,110 @@ int vt_ce_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* lo
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
+// The masked-region-token head's loss (tasks/viewpoint_select/encoder.py:323-326, 380-385): token_head = Linear +
+// Softmax, and the criterion applies log-softmax AGAIN, so per supervised row
+//     p = softmax(z),   loss = logsumexp(p) - p[y],   argmax = argmax(p) = argmax(z),
+//     dL/dp_i = softmax(p)_i - onehot_i,   dL/dz_j = p_j (dL/dp_j - sum_i dL/dp_i p_i).
+// One workgroup per row, the row (V <= 2048 classes) held in registers, three block reductions.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void ce_double_softmax_rows(const float* __restrict__ z, long ldz, const int64_t* __restrict__ y,
+                                                              float* __restrict__ loss_row, int64_t* __restrict__ amax,
+                                                              bf16_t* __restrict__ dz, long lddz, int V, int Vpad, float scale) {
+  __shared__ float red[4];
+  __shared__ float red_bv[4];
+  __shared__ int red_bi[4];
+  const long row = blockIdx.x;
+  const float* zp = z + row * ldz;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = tid * 8;
+  float v[8];
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = (c0 + i < V) ? zp[c0 + i] : -INFINITY;
+    if (v[i] > bv) { bv = v[i]; bi = c0 + i; }
+  }
+  // max and argmax (first index on ties, as torch.argmax)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float bv2 = __shfl_xor(bv, o, 64);
+    const int bi2 = __shfl_xor(bi, o, 64);
+    if (bv2 > bv || (bv2 == bv && bi2 < bi)) { bv = bv2; bi = bi2; }
+  }
+  if (lane == 0) { red_bv[wave] = bv; red_bi[wave] = bi; }
+  __syncthreads();
+  bv = red_bv[0]; bi = red_bi[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (red_bv[w] > bv || (red_bv[w] == bv && red_bi[w] < bi)) { bv = red_bv[w]; bi = red_bi[w]; }
+  // p = softmax(z)
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = (c0 + i < V) ? __expf(v[i] - bv) : 0.f; s1 += v[i]; }
+  const float inv = 1.0f / block_sum_256(s1, red);
+  // second softmax over p: s2 = sum exp(p), t = sum exp(p) p
+  float s2 = 0.f, t = 0.f;
+  float e[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] *= inv;
+    e[i] = (c0 + i < V) ? __expf(v[i]) : 0.f;
+    s2 += e[i];
+    t += e[i] * v[i];
+  }
+  s2 = block_sum_256(s2, red);
+  t = block_sum_256(t, red);
+  const int label = (int)y[row];
+  const float lse2 = __logf(s2);
+  // p[label] lives in thread label / 8
+  __shared__ float p_label;
+  if (label >= c0 && label < c0 + 8) {
+    float pl = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pl = (c0 + i == label) ? v[i] : pl;
+    p_label = pl;
+  }
+  __syncthreads();
+  const float py = p_label;
+  if (tid == 0) {
+    loss_row[row] = lse2 - py;
+    amax[row] = bi;
+  }
+  const float dot = t / s2 - py;   // sum_i (softmax(p)_i - onehot_i) p_i
+  bf16_t* dp = dz + row * lddz;
+  if (c0 < Vpad) {
+    float gz[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float dpi = e[i] / s2 - ((c0 + i == label) ? 1.0f : 0.f);
+      gz[i] = (c0 + i < V) ? v[i] * (dpi - dot) * scale : 0.f;
+    }
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(gz[2 * i], gz[2 * i + 1]);
+    *(u32x4*)(dp + c0) = o;
+  }
+}
+
+int vt_ce_double_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, long lddz,
+                                  long rows, int V, int Vpad, float scale, hipStream_t stream) {
+  if (!z || !y || !loss_row || !amax || !dz) return VT_ERR_NULL;
+  if (rows <= 0 || V <= 0 || Vpad < V || (Vpad % 8) || lddz < Vpad) return VT_ERR_BAD_SHAPE;
+  if (Vpad > 2048) return VT_ERR_UNSUPPORTED;   // the row is held in registers: 256 threads x 8 classes
+  if ((lddz % 8) || ((uintptr_t)dz & 15)) return VT_ERR_BAD_ALIGN;
+  hipLaunchKernelGGL(ce_double_softmax_rows, dim3((unsigned)rows), dim3(256), 0, stream, z, ldz, y, loss_row, amax, (bf16_t*)dz,
+                     lddz, V, Vpad, scale);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
 // x *= dropout mask * scale in place (bf16 [rows, cols], element index = row * cols + col): masks the
 // compacted image-row gradient with the mask the region-projection epilogue used.
 __global__ __launch_bounds__(256) void apply_dropout_bf16(bf16_t* __restrict__ x, long ld, long rows, int cols, DropCfg d) {

@@ -356,6 +356,20 @@ def ce_softmax_rows(z, y, V, dz, scale):
     return loss, amax
 
 
+def ce_double_softmax_rows(z, y, V, dz, scale):
+    """The token head's loss (Linear + Softmax, then CrossEntropy = a second log-softmax): returns (loss_row, argmax)
+    and fills dz bf16 [rows, Vpad] with d(scale * loss_row)/dz."""
+    _require_hip(z, y, dz)
+    rows = z.shape[0]
+    loss = torch.empty(rows, dtype=torch.float32, device=z.device)
+    amax = torch.empty(rows, dtype=torch.int64, device=z.device)
+    with _timed("ce_softmax_rows", 0.0, rows * (4.0 * V + 2.0 * dz.shape[1])):
+        rc = _lib.load().vt_ce_double_softmax_rows(_ptr(z), z.stride(0), _ptr(y), _ptr(loss), _ptr(amax), _ptr(dz),
+                                                   dz.stride(0), rows, V, dz.shape[1], float(scale), _stream())
+    _lib.check(rc, "vt_ce_double_softmax_rows")
+    return loss, amax
+
+
 def set_attn_bwd_waves(waves):
     """Tuning/test hook: 4- or 8-wave attention backward kernel (8 is the default)."""
     _lib.load().vt_debug_set_attn_bwd_waves(int(waves))

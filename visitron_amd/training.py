@@ -379,10 +379,12 @@ class PretrainEngine(object):
             y_t = tl.index_select(0, idx_t)
             lt = torch.empty((Mt, self.Cp), dtype=torch.float32, device=dev)
             ops.linear(seq_t, self._mirror(lin_tok.weight), lin_tok.bias.detach(), out=lt, out_f32=True)
-            p_t = torch.softmax(lt[:, :C], dim=-1)                      # token_head = Linear + Softmax
-            logp_t = torch.log_softmax(p_t, dim=-1)                      # criterion applies log-softmax AGAIN
-            token_loss = -logp_t.gather(1, y_t[:, None]).mean()
-            token_acc = (p_t.argmax(1) == y_t).sum().float() / Mt
+            # token_head = Linear + Softmax and the criterion applies log-softmax AGAIN: loss, argmax and the gradient
+            # through both softmaxes in one kernel
+            dlt = torch.empty((Mt, self.Cp), dtype=BF16, device=dev)
+            tok_rows, amax_t = ops.ce_double_softmax_rows(lt, y_t, C, dlt, float(grad_scale) / Mt)
+            token_loss = tok_rows.mean()
+            token_acc = (amax_t == y_t).sum().float() / Mt
         else:
             token_loss = zero / zero
             token_acc = zero / zero
@@ -425,12 +427,6 @@ class PretrainEngine(object):
             ops.wgrad([wg(g_ht, seq_w, self._grad(pr.transform.dense.weight), self._grad(pr.transform.dense.bias))], Ml)
             g32.index_add_(0, idx_w, ops.linear(g_ht, self.head_t["tr"]).float())
         if Mt > 0:
-            # d/dp of mean(-log_softmax(p)[y]) is (softmax(p) - onehot)/Mt; then back through p = softmax(logits)
-            dp = torch.exp(logp_t)
-            dp.scatter_add_(1, y_t[:, None], torch.full((Mt, 1), -1.0, device=dev))
-            dp.mul_(gs / Mt)
-            dlt = torch.zeros((Mt, self.Cp), dtype=BF16, device=dev)
-            dlt[:, :C] = (p_t * (dp - (dp * p_t).sum(1, keepdim=True))).to(BF16)
             ops.wgrad([wg(dlt[:, :C], seq_t, self._grad(lin_tok.weight), self._grad(lin_tok.bias))], Mt)
             g32.index_add_(0, idx_t, ops.linear(dlt, self.head_t["tok"]).float())
         if next_action is not None:
