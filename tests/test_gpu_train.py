@@ -341,3 +341,33 @@ def test_img_layernorm_training_matches_oracle(dev, p_h):
     wg = dict(ref.named_parameters())
     bad = {n: _rel(p.grad, wg[n].grad) for n, p in prod.named_parameters() if _rel(p.grad, wg[n].grad) > 0.08}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+def test_device_input_pipeline_feeds_the_engine(dev):
+    """visitron_amd.data (masking, location-embedding lookup, region padding on the GPU) produces the kwargs the pretrain
+    step consumes; same tensors through the oracle give the same losses."""
+    from visitron_amd import data as vdata
+    from visitron_amd.config import mini_config
+
+    cfg = mini_config()
+    ref, prod, eng = _engine_pair(cfg, 4, dev)
+    g = torch.Generator().manual_seed(2)
+    B, T, R = 4, 18, 15
+    ids = torch.randint(5, cfg.vocab_size, (B, T), generator=g).to(dev)
+    ids[:, 0] = 1
+    ids[1, 14:] = 0
+    special = (ids == 0) | (ids == 1)
+    tc = torch.full((B, T), -1, dtype=torch.long, device=dev)
+    tc[:, 2] = torch.randint(0, cfg.detector_classes, (B,), generator=g).to(dev)
+    gd = torch.Generator(device=dev).manual_seed(3)
+    inp, lab, att = vdata.mask_tokens(ids, special, 0, 3, cfg.vocab_size, 0.3, token_classes=tc, generator=gd)
+    feats = torch.rand(B, 20, cfg.img_feature_dim, generator=g).to(dev)
+    batch = vdata.assemble_batch(inp, lab, att, feats, torch.tensor([20, 15, 9, 0], device=dev),
+                                 torch.randint(0, 36, (B, 20), generator=g).to(dev), torch.randint(0, 36, (B,), generator=g).to(dev),
+                                 torch.randint(0, cfg.action_space, (B,), generator=g).to(dev), R, token_classes=tc)
+    assert batch["attention_mask"].shape == (B, T + R) and batch["img_feats"].shape == (B, R, cfg.img_feature_dim)
+    got = eng.forward_backward(batch)
+    with torch.no_grad():
+        want = ref(**{k: v.cpu() for k, v in batch.items()})
+    for i in range(4):
+        assert abs(float(got[i]) - float(want[i])) < 5e-2, (i, float(got[i]), float(want[i]))
