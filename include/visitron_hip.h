@@ -91,7 +91,9 @@ int vt_debug_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_s
  * qkv is the packed projection output [B*S, ld_qkv] = q | k | v (each nh*64 wide).  mask is the
  * caller's raw 2-D mask as fp32 [B,S] (null = all ones) when mask_additive == 0 -- the -10000
  * arithmetic of tasks/viewpoint_select/encoder.py:238-241 then happens in the kernel -- or the
- * already-additive [B,S] bias when mask_additive == 1 (what CaptionBertEncoder.forward receives).  lse (optional, [B,nh,S]) gets
+ * already-additive [B,S] bias when mask_additive == 1 (what CaptionBertEncoder.forward receives), or an additive
+ * per-query bias [B,S,S] when mask_additive == 2 (the reference's 3-D attention_mask, encoder.py:226-229; forward and
+ * vt_attention_probs_f32 only, the backward returns VT_ERR_UNSUPPORTED).  lse (optional, [B,nh,S]) gets
  * the natural-log log-sum-exp of the masked scores for the backward pass. */
 int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive,
                           const float* head_scale, void* ctx, int64_t ld_ctx, float* lse, int B, int S,

@@ -200,3 +200,37 @@ def test_output_attentions_matches_oracle(dev):
         wl, ol = refl(x, ext), prodl(x.to(dev), ext.to(dev))
     assert len(o) == len(w) == 2 and maxabs(o[1], w[1]) < 2e-2 and maxabs(o[0], w[0]) < TOL_BF16
     assert len(ol) == len(wl) == 2 and maxabs(ol[1], wl[1]) < 2e-2
+
+
+def test_three_dimensional_attention_mask(dev):
+    """attention_mask of rank 3 ([B, S, S], encoder.py:226-229): a per-query mask -> [B,1,S,S] additive bias; trunk
+    outputs, attention probabilities and the encoder called directly with the extended mask."""
+    from oracle.modeling import BertImgModelwithLocationEmbeds as OTrunk
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config(output_attentions=True)
+    ref, prod = model_pair(OTrunk, BertImgModelwithLocationEmbeds, cfg, seed=8, device=dev)
+    b = make_batch(cfg, 3, text_len=21, region_len=13, seed=5, with_labels=False)
+    S = 34
+    g = torch.Generator().manual_seed(4)
+    m3 = (torch.rand(3, S, S, generator=g) > 0.3).float()
+    m3[:, :, 0] = 1.0                       # every query keeps at least one key
+    m3 = torch.tril(m3)                     # a causal-like pattern on top of the random one
+    m3[:, :, 0] = 1.0
+    b["attention_mask"] = m3
+    with torch.no_grad():
+        want = ref(**b)
+        got = prod(**_to(b, dev))
+    assert maxabs(got[0], want[0]) < TOL_BF16 and maxabs(got[1], want[1]) < TOL_BF16
+    for pg, pw in zip(got[2], want[2]):
+        assert maxabs(pg, pw) < 2e-2
+        assert float(pg.cpu()[m3[:, None].expand_as(pg) == 0].abs().max()) < 1e-6     # masked pairs get no weight
+    # the encoder on its own, extended mask [B,1,S,S]
+    x = torch.randn(3, S, cfg.hidden_size, generator=g)
+    ext = (1.0 - m3)[:, None] * -10000.0
+    with torch.no_grad():
+        we = ref.encoder(x, ext, head_mask=[None] * cfg.num_hidden_layers)
+        ge = prod.encoder(x.to(dev), ext.to(dev), head_mask=[None] * cfg.num_hidden_layers)
+    assert maxabs(ge[0], we[0]) < TOL_BF16

@@ -707,6 +707,7 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
                               long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream,
                               const DropCfg* drop = nullptr) {
+  if (mask_additive == 2) return VT_ERR_UNSUPPORTED;   // per-query masks: forward / probabilities only
   if (!qkv || !dctx || !ctx || !lse || !delta_ws || !dqkv) return VT_ERR_NULL;
   if (head_size != 64) return VT_ERR_UNSUPPORTED;
   const int nkb = (S + 255) / 256;

@@ -24,7 +24,9 @@
 struct AttnArgs {
   const bf16_t* qkv;        // [B*S, ld_qkv]  q | k | v, each nh*64 wide
   const float* mask;        // [B, S] raw mask (1 = attend) or additive bias, or null
-  int mask_additive;        // 0: mask is raw, bias = (1-mask)*-10000;  1: mask already is the additive bias
+  int mask_additive;        // 0: mask is raw, bias = (1-mask)*-10000;  1: mask already is the additive bias;
+                            // 2: mask is an additive PER-QUERY bias [B, S, S] (the reference's 3-D attention_mask,
+                            //    tasks/viewpoint_select/encoder.py:226-229); forward / probabilities only
   const float* head_scale;  // [nh] head_mask multipliers, or null
   bf16_t* ctx;              // [B*S, ld_ctx]
   float* lse;               // [B, nh, S] natural-log log-sum-exp of the masked scores (for backward), or null
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
   const uint32_t q_elem = (uint32_t)(q0 + r) * (uint32_t)S;
+  const float* mrow3 = (a.mask && a.mask_additive == 2) ? a.mask + ((long)b * S + ((q0 + r) < S ? (q0 + r) : S - 1)) * S : nullptr;
 
   // lane-constant LDS offsets
   const int k_row_off = r * 128;                       // + kt*4096
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
       float bias = -INFINITY;
       if (key < S) {
         float add = 0.f;
-        if (a.mask) {
+        if (a.mask && a.mask_additive != 2) {
           const float mval = a.mask[(long)b * S + key];
           add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
         }
@@ -138,7 +141,13 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
         float tmax = -INFINITY;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4 bv = *(const f32x4*)(bp + 8 * g4);
+          f32x4 bv = *(const f32x4*)(bp + 8 * g4);
+          if (mrow3) {   // per-query bias row of this lane's query; the LDS bias is 0 / -inf (key range)
+            const int key0 = kc + kt * 32 + 8 * g4 + 4 * h2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (key0 + e < S) bv[e] += mrow3[key0 + e];
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             // same two roundings as the reference's scores / sqrt(d) + mask (the division by 8 is exact)
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(256) void attention_probs_d64(AttnArgs a, float* __
     }
     float add = 0.f;
     if (a.mask) {
-      const float mval = a.mask[(long)b * S + key];
+      const float mval = a.mask_additive == 2 ? a.mask[((long)b * S + q) * S + key] : a.mask[(long)b * S + key];
       add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
     }
     out[key] = __expf(fmaf(dot, a.scale, add) - lse) * hs;

@@ -298,15 +298,20 @@ def _dense_residual_ln(mod, hidden_states, input_tensor):
 
 
 def _additive_mask_2d(attention_mask, B, S):
-    """[B,1,1,S] (or [B,S]) additive mask -> contiguous fp32 [B,S]; other ranks are not served yet."""
+    """The additive extended mask CaptionBertEncoder.forward receives: [B,1,1,S] (or [B,S]) -> contiguous fp32 [B,S];
+    [B,1,S,S] (the reference's 3-D attention_mask, encoder.py:226-229) -> contiguous fp32 [B,S,S]."""
     m = attention_mask
     if m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == 1:
         m = m[:, 0, 0, :]
+    elif m.dim() == 4 and m.shape[1] == 1 and m.shape[2] == S:
+        m = m[:, 0]
+        if m.shape[0] != B:
+            m = m.expand(B, -1, -1)
+        if m.shape[2] != S:
+            raise RuntimeError("attention mask length %d does not match sequence length %d" % (m.shape[2], S))
+        return m.to(torch.float32).contiguous()
     elif m.dim() != 2:
-        raise NotImplementedError(
-            "attention masks that vary per query ([B,1,S,S]) are not implemented in the HIP path yet; got shape %s"
-            % (tuple(attention_mask.shape),)
-        )
+        raise NotImplementedError("attention mask of shape %s (per-head masks are not served)" % (tuple(attention_mask.shape),))
     if m.shape[0] != B:
         m = m.expand(B, -1)
     if m.shape[1] != S:
@@ -625,6 +630,7 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
 
         # mask: encoder.py:215-241.  The -10000 arithmetic runs in the attention kernel on the raw fp32 mask.
         mask_f32 = None
+        mask_is_additive = False
         if attention_mask is not None:
             if attention_mask.dim() == 2:
                 if attention_mask.shape != (B, S):
@@ -632,8 +638,12 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                         "attention_mask shape %s does not match [batch, text+region] = [%d, %d]"
                         % (tuple(attention_mask.shape), B, S))
                 mask_f32 = attention_mask.to(device=dev, dtype=torch.float32).contiguous()
-            elif attention_mask.dim() == 3:
-                raise NotImplementedError("3-D attention masks are not implemented in the HIP path yet")
+            elif attention_mask.dim() == 3:   # encoder.py:228-229 + :238-241: per-query mask -> additive bias [B,S,S]
+                if attention_mask.shape != (B, S, S):
+                    raise RuntimeError("3-D attention_mask shape %s does not match [%d, %d, %d]"
+                                       % (tuple(attention_mask.shape), B, S, S))
+                mask_f32 = ((1.0 - attention_mask.to(device=dev, dtype=torch.float32)) * -10000.0).contiguous()
+                mask_is_additive = True
             else:
                 raise NotImplementedError
         hs = _head_scale(head_mask, self.config.num_hidden_layers, self.config.num_attention_heads, dev)
@@ -651,7 +661,7 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
             if self.use_img_layernorm:
                 ops.layernorm(x[T:], _f32(self.LayerNorm.weight), _f32(self.LayerNorm.bias),
                               self.LayerNorm.variance_epsilon, out=x[T:], M=B * R, grp_rows=R, grp_stride=S)
-        outs = self.encoder.run(x, B, S, mask_f32, False, hs)
+        outs = self.encoder.run(x, B, S, mask_f32, mask_is_additive, hs)
         pooled = self.pooler.pooled(outs[-1], B, S)
         _check_index_error(self.embeddings)
         return outs, pooled, x, B, S

@@ -195,6 +195,18 @@ def autotune_encoder_shapes(M, H, I, training=False, device="cuda"):
     return res
 
 
+def _mask_mode(mask, mask_additive, B, S):
+    """0: raw [B,S] mask, 1: additive [B,S] bias, 2: additive per-query bias [B,S,S] (the reference's 3-D masks)."""
+    if mask is None:
+        return 0
+    assert mask.dtype == torch.float32 and mask.is_contiguous()
+    if mask.dim() == 3:
+        assert mask_additive and mask.shape == (B, S, S), "per-query masks are passed as the additive bias [B,S,S]"
+        return 2
+    assert mask.numel() == B * S
+    return 1 if mask_additive else 0
+
+
 def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None, out=None, lse=None, drop=NO_DROP):
     """qkv [B*S, 3*nh*64] bf16, mask fp32 [B,S] -> context [B*S, nh*64] bf16."""
     _require_hip(qkv, mask, head_scale, out, lse)
@@ -202,11 +214,10 @@ def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None
     H = nh * 64
     if out is None:
         out = torch.empty((B * S, H), dtype=BF16, device=qkv.device)
-    if mask is not None:
-        assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.numel() == B * S
+    mode = _mask_mode(mask, mask_additive, B, S)
     with _timed("attention_fwd_d64", 4.0 * B * nh * S * S * 64, 2.0 * B * S * 4 * H):
         rc = _lib.load().vt_attention_fwd_bf16(
-            _ptr(qkv), qkv.stride(0), _ptr(mask), 1 if mask_additive else 0, _ptr(head_scale), _ptr(out),
+            _ptr(qkv), qkv.stride(0), _ptr(mask), mode, _ptr(head_scale), _ptr(out),
             out.stride(0), _ptr(lse), B, S, nh, 64, float(drop[0]), int(drop[1]), int(drop[2]), _stream())
     _lib.check(rc, "vt_attention_fwd_bf16")
     return out
@@ -217,7 +228,7 @@ def attention_probs(qkv, lse, B, S, nh, mask=None, mask_additive=False, head_sca
     _require_hip(qkv, lse, mask, head_scale)
     assert qkv.dtype == BF16 and lse.dtype == torch.float32 and lse.numel() == B * nh * S
     probs = torch.empty((B, nh, S, S), dtype=torch.float32, device=qkv.device)
-    rc = _lib.load().vt_attention_probs_f32(_ptr(qkv), qkv.stride(0), _ptr(mask), 1 if mask_additive else 0,
+    rc = _lib.load().vt_attention_probs_f32(_ptr(qkv), qkv.stride(0), _ptr(mask), _mask_mode(mask, mask_additive, B, S),
                                             _ptr(head_scale), _ptr(lse), _ptr(probs), B, S, nh, 64, _stream())
     _lib.check(rc, "vt_attention_probs_f32")
     return probs
@@ -460,6 +471,6 @@ def encoder_forward(layer_weights, layer_acts, x, mask, mask_additive, head_scal
     _require_hip(x, mask, head_scale)
     L = len(layer_weights)
     rc = _lib.load().vt_encoder_forward_bf16(
-        layer_weights, layer_acts, L, _ptr(x), _ptr(mask), 1 if mask_additive else 0, _ptr(head_scale),
+        layer_weights, layer_acts, L, _ptr(x), _ptr(mask), _mask_mode(mask, mask_additive, B, S), _ptr(head_scale),
         B, S, H, nh, I, float(eps), float(p_hidden), float(p_attn), int(drop_seed), _stream())
     _lib.check(rc, "vt_encoder_forward_bf16")
