@@ -234,3 +234,47 @@ def test_three_dimensional_attention_mask(dev):
         we = ref.encoder(x, ext, head_mask=[None] * cfg.num_hidden_layers)
         ge = prod.encoder(x.to(dev), ext.to(dev), head_mask=[None] * cfg.num_hidden_layers)
     assert maxabs(ge[0], we[0]) < TOL_BF16
+
+
+def test_history_states_match_oracle(dev):
+    """history_state / encoder_history_states (oscar/modeling_bert.py:37-41, 148-155; encoder.py:271-274): each layer's
+    keys and values run over cat([history_i, hidden], 1); text-only trunk call, the encoder called directly, one
+    attention sub-module with the probabilities, and the image-features assertion."""
+    from oracle.modeling import BertImgModelwithLocationEmbeds as OTrunk
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config(output_attentions=True, output_hidden_states=True)
+    ref, prod = model_pair(OTrunk, BertImgModelwithLocationEmbeds, cfg, seed=12, device=dev)
+    B, T, Sh, H = 3, 18, 11, cfg.hidden_size
+    b = make_batch(cfg, B, text_len=T, region_len=4, seed=4, with_labels=False)
+    g = torch.Generator().manual_seed(8)
+    hist = [torch.randn(B, Sh, H, generator=g) for _ in range(cfg.num_hidden_layers)]
+    am = torch.ones(B, Sh + T, dtype=torch.long)
+    am[1, 3:7] = 0
+    am[2, Sh + 12:] = 0
+    args = dict(input_ids=b["input_ids"], attention_mask=am)
+    with torch.no_grad():
+        want = ref(encoder_history_states=hist, **args)
+        got = prod(encoder_history_states=[h.to(dev) for h in hist], **_to(args, dev))
+    assert len(got) == len(want) == 4
+    assert maxabs(got[0], want[0]) < TOL_BF16 and maxabs(got[1], want[1]) < TOL_BF16
+    for hg, hw in zip(got[2], want[2]):
+        assert hg.shape == hw.shape == (B, T, H) and maxabs(hg, hw) < TOL_BF16
+    for pg, pw in zip(got[3], want[3]):
+        assert pg.shape == pw.shape == (B, cfg.num_attention_heads, T, Sh + T)
+        assert maxabs(pg, pw) < 2e-2
+    # the encoder directly with the additive extended mask, and one attention sub-module
+    x = torch.randn(B, T, H, generator=g)
+    ext = ((1.0 - am.float()) * -10000.0).view(B, 1, 1, Sh + T)
+    with torch.no_grad():
+        we = ref.encoder(x, ext, head_mask=[None] * cfg.num_hidden_layers, encoder_history_states=hist)
+        ge = prod.encoder(x.to(dev), ext.to(dev), head_mask=[None] * cfg.num_hidden_layers,
+                          encoder_history_states=[h.to(dev) for h in hist])
+        wa = ref.encoder.layer[0].attention.self(x, ext, None, hist[0])
+        ga = prod.encoder.layer[0].attention.self(x.to(dev), ext.to(dev), None, hist[0].to(dev))
+    assert maxabs(ge[0], we[0]) < TOL_BF16
+    assert maxabs(ga[0], wa[0]) < TOL_BF16 and ga[1].shape == wa[1].shape and maxabs(ga[1], wa[1]) < 2e-2
+    with pytest.raises(AssertionError):
+        prod(encoder_history_states=[h.to(dev) for h in hist], **_to(b, dev))

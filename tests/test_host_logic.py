@@ -127,8 +127,10 @@ def test_mask_and_head_mask_helpers():
     assert m.shape == (2, 5) and m.dtype == torch.float32 and float(m[1, 4]) == -10000.0
     with pytest.raises(RuntimeError):
         _additive_mask_2d(torch.zeros(2, 1, 1, 4), 2, 5)
+    m3 = _additive_mask_2d(torch.zeros(2, 1, 5, 5), 2, 5)      # per-query mask -> [B,S,S]
+    assert m3.shape == (2, 5, 5) and m3.is_contiguous()
     with pytest.raises(NotImplementedError):
-        _additive_mask_2d(torch.zeros(2, 1, 5, 5), 2, 5)
+        _additive_mask_2d(torch.zeros(2, 3, 5, 5), 2, 5)       # per-head masks are not served
     assert _head_scale([None, None], 2, 3, "cpu") is None
     hs = _head_scale(torch.tensor([1.0, 0.0, 0.5]), 2, 3, "cpu")
     assert hs.shape == (2, 3) and float(hs[1, 2]) == 0.5

@@ -319,6 +319,38 @@ def _additive_mask_2d(attention_mask, B, S):
     return m.to(torch.float32).contiguous()
 
 
+def _attention_with_history(x_bf16, history_state, w_qkv, b_qkv, attention_mask, B, S, nh, head_scale, want_probs,
+                            mask_f32=None, mask_additive=True):
+    """One layer's self-attention (oscar/modeling_bert.py:34-79): x_bf16 [B*S, H]; with history_state [B, Sh, H] the
+    keys and values run over cat([history, hidden], 1) (:37-41) -- the packed projection is taken over the
+    concatenated rows and the fused kernel over Sh + S positions, of which the last S query rows are the layer's
+    context (the history rows' own queries are computed and dropped).  attention_mask: the additive extended mask over
+    the Sh + S keys (or pass mask_f32 [B, Sh+S] with its mask_additive flag).  -> (ctx bf16 [B*S, H], probs or None)."""
+    H = nh * 64
+    Sh = 0
+    xs = x_bf16
+    if history_state is not None:
+        Sh = history_state.shape[1]
+        xs = torch.cat([history_state.detach().to(BF16), x_bf16.view(B, S, H)], 1).reshape(B * (Sh + S), H).contiguous()
+    St = Sh + S
+    qkv = ops.linear(xs, w_qkv, b_qkv)
+    mask = mask_f32
+    if mask is None and attention_mask is not None:
+        mask = _additive_mask_2d(attention_mask, B, St)
+    if mask is not None and mask.dim() == 3 and Sh:
+        raise NotImplementedError("per-query attention masks together with history states are not served")
+    lse = torch.empty((B, nh, St), dtype=torch.float32, device=x_bf16.device) if want_probs else None
+    ctx = ops.attention_fwd(qkv, B, St, nh, mask=mask, mask_additive=mask_additive, head_scale=head_scale, lse=lse)
+    probs = None
+    if want_probs:
+        probs = ops.attention_probs(qkv, lse, B, St, nh, mask=mask, mask_additive=mask_additive, head_scale=head_scale)
+        if Sh:
+            probs = probs[:, :, Sh:, :].contiguous()
+    if Sh:
+        ctx = ctx.view(B, St, H)[:, Sh:].reshape(B * S, H).contiguous()
+    return ctx, probs
+
+
 def _head_scale(head_mask, L, nh, device):
     """The reference's head_mask list/tensor -> fp32 [L, nh] per-head multipliers (or None)."""
     if head_mask is None:
@@ -371,22 +403,15 @@ class CaptionBertSelfAttention(nn.Module):
         """oscar/modeling_bert.py:34-79 for one layer: packed QKV GEMM + fused attention kernel."""
         if self.attention_head_size != 64:
             raise NotImplementedError("the fused attention kernel serves head size 64")
-        if history_state is not None:
-            raise NotImplementedError("history_state is not implemented in the HIP path yet")
         _no_train_dropout(self, self.dropout.p)
         B, S, H = hidden_states.shape
         w, b = self.packed_qkv()
-        qkv = ops.linear(_as_bf16_2d(hidden_states), w, b)
-        mask = _additive_mask_2d(attention_mask, B, S) if attention_mask is not None else None
         hs = _head_scale([head_mask], 1, self.num_attention_heads, hidden_states.device)
         hs0 = None if hs is None else hs[0].contiguous()
-        lse = None
-        if self.output_attentions:
-            lse = torch.empty((B, self.num_attention_heads, S), dtype=torch.float32, device=hidden_states.device)
-        ctx = ops.attention_fwd(qkv, B, S, self.num_attention_heads, mask=mask, mask_additive=True, head_scale=hs0, lse=lse)
+        ctx, probs = _attention_with_history(_as_bf16_2d(hidden_states), history_state, w, b, attention_mask, B, S,
+                                             self.num_attention_heads, hs0, self.output_attentions)
         outputs = (ctx.view(B, S, H).to(hidden_states.dtype),)
         if self.output_attentions:   # :74-79: the probabilities after dropout (identity in eval) and head_mask
-            probs = ops.attention_probs(qkv, lse, B, S, self.num_attention_heads, mask=mask, mask_additive=True, head_scale=hs0)
             outputs = outputs + (probs.to(hidden_states.dtype),)
         return outputs
 
@@ -490,7 +515,7 @@ class CaptionBertEncoder(nn.Module):
         return ws
 
     # ---- fused run --------------------------------------------------------------------
-    def run(self, x_bf16, B, S, mask_f32, mask_additive, head_scale=None):
+    def run(self, x_bf16, B, S, mask_f32, mask_additive, head_scale=None, history=None):
         """x_bf16 [B*S,H] -> list of per-layer outputs (len L if output_hidden_states else 1 shared)."""
         if self._hidden != self._heads * 64:
             raise NotImplementedError("the fused encoder serves head size 64 (hidden = 64 * heads)")
@@ -500,6 +525,11 @@ class CaptionBertEncoder(nn.Module):
         pk = self.packed()
         ws = self._workspace(B * S, B, x_bf16.device, self.output_hidden_states)
         self._last_attentions = None
+        if history is not None:   # encoder_history_states: layer i attends over cat([history[i], hidden], 1) (:148-155)
+            probs = [] if self.output_attentions else None
+            outs = self._run_unrolled(pk, ws, x_bf16, B, S, mask_f32, mask_additive, head_scale, probs, history)
+            self._last_attentions = probs
+            return outs
         if self.output_attentions:   # per-layer probabilities need each layer's qkv: the op-by-op launch sequence
             probs = []
             outs = self._run_unrolled(pk, ws, x_bf16, B, S, mask_f32, mask_additive, head_scale, probs)
@@ -511,7 +541,7 @@ class CaptionBertEncoder(nn.Module):
                             self._hidden, self._heads, self._inter, self._eps)
         return ws["outs"]
 
-    def _run_unrolled(self, pk, ws, x, B, S, mask, mask_additive, head_scale, probs=None):
+    def _run_unrolled(self, pk, ws, x, B, S, mask, mask_additive, head_scale, probs=None, history=None):
         """The launch sequence of vt_encoder_forward_bf16 issued op by op (same kernels, same buffers); with `probs` (a
         list) also each layer's attention probabilities (output_attentions)."""
         sh, nh, eps = ws["shared"], self._heads, self._eps
@@ -520,12 +550,19 @@ class CaptionBertEncoder(nn.Module):
         for i, t in enumerate(pk.tensors):
             out = ws["outs"][i]
             hs_i = None if head_scale is None else head_scale[i].contiguous()
-            ops.linear(cur, t["w_qkv"], t["b_qkv"], out=sh["qkv"])
-            ops.attention_fwd(sh["qkv"], B, S, nh, mask=mask, mask_additive=mask_additive, head_scale=hs_i, out=sh["ctx"],
-                              lse=lse)
-            if probs is not None:
-                probs.append(ops.attention_probs(sh["qkv"], lse, B, S, nh, mask=mask, mask_additive=mask_additive,
-                                                 head_scale=hs_i))
+            if history is not None:
+                ctx_i, p_i = _attention_with_history(cur, history[i], t["w_qkv"], t["b_qkv"], None, B, S, nh, hs_i,
+                                                     probs is not None, mask_f32=mask, mask_additive=mask_additive)
+                sh["ctx"].copy_(ctx_i)
+                if probs is not None:
+                    probs.append(p_i)
+            else:
+                ops.linear(cur, t["w_qkv"], t["b_qkv"], out=sh["qkv"])
+                ops.attention_fwd(sh["qkv"], B, S, nh, mask=mask, mask_additive=mask_additive, head_scale=hs_i,
+                                  out=sh["ctx"], lse=lse)
+                if probs is not None:
+                    probs.append(ops.attention_probs(sh["qkv"], lse, B, S, nh, mask=mask, mask_additive=mask_additive,
+                                                     head_scale=hs_i))
             ops.linear(sh["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=sh["attn_pre"])
             ops.layernorm(sh["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=sh["attn_out"])
             ops.linear(sh["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=sh["mid"])
@@ -536,13 +573,12 @@ class CaptionBertEncoder(nn.Module):
 
     def forward(self, hidden_states, attention_mask, head_mask=None, encoder_history_states=None):
         """oscar/modeling_bert.py:140-169.  attention_mask is the ADDITIVE extended mask [B,1,1,S]."""
-        if encoder_history_states is not None:
-            raise NotImplementedError("encoder_history_states is not implemented in the HIP path yet")
         B, S, H = hidden_states.shape
         x = _as_bf16_2d(hidden_states)
-        mask = _additive_mask_2d(attention_mask, B, S) if attention_mask is not None else None
+        Sh = 0 if encoder_history_states is None else encoder_history_states[0].shape[1]
+        mask = _additive_mask_2d(attention_mask, B, Sh + S) if attention_mask is not None else None
         hs = _head_scale(head_mask, len(self.layer), self._heads, hidden_states.device)
-        outs = self.run(x, B, S, mask, True, hs)
+        outs = self.run(x, B, S, mask, True, hs, history=encoder_history_states)
         dt = hidden_states.dtype
         last = outs[-1].view(B, S, H).to(dt)
         outputs = (last,)
@@ -621,9 +657,12 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
         ops._require_hip(input_ids)
         dev = input_ids.device
         B, T = input_ids.shape
+        Sh = 0
         if encoder_history_states:
             assert img_feats is None, "Cannot take image features while using encoder history states"
-            raise NotImplementedError("encoder_history_states is not implemented in the HIP path yet")
+            Sh = encoder_history_states[0].shape[1]
+        else:
+            encoder_history_states = None
         R = 0 if img_feats is None else img_feats.shape[1]
         S = T + R
         H = self.config.hidden_size
@@ -633,10 +672,10 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
         mask_is_additive = False
         if attention_mask is not None:
             if attention_mask.dim() == 2:
-                if attention_mask.shape != (B, S):
+                if attention_mask.shape != (B, Sh + S):
                     raise RuntimeError(
-                        "attention_mask shape %s does not match [batch, text+region] = [%d, %d]"
-                        % (tuple(attention_mask.shape), B, S))
+                        "attention_mask shape %s does not match [batch, history+text+region] = [%d, %d]"
+                        % (tuple(attention_mask.shape), B, Sh + S))
                 mask_f32 = attention_mask.to(device=dev, dtype=torch.float32).contiguous()
             elif attention_mask.dim() == 3:   # encoder.py:228-229 + :238-241: per-query mask -> additive bias [B,S,S]
                 if attention_mask.shape != (B, S, S):
@@ -661,7 +700,7 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
             if self.use_img_layernorm:
                 ops.layernorm(x[T:], _f32(self.LayerNorm.weight), _f32(self.LayerNorm.bias),
                               self.LayerNorm.variance_epsilon, out=x[T:], M=B * R, grp_rows=R, grp_stride=S)
-        outs = self.encoder.run(x, B, S, mask_f32, mask_is_additive, hs)
+        outs = self.encoder.run(x, B, S, mask_f32, mask_is_additive, hs, history=encoder_history_states)
         pooled = self.pooler.pooled(outs[-1], B, S)
         _check_index_error(self.embeddings)
         return outs, pooled, x, B, S
