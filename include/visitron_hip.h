@@ -180,6 +180,37 @@ int vt_ce_double_softmax_rows(const float* z, int64_t ldz, const int64_t* y, flo
                               void* dz, int64_t lddz, int64_t rows, int V, int Vpad, float scale,
                               vt_stream_t stream);
 
+/* ---- rollout caller around the trunk: tasks/viewpoint_select/agent_models.py ---- */
+
+/* One LSTM time step with torch.nn.LSTM / nn.LSTMCell arithmetic (gate order i, f, g, o), replacing the recurrent
+ * half of OscarEncoder.forward's nn.LSTM over the packed trunk output (agent_models.py:285-301) and the
+ * nn.LSTMCell of AttnDecoderLSTM.forward (:416):  gates = xproj + h_prev . w_hh^T, c <- sig(f) c + sig(i) tanh(g)
+ * (in place), h_out = sig(o) tanh(c).  xproj fp32 rows (row b at xproj + b*ldx, 4*hs wide) = x . W_ih^T + b_ih +
+ * b_hh from vt_linear_bf16_ex; w_hh bf16 [4*hs, hs]; hs a multiple of 128; h_out must not alias h_prev.
+ * lengths (optional int32 [B]) gives pack_padded_sequence semantics: a row with t >= lengths[b] keeps its state
+ * and writes zeros to its seq_out position.  seq_out (optional): row b at seq_out + b*ld_seq, hs wide. */
+int vt_lstm_step_f32(const float* xproj, int64_t ldx, const float* h_prev, float* h_out, float* c, const void* w_hh,
+                     const int32_t* lengths, float* seq_out, int64_t ld_seq, int B, int hs, int t,
+                     vt_stream_t stream);
+
+/* The whole recurrence of one nn.LSTM direction over a padded batch (agent_models.py:285-301): T launches of the
+ * step above issued from one call.  xproj fp32 [B, S, 4*hs] (element strides ldx_b / ldx_t); h2 = two fp32 [B, hs]
+ * buffers (h2[0] holds the initial state, the final state is left in h2[0]); c fp32 [B, hs] in place; seq_out fp32
+ * (strides lds_b / lds_t, hs wide per position; optional).  reverse != 0 walks t = T-1 .. 0 (the second direction of
+ * a bidirectional LSTM: with the packed rule each row starts at its own last position). */
+int vt_lstm_sequence_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float* h2_0, float* h2_1, float* c,
+                         const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
+                         int B, int hs, int T, int reverse, vt_stream_t stream);
+
+/* SoftDotAttention.forward after linear_in (agent_models.py:336-349): attn[b,l] = context[b,l,:] . target[b,:];
+ * mask (uint8 [B,L], nonzero = masked) -> -inf; softmax over l; weighted[b,:] = sum_l p[l] context[b,l,:].
+ * context fp32 with element strides ld_batch / ld_row.  weighted (optional) fp32 [B,D]; attn (optional) fp32 [B,L]
+ * receives the probabilities (output_prob != 0) or the masked logits (the reference's `logit` aliases the masked
+ * tensor, :339-343). */
+int vt_softdot_attention_f32(const float* target, const float* context, int64_t ld_batch, int64_t ld_row,
+                             const uint8_t* mask, float* weighted, float* attn, int B, int L, int D, int output_prob,
+                             vt_stream_t stream);
+
 /* out[c, r] = in[r, c] (bf16; R, C multiples of 8): refreshes the transposed weight copies that the
  * dgrad GEMMs consume (vt_layer_weights_t). */
 int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream);

@@ -1,0 +1,104 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU fp32 restatement of the rollout caller around the trunk.
+
+Follows tasks/viewpoint_select/agent_models.py: OscarEncoder (:192-310), SoftDotAttention (:313-357),
+AttnDecoderLSTM (:360-428).  The recurrent arithmetic is torch.nn.LSTM / nn.LSTMCell with
+pack_padded_sequence / pad_packed_sequence -- the same torch calls the reference makes, so the dependency's own
+implementation is what pins the packed-sequence behaviour (rows past their length keep state, padded outputs are
+zero, the padded length is max(lengths)).  Parity unpinned by the reference: it holds no tests or fixtures for this
+path.  Only tests/ may import this module; the product (visitron_amd/rollout.py) never does.
+"""
+import torch
+import torch.nn as nn
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+
+class SoftDotAttention(nn.Module):
+    """agent_models.py:313-357 (Luong-style dot attention)."""
+
+    def __init__(self, query_dim, ctx_dim):
+        super().__init__()
+        self.linear_in = nn.Linear(query_dim, ctx_dim, bias=False)        # :323
+        self.linear_out = nn.Linear(query_dim + ctx_dim, query_dim, bias=False)  # :325
+
+    def forward(self, h, context, mask=None, output_tilde=True, output_prob=True):
+        target = self.linear_in(h).unsqueeze(2)                           # :336
+        attn = torch.bmm(context, target).squeeze(2)                      # :339
+        logit = attn                                                      # :340 an alias: the fill below shows in it
+        if mask is not None:
+            attn.masked_fill_(mask.bool(), -float("inf"))                 # :342-344
+        attn = torch.softmax(attn, dim=1)                                 # :345 nn.Softmax() on a 2-D input -> dim 1
+        weighted_context = torch.bmm(attn.unsqueeze(1), context).squeeze(1)   # :348-350
+        if not output_prob:
+            attn = logit                                                  # :351-352
+        if output_tilde:
+            h_tilde = torch.tanh(self.linear_out(torch.cat((weighted_context, h), 1)))   # :354-355
+            return h_tilde, attn
+        return weighted_context, attn
+
+
+class AttnDecoderLSTM(nn.Module):
+    """agent_models.py:360-428: one decoder step."""
+
+    def __init__(self, angle_feat_size, embedding_size, hidden_size, dropout_ratio, feature_size=2048 + 4):
+        super().__init__()
+        self.embedding_size, self.feature_size, self.hidden_size = embedding_size, feature_size, hidden_size
+        self.embedding = nn.Sequential(nn.Linear(angle_feat_size, embedding_size), nn.Tanh())   # :375-377
+        self.drop = nn.Dropout(p=dropout_ratio)
+        self.lstm = nn.LSTMCell(embedding_size + feature_size, hidden_size)                   # :379
+        self.feat_att_layer = SoftDotAttention(hidden_size, feature_size)
+        self.attention_layer = SoftDotAttention(hidden_size, hidden_size)
+        self.candidate_att_layer = SoftDotAttention(hidden_size, feature_size)
+
+    def forward(self, action, feature, cand_feat, h_0, prev_h1, c_0, ctx, ctx_mask=None):
+        action_embeds = self.drop(self.embedding(action))                                     # :406-409
+        prev_h1_drop = self.drop(prev_h1)
+        attn_feat, _ = self.feat_att_layer(prev_h1_drop, feature, output_tilde=False)         # :411-412
+        concat_input = torch.cat((action_embeds, attn_feat), 1)                               # :414-416
+        h_1, c_1 = self.lstm(concat_input, (prev_h1, c_0))                                    # :417 (h_0 is unused)
+        h_tilde, _alpha = self.attention_layer(self.drop(h_1), ctx, ctx_mask)                 # :419-420
+        _, logit = self.candidate_att_layer(self.drop(h_tilde), cand_feat, output_prob=False)  # :423-425
+        return h_1, c_1, logit, h_tilde
+
+
+class OscarEncoder(nn.Module):
+    """agent_models.py:192-310: trunk over the instruction, then an LSTM over the packed trunk output."""
+
+    def __init__(self, args, bert, hidden_size, decoder_hidden_size, dropout_ratio, bidirectional=False, num_layers=1,
+                 reverse_input=False):
+        super().__init__()
+        self.transformer_hidden_size = 768 if bert is None else bert.config.hidden_size   # the reference hard-codes 768
+        self.reverse_input = reverse_input
+        self.dec_hidden_size = decoder_hidden_size
+        self.args = args
+        self.bert = bert
+        self.hidden_size = hidden_size
+        self.drop = nn.Dropout(p=dropout_ratio)
+        self.num_directions = 2 if bidirectional else 1
+        self.num_layers = num_layers
+        self.lstm = nn.LSTM(self.transformer_hidden_size, hidden_size, num_layers, batch_first=True,
+                            dropout=dropout_ratio, bidirectional=bidirectional)
+        self.encoder_lstm2decoder_ht = nn.Linear(hidden_size * self.num_directions, decoder_hidden_size)
+        self.encoder_lstm2decoder_ct = nn.Linear(hidden_size * self.num_directions, decoder_hidden_size)
+
+    def forward(self, inputs, lengths, mask, position_ids=None, token_type_ids=None):
+        att_mask = ~mask                                                  # :267 bitwise NOT (uint8 masks give 254/255)
+        outputs = self.bert(inputs, token_type_ids=token_type_ids, attention_mask=att_mask, position_ids=position_ids)
+        output = outputs[0]
+        if self.reverse_input:
+            raise NotImplementedError("reverse_input is constructed False by every reference caller (agent.py:110-117)")
+        B = inputs.size(0)
+        h0 = torch.zeros(self.num_layers * self.num_directions, B, self.hidden_size)   # :238-254
+        c0 = torch.zeros_like(h0)
+        packed = pack_padded_sequence(output, lengths, batch_first=True)               # :286
+        enc_h, (enc_h_t, enc_c_t) = self.lstm(packed, (h0, c0))
+        if self.num_directions == 2:                                                   # :289-297
+            h_t = torch.cat((enc_h_t[-1], enc_h_t[-2]), 1)
+            c_t = torch.cat((enc_c_t[-1], enc_c_t[-2]), 1)
+        else:
+            h_t, c_t = enc_h_t[-1], enc_c_t[-1]
+        decoder_init = torch.tanh(self.encoder_lstm2decoder_ht(h_t))                   # :299
+        if self.hidden_size * self.num_directions != self.dec_hidden_size:
+            c_t = self.encoder_lstm2decoder_ct(c_t)                                    # :300-301
+        ctx, _ = pad_packed_sequence(enc_h, batch_first=True)                          # :303
+        ctx = self.drop(ctx)
+        return ctx, decoder_init, c_t

@@ -1,0 +1,75 @@
+"""Rollout caller at the reference's sizes (agent.py:110-125: trunk S=511 text-only, encoder LSTM 768->512, decoder
+hidden 512, features 2048+4, 36 views): OscarEncoder.forward and one AttnDecoderLSTM step on the GPU, HIP-event timed,
+with the per-kernel split from ops.profile_*.  Usage: python tools/rollout_bench.py [B] [S]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visitron_amd import ops  # noqa: E402
+from visitron_amd.config import BertConfig  # noqa: E402
+from visitron_amd.modeling import BertImgModelwithLocationEmbeds  # noqa: E402
+from visitron_amd.rollout import AttnDecoderLSTM, OscarEncoder  # noqa: E402
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, (time.perf_counter() - t0) * 1e3 / reps
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 511
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    bert = BertImgModelwithLocationEmbeds(cfg).eval().to(dev)
+    enc = OscarEncoder(None, bert, 512, 512, 0.5).eval().to(dev)
+    dec = AttnDecoderLSTM(4, 64, 512, 0.5, feature_size=2048 + 4).eval().to(dev)
+    g = torch.Generator().manual_seed(1)
+    lengths = torch.sort(torch.randint(S // 4, S + 1, (B,), generator=g), descending=True).values
+    lengths[0] = S
+    ids = torch.randint(1000, cfg.vocab_size, (B, S), generator=g)
+    pad = torch.arange(S)[None, :] >= lengths[:, None]
+    ids[pad] = 0
+    ids, mask = ids.to(dev), pad.byte().to(dev)
+    out = {}
+
+    def run_enc():
+        out["enc"] = enc(ids, lengths, mask)
+
+    ms, wall = timed(run_enc, 5)
+    print("OscarEncoder.forward  B=%d S=%d: %.2f ms GPU (%.2f ms wall) -> %.0f instructions/s" % (B, S, ms, wall, B / ms * 1e3))
+    ops.profile_begin()
+    run_enc()
+    for k, v in sorted(ops.profile_end().items(), key=lambda kv: -kv[1]["ms"]):
+        print("   %-22s %8.3f ms  n=%d" % (k, v["ms"], v["n"]))
+    ctx, h_t, c_t = out["enc"]
+    action = torch.randn(B, 4, device=dev)
+    feature = torch.randn(B, 36, 2052, device=dev).abs()
+    cand = torch.randn(B, 12, 2052, device=dev).abs()
+    h1 = h_t
+
+    def run_dec():
+        out["dec"] = dec(action, feature, cand, h_t, h1, c_t, ctx, mask[:, : ctx.shape[1]])
+
+    ms, wall = timed(run_dec, 20)
+    print("AttnDecoderLSTM step  B=%d: %.3f ms GPU (%.3f ms wall)" % (B, ms, wall))
+    ops.profile_begin()
+    run_dec()
+    for k, v in sorted(ops.profile_end().items(), key=lambda kv: -kv[1]["ms"]):
+        print("   %-22s %8.3f ms  n=%d" % (k, v["ms"], v["n"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,12 @@ SIGNATURES = {
                                    c_int, c_float, c_void_p]),
     "vt_ce_double_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                    c_int, c_float, c_void_p]),
+    "vt_lstm_step_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                 c_int, c_int, c_int, c_void_p]),
+    "vt_lstm_sequence_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_softdot_attention_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                         c_int, c_int, c_void_p]),
     "vt_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "vt_dgelu_mul_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vt_encoder_backward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerWeightsT),

@@ -52,6 +52,9 @@ void vt_attn_bwd_set_waves(int w);
 
 #include "wgrad_common.hpp"
 int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream);
+#include "rollout_args.hpp"
+int vt_lstm_step_dispatch(const LstmStepArgs& a, hipStream_t stream);
+int vt_softdot_dispatch(const SoftDotArgs& a, hipStream_t stream);
 
 extern "C" {
 
@@ -147,6 +150,46 @@ int vt_ce_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* los
 int vt_ce_double_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz,
                               int64_t lddz, int64_t rows, int V, int Vpad, float scale, vt_stream_t stream) {
   return vt_ce_double_softmax_dispatch(z, ldz, y, loss_row, amax, dz, lddz, rows, V, Vpad, scale, (hipStream_t)stream);
+}
+
+int vt_lstm_step_f32(const float* xproj, int64_t ldx, const float* h_prev, float* h_out, float* c, const void* w_hh,
+                     const int32_t* lengths, float* seq_out, int64_t ld_seq, int B, int hs, int t, vt_stream_t stream) {
+  LstmStepArgs a;
+  a.xproj = xproj; a.ldx = ldx; a.h_prev = h_prev; a.h_out = h_out; a.c = c; a.w_hh = (const bf16_t*)w_hh;
+  a.lengths = lengths; a.seq_out = seq_out; a.ld_seq = ld_seq; a.B = B; a.hs = hs; a.t = t;
+  return vt_lstm_step_dispatch(a, (hipStream_t)stream);
+}
+
+int vt_lstm_sequence_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float* h2_0, float* h2_1, float* c,
+                         const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
+                         int B, int hs, int T, int reverse, vt_stream_t stream) {
+  if (!xproj || !h2_0 || !h2_1 || !c || !w_hh) return VT_ERR_NULL;
+  if (T <= 0) return VT_ERR_BAD_SHAPE;
+  float* hb[2] = {h2_0, h2_1};
+  for (int i = 0; i < T; ++i) {
+    const int t = reverse ? T - 1 - i : i;
+    LstmStepArgs a;
+    a.xproj = xproj + (int64_t)t * ldx_t; a.ldx = ldx_b; a.h_prev = hb[i & 1]; a.h_out = hb[(i + 1) & 1]; a.c = c;
+    a.w_hh = (const bf16_t*)w_hh; a.lengths = lengths; a.seq_out = seq_out ? seq_out + (int64_t)t * lds_t : nullptr;
+    a.ld_seq = lds_b; a.B = B; a.hs = hs; a.t = t;
+    const int rc = vt_lstm_step_dispatch(a, (hipStream_t)stream);
+    if (rc != VT_OK) return rc;
+  }
+  if (T & 1) {
+    if (hipMemcpyAsync(h2_0, h2_1, (size_t)B * hs * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) !=
+        hipSuccess)
+      return VT_ERR_HIP;
+  }
+  return VT_OK;
+}
+
+int vt_softdot_attention_f32(const float* target, const float* context, int64_t ld_batch, int64_t ld_row,
+                             const uint8_t* mask, float* weighted, float* attn, int B, int L, int D, int output_prob,
+                             vt_stream_t stream) {
+  SoftDotArgs a;
+  a.target = target; a.context = context; a.ld_batch = ld_batch; a.ld_row = ld_row; a.mask = mask;
+  a.weighted = weighted; a.attn = attn; a.B = B; a.L = L; a.D = D; a.output_prob = output_prob;
+  return vt_softdot_dispatch(a, (hipStream_t)stream);
 }
 
 int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream) {

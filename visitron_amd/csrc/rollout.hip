@@ -1,0 +1,190 @@
+// Kernels of the rollout caller around the trunk: tasks/viewpoint_select/agent_models.py
+//   * OscarEncoder.forward :256-310  -- nn.LSTM over the packed trunk output (one lstm_step launch per position)
+//   * SoftDotAttention.forward :328-357  -- softdot_attention
+//   * AttnDecoderLSTM.forward :384-428  -- nn.LSTMCell = one lstm_step, three softdot_attention
+// The dense projections of these modules go through the NT GEMM (gemm_bf16.hip); what is here is the part with no
+// GEMM shape: the recurrent product h . W_hh^T fused with the gate arithmetic, and the batched dot / softmax / weighted
+// sum over a short context.
+#include "common.hpp"
+#include "rollout_args.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// One LSTM time step (torch.nn.LSTM / LSTMCell semantics, gate order i, f, g, o):
+//   gates = xproj + h_prev . W_hh^T          xproj = x . W_ih^T + b_ih + b_hh (the caller's GEMM)
+//   c' = sigmoid(f) * c + sigmoid(i) * tanh(g);  h' = sigmoid(o) * tanh(c')
+// Packed-sequence rule (pack_padded_sequence / pad_packed_sequence, agent_models.py:286-301): a row with
+// t >= lengths[b] keeps its state and its output position is zero.
+//
+// One workgroup = 16 hidden units x 16 batch rows; its 4 waves split K = hs four ways and each runs the 4 gates'
+// 16x16x32 MFMAs with W_hh rows on the A port and the h rows on the B port (both straight from global / L2: W_hh is
+// 2 MiB at hs = 512 and is re-read every step), so a lane ends with D[hidden = 4*(lane/16)+r][batch = lane%16].
+// The partial sums meet in LDS and each of the 256 threads finishes one (hidden, batch) element.
+
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  const float e = __expf(-2.0f * fabsf(x));
+  return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+}
+
+__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
+  __shared__ f32x4 part[4][4][64];   // [wave][gate][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int hs = a.hs;
+  const int kq = hs >> 2;                       // this wave's K range: [wave*kq, (wave+1)*kq), kq % 32 == 0
+  const int kl = (lane >> 4) * 8;               // the lane's 8 consecutive k inside a 32-wide MFMA step
+  const int brow = b0 + (lane & 15);
+  const bool bvalid = brow < a.B;
+  const float* hp = a.h_prev + (long)(bvalid ? brow : 0) * hs + wave * kq + kl;
+  const bf16_t* wp = a.w_hh + (long)(h0 + (lane & 15)) * hs + wave * kq + kl;
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < kq; k += 32) {
+    const f32x4 x0 = *(const f32x4*)(hp + k), x1 = *(const f32x4*)(hp + k + 4);
+    u32x4 hb;
+    hb[0] = pack_bf16x2(x0[0], x0[1]); hb[1] = pack_bf16x2(x0[2], x0[3]);
+    hb[2] = pack_bf16x2(x1[0], x1[1]); hb[3] = pack_bf16x2(x1[2], x1[3]);
+    if (!bvalid) hb = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x4 wv = *(const u32x4*)(wp + (long)g * hs * hs + k);
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, hb),
+                                                       acc[g], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) part[wave][g][lane] = acc[g];
+  __syncthreads();
+  // thread (lane, r = wave): element hidden = h0 + 4*(lane/16) + r, batch = b0 + lane%16
+  const int r = wave;
+  const int hid = h0 + 4 * (lane >> 4) + r;
+  if (!bvalid) return;
+  float gate[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float s = a.xproj[(long)brow * a.ldx + (long)g * hs + hid];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += ((const float*)&part[w][g][lane])[r];
+    gate[g] = s;
+  }
+  const long e = (long)brow * hs + hid;
+  const bool active = a.lengths == nullptr || a.t < a.lengths[brow];
+  if (active) {
+    const float cn = sigmoidf_(gate[1]) * a.c[e] + sigmoidf_(gate[0]) * tanhf_(gate[2]);
+    const float hn = sigmoidf_(gate[3]) * tanhf_(cn);
+    a.c[e] = cn;
+    a.h_out[e] = hn;
+    if (a.seq_out) a.seq_out[(long)brow * a.ld_seq + hid] = hn;
+  } else {
+    a.h_out[e] = a.h_prev[e];
+    if (a.seq_out) a.seq_out[(long)brow * a.ld_seq + hid] = 0.f;
+  }
+}
+
+int vt_lstm_step_dispatch(const LstmStepArgs& a, hipStream_t stream) {
+  if (!a.xproj || !a.h_prev || !a.h_out || !a.c || !a.w_hh) return VT_ERR_NULL;
+  if (a.B <= 0 || a.hs <= 0 || (a.hs % 128) != 0 || a.t < 0) return VT_ERR_BAD_SHAPE;   // 4 waves x 32-wide MFMA steps
+  if (a.h_prev == a.h_out) return VT_ERR_UNSUPPORTED;
+  if ((((uintptr_t)a.h_prev) | ((uintptr_t)a.w_hh)) & 15) return VT_ERR_BAD_ALIGN;
+  hipLaunchKernelGGL(lstm_step_kernel, dim3(a.hs / 16, (a.B + 15) / 16), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SoftDotAttention.forward (agent_models.py:328-357) after linear_in:
+//   attn[b, l] = context[b, l, :] . target[b, :]                     (:338, torch.bmm)
+//   mask != 0 -> -inf  (in place, so the returned "logit" alias is masked too, :339-343)
+//   p = softmax(attn) over l (:344)                                   weighted[b, :] = sum_l p[l] context[b, l, :] (:349)
+// One workgroup per batch row; logits / probabilities live in LDS.  fp32 throughout (the context is the caller's
+// fp32 feature tensor: the kernel is a pure read of it, twice, the second time from L2).
+
+__global__ __launch_bounds__(256) void softdot_kernel(SoftDotArgs a) {
+  extern __shared__ float sl[];          // [L] logits -> probabilities, then [8] reduction scratch
+  float* red = sl + a.L;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* ctx = a.context + (long)b * a.ld_batch;
+  const float* tg = a.target + (long)b * a.D;
+  const bool vec = ((a.D & 3) == 0) && ((a.ld_row & 3) == 0) && ((a.ld_batch & 3) == 0) &&
+                   ((((uintptr_t)a.context) | ((uintptr_t)a.target)) & 15) == 0;
+  for (int l = wave; l < a.L; l += 4) {
+    const float* row = ctx + (long)l * a.ld_row;
+    float s = 0.f;
+    if (vec) {
+      for (int d = lane * 4; d < a.D; d += 256) {
+        const f32x4 c = *(const f32x4*)(row + d), t = *(const f32x4*)(tg + d);
+        s += c[0] * t[0] + c[1] * t[1] + c[2] * t[2] + c[3] * t[3];
+      }
+    } else {
+      for (int d = lane; d < a.D; d += 64) s += row[d] * tg[d];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+      if (a.mask && a.mask[(long)b * a.L + l]) s = -INFINITY;
+      sl[l] = s;
+    }
+  }
+  __syncthreads();
+  if (a.attn && !a.output_prob)
+    for (int l = tid; l < a.L; l += 256) a.attn[(long)b * a.L + l] = sl[l];
+  if (!a.weighted && !(a.attn && a.output_prob)) return;
+  // softmax over L
+  float m = -INFINITY;
+  for (int l = tid; l < a.L; l += 256) m = fmaxf(m, sl[l]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float z = 0.f;
+  for (int l = tid; l < a.L; l += 256) {
+    const float e = expf(sl[l] - m);      // every key masked: -inf - -inf = NaN, as torch's softmax gives
+    sl[l] = e;
+    z += e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+  if (lane == 0) red[4 + wave] = z;
+  __syncthreads();
+  z = (red[4] + red[5]) + (red[6] + red[7]);
+  const float inv = 1.0f / z;
+  for (int l = tid; l < a.L; l += 256) {
+    const float p = sl[l] * inv;
+    sl[l] = p;
+    if (a.attn && a.output_prob) a.attn[(long)b * a.L + l] = p;
+  }
+  __syncthreads();
+  if (!a.weighted) return;
+  if (vec) {
+    for (int d = tid * 4; d < a.D; d += 1024) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int l = 0; l < a.L; ++l) {
+        const float p = sl[l];
+        if (p != 0.f) {                   // masked keys carry probability exactly 0 (and 0 * inf must not appear)
+          const f32x4 c = *(const f32x4*)(ctx + (long)l * a.ld_row + d);
+          acc[0] += p * c[0]; acc[1] += p * c[1]; acc[2] += p * c[2]; acc[3] += p * c[3];
+        }
+      }
+      *(f32x4*)(a.weighted + (long)b * a.D + d) = acc;
+    }
+  } else {
+    for (int d = tid; d < a.D; d += 256) {
+      float acc = 0.f;
+      for (int l = 0; l < a.L; ++l) {
+        const float p = sl[l];
+        if (p != 0.f) acc += p * ctx[(long)l * a.ld_row + d];
+      }
+      a.weighted[(long)b * a.D + d] = acc;
+    }
+  }
+}
+
+int vt_softdot_dispatch(const SoftDotArgs& a, hipStream_t stream) {
+  if (!a.target || !a.context) return VT_ERR_NULL;
+  if (!a.weighted && !a.attn) return VT_ERR_NULL;
+  if (a.B <= 0 || a.L <= 0 || a.D <= 0 || a.L > 8192) return VT_ERR_BAD_SHAPE;
+  if (a.weighted && (((uintptr_t)a.weighted) & 15)) return VT_ERR_BAD_ALIGN;
+  hipLaunchKernelGGL(softdot_kernel, dim3(a.B), dim3(256), (size_t)(a.L + 8) * sizeof(float), stream, a);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

@@ -1,0 +1,24 @@
+// Argument blocks of the rollout kernels (rollout.hip), shared with the C-ABI layer (capi.hip).
+#pragma once
+#include "common.hpp"
+
+struct LstmStepArgs {
+  const float* xproj; long ldx;      // row b at xproj + b * ldx (already offset to position t), 4*hs wide
+  const float* h_prev;               // [B, hs]
+  float* h_out;                      // [B, hs]  (must not alias h_prev: other workgroups still read it)
+  float* c;                          // [B, hs]  updated in place
+  const bf16_t* w_hh;                // [4*hs, hs]
+  const int* lengths;                // [B] or null (all rows active)
+  float* seq_out; long ld_seq;       // optional: row b at seq_out + b * ld_seq (already offset to position t), hs wide
+  int B, hs, t;
+};
+
+struct SoftDotArgs {
+  const float* target;          // [B, D]
+  const float* context;         // [B, L, D], row stride ld_row, batch stride ld_batch (elements)
+  long ld_batch, ld_row;
+  const unsigned char* mask;    // [B, L] (nonzero = masked) or null
+  float* weighted;              // [B, D] or null
+  float* attn;                  // [B, L] or null: probabilities (output_prob) or the masked logits
+  int B, L, D, output_prob;
+};

@@ -474,3 +474,70 @@ def encoder_forward(layer_weights, layer_acts, x, mask, mask_additive, head_scal
         layer_weights, layer_acts, L, _ptr(x), _ptr(mask), _mask_mode(mask, mask_additive, B, S), _ptr(head_scale),
         B, S, H, nh, I, float(eps), float(p_hidden), float(p_attn), int(drop_seed), _stream())
     _lib.check(rc, "vt_encoder_forward_bf16")
+
+
+# ---- rollout caller (tasks/viewpoint_select/agent_models.py) ---------------------------------------------------
+def lstm_step(xproj, h_prev, h_out, c, w_hh, t=0, lengths=None, seq_out=None):
+    """One nn.LSTM / nn.LSTMCell step: xproj fp32 [B, 4*hs] view (row stride free) = x @ W_ih.T + b_ih + b_hh;
+    h_prev / h_out / c fp32 [B, hs] (c in place, h ping-pong); w_hh bf16 [4*hs, hs]; lengths int32 [B] gives the
+    packed-sequence rule; seq_out fp32 [B, hs] view (row stride free) of the padded output at position t."""
+    _require_hip(xproj, h_prev, h_out, c, w_hh, lengths, seq_out)
+    B, hs = h_prev.shape
+    assert xproj.dtype == torch.float32 and xproj.shape == (B, 4 * hs) and xproj.stride(1) == 1
+    assert w_hh.dtype == BF16 and w_hh.shape == (4 * hs, hs) and w_hh.is_contiguous()
+    for s in (h_prev, h_out, c):
+        assert s.dtype == torch.float32 and s.shape == (B, hs) and s.is_contiguous()
+    if lengths is not None:
+        assert lengths.dtype == torch.int32 and lengths.shape == (B,) and lengths.is_contiguous()
+    if seq_out is not None:
+        assert seq_out.dtype == torch.float32 and seq_out.shape == (B, hs) and seq_out.stride(1) == 1
+    with _timed("lstm_step", 2.0 * B * 4 * hs * hs, 2.0 * 4 * hs * hs + 4.0 * B * hs * 8):
+        rc = _lib.load().vt_lstm_step_f32(
+            _ptr(xproj), xproj.stride(0), _ptr(h_prev), _ptr(h_out), _ptr(c), _ptr(w_hh), _ptr(lengths), _ptr(seq_out),
+            0 if seq_out is None else seq_out.stride(0), B, hs, int(t), _stream())
+    _lib.check(rc, "vt_lstm_step_f32")
+    return h_out
+
+
+def softdot_attention(target, context, mask=None, want_weighted=True, want_attn=True, output_prob=True):
+    """SoftDotAttention after linear_in: target fp32 [B,D], context fp32 [B,L,D] (last dim contiguous), mask
+    bool/uint8 [B,L] (nonzero = masked) -> (weighted fp32 [B,D] | None, attn fp32 [B,L] | None)."""
+    _require_hip(target, context, mask)
+    B, L, D = context.shape
+    assert target.dtype == torch.float32 and target.shape == (B, D) and target.is_contiguous()
+    assert context.dtype == torch.float32 and context.stride(2) == 1
+    m8 = None
+    if mask is not None:
+        assert mask.shape == (B, L)
+        m8 = (mask if mask.dtype == torch.uint8 else mask.to(torch.bool).view(torch.uint8)).contiguous()
+    weighted = torch.empty((B, D), dtype=torch.float32, device=target.device) if want_weighted else None
+    attn = torch.empty((B, L), dtype=torch.float32, device=target.device) if want_attn else None
+    with _timed("softdot_attention", 4.0 * B * L * D, 4.0 * B * L * D):
+        rc = _lib.load().vt_softdot_attention_f32(
+            _ptr(target), _ptr(context), context.stride(0), context.stride(1), _ptr(m8), _ptr(weighted), _ptr(attn),
+            B, L, D, 1 if output_prob else 0, _stream())
+    _lib.check(rc, "vt_softdot_attention_f32")
+    return weighted, attn
+
+
+def lstm_sequence(xproj, h2, c, w_hh, T, lengths=None, seq_out=None, reverse=False):
+    """One nn.LSTM direction over a padded batch: xproj fp32 [B,S,4*hs] (last dim contiguous), h2 = (h, scratch) two
+    fp32 [B,hs] buffers (h: initial state in, final state out), c fp32 [B,hs] in place, seq_out fp32 [B,T,hs] view."""
+    _require_hip(xproj, h2[0], h2[1], c, w_hh, lengths, seq_out)
+    B, hs = c.shape
+    assert xproj.dtype == torch.float32 and xproj.dim() == 3 and xproj.shape[0] == B and xproj.shape[2] == 4 * hs
+    assert xproj.stride(2) == 1 and 0 < T <= xproj.shape[1]
+    assert w_hh.dtype == BF16 and w_hh.shape == (4 * hs, hs) and w_hh.is_contiguous()
+    for s in (h2[0], h2[1], c):
+        assert s.dtype == torch.float32 and s.shape == (B, hs) and s.is_contiguous()
+    if lengths is not None:
+        assert lengths.dtype == torch.int32 and lengths.shape == (B,) and lengths.is_contiguous()
+    if seq_out is not None:
+        assert seq_out.dtype == torch.float32 and seq_out.shape == (B, T, hs) and seq_out.stride(2) == 1
+    with _timed("lstm_step", 2.0 * T * B * 4 * hs * hs, T * (2.0 * 4 * hs * hs + 4.0 * B * hs * 8)):
+        rc = _lib.load().vt_lstm_sequence_f32(
+            _ptr(xproj), xproj.stride(0), xproj.stride(1), _ptr(h2[0]), _ptr(h2[1]), _ptr(c), _ptr(w_hh), _ptr(lengths),
+            _ptr(seq_out), 0 if seq_out is None else seq_out.stride(0), 0 if seq_out is None else seq_out.stride(1),
+            B, hs, int(T), 1 if reverse else 0, _stream())
+    _lib.check(rc, "vt_lstm_sequence_f32")
+    return h2[0]

@@ -1,0 +1,222 @@
+"""The rollout caller around the trunk, served by the HIP library -- inference only.
+
+Drop-ins for tasks/viewpoint_select/agent_models.py: `OscarEncoder` (:192-310), `SoftDotAttention` (:313-357) and
+`AttnDecoderLSTM` (:360-428): same constructor arguments, parameter names (so the reference's state dicts load:
+`lstm.weight_ih_l0`, `feat_att_layer.linear_in.weight`, ...), argument meaning and return values.  `nn.LSTM` /
+`nn.LSTMCell` are kept as parameter containers only; their arithmetic runs in vt_lstm_sequence_f32 / vt_lstm_step_f32,
+the dot attentions in vt_softdot_attention_f32, every dense projection in the NT GEMM.  No CPU fallback; training-mode
+dropout and autograd through these modules are not served (NotImplementedError / detached outputs).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_NONE, ACT_TANH, BF16, round_up
+
+
+def _no_train_dropout(module, p):
+    if module.training and p > 0.0:
+        raise NotImplementedError("the rollout modules are served for inference (model.eval()); dropout p=%g in "
+                                  "training mode is not implemented in the HIP path" % p)
+
+
+class _Packed(object):
+    """bf16 copies of a module's weights padded to the GEMM's K granule, rebuilt when a parameter changes."""
+
+    def __init__(self):
+        self._key, self._val = None, None
+
+    def get(self, params, build):
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key != self._key:
+            self._val, self._key = build(), key
+        return self._val
+
+
+def _pad_weight(w):
+    N, K = w.shape
+    out = torch.zeros((N, round_up(K, 64)), dtype=BF16, device=w.device)
+    out[:, :K] = w.detach().to(BF16)
+    return out
+
+
+def _f32c(x):
+    x = x.detach()
+    return x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+
+
+def _dense(x_parts, w_pad, bias=None, act=ACT_NONE):
+    """act([x_parts...] @ W.T + bias) in fp32: x_parts = one or two fp32 [M, d] tensors K-concatenated into the bf16
+    operand (vt_pack_concat_bf16), W pre-padded bf16 [N, kpad]."""
+    s0 = _f32c(x_parts[0])
+    s1 = _f32c(x_parts[1]) if len(x_parts) > 1 else None
+    a = ops.pack_concat(s0, s1, w_pad.shape[1])
+    N = w_pad.shape[0]
+    buf = torch.empty((a.shape[0], round_up(N, 4)), dtype=torch.float32, device=a.device)
+    ops.linear(a, w_pad, bias, act=act, out=buf, out_f32=True)
+    return buf if buf.shape[1] == N else buf[:, :N]
+
+
+class SoftDotAttention(nn.Module):
+    """agent_models.py:313-357."""
+
+    def __init__(self, query_dim, ctx_dim):
+        super().__init__()
+        self.linear_in = nn.Linear(query_dim, ctx_dim, bias=False)
+        self.sm = nn.Softmax(dim=1)
+        self.linear_out = nn.Linear(query_dim + ctx_dim, query_dim, bias=False)
+        self.tanh = nn.Tanh()
+        self._pk = _Packed()
+
+    def _weights(self):
+        return self._pk.get((self.linear_in.weight, self.linear_out.weight),
+                            lambda: (_pad_weight(self.linear_in.weight), _pad_weight(self.linear_out.weight)))
+
+    def attend(self, h, context, mask, want_weighted, want_attn, output_prob):
+        w_in, _ = self._weights()
+        target = _dense((h,), w_in).contiguous()
+        return ops.softdot_attention(target, _ctx_f32(context), mask, want_weighted, want_attn, output_prob)
+
+    def forward(self, h, context, mask=None, output_tilde=True, output_prob=True):
+        ops._require_hip(h, context)
+        weighted, attn = self.attend(h, context, mask, True, True, output_prob)
+        if output_tilde:
+            h_tilde = _dense((weighted, h), self._weights()[1], act=ACT_TANH)
+            return h_tilde, attn
+        return weighted, attn
+
+
+def _ctx_f32(context):
+    c = context.detach()
+    if c.dtype != torch.float32:
+        c = c.float()
+    return c if c.stride(-1) == 1 else c.contiguous()
+
+
+class AttnDecoderLSTM(nn.Module):
+    """agent_models.py:360-428: one decoder step (3 dot attentions around an LSTM cell)."""
+
+    def __init__(self, angle_feat_size, embedding_size, hidden_size, dropout_ratio, feature_size=2048 + 4):
+        super().__init__()
+        self.embedding_size = embedding_size
+        self.feature_size = feature_size
+        self.hidden_size = hidden_size
+        self.embedding = nn.Sequential(nn.Linear(angle_feat_size, self.embedding_size), nn.Tanh())
+        self.drop = nn.Dropout(p=dropout_ratio)
+        self.lstm = nn.LSTMCell(embedding_size + feature_size, hidden_size)   # parameter container
+        self.feat_att_layer = SoftDotAttention(hidden_size, feature_size)
+        self.attention_layer = SoftDotAttention(hidden_size, hidden_size)
+        self.candidate_att_layer = SoftDotAttention(hidden_size, feature_size)
+        self._pk = _Packed()
+
+    def _weights(self):
+        emb, cell = self.embedding[0], self.lstm
+
+        def build():
+            return dict(w_emb=_pad_weight(emb.weight), b_emb=_f32c(emb.bias), w_ih=_pad_weight(cell.weight_ih),
+                        b=(cell.bias_ih.detach().float() + cell.bias_hh.detach().float()).contiguous(),
+                        w_hh=cell.weight_hh.detach().to(BF16).contiguous())
+
+        return self._pk.get((emb.weight, emb.bias, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh), build)
+
+    def forward(self, action, feature, cand_feat, h_0, prev_h1, c_0, ctx, ctx_mask=None):
+        ops._require_hip(action, feature, cand_feat, prev_h1, c_0, ctx)
+        _no_train_dropout(self, self.drop.p)
+        w = self._weights()
+        action_embeds = _dense((action,), w["w_emb"], w["b_emb"], act=ACT_TANH)                 # :406
+        attn_feat, _ = self.feat_att_layer.attend(prev_h1, feature, None, True, False, True)      # :411-412
+        xproj = _dense((action_embeds, attn_feat), w["w_ih"], w["b"])                             # :414-417, x half
+        hp = _f32c(prev_h1)
+        h_1 = torch.empty_like(hp)
+        c_1 = _f32c(c_0).clone()
+        ops.lstm_step(xproj, hp, h_1, c_1, w["w_hh"])                                             # :417, h half + gates
+        h_tilde, _ = self.attention_layer(h_1, ctx, ctx_mask)                                     # :419-420
+        _, logit = self.candidate_att_layer.attend(h_tilde, cand_feat, None, False, True, False)  # :423-425
+        return h_1, c_1, logit, h_tilde
+
+
+class OscarEncoder(nn.Module):
+    """agent_models.py:192-310: the trunk over the instruction tokens, an LSTM over its packed output, and the two
+    projections that initialise the decoder."""
+
+    def __init__(self, args, bert, hidden_size, decoder_hidden_size, dropout_ratio, bidirectional=False, num_layers=1,
+                 reverse_input=False):
+        super().__init__()
+        self.transformer_hidden_size = 768 if bert is None else bert.config.hidden_size   # the reference hard-codes 768
+        self.reverse_input = reverse_input
+        self.dec_hidden_size = decoder_hidden_size
+        self.args = args
+        self.bert = bert
+        self.hidden_size = hidden_size
+        self.drop = nn.Dropout(p=dropout_ratio)
+        self.num_directions = 2 if bidirectional else 1
+        self.num_layers = num_layers
+        self.lstm = nn.LSTM(self.transformer_hidden_size, self.hidden_size, self.num_layers, batch_first=True,
+                            dropout=dropout_ratio, bidirectional=bidirectional)     # parameter container
+        self.encoder_lstm2decoder_ht = nn.Linear(hidden_size * self.num_directions, decoder_hidden_size)
+        self.encoder_lstm2decoder_ct = nn.Linear(hidden_size * self.num_directions, decoder_hidden_size)
+        self._pk = _Packed()
+
+    def _weights(self):
+        L = self.lstm
+        names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+        if self.num_directions == 2:
+            names += [n + "_reverse" for n in names]
+        ps = [getattr(L, n) for n in names] + [self.encoder_lstm2decoder_ht.weight, self.encoder_lstm2decoder_ct.weight]
+
+        def build():
+            dirs = []
+            for sfx in ["", "_reverse"][: self.num_directions]:
+                wih, whh = getattr(L, "weight_ih_l0" + sfx), getattr(L, "weight_hh_l0" + sfx)
+                b = getattr(L, "bias_ih_l0" + sfx).detach().float() + getattr(L, "bias_hh_l0" + sfx).detach().float()
+                dirs.append((_pad_weight(wih), b.contiguous(), whh.detach().to(BF16).contiguous()))
+            return dict(dirs=dirs, w_ht=_pad_weight(self.encoder_lstm2decoder_ht.weight),
+                        w_ct=_pad_weight(self.encoder_lstm2decoder_ct.weight))
+
+        return self._pk.get(ps, build)
+
+    def forward(self, inputs, lengths, mask, position_ids=None, token_type_ids=None):
+        ops._require_hip(inputs)
+        _no_train_dropout(self, self.drop.p)
+        if self.num_layers != 1:
+            raise NotImplementedError("stacked encoder LSTMs (num_layers > 1) are not served")
+        if self.reverse_input:
+            raise NotImplementedError("reverse_input is not served (every reference caller leaves it False)")
+        att_mask = ~mask                                               # :267 (uint8 masks: 254/255, the trunk keeps that)
+        B, S = inputs.shape
+        H = self.transformer_hidden_size
+        if hasattr(self.bert, "run_trunk"):                            # the bf16 rows, without the fp32 round trip
+            outs, _, _, _, _ = self.bert.run_trunk(inputs, token_type_ids, att_mask, position_ids)
+            seq = outs[-1]
+        else:
+            seq = self.bert(inputs, token_type_ids=token_type_ids, attention_mask=att_mask,
+                            position_ids=position_ids)[0].detach().reshape(B * S, H).to(BF16).contiguous()
+        lens = torch.as_tensor(lengths).to("cpu", torch.int64)
+        if lens.numel() != B or int(lens.min()) <= 0 or int(lens.max()) > S:
+            raise RuntimeError("lengths must hold one value in 1..%d per sequence" % S)
+        if bool((lens[1:] > lens[:-1]).any()):   # pack_padded_sequence(enforce_sorted=True), :286
+            raise RuntimeError("`lengths` array must be sorted in decreasing order")
+        T = int(lens.max())
+        dev = inputs.device
+        lens_dev = lens.to(dev, torch.int32)
+        w = self._weights()
+        hs, D = self.hidden_size, self.num_directions
+        ctx = torch.empty((B, T, D * hs), dtype=torch.float32, device=dev)
+        finals = []
+        for d, (w_ih, b, w_hh) in enumerate(w["dirs"]):
+            xproj = torch.empty((B * S, 4 * hs), dtype=torch.float32, device=dev)
+            ops.linear(seq, w_ih, b, out=xproj, out_f32=True)
+            h2 = (torch.zeros((B, hs), dtype=torch.float32, device=dev), torch.empty((B, hs), dtype=torch.float32, device=dev))
+            c = torch.zeros((B, hs), dtype=torch.float32, device=dev)                      # init_state :238-254
+            ops.lstm_sequence(xproj.view(B, S, 4 * hs), h2, c, w_hh, T, lens_dev, ctx[:, :, d * hs:(d + 1) * hs],
+                              reverse=(d == 1))
+            finals.append((h2[0], c))
+        if D == 2:                                                     # :289-294: (reverse, forward) order
+            h_t = torch.cat((finals[1][0], finals[0][0]), 1)
+            c_t = torch.cat((finals[1][1], finals[0][1]), 1)
+        else:
+            h_t, c_t = finals[0]
+        decoder_init = _dense((h_t,), w["w_ht"], _f32c(self.encoder_lstm2decoder_ht.bias), act=ACT_TANH)   # :299
+        if hs * D != self.dec_hidden_size:
+            c_t = _dense((c_t,), w["w_ct"], _f32c(self.encoder_lstm2decoder_ct.bias))                       # :300-301
+        return ctx, decoder_init, c_t
