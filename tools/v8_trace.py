@@ -21,6 +21,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 buf = torch.zeros(256 * 64 + 8, dtype=torch.int64, device=dev)
 buf[256 * 64] = int(float(sys.argv[3]) * 100) if len(sys.argv) > 3 else 0   # stagger window in us
+buf[256 * 64 + 1] = int(sys.argv[5]) if len(sys.argv) > 5 else 0             # 1: every tile fetches tile (0,0)'s operands
 _lib.load().vt_debug_set_gemm_trace(buf.data_ptr())
 ops.linear(x, w, out=y, **kw)
 torch.cuda.synchronize()

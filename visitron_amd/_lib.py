@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvisitron_hip.so")
+LIB_PATH = os.environ.get("VT_HIP_LIB", LIB_PATH)   # A/B builds of the kernels (tools/): same ABI, other path
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 c_uint64, c_uint32 = ctypes.c_uint64, ctypes.c_uint32
