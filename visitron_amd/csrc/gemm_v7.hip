@@ -445,10 +445,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   const char* cur_x = nullptr;
   const char* cur_w = nullptr;
   unsigned cur_xb = 0, cur_wb = 0;
+  const int dbg_same = g.trace ? (int)g.trace[256 * 64 + 1] : 0;   // experiment: every tile fetches tile (0,0)'s operands
   auto cursor_tile = [&]() {
     if (cur_t < c1) {
       int m0, n0;
       tile_origin(cur_t, m0, n0);
+      if (dbg_same) { m0 = 0; n0 = 0; }
       const int rows_x = g.M - m0 < 256 ? g.M - m0 : 256;
       const int rows_w = g.N - n0 < 256 ? g.N - n0 : 256;
       cur_x = (const char*)(g.A + (long)m0 * g.lda);
