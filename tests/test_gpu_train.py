@@ -371,3 +371,51 @@ def test_device_input_pipeline_feeds_the_engine(dev):
         want = ref(**{k: v.cpu() for k, v in batch.items()})
     for i in range(4):
         assert abs(float(got[i]) - float(want[i])) < 5e-2, (i, float(got[i]), float(want[i]))
+
+
+def _same_or_both_nan(a, b, tol):
+    a, b = float(torch.as_tensor(a).detach()), float(torch.as_tensor(b).detach())
+    return (a != a and b != b) or abs(a - b) < tol
+
+
+def test_edge_cases_ignored_labels_partial_actions_single_sequence(dev):
+    """The criterion's ignore_index = -1 corners (encoder.py:321, 380-431): no supervised MLM row at all (the
+    reference's CrossEntropyLoss then returns NaN and so does the total loss), no region-token row, next_action
+    ignored for part of the batch (mean over the valid ones; the accuracy still divides by the whole batch), and a
+    batch of ONE sequence with a single supervised position."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config()
+    ref, prod, eng = _engine_pair(cfg, 31, dev)
+    b = make_batch(cfg, 4, text_len=12, region_len=6, seed=2)
+    cases = []
+    c = {k: v.clone() for k, v in b.items()}
+    c["labels"].fill_(-1)                                   # no MLM target anywhere
+    cases.append(("no_mlm", c))
+    c = {k: v.clone() for k, v in b.items()}
+    c["token_labels"].fill_(-1)                             # no region-token target anywhere
+    cases.append(("no_tok", c))
+    c = {k: v.clone() for k, v in b.items()}
+    c["next_action"][1] = -1
+    c["next_action"][3] = -1                                # half of the actions ignored
+    cases.append(("part_act", c))
+    one = make_batch(cfg, 1, text_len=9, region_len=3, seed=5)
+    one["labels"].fill_(-1)
+    one["labels"][0, 4] = int(one["input_ids"][0, 4])
+    cases.append(("single", one))
+    for name, c in cases:
+        ref.zero_grad()
+        want = ref(**c)
+        got = eng.forward_backward({k: v.to(dev) for k, v in c.items()})
+        torch.cuda.synchronize()
+        for i in range(4):
+            assert _same_or_both_nan(got[i], want[i], 5e-2), (name, i, float(got[i]), float(want[i]))
+        for i in range(4, 7):
+            assert _same_or_both_nan(got[i], want[i], 1e-6), (name, i, float(got[i]), float(want[i]))
+        if name in ("part_act", "single"):                  # finite losses: the gradients must agree too
+            want[0].backward()
+            wg = dict(ref.named_parameters())
+            bad = {n: _rel(p.grad, wg[n].grad) for n, p in prod.named_parameters() if wg[n].grad is not None}
+            bad = {n: e for n, e in bad.items() if e > 0.08}
+            assert not bad, (name, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
