@@ -419,3 +419,51 @@ def test_edge_cases_ignored_labels_partial_actions_single_sequence(dev):
             bad = {n: _rel(p.grad, wg[n].grad) for n, p in prod.named_parameters() if wg[n].grad is not None}
             bad = {n: e for n, e in bad.items() if e > 0.08}
             assert not bad, (name, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
+
+
+def test_rccl_all_reduce_path_single_rank(dev):
+    """The communicator calls of the data-parallel step on the real backend ("nccl" = RCCL) with a one-rank group:
+    bucketed async all-reduces of slab slices launched from inside the chunked backward, waited on before AdamW,
+    and the 7-float metrics message.  With one rank the sum is the identity, so gradients must equal the plain
+    path's; what this covers is that RCCL accepts these calls (views of the flat fp32 slab, async handles, the
+    side stream) on the device -- the multi-rank arithmetic is covered by tests/test_distributed_gloo.py."""
+    import os
+
+    import torch.distributed as dist
+
+    from visitron_amd.config import mini_config
+    from visitron_amd.distributed import all_reduce_metrics, all_reduce_ranges
+    from visitron_amd.synth import make_batch
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg = mini_config(num_hidden_layers=4)
+        _, prod, eng = _engine_pair(cfg, 23, dev, lr=0.0, bucket_mb=0.05)
+        assert eng.world == 1
+        b = {k: v.to(dev) for k, v in make_batch(cfg, 3, text_len=14, region_len=6, seed=4).items()}
+        eng.forward_backward(b)
+        want = eng.flat.g.clone()
+        handles, n_calls = [], [0]
+
+        def launch(rng):
+            n_calls[0] += 1
+            all_reduce_ranges(eng.flat.g, rng, eng.bucket_elems, None, handles)
+
+        out = eng.train_step(b, layers_per_chunk=2, _force_comm=launch)
+        for h in handles:
+            h.wait()
+        torch.cuda.synchronize()
+        assert n_calls[0] >= 3 and len(handles) > n_calls[0]          # several chunks, several buckets each
+        assert float((eng.flat.g - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        m = all_reduce_metrics(list(out))
+        assert len(m) == 7 and abs(float(m[0]) - float(out[0])) < 1e-6
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev)      # bench.py's max-over-ranks of the elapsed time
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        assert float(t.item()) == 1.5
+    finally:
+        dist.destroy_process_group()
