@@ -66,6 +66,30 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// Keep flags of a lane's 16 score elements in the backward tiles: element i = query qbase + (i&3) + 8*(i>>2), this
+// lane's key.  vt_keep pairs the elements (q, 2m) and (q, 2m+1) on one hash word (S even), and here those two sit in
+// NEIGHBOURING LANES, so each lane hashes 8 of its 16 queries and takes the other 8 words from lane ^ 1 (DPP
+// quad_perm [1,0,3,2]) instead of hashing all 16.  Needs every lane active (the callers' control flow is uniform).
+__device__ __forceinline__ void attn_bwd_keep16(const DropCfg& dr, uint32_t qbase, uint32_t key, uint32_t S, bool (&keep)[16]) {
+  if ((S & 1u) == 0) {
+    const uint32_t par = key & 1u;
+    const bool odd = par != 0;
+    const uint32_t fsh = par << 4;   // this key's 16-bit field of the shared word
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t qm = qbase + (uint32_t)(((2 * j) & 3) + 8 * ((2 * j) >> 2)) + par;   // query of element 2j + par
+      const uint32_t hm = vt_hash32(dr.seed, (qm * S + key) >> 1);
+      const uint32_t hp = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);   // the neighbour's: element 2j + 1 - par
+      const uint32_t h0 = odd ? hp : hm, h1 = odd ? hm : hp;
+      keep[2 * j] = ((h0 >> fsh) & 0xffffu) >= dr.thresh;
+      keep[2 * j + 1] = ((h1 >> fsh) & 0xffffu) >= dr.thresh;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) keep[i] = vt_keep(dr, (qbase + (uint32_t)((i & 3) + 8 * (i >> 2))) * S + key);
+  }
+}
+
 __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -238,6 +262,8 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
       }
       // P = exp(s/8 + mask - lse);  dS = P (dP - delta) / 8
       f32x16 pacc;
+      bool keep[16];
+      if (dr.thresh) attn_bwd_keep16(dr, (uint32_t)(sl * 32 + 4 * h2), (uint32_t)(kb0 + 64 * wave + 32 * kt + r), (uint32_t)S, keep);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
@@ -247,10 +273,8 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
           const float p = __builtin_amdgcn_exp2f((s - lse4[g4][e]) * LOG2E);
           float dpv = dpacc[i], pv = p;
           if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
-            const uint32_t q = (uint32_t)(sl * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2);
-            const bool keep = vt_keep(dr, q * (uint32_t)S + (uint32_t)(kb0 + 64 * wave + 32 * kt + r));
-            dpv = keep ? dpv * dr.scale : 0.f;
-            pv = keep ? p * dr.scale : 0.f;
+            dpv = keep[i] ? dpv * dr.scale : 0.f;
+            pv = keep[i] ? p * dr.scale : 0.f;
           }
           pacc[i] = pv;
           sacc[i] = p * (dpv - del4[g4][e]) * a.scale;  // dS' (scale folded in)
@@ -536,6 +560,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       }
       // P = exp(s/8 + mask - lse);  dS = P (dP - delta) / 8
       f32x16 pacc;
+      bool keep[16];
+      if (dr.thresh) attn_bwd_keep16(dr, (uint32_t)(sl * 32 + 4 * h2), (uint32_t)(kb0 + 32 * wave + r), (uint32_t)S, keep);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const f32x4 lse4_g = *(const f32x4*)(rowv + 8 * g4 + 4 * h2);
@@ -547,10 +573,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
           const float p = __builtin_amdgcn_exp2f((s - lse4_g[e]) * LOG2E);
           float dpv = dpacc[i], pv = p;
           if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
-            const uint32_t q = (uint32_t)(sl * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2);
-            const bool keep = vt_keep(dr, q * (uint32_t)S + (uint32_t)(kb0 + 32 * wave + r));
-            dpv = keep ? dpv * dr.scale : 0.f;
-            pv = keep ? p * dr.scale : 0.f;
+            dpv = keep[i] ? dpv * dr.scale : 0.f;
+            pv = keep[i] ? p * dr.scale : 0.f;
           }
           pacc[i] = pv;
           sacc[i] = p * (dpv - del4_g[e]) * a.scale;  // dS' (scale folded in)
