@@ -215,6 +215,11 @@ int vt_softdot_attention_f32(const float* target, const float* context, int64_t 
  * dgrad GEMMs consume (vt_layer_weights_t). */
 int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream);
 
+/* vt_transpose_bf16 for n matrices in one launch (arrays of n entries each): the per-step refresh of all encoder
+ * layers' transposed weight copies. */
+int vt_transpose_batch_bf16(const void* const* in, const int64_t* ldi, void* const* out, const int64_t* ldo, const int* R,
+                            const int* C, int n, vt_stream_t stream);
+
 /* out[row, :] = bf16([s0[row, 0:d0] | s1[row, 0:d1] | zeros to kpad]) -- builds the K-concatenated
  * operand that turns img_embedding(img_feats) + location_embeds(loc) (encoder.py:277-279) into
  * one GEMM. */

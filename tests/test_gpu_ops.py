@@ -643,3 +643,26 @@ def test_fused_double_softmax_ce_rows(dev, rows, V):
     assert torch.equal(am.cpu(), p.argmax(1))
     assert maxabs(dz[:, :V], zr.grad) < 1e-2 * float(zr.grad.abs().max()) + 1e-6
     assert float(dz[:, V:].float().abs().max() if Vp > V else 0.0) == 0.0
+
+
+def test_transpose_batch(dev):
+    """vt_transpose_batch_bf16: several matrices of different shapes (row strides included) in one launch, against the
+    single-matrix kernel's definition out[c, r] = in[r, c]."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (64, 8), (72, 200)]
+    pairs, wants = [], []
+    for i, (R, C) in enumerate(shapes):
+        base = torch.randn(R, C + 8 * (i % 2), generator=g).to(dev, torch.bfloat16)
+        src = base[:, :C]                                  # every other one with a row stride
+        out = torch.full((C, R), 7.0, dtype=torch.bfloat16, device=dev)
+        pairs.append((src, out))
+        wants.append(src.t().contiguous())
+    tb = ops.TransposeBatch(pairs)
+    tb.run()
+    torch.cuda.synchronize()
+    for (src, out), want in zip(pairs, wants):
+        assert torch.equal(out, want)
+    with pytest.raises(AssertionError):
+        ops.TransposeBatch([(pairs[0][0], pairs[1][1])])   # shape mismatch is refused on the host

@@ -84,6 +84,7 @@ SIGNATURES = {
     "vt_softdot_attention_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          c_int, c_int, c_void_p]),
     "vt_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "vt_transpose_batch_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vt_dgelu_mul_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "vt_encoder_backward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerWeightsT),
                                          ctypes.POINTER(LayerActs), ctypes.POINTER(LayerGrads), c_int, c_void_p,

@@ -43,6 +43,8 @@ int vt_embed_layernorm_dispatch(const int64_t* ids, const int64_t* type_ids, con
 int vt_pack_concat_dispatch(const float* s0, int d0, const float* s1, int d1, void* out, int kpad, long rows,
                             hipStream_t stream);
 
+int vt_transpose_batch_dispatch(const void* const* in, const long* ldi, void* const* out, const long* ldo, const int* R,
+                                const int* C, int n, hipStream_t stream);
 void vt_gemm_set_variant(int v);
 void vt_gemm_set_trace(void* p);
 void vt_wgrad_set_tile(int tn);
@@ -194,6 +196,11 @@ int vt_softdot_attention_f32(const float* target, const float* context, int64_t 
 
 int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream) {
   return vt_transpose_dispatch(in, ldi, out, ldo, R, C, (hipStream_t)stream);
+}
+
+int vt_transpose_batch_bf16(const void* const* in, const int64_t* ldi, void* const* out, const int64_t* ldo, const int* R,
+                            const int* C, int n, vt_stream_t stream) {
+  return vt_transpose_batch_dispatch(in, (const long*)ldi, out, (const long*)ldo, R, C, n, (hipStream_t)stream);
 }
 
 int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_stream_t stream) {

@@ -685,6 +685,67 @@ int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, 
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
+// The same for a batch of matrices in ONE launch (blockIdx.z = matrix): after an optimizer step the 48 layer weights
+// are re-transposed, and 48 five-microsecond launches cost more in gaps than in work.
+struct TransposeBatch {
+  const bf16_t* in[64];
+  bf16_t* out[64];
+  int ldi[64], ldo[64], R[64], C[64];
+};
+__global__ __launch_bounds__(256) void transpose_batch_bf16(TransposeBatch b) {
+  __shared__ bf16_t tile[64][72];
+  const int z = blockIdx.z;
+  const int R = b.R[z], C = b.C[z];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  if (r0 >= R || c0 >= C) return;   // the grid covers the largest matrix of the batch
+  const bf16_t* __restrict__ in = b.in[z];
+  bf16_t* __restrict__ out = b.out[z];
+  const long ldi = b.ldi[z], ldo = b.ldo[z];
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int chunk = t + 256 * it;
+    const int r = chunk >> 3, cc = (chunk & 7) * 8;
+    u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+    if (r0 + r < R && c0 + cc < C) v = *(const u32x4*)(in + (long)(r0 + r) * ldi + c0 + cc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tile[cc + 2 * i][r] = (bf16_t)(v[i] & 0xffffu);
+      tile[cc + 2 * i + 1][r] = (bf16_t)(v[i] >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int chunk = t + 256 * it;
+    const int c = chunk >> 3, rr = (chunk & 7) * 8;
+    if (c0 + c < C && r0 + rr < R) *(u32x4*)(out + (long)(c0 + c) * ldo + r0 + rr) = *(const u32x4*)(&tile[c][rr]);
+  }
+}
+
+int vt_transpose_batch_dispatch(const void* const* in, const long* ldi, void* const* out, const long* ldo, const int* R,
+                                const int* C, int n, hipStream_t stream) {
+  if (!in || !out || !ldi || !ldo || !R || !C) return VT_ERR_NULL;
+  if (n <= 0) return VT_ERR_BAD_SHAPE;
+  for (int base = 0; base < n; base += 64) {
+    const int cnt = n - base < 64 ? n - base : 64;
+    TransposeBatch b;
+    int maxR = 0, maxC = 0;
+    for (int i = 0; i < 64; ++i) {
+      const int j = base + (i < cnt ? i : 0);
+      if (!in[j] || !out[j]) return VT_ERR_NULL;
+      if (R[j] <= 0 || C[j] <= 0 || (R[j] % 8) || (C[j] % 8)) return VT_ERR_BAD_SHAPE;
+      if ((ldi[j] % 8) || (ldo[j] % 8) || (((uintptr_t)in[j] | (uintptr_t)out[j]) & 15)) return VT_ERR_BAD_ALIGN;
+      b.in[i] = (const bf16_t*)in[j]; b.out[i] = (bf16_t*)out[j]; b.ldi[i] = (int)ldi[j]; b.ldo[i] = (int)ldo[j];
+      b.R[i] = R[j]; b.C[i] = C[j];
+      if (i < cnt) { maxR = R[j] > maxR ? R[j] : maxR; maxC = C[j] > maxC ? C[j] : maxC; }
+    }
+    hipLaunchKernelGGL(transpose_batch_bf16, dim3((maxC + 63) / 64, (maxR + 63) / 64, cnt), dim3(256), 0, stream, b);
+    if (hipGetLastError() != hipSuccess) return VT_ERR_HIP;
+  }
+  return VT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused softmax cross-entropy over the MLM logits (tasks/viewpoint_select/encoder.py:387-389 + the
 // argmax of :399 + the backward of the criterion): per supervised row, ONE kernel produces

@@ -415,6 +415,29 @@ def transpose(src, out):
     return out
 
 
+class TransposeBatch(object):
+    """A fixed list of (src, out) bf16 matrix pairs transposed by ONE launch (vt_transpose_batch_bf16): the argument
+    arrays are built once, `run()` re-issues the launch (the tensors must keep their storage)."""
+
+    def __init__(self, pairs):
+        n = len(pairs)
+        self.n, self._keep = n, list(pairs)
+        self.src, self.dst = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        self.ldi, self.ldo = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)()
+        self.R, self.C = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+        for i, (s_, o_) in enumerate(pairs):
+            _require_hip(s_, o_)
+            assert s_.dtype == BF16 and o_.dtype == BF16 and s_.stride(1) == 1 and o_.stride(1) == 1
+            assert o_.shape == (s_.shape[1], s_.shape[0])
+            self.src[i], self.dst[i] = s_.data_ptr(), o_.data_ptr()
+            self.ldi[i], self.ldo[i] = s_.stride(0), o_.stride(0)
+            self.R[i], self.C[i] = s_.shape
+
+    def run(self):
+        rc = _lib.load().vt_transpose_batch_bf16(self.src, self.ldi, self.dst, self.ldo, self.R, self.C, self.n, _stream())
+        _lib.check(rc, "vt_transpose_batch_bf16")
+
+
 def dgelu_mul(g, h, out=None):
     """g * d (d = saved gelu' values), bf16 contiguous."""
     _require_hip(g, h, out)

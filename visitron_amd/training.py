@@ -159,10 +159,12 @@ class PretrainEngine(object):
         self.fb_count = 0
         self.last_drop_seed = 0
         self._wt_dirty = True
+        self._wt_batch = None
         self._build_tables()
 
     # ------------------------------------------------------------------------------ tables
     def _build_tables(self):
+        self._wt_batch = None
         m, f, cfg = self.model, self.flat, self.cfg
         L, H, I = cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size
         self.w_tab = (_lib.LayerWeights * L)()
@@ -238,19 +240,21 @@ class PretrainEngine(object):
         if not self._wt_dirty:
             return
         m, D = self.model, self.model.bert.img_dim
-        for t, wt in self.wt:
-            ops.transpose(t["w_qkv"], wt["wt_qkv"])
-            ops.transpose(t["w_ao"], wt["wt_ao"])
-            ops.transpose(t["w_in"], wt["wt_in"])
-            ops.transpose(t["w_out"], wt["wt_out"])
+        if self._wt_batch is None:   # all layers' four matrices + the two square head matrices: one launch
+            pairs = []
+            for t, wt in self.wt:
+                pairs += [(t["w_qkv"], wt["wt_qkv"]), (t["w_ao"], wt["wt_ao"]), (t["w_in"], wt["wt_in"]),
+                          (t["w_out"], wt["wt_out"])]
+            pairs += [(self._mirror(m.mlmhead.predictions.transform.dense.weight), self.head_t["tr"]),
+                      (self._mirror(m.bert.pooler.dense.weight), self.head_t["pool"])]
+            self._wt_batch = ops.TransposeBatch(pairs)
+        self._wt_batch.run()
         V = m.mlmhead.predictions.decoder.weight.shape[0]
         C = m.token_head[0].weight.shape[0]
         A = m.next_action.linear.weight.shape[0]
         self.head_t["dec"][:, :V].copy_(self._mirror(m.mlmhead.predictions.decoder.weight).t())
-        ops.transpose(self._mirror(m.mlmhead.predictions.transform.dense.weight), self.head_t["tr"])
         self.head_t["tok"][:, :C].copy_(self._mirror(m.token_head[0].weight).t())
         self.head_t["act"][:, :A].copy_(self._mirror(m.next_action.linear.weight).t())
-        ops.transpose(self._mirror(m.bert.pooler.dense.weight), self.head_t["pool"])
         self.w_img[:, :D].copy_(self._mirror(m.bert.img_embedding.weight))
         self.w_img[:, D:D + 128].copy_(self._mirror(m.bert.location_embeds.weight))
         torch.add(m.bert.img_embedding.bias.detach(), m.bert.location_embeds.bias.detach(), out=self.b_img)
