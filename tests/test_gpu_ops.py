@@ -651,18 +651,23 @@ def test_transpose_batch(dev):
     from visitron_amd import ops
 
     g = torch.Generator().manual_seed(3)
-    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (64, 8), (72, 200)]
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (64, 8), (72, 200), (1601, 768), (36, 64)]
     pairs, wants = [], []
     for i, (R, C) in enumerate(shapes):
         base = torch.randn(R, C + 8 * (i % 2), generator=g).to(dev, torch.bfloat16)
         src = base[:, :C]                                  # every other one with a row stride
-        out = torch.full((C, R), 7.0, dtype=torch.bfloat16, device=dev)
+        Rp = (R + 63) // 64 * 64 if R % 8 else R           # a row count off the 8-grid needs a padded output row
+        out = torch.full((C, Rp), 7.0, dtype=torch.bfloat16, device=dev)
         pairs.append((src, out))
         wants.append(src.t().contiguous())
     tb = ops.TransposeBatch(pairs)
     tb.run()
     torch.cuda.synchronize()
     for (src, out), want in zip(pairs, wants):
-        assert torch.equal(out, want)
+        R = src.shape[0]
+        assert torch.equal(out[:, :R], want)
+        if R % 8:                                          # the rest of the last 8-group is zero, beyond it untouched
+            r8 = (R + 7) // 8 * 8
+            assert float(out[:, R:r8].abs().max()) == 0.0 and float(out[:, r8:].min()) == 7.0
     with pytest.raises(AssertionError):
         ops.TransposeBatch([(pairs[0][0], pairs[1][1])])   # shape mismatch is refused on the host

@@ -691,13 +691,17 @@ struct TransposeBatch {
   const bf16_t* in[64];
   bf16_t* out[64];
   int ldi[64], ldo[64], R[64], C[64];
+  int blk_begin[65];   // first workgroup of each matrix in the 1-D grid (64x64-element tiles, column-tile fastest)
 };
-__global__ __launch_bounds__(256) void transpose_batch_bf16(TransposeBatch b) {
+__global__ __launch_bounds__(256) void transpose_batch_bf16(TransposeBatch b, int n) {
   __shared__ bf16_t tile[64][72];
-  const int z = blockIdx.z;
+  int z = 0;
+  for (int i = 1; i < n; ++i)   // wave-uniform scan
+    if ((int)blockIdx.x >= b.blk_begin[i]) z = i;
   const int R = b.R[z], C = b.C[z];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  if (r0 >= R || c0 >= C) return;   // the grid covers the largest matrix of the batch
+  const int local = blockIdx.x - b.blk_begin[z];
+  const int bx = (C + 63) >> 6;
+  const int r0 = (local / bx) * 64, c0 = (local % bx) * 64;
   const bf16_t* __restrict__ in = b.in[z];
   bf16_t* __restrict__ out = b.out[z];
   const long ldi = b.ldi[z], ldo = b.ldo[z];
@@ -730,17 +734,21 @@ int vt_transpose_batch_dispatch(const void* const* in, const long* ldi, void* co
   for (int base = 0; base < n; base += 64) {
     const int cnt = n - base < 64 ? n - base : 64;
     TransposeBatch b;
-    int maxR = 0, maxC = 0;
+    int blocks = 0;
     for (int i = 0; i < 64; ++i) {
       const int j = base + (i < cnt ? i : 0);
       if (!in[j] || !out[j]) return VT_ERR_NULL;
-      if (R[j] <= 0 || C[j] <= 0 || (R[j] % 8) || (C[j] % 8)) return VT_ERR_BAD_SHAPE;
+      // a row count that is not a multiple of 8 is served when the output rows have room for the rounded-up count
+      // (the tail of the last 8-element group is written as zeros: padding columns of the transposed copy)
+      if (R[j] <= 0 || C[j] <= 0 || (C[j] % 8) || ldo[j] < ((R[j] + 7) & ~7)) return VT_ERR_BAD_SHAPE;
       if ((ldi[j] % 8) || (ldo[j] % 8) || (((uintptr_t)in[j] | (uintptr_t)out[j]) & 15)) return VT_ERR_BAD_ALIGN;
       b.in[i] = (const bf16_t*)in[j]; b.out[i] = (bf16_t*)out[j]; b.ldi[i] = (int)ldi[j]; b.ldo[i] = (int)ldo[j];
       b.R[i] = R[j]; b.C[i] = C[j];
-      if (i < cnt) { maxR = R[j] > maxR ? R[j] : maxR; maxC = C[j] > maxC ? C[j] : maxC; }
+      b.blk_begin[i] = blocks;
+      if (i < cnt) blocks += ((R[j] + 63) / 64) * ((C[j] + 63) / 64);
     }
-    hipLaunchKernelGGL(transpose_batch_bf16, dim3((maxC + 63) / 64, (maxR + 63) / 64, cnt), dim3(256), 0, stream, b);
+    b.blk_begin[64] = blocks;
+    hipLaunchKernelGGL(transpose_batch_bf16, dim3(blocks), dim3(256), 0, stream, b, cnt);
     if (hipGetLastError() != hipSuccess) return VT_ERR_HIP;
   }
   return VT_OK;

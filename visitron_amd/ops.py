@@ -428,7 +428,7 @@ class TransposeBatch(object):
         for i, (s_, o_) in enumerate(pairs):
             _require_hip(s_, o_)
             assert s_.dtype == BF16 and o_.dtype == BF16 and s_.stride(1) == 1 and o_.stride(1) == 1
-            assert o_.shape == (s_.shape[1], s_.shape[0])
+            assert o_.shape[0] == s_.shape[1] and o_.shape[1] >= s_.shape[0]   # wider: zero-padded column tail
             self.src[i], self.dst[i] = s_.data_ptr(), o_.data_ptr()
             self.ldi[i], self.ldo[i] = s_.stride(0), o_.stride(0)
             self.R[i], self.C[i] = s_.shape

@@ -246,15 +246,15 @@ class PretrainEngine(object):
                 pairs += [(t["w_qkv"], wt["wt_qkv"]), (t["w_ao"], wt["wt_ao"]), (t["w_in"], wt["wt_in"]),
                           (t["w_out"], wt["wt_out"])]
             pairs += [(self._mirror(m.mlmhead.predictions.transform.dense.weight), self.head_t["tr"]),
-                      (self._mirror(m.bert.pooler.dense.weight), self.head_t["pool"])]
+                      (self._mirror(m.bert.pooler.dense.weight), self.head_t["pool"]),
+                      (self._mirror(m.mlmhead.predictions.decoder.weight), self.head_t["dec"]),
+                      (self._mirror(m.token_head[0].weight), self.head_t["tok"]),
+                      (self._mirror(m.next_action.linear.weight), self.head_t["act"])]
             self._wt_batch = ops.TransposeBatch(pairs)
         self._wt_batch.run()
         V = m.mlmhead.predictions.decoder.weight.shape[0]
         C = m.token_head[0].weight.shape[0]
         A = m.next_action.linear.weight.shape[0]
-        self.head_t["dec"][:, :V].copy_(self._mirror(m.mlmhead.predictions.decoder.weight).t())
-        self.head_t["tok"][:, :C].copy_(self._mirror(m.token_head[0].weight).t())
-        self.head_t["act"][:, :A].copy_(self._mirror(m.next_action.linear.weight).t())
         self.w_img[:, :D].copy_(self._mirror(m.bert.img_embedding.weight))
         self.w_img[:, D:D + 128].copy_(self._mirror(m.bert.location_embeds.weight))
         torch.add(m.bert.img_embedding.bias.detach(), m.bert.location_embeds.bias.detach(), out=self.b_img)
