@@ -97,6 +97,29 @@ __device__ __forceinline__ void gelu_erf_both2(f32x2 x, f32x2& g, f32x2& dg) {
   g = x * cdf;
   dg = cdf + x * (e * 0.3989422804014327f);
 }
+// Four elements at a time: the same arithmetic as gelu_erf_both2 on two independent pairs written as 4-vector
+// expressions, so consecutive packed instructions belong to different dependency chains (a packed fp32 result needs a
+// wait state before a dependent VALU read; with a single pair hipcc fills it with s_nop, 20 % of the epilogue's issue
+// slots at one wave per SIMD).
+__device__ __forceinline__ void gelu_erf_both4(f32x4 x, f32x4& g, f32x4& dg) {
+  const f32x4 ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
+  const f32x4 den = ax * 0.3275911f + 1.0f;
+  const f32x4 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1]), __builtin_amdgcn_rcpf(den[2]),
+                   __builtin_amdgcn_rcpf(den[3])};
+  f32x4 y = t * 0.5307027145f - 0.7265760135f;
+  y = y * t + 0.7107068705f;
+  y = y * t - 0.142248368f;
+  y = y * t + 0.127414796f;
+  const f32x4 q = y * t;
+  const f32x4 a2 = (ax * ax) * -1.4426950408889634f;
+  const f32x4 e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1]), __builtin_amdgcn_exp2f(a2[2]),
+                   __builtin_amdgcn_exp2f(a2[3])};
+  const f32x4 h = 0.5f - q * e;
+  const f32x4 hs = {copysignf(h[0], x[0]), copysignf(h[1], x[1]), copysignf(h[2], x[2]), copysignf(h[3], x[3])};
+  const f32x4 cdf = hs + 0.5f;
+  g = x * cdf;
+  dg = cdf + x * (e * 0.3989422804014327f);
+}
 __device__ __forceinline__ float tanh_fast(float x) {
   // tanh(x) = 1 - 2/(exp(2x)+1); saturates cleanly for |x| large
   const float e = __expf(2.0f * x);

@@ -76,14 +76,13 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
     const int so_row = 128 * wm + 16 * (MT);                                                              \
     if (has_c2) {   /* saved for the backward pass: the activation's derivative (GELU) or the pre-activation */ \
       float d2[16];                                                                                       \
-      _Pragma("unroll") for (int i = 0; i < 16; i += 2) {                                                 \
+      _Pragma("unroll") for (int i = 0; i < 16; i += 4) {                                                 \
         if (ACT == ACT_GELU) {                                                                            \
-          f32x2 gg, dd;                                                                                   \
-          gelu_erf_both2((f32x2){v[i], v[i + 1]}, gg, dd);                                                \
-          v[i] = gg[0]; v[i + 1] = gg[1]; d2[i] = dd[0]; d2[i + 1] = dd[1];                               \
+          f32x4 gg, dd;                                                                                   \
+          gelu_erf_both4((f32x4){v[i], v[i + 1], v[i + 2], v[i + 3]}, gg, dd);                            \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) { v[i + e] = gg[e]; d2[i + e] = dd[e]; }          \
         } else {                                                                                          \
-          d2[i] = v[i]; d2[i + 1] = v[i + 1];                                                             \
-          v[i] = apply_act<ACT>(v[i]); v[i + 1] = apply_act<ACT>(v[i + 1]);                               \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) { d2[i + e] = v[i + e]; v[i + e] = apply_act<ACT>(v[i + e]); } \
         }                                                                                                 \
       }                                                                                                   \
       u32x4 p0, p1;                                                                                       \
