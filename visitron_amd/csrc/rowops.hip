@@ -23,61 +23,97 @@ struct LnArgs {
 
 template <int CH>
 __global__ __launch_bounds__(256) void layernorm_rows(LnArgs a) {
+  // One wave = LN_ROWS consecutive rows at once: their loads are all in flight together and the scale / shift vectors
+  // (6 KiB of fp32 against 1.5 KiB per row) are fetched once per wave instead of once per row.
+  constexpr int LN_ROWS = 4;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.M) return;
-  const long prow = a.grp_rows ? (long)(row / a.grp_rows) * a.grp_stride + (row % a.grp_rows) : (long)row;
-  const bf16_t* xp = a.x + prow * a.ldx;
-  float v[CH][8];
-  float s = 0.f;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
+  if (row0 >= a.M) return;
+  u32x4 w[LN_ROWS][CH];
+  long prow[LN_ROWS];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int col = (lane + 64 * c) * 8;
-    if (col < a.H) {
-      const u32x4 w = *(const u32x4*)(xp + col);
+  for (int r = 0; r < LN_ROWS; ++r) {
+    const int row = row0 + r < a.M ? row0 + r : a.M - 1;   // the tail repeats the last row (its store is skipped)
+    prow[r] = a.grp_rows ? (long)(row / a.grp_rows) * a.grp_stride + (row % a.grp_rows) : (long)row;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { v[c][2 * i] = bf16lo(w[i]); v[c][2 * i + 1] = bf16hi(w[i]); }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s += v[c][i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      w[r][c] = col < a.H ? *(const u32x4*)(a.x + prow[r] * a.ldx + col) : (u32x4){0u, 0u, 0u, 0u};
     }
   }
-  const float invH = 1.0f / (float)a.H;
-  const float u = wave_sum(s) * invH;
-  float ss = 0.f;
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int col = (lane + 64 * c) * 8;
-    if (col < a.H) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { const float d = v[c][i] - u; ss += d * d; }
-    }
-  }
-  const float var = wave_sum(ss) * invH;
-  const float rs = 1.0f / sqrtf(var + a.eps);
-  if (lane == 0) {
-    if (a.mean) a.mean[row] = u;
-    if (a.rstd) a.rstd[row] = rs;
-  }
-  bf16_t* yp = a.y + prow * a.ldy;
+  float gam[CH][8], bet[CH][8];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int col = (lane + 64 * c) * 8;
     if (col < a.H) {
       const f32x4 g0 = *(const f32x4*)(a.gamma + col), g1 = *(const f32x4*)(a.gamma + col + 4);
       const f32x4 b0 = *(const f32x4*)(a.beta + col), b1 = *(const f32x4*)(a.beta + col + 4);
-      float o[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        o[i] = (v[c][i] - u) * rs * g0[i] + b0[i];
-        o[4 + i] = (v[c][4 + i] - u) * rs * g1[i] + b1[i];
+      for (int i = 0; i < 4; ++i) { gam[c][i] = g0[i]; gam[c][4 + i] = g1[i]; bet[c][i] = b0[i]; bet[c][4 + i] = b1[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { gam[c][i] = 0.f; bet[c][i] = 0.f; }
+    }
+  }
+  const float invH = 1.0f / (float)a.H;
+  float u[LN_ROWS], rs[LN_ROWS];
+#pragma unroll
+  for (int r = 0; r < LN_ROWS; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s += bf16lo(w[r][c][i]) + bf16hi(w[r][c][i]);   // columns past H hold zeros
+    u[r] = s;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) u[r] += __shfl_xor(u[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < LN_ROWS; ++r) {
+    u[r] *= invH;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      if (col < a.H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d0 = bf16lo(w[r][c][i]) - u[r], d1 = bf16hi(w[r][c][i]) - u[r];
+          ss += d0 * d0 + d1 * d1;
+        }
       }
-      u32x4 w;
+    }
+    rs[r] = ss;
+  }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
-      *(u32x4*)(yp + col) = w;
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) rs[r] += __shfl_xor(rs[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < LN_ROWS; ++r) {
+    const int row = row0 + r;
+    if (row >= a.M) break;
+    const float rstd = 1.0f / sqrtf(rs[r] * invH + a.eps);
+    if (lane == 0) {
+      if (a.mean) a.mean[row] = u[r];
+      if (a.rstd) a.rstd[row] = rstd;
+    }
+    bf16_t* yp = a.y + prow[r] * a.ldy;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (lane + 64 * c) * 8;
+      if (col < a.H) {
+        u32x4 o4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float o0 = (bf16lo(w[r][c][i]) - u[r]) * rstd * gam[c][2 * i] + bet[c][2 * i];
+          const float o1 = (bf16hi(w[r][c][i]) - u[r]) * rstd * gam[c][2 * i + 1] + bet[c][2 * i + 1];
+          o4[i] = pack_bf16x2(o0, o1);
+        }
+        *(u32x4*)(yp + col) = o4;
+      }
     }
   }
 }
@@ -91,7 +127,7 @@ int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const floa
   LnArgs a;
   a.x = (const bf16_t*)x; a.ldx = ldx; a.y = (bf16_t*)y; a.ldy = ldy; a.gamma = gamma; a.beta = beta;
   a.mean = mean; a.rstd = rstd; a.M = M; a.H = H; a.grp_rows = grp_rows; a.grp_stride = grp_stride; a.eps = eps;
-  const dim3 grid((M + 3) / 4), block(256);
+  const dim3 grid((M + 15) / 16), block(256);   // 4 waves x 4 rows per workgroup
   const int ch = (H + 511) / 512;
   if (ch == 1) hipLaunchKernelGGL(layernorm_rows<1>, grid, block, 0, stream, a);
   else if (ch == 2) hipLaunchKernelGGL(layernorm_rows<2>, grid, block, 0, stream, a);
