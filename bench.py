@@ -227,6 +227,7 @@ def main():
         }
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()   # rank 0's kernel-timing replay and print are done before any rank tears the group down
         dist.destroy_process_group()
 
 
