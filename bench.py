@@ -221,6 +221,7 @@ def main():
             "fwd_samples_per_sec": None if fwd_value is None else round(fwd_value, 2),
             "mfma_frac_whole_forward": round(f_enc * (fwd_value if train else value) / world / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": roofline,
+            "device": device_info(dev),
             "cpu_baseline": cpu_baseline,
             "kernels_ms_per_step": None if kernels is None else {
                 k: round(v["ms"] / 3, 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])},
@@ -229,6 +230,18 @@ def main():
     if dist is not None:
         dist.barrier()   # rank 0's kernel-timing replay and print are done before any rank tears the group down
         dist.destroy_process_group()
+
+
+def device_info(dev):
+    """What the roofline constants refer to: the device as the runtime reports it (name, CU count, peak shader clock)
+    beside the peak used (dense bf16 MFMA, MI355X_MICROARCH.md)."""
+    pr = torch.cuda.get_device_properties(dev)
+    info = {"name": pr.name, "compute_units": pr.multi_processor_count, "peak_bf16_tflops_used": PEAK_BF16_TFLOPS,
+            "hbm_gib": round(pr.total_memory / 2 ** 30, 1)}
+    clk = getattr(pr, "clock_rate", None)
+    if clk:
+        info["max_shader_clock_mhz"] = round(clk / 1e3)
+    return info
 
 
 def run_cpu_baseline(cfg, T, R, train):
