@@ -465,5 +465,28 @@ def test_rccl_all_reduce_path_single_rank(dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
         assert float(t.item()) == 1.5
+
+        # the reference's own DDP wrapping (pretrain.py:96-102: DistributedDataParallel(model, device_ids=[...],
+        # find_unused_parameters=True)) around the drop-in module: loss.backward() must deliver every parameter's
+        # gradient through autograd so that DDP's hooks fire and its bucket all-reduce runs
+        from oracle.modeling import PreTrainOscar as OModel
+        from visitron_amd.modeling import PreTrainOscar
+
+        ref, prod2 = model_pair(OModel, PreTrainOscar, cfg, seed=29, device=dev)
+        prod2.train()
+        ddp = torch.nn.parallel.DistributedDataParallel(prod2, device_ids=[dev.index], find_unused_parameters=True)
+        bc = make_batch(cfg, 3, text_len=14, region_len=6, seed=8)
+        out2 = ddp(**{k: v.to(dev) for k, v in bc.items()})
+        loss = out2[0]
+        loss /= 1                                                     # pretrain.py:170 divides in place by world_size
+        loss.backward()
+        torch.cuda.synchronize()
+        ref.train()
+        want2 = ref(**bc)
+        want2[0].backward()
+        wg = dict(ref.named_parameters())
+        for n, p in prod2.named_parameters():
+            assert p.grad is not None, n
+            assert _rel(p.grad, wg[n].grad) < 0.08, n
     finally:
         dist.destroy_process_group()
