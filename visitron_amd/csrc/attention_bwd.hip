@@ -75,10 +75,13 @@ __device__ __forceinline__ void attn_bwd_keep16(const DropCfg& dr, uint32_t qbas
     const uint32_t par = key & 1u;
     const bool odd = par != 0;
     const uint32_t fsh = par << 4;   // this key's 16-bit field of the shared word
+    // pair index of (query q, this key) = q * (S/2) + (key >> 1): linear in q, so the hash's first multiply is taken
+    // once (for query qbase + par) and the other seven queries are reached by adding multiples of (S/2) * C1
+    const uint32_t qstep = (S >> 1) * VT_HASH_C1;
+    const uint32_t x0 = vt_hash_pre(dr.seed, (qbase + par) * (S >> 1) + (key >> 1));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t qm = qbase + (uint32_t)(((2 * j) & 3) + 8 * ((2 * j) >> 2)) + par;   // query of element 2j + par
-      const uint32_t hm = vt_hash32(dr.seed, (qm * S + key) >> 1);
+      const uint32_t hm = vt_hash_fin(x0 + (uint32_t)(((2 * j) & 3) + 8 * ((2 * j) >> 2)) * qstep);   // element 2j + par
       const uint32_t hp = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);   // the neighbour's: element 2j + 1 - par
       const uint32_t h0 = odd ? hp : hm, h1 = odd ? hm : hp;
       keep[2 * j] = ((h0 >> fsh) & 0xffffu) >= dr.thresh;

@@ -177,12 +177,14 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
           typedef __attribute__((ext_vector_type(8))) short short8v;
           u32x4 pbw;
           if (dr.thresh) {  // drop probabilities AFTER the row sum was taken (the normaliser uses all of them)
+            // S even: the tile's eight key pairs sit at fixed offsets from one pair index -> one multiply per half tile
+            const uint32_t xb = vt_hash_pre(dr.seed, (q_elem + (uint32_t)(kc + kt * 32 + 4 * h2)) >> 1);
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {   // elements i, i+1 are neighbouring keys: one hash for both (S even)
               const int i = 8 * s2 + j;
               const uint32_t e = q_elem + (uint32_t)(kc + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2);
               bool k0, k1;
-              if ((S & 1) == 0) vt_keep2(dr, e, k0, k1);
+              if ((S & 1) == 0) vt_keep2_pre(dr, xb + (uint32_t)(((i & 3) + 8 * (i >> 2)) >> 1) * VT_HASH_C1, k0, k1);
               else { k0 = vt_keep(dr, e); k1 = vt_keep(dr, e + 1); }
               sacc[i] = k0 ? sacc[i] * dr.scale : 0.f;
               sacc[i + 1] = k1 ? sacc[i + 1] * dr.scale : 0.f;

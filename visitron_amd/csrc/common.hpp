@@ -148,11 +148,16 @@ struct DropCfg {
   uint32_t seed;     // site seed
   float scale;       // 1 / (1 - p)
 };
-__host__ __device__ __forceinline__ uint32_t vt_hash32(uint32_t seed, uint32_t idx) {
-  uint32_t x = (idx ^ seed) * 0x9E3779B1u;
+// hash32(seed, idx) = fin((idx + seed) * C1).  The first multiply is LINEAR in idx, so a run of pair indices
+// base + k needs it once: pre(base + k) = pre(base) + k * C1 (an add of a constant); only the second multiply of
+// the finishing rounds is paid per hash word.
+#define VT_HASH_C1 0x9E3779B1u
+__host__ __device__ __forceinline__ uint32_t vt_hash_pre(uint32_t seed, uint32_t idx) { return (idx + seed) * VT_HASH_C1; }
+__host__ __device__ __forceinline__ uint32_t vt_hash_fin(uint32_t x) {
   x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13; x ^= x << 7; x ^= x >> 17;
   return x;
 }
+__host__ __device__ __forceinline__ uint32_t vt_hash32(uint32_t seed, uint32_t idx) { return vt_hash_fin(vt_hash_pre(seed, idx)); }
 __host__ __device__ __forceinline__ bool vt_keep(const DropCfg& d, uint32_t idx) {
   const uint32_t h = vt_hash32(d.seed, idx >> 1);
   return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= d.thresh;
@@ -164,13 +169,20 @@ __host__ __device__ __forceinline__ void vt_keep2(const DropCfg& d, uint32_t idx
   k1 = (h >> 16) >= d.thresh;
 }
 // v[0..N) *= keep / (1-p) for N consecutive elements starting at e0 (N even); pairs share a hash when e0 is even
+// the two keep flags of the pair whose pre-multiplied index is x (see vt_hash_pre)
+__host__ __device__ __forceinline__ void vt_keep2_pre(const DropCfg& d, uint32_t x, bool& k0, bool& k1) {
+  const uint32_t h = vt_hash_fin(x);
+  k0 = (h & 0xffffu) >= d.thresh;
+  k1 = (h >> 16) >= d.thresh;
+}
 template <int N>
 __device__ __forceinline__ void vt_drop_run(const DropCfg& d, uint32_t e0, float (&v)[N]) {
   if ((e0 & 1u) == 0) {
+    const uint32_t x0 = vt_hash_pre(d.seed, e0 >> 1);   // consecutive pairs: one multiply for the run
 #pragma unroll
     for (int i = 0; i < N; i += 2) {
       bool k0, k1;
-      vt_keep2(d, e0 + i, k0, k1);
+      vt_keep2_pre(d, x0 + (uint32_t)(i >> 1) * VT_HASH_C1, k0, k1);
       v[i] = k0 ? v[i] * d.scale : 0.f;
       v[i + 1] = k1 ? v[i + 1] * d.scale : 0.f;
     }
