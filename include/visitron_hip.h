@@ -202,6 +202,14 @@ int vt_lstm_sequence_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float
                          const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
                          int B, int hs, int T, int reverse, vt_stream_t stream);
 
+/* out[M,N] (fp32) = act([x0 | x1] . W^T + bias) for a handful of rows: the dense layers of the decoder step
+ * (AttnDecoderLSTM.forward, agent_models.py:406-425; SoftDotAttention.linear_in / linear_out :336, :354-355 with its
+ * torch.cat folded in).  x0 [M,K0], x1 [M,K1] (optional) fp32 with K0, K1 multiples of 4; W bf16 [N, Kpad] zero-padded
+ * past K0 + K1, Kpad a multiple of 32; act 0 = none, 2 = tanh. */
+int vt_skinny_linear_f32(const float* x0, int64_t ld0, int K0, const float* x1, int64_t ld1, int K1, const void* w,
+                         int64_t ldw, const float* bias, float* out, int64_t ldo, int M, int N, int Kpad, int act,
+                         vt_stream_t stream);
+
 /* SoftDotAttention.forward after linear_in (agent_models.py:336-349): attn[b,l] = context[b,l,:] . target[b,:];
  * mask (uint8 [B,L], nonzero = masked) -> -inf; softmax over l; weighted[b,:] = sum_l p[l] context[b,l,:].
  * context fp32 with element strides ld_batch / ld_row.  weighted (optional) fp32 [B,D]; attn (optional) fp32 [B,L]

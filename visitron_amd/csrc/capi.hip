@@ -57,6 +57,7 @@ int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream);
 #include "rollout_args.hpp"
 int vt_lstm_step_dispatch(const LstmStepArgs& a, hipStream_t stream);
 int vt_softdot_dispatch(const SoftDotArgs& a, hipStream_t stream);
+int vt_skinny_linear_dispatch(const SkinnyArgs& a, hipStream_t stream);
 
 extern "C" {
 
@@ -183,6 +184,15 @@ int vt_lstm_sequence_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float
       return VT_ERR_HIP;
   }
   return VT_OK;
+}
+
+int vt_skinny_linear_f32(const float* x0, int64_t ld0, int K0, const float* x1, int64_t ld1, int K1, const void* w,
+                         int64_t ldw, const float* bias, float* out, int64_t ldo, int M, int N, int Kpad, int act,
+                         vt_stream_t stream) {
+  SkinnyArgs a;
+  a.x0 = x0; a.ld0 = ld0; a.K0 = K0; a.x1 = x1; a.ld1 = ld1; a.K1 = K1; a.w = (const bf16_t*)w; a.ldw = ldw;
+  a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.Kpad = Kpad; a.act = act;
+  return vt_skinny_linear_dispatch(a, (hipStream_t)stream);
 }
 
 int vt_softdot_attention_f32(const float* target, const float* context, int64_t ld_batch, int64_t ld_row,

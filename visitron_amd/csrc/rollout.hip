@@ -99,15 +99,17 @@ int vt_lstm_step_dispatch(const LstmStepArgs& a, hipStream_t stream) {
 // One workgroup per batch row; logits / probabilities live in LDS.  fp32 throughout (the context is the caller's
 // fp32 feature tensor: the kernel is a pure read of it, twice, the second time from L2).
 
-__global__ __launch_bounds__(256) void softdot_kernel(SoftDotArgs a) {
-  extern __shared__ float sl[];          // [L] logits -> probabilities, then [8] reduction scratch
+#define SD_WAVES 16
+__global__ __launch_bounds__(64 * SD_WAVES) void softdot_kernel(SoftDotArgs a, int parts) {
+  extern __shared__ float sl[];          // [L] logits -> probabilities | [2 * SD_WAVES] reduction scratch | [parts][D] partial sums
   float* red = sl + a.L;
+  float* psum = red + 2 * SD_WAVES;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* ctx = a.context + (long)b * a.ld_batch;
   const float* tg = a.target + (long)b * a.D;
   const bool vec = ((a.D & 3) == 0) && ((a.ld_row & 3) == 0) && ((a.ld_batch & 3) == 0) &&
                    ((((uintptr_t)a.context) | ((uintptr_t)a.target)) & 15) == 0;
-  for (int l = wave; l < a.L; l += 4) {
+  for (int l = wave; l < a.L; l += SD_WAVES) {
     const float* row = ctx + (long)l * a.ld_row;
     float s = 0.f;
     if (vec) {
@@ -127,56 +129,69 @@ __global__ __launch_bounds__(256) void softdot_kernel(SoftDotArgs a) {
   }
   __syncthreads();
   if (a.attn && !a.output_prob)
-    for (int l = tid; l < a.L; l += 256) a.attn[(long)b * a.L + l] = sl[l];
+    for (int l = tid; l < a.L; l += 64 * SD_WAVES) a.attn[(long)b * a.L + l] = sl[l];
   if (!a.weighted && !(a.attn && a.output_prob)) return;
   // softmax over L
   float m = -INFINITY;
-  for (int l = tid; l < a.L; l += 256) m = fmaxf(m, sl[l]);
+  for (int l = tid; l < a.L; l += 64 * SD_WAVES) m = fmaxf(m, sl[l]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if (lane == 0) red[wave] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < SD_WAVES; ++w) m = fmaxf(m, red[w]);
   float z = 0.f;
-  for (int l = tid; l < a.L; l += 256) {
+  for (int l = tid; l < a.L; l += 64 * SD_WAVES) {
     const float e = expf(sl[l] - m);      // every key masked: -inf - -inf = NaN, as torch's softmax gives
     sl[l] = e;
     z += e;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
-  if (lane == 0) red[4 + wave] = z;
+  if (lane == 0) red[SD_WAVES + wave] = z;
   __syncthreads();
-  z = (red[4] + red[5]) + (red[6] + red[7]);
+  z = 0.f;
+#pragma unroll
+  for (int w = 0; w < SD_WAVES; ++w) z += red[SD_WAVES + w];
   const float inv = 1.0f / z;
-  for (int l = tid; l < a.L; l += 256) {
+  for (int l = tid; l < a.L; l += 64 * SD_WAVES) {
     const float p = sl[l] * inv;
     sl[l] = p;
     if (a.attn && a.output_prob) a.attn[(long)b * a.L + l] = p;
   }
   __syncthreads();
   if (!a.weighted) return;
-  if (vec) {
-    for (int d = tid * 4; d < a.D; d += 1024) {
+  // weighted[d] = sum_l p[l] ctx[l][d]: thread = (column group g, key part): part sums every parts-th key, the parts
+  // meet in LDS.  A masked key carries probability exactly 0 and is skipped (0 * inf must not appear).
+  const int gw = vec ? 4 : 1;
+  const int G = (a.D + gw - 1) / gw;
+  const int g = tid % G, part = tid / G;
+  if (tid < G * parts) {
+    if (vec) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int l = 0; l < a.L; ++l) {
+      for (int l = part; l < a.L; l += parts) {
         const float p = sl[l];
-        if (p != 0.f) {                   // masked keys carry probability exactly 0 (and 0 * inf must not appear)
-          const f32x4 c = *(const f32x4*)(ctx + (long)l * a.ld_row + d);
+        if (p != 0.f) {
+          const f32x4 c = *(const f32x4*)(ctx + (long)l * a.ld_row + 4 * g);
           acc[0] += p * c[0]; acc[1] += p * c[1]; acc[2] += p * c[2]; acc[3] += p * c[3];
         }
       }
-      *(f32x4*)(a.weighted + (long)b * a.D + d) = acc;
-    }
-  } else {
-    for (int d = tid; d < a.D; d += 256) {
+      *(f32x4*)(psum + (long)part * a.D + 4 * g) = acc;
+    } else {
       float acc = 0.f;
-      for (int l = 0; l < a.L; ++l) {
+      for (int l = part; l < a.L; l += parts) {
         const float p = sl[l];
-        if (p != 0.f) acc += p * ctx[(long)l * a.ld_row + d];
+        if (p != 0.f) acc += p * ctx[(long)l * a.ld_row + g];
       }
-      a.weighted[(long)b * a.D + d] = acc;
+      psum[(long)part * a.D + g] = acc;
     }
+  }
+  __syncthreads();
+  for (int d = tid; d < a.D; d += 64 * SD_WAVES) {
+    float acc = 0.f;
+    for (int q = 0; q < parts; ++q) acc += psum[(long)q * a.D + d];
+    a.weighted[(long)b * a.D + d] = acc;
   }
 }
 
@@ -185,6 +200,76 @@ int vt_softdot_dispatch(const SoftDotArgs& a, hipStream_t stream) {
   if (!a.weighted && !a.attn) return VT_ERR_NULL;
   if (a.B <= 0 || a.L <= 0 || a.D <= 0 || a.L > 8192) return VT_ERR_BAD_SHAPE;
   if (a.weighted && (((uintptr_t)a.weighted) & 15)) return VT_ERR_BAD_ALIGN;
-  hipLaunchKernelGGL(softdot_kernel, dim3(a.B), dim3(256), (size_t)(a.L + 8) * sizeof(float), stream, a);
+  const bool vec = ((a.D & 3) == 0) && ((a.ld_row & 3) == 0) && ((a.ld_batch & 3) == 0) &&
+                   ((((uintptr_t)a.context) | ((uintptr_t)a.target)) & 15) == 0;
+  const int G = vec ? a.D / 4 : a.D;
+  if (G > 64 * SD_WAVES) return VT_ERR_BAD_SHAPE;   // D <= 4096 (1024 unaligned)
+  int parts = (64 * SD_WAVES) / G;
+  if (parts > 8) parts = 8;                          // 8 x D floats of LDS
+  if (parts > a.L) parts = a.L;
+  const size_t lds = ((size_t)a.L + 2 * SD_WAVES + (size_t)parts * a.D) * sizeof(float);
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)softdot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VT_ERR_HIP;
+  hipLaunchKernelGGL(softdot_kernel, dim3(a.B), dim3(64 * SD_WAVES), lds, stream, a, parts);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense layer on a handful of rows (the decoder step's projections, agent_models.py:406-425: 64 or fewer rows against
+// weight matrices of 0.1-9 MB): out = act([x0 | x1] . W^T + bias) in fp32 from fp32 activations and bf16 weights.
+// The 256x256-tile GEMM would run such a shape on N/256 workgroups; here one workgroup = 16 output columns x 16 rows,
+// its 4 waves take every fourth 32-wide K-step (W rows on the MFMA A port, the activations converted to bf16 on the B
+// port, both straight from L2), partial sums meet in LDS.  Also folds the K-concatenation (torch.cat of the weighted
+// context and the query, :354) and the bf16 packing that the big kernel needs as separate launches.
+__global__ __launch_bounds__(256) void skinny_linear_kernel(SkinnyArgs a) {
+  __shared__ f32x4 part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int kl = (lane >> 4) * 8;
+  int wrow = n0 + (lane & 15);
+  wrow = wrow < a.N ? wrow : a.N - 1;
+  const int xrow = m0 + (lane & 15);
+  const bool xok = xrow < a.M;
+  const bf16_t* wp = a.w + (long)wrow * a.ldw + kl;
+  const float* p0 = a.x0 + (long)(xok ? xrow : 0) * a.ld0;
+  const float* p1 = a.x1 ? a.x1 + (long)(xok ? xrow : 0) * a.ld1 : nullptr;
+  const int K = a.K0 + a.K1;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = wave * 32; k < a.Kpad; k += 128) {
+    const int kk = k + kl;
+    f32x4 v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = kk + 4 * h;
+      v[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (xok && c < K) v[h] = c < a.K0 ? *(const f32x4*)(p0 + c) : *(const f32x4*)(p1 + (c - a.K0));   // K0, K % 4 == 0
+    }
+    u32x4 xb;
+    xb[0] = pack_bf16x2(v[0][0], v[0][1]); xb[1] = pack_bf16x2(v[0][2], v[0][3]);
+    xb[2] = pack_bf16x2(v[1][0], v[1][1]); xb[3] = pack_bf16x2(v[1][2], v[1][3]);
+    const u32x4 wv = *(const u32x4*)(wp + k);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  // thread (lane, r = wave): column n0 + 4*(lane/16) + r of row m0 + lane%16
+  const int n = n0 + 4 * (lane >> 4) + wave;
+  if (!xok || n >= a.N) return;
+  float s = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) s += ((const float*)&part[w][lane])[wave];
+  if (a.act == 2) s = tanhf_(s);
+  a.out[(long)xrow * a.ldo + n] = s;
+}
+
+int vt_skinny_linear_dispatch(const SkinnyArgs& a, hipStream_t stream) {
+  if (!a.x0 || !a.w || !a.out) return VT_ERR_NULL;
+  if (a.M <= 0 || a.N <= 0 || a.K0 <= 0 || a.K1 < 0 || (a.K1 > 0 && !a.x1)) return VT_ERR_BAD_SHAPE;
+  if ((a.K0 & 3) || (a.K1 & 3) || (a.Kpad & 31) || a.Kpad < a.K0 + a.K1 || a.ldw < a.Kpad) return VT_ERR_BAD_SHAPE;
+  if ((a.ld0 & 3) || (a.K1 && (a.ld1 & 3)) || (a.ldw & 7)) return VT_ERR_BAD_ALIGN;
+  if ((((uintptr_t)a.x0) | ((uintptr_t)a.x1) | ((uintptr_t)a.w)) & 15) return VT_ERR_BAD_ALIGN;
+  if (a.act != 0 && a.act != 2) return VT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(skinny_linear_kernel, dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }

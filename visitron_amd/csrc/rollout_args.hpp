@@ -22,3 +22,12 @@ struct SoftDotArgs {
   float* attn;                  // [B, L] or null: probabilities (output_prob) or the masked logits
   int B, L, D, output_prob;
 };
+
+struct SkinnyArgs {
+  const float* x0; long ld0; int K0;   // [M, K0] fp32
+  const float* x1; long ld1; int K1;   // [M, K1] fp32 or null: K-concatenated behind x0 (K0 % 4 == 0)
+  const bf16_t* w; long ldw;           // [N, Kpad] bf16, zero past K0 + K1; Kpad % 32 == 0
+  const float* bias;                   // [N] or null
+  float* out; long ldo;                // [M, N] fp32
+  int M, N, Kpad, act;                 // act: 0 none, 2 tanh
+};

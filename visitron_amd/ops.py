@@ -564,3 +564,24 @@ def lstm_sequence(xproj, h2, c, w_hh, T, lengths=None, seq_out=None, reverse=Fal
             B, hs, int(T), 1 if reverse else 0, _stream())
     _lib.check(rc, "vt_lstm_sequence_f32")
     return h2[0]
+
+
+def skinny_linear(x0, w_pad, bias=None, x1=None, act=ACT_NONE):
+    """act([x0 | x1] @ W.T + bias) in fp32 for a handful of rows: x0 [M,K0], x1 [M,K1] fp32 (row strides allowed, K0 and
+    K1 multiples of 4), w_pad bf16 [N, Kpad] zero-padded past K0 + K1 (Kpad a multiple of 32)."""
+    _require_hip(x0, x1, w_pad, bias)
+    assert x0.dtype == torch.float32 and x0.dim() == 2 and x0.stride(1) == 1
+    M, K0 = x0.shape
+    K1 = 0
+    if x1 is not None:
+        assert x1.dtype == torch.float32 and x1.shape[0] == M and x1.stride(1) == 1
+        K1 = x1.shape[1]
+    assert w_pad.dtype == BF16 and w_pad.stride(1) == 1
+    N, Kpad = w_pad.shape
+    out = torch.empty((M, N), dtype=torch.float32, device=x0.device)
+    with _timed("skinny_linear", 2.0 * M * N * (K0 + K1), 2.0 * N * Kpad):
+        rc = _lib.load().vt_skinny_linear_f32(
+            _ptr(x0), x0.stride(0), K0, _ptr(x1), 0 if x1 is None else x1.stride(0), K1, _ptr(w_pad), w_pad.stride(0),
+            _ptr(bias), _ptr(out), out.stride(0), M, N, Kpad, int(act), _stream())
+    _lib.check(rc, "vt_skinny_linear_f32")
+    return out

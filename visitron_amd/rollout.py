@@ -14,6 +14,9 @@ from . import ops
 from .ops import ACT_NONE, ACT_TANH, BF16, round_up
 
 
+SKINNY_ROWS = 256   # up to this many rows the dense layers take vt_skinny_linear_f32 instead of the tiled GEMM
+
+
 def _no_train_dropout(module, p):
     if module.training and p > 0.0:
         raise NotImplementedError("the rollout modules are served for inference (model.eval()); dropout p=%g in "
@@ -50,6 +53,9 @@ def _dense(x_parts, w_pad, bias=None, act=ACT_NONE):
     operand (vt_pack_concat_bf16), W pre-padded bf16 [N, kpad]."""
     s0 = _f32c(x_parts[0])
     s1 = _f32c(x_parts[1]) if len(x_parts) > 1 else None
+    if s0.shape[0] <= SKINNY_ROWS and s0.shape[1] % 4 == 0 and (s1 is None or s1.shape[1] % 4 == 0) \
+            and act in (ACT_NONE, ACT_TANH):
+        return ops.skinny_linear(s0, w_pad, bias, s1, act)   # a few rows: one launch, no packing pass
     a = ops.pack_concat(s0, s1, w_pad.shape[1])
     N = w_pad.shape[0]
     buf = torch.empty((a.shape[0], round_up(N, 4)), dtype=torch.float32, device=a.device)
