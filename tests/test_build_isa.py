@@ -60,3 +60,14 @@ def test_wgrad_v8_fragment_registers_are_left_alone(tmp_path):
         hit = [r for r in regs if 96 <= r <= 227]
         if hit:
             assert t.startswith("v_mov_b32 v22") and "0x3f803f80" in t, t   # the ones operand, set once at entry
+
+
+def test_generated_wgrad_step_is_current():
+    """visitron_amd/csrc/wgrad_v8_step.inc is generated (tools/gen_wgrad_step.py): the committed file must be what the
+    generator prints."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_wgrad_step.py")], check=True,
+                         stdout=subprocess.PIPE).stdout.decode()
+    assert out == open(os.path.join(CSRC, "wgrad_v8_step.inc")).read()
