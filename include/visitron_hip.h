@@ -64,7 +64,8 @@ int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const
                    const void* R, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int act,
                    int out_f32, int grp_rows, int grp_stride, vt_stream_t stream);
 
-/* Same, plus C2: optional second bf16 output saved for backward, row stride ldc2 -- gelu'(acc + bias)
+/* Same (same reference lines; in training also the dgrad GEMMs of loss.backward(), tasks/viewpoint_select/pretrain.py:191),
+ * plus C2: optional second bf16 output saved for backward, row stride ldc2 -- gelu'(acc + bias)
  * when act == VT_ACT_GELU (what the backward of BertIntermediate multiplies by), else acc + bias --
  * and act == VT_ACT_MUL (out = acc * R). */
 int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
@@ -126,7 +127,9 @@ int vt_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
                       const float* beta, float* mean, float* rstd, int M, int H, float eps,
                       int grp_rows, int grp_stride, vt_stream_t stream);
 
-/* Backward of vt_layernorm_bf16: dx, and dgamma / dbeta (fp32, overwritten or accumulated).  x is the
+/* Backward of vt_layernorm_bf16 (autograd of BertLayerNorm in BertSelfOutput / BertOutput, oscar/modeling_bert.py:94,120, and
+ * of the image LayerNorm, encoder.py:280-281, inside loss.backward(), pretrain.py:191): dx, and dgamma / dbeta (fp32,
+ * overwritten or accumulated).  x is the
  * pre-LayerNorm input (statistics are recomputed).  partial_ws: fp32 scratch of 1024 * 2 * H floats. */
 int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* gamma,
                           void* dx, int64_t lddx, float* dgamma, float* dbeta, float* partial_ws, int M, int H,
@@ -135,7 +138,8 @@ int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ld
 /* (dx_dropped, optional: dx * mask / (1-p) of the given site = the gradient of the dense output that was
  * dropped out before the residual add.) */
 
-/* out = g * d, bf16, n elements (n % 8 == 0), d = saved gelu' values: the dGELU of the MLM-head transform. */
+/* out = g * d, bf16, n elements (n % 8 == 0), d = saved gelu' values: the dGELU of the MLM-head transform
+ * (BertOnlyMLMHead's dense + gelu, constructed at encoder.py:322, in loss.backward(), pretrain.py:191). */
 int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_stream_t stream);
 
 /* BertEmbeddings (called at tasks/viewpoint_select/encoder.py:267-269): y[b*S + t, :] =
@@ -148,7 +152,8 @@ int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_
                        int n_word, int n_pos, int n_type, float eps, int* err_flag, float drop_p,
                        uint64_t drop_seed, vt_stream_t stream);
 
-/* Backward of vt_embed_layernorm: de[B*T,H] fp32 = gradient w.r.t. (word + pos + type) per token (for
+/* Backward of vt_embed_layernorm (autograd of the BertEmbeddings call, encoder.py:267-269, in loss.backward(),
+ * pretrain.py:191): de[B*T,H] fp32 = gradient w.r.t. (word + pos + type) per token (for
  * the three table scatter-adds), dgamma / dbeta of the embedding LayerNorm.  g: gradient rows b*S+t
  * of the [B,S,H] bf16 buffer.  partial_ws: 1024 * 2 * H floats. */
 int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids,
@@ -219,12 +224,13 @@ int vt_softdot_attention_f32(const float* target, const float* context, int64_t 
                              const uint8_t* mask, float* weighted, float* attn, int B, int L, int D, int output_prob,
                              vt_stream_t stream);
 
-/* out[c, r] = in[r, c] (bf16; R, C multiples of 8): refreshes the transposed weight copies that the
+/* out[c, r] = in[r, c] (bf16; R, C multiples of 8): refreshes the transposed weight copies (W^T of every nn.Linear on the
+ * path, oscar/modeling_bert.py:43-45,94,119,120) that the
  * dgrad GEMMs consume (vt_layer_weights_t). */
 int vt_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, vt_stream_t stream);
 
 /* vt_transpose_bf16 for n matrices in one launch (arrays of n entries each): the per-step refresh of all encoder
- * layers' transposed weight copies. */
+ * layers' and heads' transposed weight copies after optimizer.step() (pretrain.py:192). */
 int vt_transpose_batch_bf16(const void* const* in, const int64_t* ldi, void* const* out, const int64_t* ldo, const int* R,
                             const int* C, int n, vt_stream_t stream);
 
