@@ -322,6 +322,19 @@ int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weig
                              const vt_bwd_workspace* ws, int B, int S, int H, int nh, int I, float ln_eps,
                              int accumulate, float p_hidden, float p_attn, uint64_t drop_seed, int layer0,
                              vt_stream_t stream);
+
+/* The same loop with the weight gradients of layer l on side_stream while the main stream goes on with layer l-1
+ * (the grouped wgrad launch occupies 216 of 256 CUs; LayerNorm backward and the other non-persistent kernels of the next
+ * layer fill the rest).  ws_b: a second workspace whose g_pre, g_pre_d, g_pre2, g_pre2_d, g_mid and g_qkv are buffers of
+ * their own (the other members may alias ws's); layer l works in set (layer0 + l) & 1.  Ordering is by events created
+ * once per device inside the library; on return the main stream has been made to wait for every wgrad of the call.
+ * ws_b == NULL or side_stream == NULL / == stream: identical to vt_encoder_backward_bf16. */
+int vt_encoder_backward_overlap_bf16(const vt_layer_weights* layers, const vt_layer_weights_t* layers_t,
+                                     const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers,
+                                     const void* x, const float* mask, int mask_additive, void* g,
+                                     const vt_bwd_workspace* ws, const vt_bwd_workspace* ws_b, int B, int S, int H, int nh,
+                                     int I, float ln_eps, int accumulate, float p_hidden, float p_attn,
+                                     uint64_t drop_seed, int layer0, vt_stream_t stream, vt_stream_t side_stream);
 /* (p_hidden, p_attn, drop_seed: the values the forward used; layer0 = index of layers[0] in the full
  * stack when the backward is run over a sub-range of layers.) */
 

@@ -314,16 +314,49 @@ int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts*
 // 4 dgrad GEMMs (residual adds and the dGELU fused in their epilogues), 2 LayerNorm backwards, the
 // fused attention backward and ONE grouped weight-gradient launch for the layer's four matrices
 // (bias gradients ride along in it).
-int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weights_t* layers_t,
-                             const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers, const void* x,
-                             const float* mask, int mask_additive, void* g, const vt_bwd_workspace* ws, int B, int S,
-                             int H, int nh, int I, float ln_eps, int accumulate, float p_hidden, float p_attn,
-                             uint64_t drop_seed, int layer0, vt_stream_t stream_) {
-  if (!layers || !layers_t || !acts || !grads || !x || !g || !ws) return VT_ERR_NULL;
-  if (p_hidden > 0.f && (!ws->g_pre_d || !ws->g_pre2_d)) return VT_ERR_NULL;
+}  // extern "C"
+
+// Events that order the weight-gradient launches on the side stream against the dgrad chain (one pair per layer of
+// a call; created once per device, never destroyed: a few dozen host-side handles).
+#define VT_BWD_MAX_LAYERS 64
+static hipEvent_t* bwd_events(int which) {
+  static hipEvent_t ev[16][2][VT_BWD_MAX_LAYERS];
+  static bool made[16] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!made[dev]) {
+    for (int k = 0; k < 2; ++k)
+      for (int i = 0; i < VT_BWD_MAX_LAYERS; ++i)
+        if (hipEventCreateWithFlags(&ev[dev][k][i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    made[dev] = true;
+  }
+  return ev[dev][which];
+}
+
+// The reverse layer loop.  With a second workspace set (ws_b) and a side stream the four weight gradients of layer l
+// run on the side stream while the main stream goes on with layer l-1: the grouped wgrad launch keeps 216 of the 256
+// CUs busy (108 tiles x 2 row ranges), the next layer's LayerNorm backward and whatever else is not a persistent
+// kernel fills the rest.  Layer l works in workspace set (layer0 + l) & 1, so the buffers a wgrad still reads are
+// rewritten two layers later, behind a wait on that wgrad's completion event; before returning the main stream waits
+// for every wgrad of the call.
+static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_weights_t* layers_t,
+                                 const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers, const void* x,
+                                 const float* mask, int mask_additive, void* g, const vt_bwd_workspace* ws_a,
+                                 const vt_bwd_workspace* ws_b, int B, int S, int H, int nh, int I, float ln_eps,
+                                 int accumulate, float p_hidden, float p_attn, uint64_t drop_seed, int layer0,
+                                 hipStream_t stream, hipStream_t side) {
+  if (!layers || !layers_t || !acts || !grads || !x || !g || !ws_a) return VT_ERR_NULL;
+  const bool overlap = ws_b != nullptr && side != nullptr && side != stream;
+  for (int k = 0; k < (overlap ? 2 : 1); ++k) {
+    const vt_bwd_workspace* ws = k ? ws_b : ws_a;
+    if (p_hidden > 0.f && (!ws->g_pre_d || !ws->g_pre2_d)) return VT_ERR_NULL;
+    if (!ws->g_pre || !ws->g_pre2 || !ws->g_mid || !ws->g_ctx || !ws->g_qkv || !ws->delta || !ws->ln_partial) return VT_ERR_NULL;
+  }
   if (num_layers <= 0 || B <= 0 || S <= 0 || nh <= 0 || H != nh * 64 || (I % 64)) return VT_ERR_BAD_SHAPE;
-  if (!ws->g_pre || !ws->g_pre2 || !ws->g_mid || !ws->g_ctx || !ws->g_qkv || !ws->delta || !ws->ln_partial) return VT_ERR_NULL;
-  hipStream_t stream = (hipStream_t)stream_;
+  if (overlap && num_layers > VT_BWD_MAX_LAYERS) return VT_ERR_BAD_SHAPE;
+  hipEvent_t* ev_in = overlap ? bwd_events(0) : nullptr;    // E[l]: layer l's wgrad operands are complete (main)
+  hipEvent_t* ev_done = overlap ? bwd_events(1) : nullptr;  // F[l]: layer l's wgrad has finished (side)
+  if (overlap && (!ev_in || !ev_done)) return VT_ERR_HIP;
   const int M = B * S;
   for (int l = num_layers - 1; l >= 0; --l) {
     const vt_layer_weights& w = layers[l];
@@ -332,6 +365,9 @@ int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weig
     const vt_layer_grads& d = grads[l];
     if (!a.mid_pre || !a.lse) return VT_ERR_NULL;
     const void* x_in = l == 0 ? x : acts[l - 1].out;
+    const vt_bwd_workspace* ws = (overlap && ((layer0 + l) & 1)) ? ws_b : ws_a;
+    // this layer rewrites the set that the wgrad of layer l + 2 reads
+    if (overlap && l + 2 < num_layers && hipStreamWaitEvent(stream, ev_done[l + 2], 0) != hipSuccess) return VT_ERR_HIP;
     int rc;
     // dropout sites of this layer (the forward used layer index layer0 + l)
     const DropCfg d_att = vt_make_drop(p_attn, drop_seed, VT_SITE_ATTN(layer0 + l));
@@ -377,10 +413,42 @@ int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weig
     set(2, ws->g_qkv, 3L * H, x_in, H, d.d_w_qkv, d.d_b_qkv, 3 * H, H);
     set(3, g_pre2_dn, H, a.ctx, H, d.d_w_ao, d.d_b_ao, H, H);
     for (int i = 4; i < WG_MAX_PROBLEMS; ++i) wa.p[i] = wa.p[0];
-    rc = vt_wgrad_dispatch(wa, stream);
-    if (rc) return rc;
+    if (overlap) {
+      if (hipEventRecord(ev_in[l], stream) != hipSuccess || hipStreamWaitEvent(side, ev_in[l], 0) != hipSuccess) return VT_ERR_HIP;
+      rc = vt_wgrad_dispatch(wa, side);
+      if (rc) return rc;
+      if (hipEventRecord(ev_done[l], side) != hipSuccess) return VT_ERR_HIP;
+    } else {
+      rc = vt_wgrad_dispatch(wa, stream);
+      if (rc) return rc;
+    }
   }
+  if (overlap)   // the caller's next work on the main stream (all-reduce, optimizer) sees every weight gradient
+    for (int l = (num_layers < 2 ? num_layers : 2) - 1; l >= 0; --l)
+      if (hipStreamWaitEvent(stream, ev_done[l], 0) != hipSuccess) return VT_ERR_HIP;
   return VT_OK;
+}
+
+extern "C" {
+
+int vt_encoder_backward_bf16(const vt_layer_weights* layers, const vt_layer_weights_t* layers_t,
+                             const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers, const void* x,
+                             const float* mask, int mask_additive, void* g, const vt_bwd_workspace* ws, int B, int S,
+                             int H, int nh, int I, float ln_eps, int accumulate, float p_hidden, float p_attn,
+                             uint64_t drop_seed, int layer0, vt_stream_t stream) {
+  return encoder_backward_impl(layers, layers_t, acts, grads, num_layers, x, mask, mask_additive, g, ws, nullptr, B, S, H,
+                               nh, I, ln_eps, accumulate, p_hidden, p_attn, drop_seed, layer0, (hipStream_t)stream, nullptr);
+}
+
+int vt_encoder_backward_overlap_bf16(const vt_layer_weights* layers, const vt_layer_weights_t* layers_t,
+                                     const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers,
+                                     const void* x, const float* mask, int mask_additive, void* g,
+                                     const vt_bwd_workspace* ws, const vt_bwd_workspace* ws_b, int B, int S, int H, int nh,
+                                     int I, float ln_eps, int accumulate, float p_hidden, float p_attn,
+                                     uint64_t drop_seed, int layer0, vt_stream_t stream, vt_stream_t side_stream) {
+  return encoder_backward_impl(layers, layers_t, acts, grads, num_layers, x, mask, mask_additive, g, ws, ws_b, B, S, H, nh,
+                               I, ln_eps, accumulate, p_hidden, p_attn, drop_seed, layer0, (hipStream_t)stream,
+                               (hipStream_t)side_stream);
 }
 
 }  // extern "C"

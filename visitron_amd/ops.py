@@ -450,9 +450,19 @@ def dgelu_mul(g, h, out=None):
 
 
 def encoder_backward(layer_weights, layer_weights_t, layer_acts, layer_grads, x, mask, mask_additive, g, ws,
-                     B, S, H, nh, I, eps, accumulate=False, p_hidden=0.0, p_attn=0.0, drop_seed=0, layer0=0):
-    """Reverse layer loop in C; g [B*S,H] bf16 is updated in place to dL/dx."""
+                     B, S, H, nh, I, eps, accumulate=False, p_hidden=0.0, p_attn=0.0, drop_seed=0, layer0=0,
+                     ws_b=None, side_stream=None):
+    """Reverse layer loop in C; g [B*S,H] bf16 is updated in place to dL/dx.  With a second workspace set and a side
+    stream (torch.cuda.Stream) the weight gradients of a layer run beside the next layer's dgrad chain."""
     _require_hip(x, mask, g)
+    if ws_b is not None and side_stream is not None:
+        rc = _lib.load().vt_encoder_backward_overlap_bf16(
+            layer_weights, layer_weights_t, layer_acts, layer_grads, len(layer_weights), _ptr(x), _ptr(mask),
+            1 if mask_additive else 0, _ptr(g), ctypes.byref(ws), ctypes.byref(ws_b), B, S, H, nh, I, float(eps),
+            1 if accumulate else 0, float(p_hidden), float(p_attn), int(drop_seed), int(layer0), _stream(),
+            ctypes.c_void_p(side_stream.cuda_stream))
+        _lib.check(rc, "vt_encoder_backward_overlap_bf16")
+        return
     rc = _lib.load().vt_encoder_backward_bf16(
         layer_weights, layer_weights_t, layer_acts, layer_grads, len(layer_weights), _ptr(x), _ptr(mask),
         1 if mask_additive else 0, _ptr(g), ctypes.byref(ws), B, S, H, nh, I, float(eps), 1 if accumulate else 0,
