@@ -170,12 +170,11 @@ class PretrainEngine(object):
         self.last_drop_seed = 0
         self._wt_dirty = True
         self._wt_batch = None
-        # weight gradients on a side stream beside the next layer's dgrad chain.  Measured: +1 % when the GEMMs are the
-        # one-tile-per-workgroup kernels (the multi-rank case, where the persistent kernel is not used), -1 % with the
-        # persistent kernel (its workgroups queue behind the wgrad's and still do a full share each) -> on for
-        # world > 1 only; VT_OVERLAP_WGRAD=0/1 overrides
-        ov = os.environ.get("VT_OVERLAP_WGRAD")
-        self.overlap_wgrad = (self.world > 1) if ov is None else (ov != "0")
+        # weight gradients on a side stream beside the next layer's dgrad chain: opt-in (VT_OVERLAP_WGRAD=1 or the
+        # attribute).  Measured on one GPU: +1 % when the GEMMs are the one-tile-per-workgroup kernels, -1 % with the
+        # persistent kernel (its workgroups queue behind the wgrad's and still do a full share each); with a second
+        # process on the same GPU it lost a lot, and beside RCCL's kernels it could not be measured here.
+        self.overlap_wgrad = os.environ.get("VT_OVERLAP_WGRAD", "0") != "0"
         self._side_stream = None
         self._build_tables()
 
