@@ -51,6 +51,9 @@ def main():
                          "params.py:299, and BERT-base attention_probs_dropout_prob 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-fwd-rate", action="store_true",
+                    help="skip the forward-only rate measured after the timed region (profiler runs: the trace then "
+                         "holds the timed step's kernels only)")
     a = ap.parse_args()
     if a.batch is None:
         a.batch = 256 if a.mode == "train" else 64
@@ -139,7 +142,7 @@ def main():
 
     # forward-only rate in the same process (train mode): not part of the timed region above
     fwd_value = None
-    if train:
+    if train and not a.no_fwd_rate:
         for _ in range(3):
             fwd_step()
         sync_all()
@@ -219,7 +222,8 @@ def main():
             "encoder_flops_per_seq_fwd": f_enc,
             "mfma_frac_whole_step": round((3 if train else 1) * f_enc * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
             "fwd_samples_per_sec": None if fwd_value is None else round(fwd_value, 2),
-            "mfma_frac_whole_forward": round(f_enc * (fwd_value if train else value) / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "mfma_frac_whole_forward": (None if (train and fwd_value is None) else
+                                        round(f_enc * (fwd_value if train else value) / world / (PEAK_BF16_TFLOPS * 1e12), 4)),
             "roofline": roofline,
             "device": device_info(dev),
             "cpu_baseline": cpu_baseline,

@@ -147,6 +147,11 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
     if key in _tuned:
         return _tuned[key]
     lib = _lib.load()
+    saved = _tune_file_table().get("%d,%d,%d,%d" % key)
+    if saved is not None and (saved != 16 or PERSISTENT_GEMM_OK):   # VT_TUNE_FILE: a previous run's choices
+        lib.vt_gemm_tune(M, N, K, act, int(saved))
+        _tuned[key] = int(saved)
+        return _tuned[key]
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g).to(device, BF16)
     w = (torch.randn(N, K, generator=g) * 0.03).to(device, BF16)
@@ -179,7 +184,36 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
     lib.vt_debug_set_gemm_variant(-1)
     lib.vt_gemm_tune(M, N, K, act, best)
     _tuned[key] = best
+    _tune_file_store(key, best)
     return best
+
+
+_tune_file = None
+
+
+def _tune_file_table():
+    """VT_TUNE_FILE=<json>: the autotuner's choices are read from / added to this file, so a later process (a profiler
+    run, a serving start-up) skips the timing launches.  Unset: no file."""
+    global _tune_file
+    if _tune_file is None:
+        _tune_file = {}
+        path = os.environ.get("VT_TUNE_FILE")
+        if path and os.path.exists(path):
+            import json
+            with open(path) as fh:
+                _tune_file = dict(json.load(fh))
+    return _tune_file
+
+
+def _tune_file_store(key, best):
+    path = os.environ.get("VT_TUNE_FILE")
+    if not path:
+        return
+    import json
+    tab = _tune_file_table()
+    tab["%d,%d,%d,%d" % key] = int(best)
+    with open(path, "w") as fh:
+        json.dump(tab, fh, indent=0, sort_keys=True)
 
 
 def autotune_encoder_shapes(M, H, I, training=False, device="cuda"):
