@@ -177,10 +177,10 @@ def main():
             # HBM bytes per launch of the same kernels: not measurable from inside this process; taken from the
             # committed PMC passes of this command (profiles/README.md), null when that file is absent
             traffic, traffic_src = None, None
-            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "train_b256_pmc_hbm_traffic_v3.json")
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "train_b256_pmc_hbm_traffic_v5.json")
             if train and a.batch == 256 and os.path.exists(tp):
                 tj = json.load(open(tp))
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01/train_b256_pmc_hbm_traffic_v3.json"
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01/train_b256_pmc_hbm_traffic_v5.json"
             roofline = {
                 "kernel": "gemm_nt_bf16 (NT GEMM family; per shape the autotuner picks among the persistent 256x256-tile "
                           "kernel with 128x128 wave tiles / AGPR accumulators and the older 128x128 .. 256x256 tiles)",
