@@ -335,6 +335,34 @@ int vt_encoder_backward_overlap_bf16(const vt_layer_weights* layers, const vt_la
                                      const vt_bwd_workspace* ws, const vt_bwd_workspace* ws_b, int B, int S, int H, int nh,
                                      int I, float ln_eps, int accumulate, float p_hidden, float p_attn,
                                      uint64_t drop_seed, int layer0, vt_stream_t stream, vt_stream_t side_stream);
+
+/* ---- compacted rows: the training step without its padding rows ------------------------------------------------
+ * The reference computes every position of the padded [B, S] batch (text tails and missing regions carry attention
+ * mask 0, data_loader_pretrain.py:666-690).  Nothing in a training step reads those rows: as keys they get probability
+ * exactly 0 (encoder.py:238-241: -10000 underflows in the softmax), their labels are -1, their gradient is exactly 0.
+ * The *_seq_* entry points run the same kernels on the `rows` real rows only: sequence b occupies rows seq_start[b] ..
+ * seq_start[b] + seq_len[b] of every activation (seq_len[b] <= S), all of its keys are attended (no mask argument);
+ * lse / delta keep their [B, nh, S] layout.  Losses and gradients equal the padded run's; outputs AT padding positions
+ * do not exist, so inference keeps the padded entry points. */
+int vt_attention_fwd_seq_bf16(const void* qkv, int64_t ld_qkv, const float* head_scale, void* ctx, int64_t ld_ctx,
+                              float* lse, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
+                              uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, vt_stream_t stream);
+int vt_attention_bwd_seq_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
+                              int64_t ld_ctx, const float* lse, float* delta_ws, void* dqkv, int64_t ld_dqkv,
+                              float* dq32_ws, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
+                              uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, int64_t rows,
+                              vt_stream_t stream);
+int vt_encoder_forward_seq_bf16(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers, const void* x,
+                                const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps, float p_hidden,
+                                float p_attn, uint64_t drop_seed, int64_t rows, const int32_t* seq_start,
+                                const int32_t* seq_len, vt_stream_t stream);
+/* (ws_b / side_stream as in vt_encoder_backward_overlap_bf16; both may be NULL) */
+int vt_encoder_backward_seq_bf16(const vt_layer_weights* layers, const vt_layer_weights_t* layers_t,
+                                 const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers, const void* x,
+                                 void* g, const vt_bwd_workspace* ws, const vt_bwd_workspace* ws_b, int B, int S, int H,
+                                 int nh, int I, float ln_eps, int accumulate, float p_hidden, float p_attn,
+                                 uint64_t drop_seed, int layer0, int64_t rows, const int32_t* seq_start,
+                                 const int32_t* seq_len, vt_stream_t stream, vt_stream_t side_stream);
 /* (p_hidden, p_attn, drop_seed: the values the forward used; layer0 = index of layers[0] in the full
  * stack when the backward is run over a sub-range of layers.) */
 

@@ -671,3 +671,79 @@ def test_transpose_batch(dev):
             assert float(out[:, R:r8].abs().max()) == 0.0 and float(out[:, r8:].min()) == 7.0
     with pytest.raises(AssertionError):
         ops.TransposeBatch([(pairs[0][0], pairs[1][1])])   # shape mismatch is refused on the host
+
+
+@pytest.mark.parametrize("B,S,nh,waves", [(5, 228, 3, 8), (3, 300, 2, 8), (4, 228, 2, 4), (2, 656, 1, 8)])
+def test_attention_on_compacted_rows_equals_masked_padded_run(dev, B, S, nh, waves):
+    """The *_seq_* attention entry points (rows of padded keys dropped, per-sequence start / length) against the padded
+    kernels with the same keys masked: context rows, log-sum-exp and the packed q|k|v gradient of the real rows agree."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    H = nh * 64
+    lens = torch.randint(S // 3, S + 1, (B,), generator=g)
+    lens[0] = S                                        # one full sequence, one short
+    lens[-1] = max(1, S // 5)
+    keep = torch.arange(S)[None, :] < lens[:, None]
+    qkv = _rand((B * S, 3 * H), g, 0.8).to(dev, BF16)
+    # in a training step the context gradient of a padding row is exactly zero (nothing reads that row); a padded QUERY
+    # with a gradient would otherwise add to the real keys' dK / dV
+    dctx = (_rand((B * S, H), g) * keep.reshape(-1, 1).float()).to(dev, BF16)
+    mask = keep.float().to(dev)
+    ops.set_attn_bwd_waves(waves)
+    try:
+        lse_p = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
+        ctx_p = ops.attention_fwd(qkv, B, S, nh, mask=mask, lse=lse_p)
+        dq_p = ops.attention_bwd(qkv, dctx, ctx_p, lse_p, B, S, nh, mask=mask)
+        seq = ops.SeqLayout(keep.to(dev))
+        assert seq.rows == int(lens.sum())
+        qkv_c = qkv.index_select(0, seq.index).contiguous()
+        dctx_c = dctx.index_select(0, seq.index).contiguous()
+        lse_c = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
+        ctx_c = ops.attention_fwd(qkv_c, B, S, nh, lse=lse_c, seq=seq)
+        dq_c = ops.attention_bwd(qkv_c, dctx_c, ctx_c, lse_c, B, S, nh, seq=seq)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_attn_bwd_waves(8)
+    assert ctx_c.shape == (seq.rows, H) and dq_c.shape == (seq.rows, 3 * H)
+    assert maxabs(ctx_c, ctx_p.index_select(0, seq.index)) < 1e-6
+    kq = keep[:, None, :].expand(B, nh, S)
+    assert maxabs(lse_c.cpu()[kq], lse_p.cpu()[kq]) < 1e-5
+    want = dq_p.index_select(0, seq.index).float()
+    assert maxabs(dq_c, want) <= 2e-2 * float(want.abs().max())          # (dQ sums run over fewer zero terms)
+    # the padded run's gradient at the padding rows: dK, dV are exactly zero there (masked keys weigh nothing)
+    pad_rows = torch.nonzero(~keep.reshape(-1)).flatten().to(dev)
+    if pad_rows.numel():
+        assert float(dq_p.index_select(0, pad_rows)[:, H:].float().abs().max()) == 0.0
+
+
+def test_attention_dropout_on_compacted_rows_matches_autograd(dev):
+    """Dropout on compacted rows: the element index is q * len_b + key (the sequence's own length); torch reference on
+    the kernel's own keep-mask, per sequence."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(12)
+    B, S, nh = 3, 64, 2
+    H = nh * 64
+    lens = torch.tensor([64, 40, 17])
+    keep = torch.arange(S)[None, :] < lens[:, None]
+    seq = ops.SeqLayout(keep.to(dev))
+    drop = (0.2, 99, ops.site_attn(1))
+    qkv = _rand((seq.rows, 3 * H), g, 0.8)
+    dctx = _rand((seq.rows, H), g)
+    lse = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
+    ctx = ops.attention_fwd(qkv.to(dev, BF16), B, S, nh, lse=lse, drop=drop, seq=seq)
+    dq = ops.attention_bwd(qkv.to(dev, BF16), dctx.to(dev, BF16), ctx, lse, B, S, nh, drop=drop, seq=seq)
+    torch.cuda.synchronize()
+    off = 0
+    for b in range(B):
+        n = int(lens[b])
+        x = qkv[off:off + n].to(BF16).float().requires_grad_(True)
+        t = x.view(n, 3, nh, 64).permute(1, 2, 0, 3)
+        p = torch.softmax(t[0] @ t[1].transpose(-1, -2) / 8.0, -1)
+        km = torch.stack([ops.dropout_mask(n * n, drop, head_index=b * nh + h, device=dev).view(n, n) for h in range(nh)]).float().cpu()
+        o = ((p * km / 0.8) @ t[2]).permute(1, 0, 2).reshape(n, H)
+        o.backward(dctx[off:off + n].to(BF16).float())
+        assert maxabs(ctx[off:off + n], o.detach()) < 3e-2
+        assert maxabs(dq[off:off + n], x.grad) < 3e-2 * (1 + float(x.grad.abs().max()))
+        off += n

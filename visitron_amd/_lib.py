@@ -97,6 +97,19 @@ SIGNATURES = {
                                                  c_void_p, c_int, c_void_p, ctypes.POINTER(BwdWorkspace),
                                                  ctypes.POINTER(BwdWorkspace), c_int, c_int, c_int, c_int, c_int, c_float,
                                                  c_int, c_float, c_float, c_uint64, c_int, c_void_p, c_void_p]),
+    "vt_attention_fwd_seq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int]
+                                  + DROP + [c_void_p, c_void_p, c_void_p]),
+    "vt_attention_bwd_seq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                          c_int64, c_void_p, c_int, c_int, c_int, c_int] + DROP
+                                  + [c_void_p, c_void_p, c_int64, c_void_p]),
+    "vt_encoder_forward_seq_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerActs), c_int, c_void_p, c_void_p,
+                                            c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_uint64, c_int64,
+                                            c_void_p, c_void_p, c_void_p]),
+    "vt_encoder_backward_seq_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerWeightsT),
+                                             ctypes.POINTER(LayerActs), ctypes.POINTER(LayerGrads), c_int, c_void_p, c_void_p,
+                                             ctypes.POINTER(BwdWorkspace), ctypes.POINTER(BwdWorkspace), c_int, c_int, c_int,
+                                             c_int, c_int, c_float, c_int, c_float, c_float, c_uint64, c_int, c_int64,
+                                             c_void_p, c_void_p, c_void_p, c_void_p]),
     "vt_attention_fwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_int, c_int, c_int, c_int] + DROP + [c_void_p]),
     "vt_layernorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -37,6 +37,8 @@ struct AttnBwdArgs {
   float* dq32;          // [B*S, nh*64] fp32 accumulation slab (zeroed) when S > 256, else null
   long ld_qkv, ld_d, ld_dqkv;
   int B, S, nh;
+  const int* seq_start;   // compacted rows (see attention_fwd.hip): sequence b = rows seq_start[b] .. + seq_len[b];
+  const int* seq_len;     // lse / delta keep their [B, nh, S] layout.  Null: sequence b = rows b*S .. b*S + S
   float scale;          // 1 / sqrt(head_size)
   DropCfg drop;         // the forward's attention-probability dropout (same seed / indexing)
 };
@@ -101,13 +103,16 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   const int r = lane & 31, h2 = lane >> 5;
   const int b = blockIdx.y, head = blockIdx.x;
   const int kb0 = blockIdx.z * 256;   // first key of this workgroup's key block
-  const int S = a.S, H = a.nh * 64;
+  const int Smax = a.S, H = a.nh * 64;
+  const int S = a.seq_len ? a.seq_len[b] : a.S;                       // this sequence's rows
+  const long row0 = a.seq_start ? (long)a.seq_start[b] : (long)b * a.S;
+  if (kb0 >= S) return;                                               // uniform: a key block past a short sequence
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  const bf16_t* base = a.qkv + (long)b * S * a.ld_qkv + head * 64;
-  const bf16_t* dobase = a.dctx + (long)b * S * a.ld_d + head * 64;
-  const float* lse_p = a.lse + ((long)b * a.nh + head) * S;
-  const float* del_p = a.delta + ((long)b * a.nh + head) * S;
+  const bf16_t* base = a.qkv + row0 * a.ld_qkv + head * 64;
+  const bf16_t* dobase = a.dctx + row0 * a.ld_d + head * 64;
+  const float* lse_p = a.lse + ((long)b * a.nh + head) * Smax;
+  const float* del_p = a.delta + ((long)b * a.nh + head) * Smax;
   const int nslices = (S + 31) >> 5;
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
     if (key < S) {
       add = 0.f;
       if (a.mask) {
-        const float mval = a.mask[(long)b * S + key];
+        const float mval = a.mask[(long)b * Smax + key];
         add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
       }
     }
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
           u32x2 w;
           w[0] = pack_bf16x2(v[0], v[1]);
           w[1] = pack_bf16x2(v[2], v[3]);
-          *(u32x2*)(a.dqkv + ((long)b * S + q) * a.ld_dqkv + head * 64 + 16 * wave + 4 * g) = w;
+          *(u32x2*)(a.dqkv + (row0 + q) * a.ld_dqkv + head * 64 + 16 * wave + 4 * g) = w;
         }
       }
     } else {
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
       for (int rr = 0; rr < 8; ++rr) {
         const int ql = 8 * wave + rr;
         const int q = sl * 32 + ql;
-        if (q < S) atomicAdd(a.dq32 + ((long)b * S + q) * H + head * 64 + lane, st[ql * 64 + lane]);
+        if (q < S) atomicAdd(a.dq32 + (row0 + q) * H + head * 64 + lane, st[ql * 64 + lane]);
       }
       // the staging tile is rewritten only after the next slice's barrier, which every wave reaches
       // after these reads
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   for (int kt = 0; kt < 2; ++kt) {
     const int key = kb0 + 64 * wave + 32 * kt + r;
     if (key >= S) continue;
-    bf16_t* orow = a.dqkv + ((long)b * S + key) * a.ld_dqkv + head * 64 + 16 * h2;
+    bf16_t* orow = a.dqkv + (row0 + key) * a.ld_dqkv + head * 64 + 16 * h2;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       u32x4 k0, k1, v0, v1;
@@ -403,13 +408,16 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   const int r = lane & 31, h2 = lane >> 5;
   const int b = blockIdx.y, head = blockIdx.x;
   const int kb0 = blockIdx.z * 256;   // first key of this workgroup's key block
-  const int S = a.S, H = a.nh * 64;
+  const int Smax = a.S, H = a.nh * 64;
+  const int S = a.seq_len ? a.seq_len[b] : a.S;                       // this sequence's rows
+  const long row0 = a.seq_start ? (long)a.seq_start[b] : (long)b * a.S;
+  if (kb0 >= S) return;                                               // uniform: a key block past a short sequence
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  const bf16_t* base = a.qkv + (long)b * S * a.ld_qkv + head * 64;
-  const bf16_t* dobase = a.dctx + (long)b * S * a.ld_d + head * 64;
-  const float* lse_p = a.lse + ((long)b * a.nh + head) * S;
-  const float* del_p = a.delta + ((long)b * a.nh + head) * S;
+  const bf16_t* base = a.qkv + row0 * a.ld_qkv + head * 64;
+  const bf16_t* dobase = a.dctx + row0 * a.ld_d + head * 64;
+  const float* lse_p = a.lse + ((long)b * a.nh + head) * Smax;
+  const float* del_p = a.delta + ((long)b * a.nh + head) * Smax;
   const int nslices = (S + 31) >> 5;
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
     if (key < S) {
       add = 0.f;
       if (a.mask) {
-        const float mval = a.mask[(long)b * S + key];
+        const float mval = a.mask[(long)b * Smax + key];
         add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
       }
     }
@@ -645,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
         u32x2 w;
         w[0] = pack_bf16x2(dq0[0], dq0[1]);
         w[1] = pack_bf16x2(dq0[2], dq0[3]);
-        *(u32x2*)(a.dqkv + ((long)b * S + q) * a.ld_dqkv + head * 64 + 16 * dqd + 4 * g) = w;
+        *(u32x2*)(a.dqkv + (row0 + q) * a.ld_dqkv + head * 64 + 16 * dqd + 4 * g) = w;
       }
     } else {
       // several key blocks: transpose the slice's dQ^T through LDS, then add whole 256-byte row
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       for (int rr = 0; rr < 4; ++rr) {
         const int ql = 4 * wave + rr;
         const int q = sl * 32 + ql;
-        if (q < S) atomicAdd(a.dq32 + ((long)b * S + q) * H + head * 64 + lane, st[ql * 64 + lane]);
+        if (q < S) atomicAdd(a.dq32 + (row0 + q) * H + head * 64 + lane, st[ql * 64 + lane]);
       }
       // the staging tile is rewritten only after the next slice's barrier, which every wave reaches
       // after these reads
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   for (int kt = 0; kt < 1; ++kt) {
     const int key = kb0 + 32 * wave + r;
     if (key >= S) continue;
-    bf16_t* orow = a.dqkv + ((long)b * S + key) * a.ld_dqkv + head * 64 + 16 * h2;
+    bf16_t* orow = a.dqkv + (row0 + key) * a.ld_dqkv + head * 64 + 16 * h2;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       u32x4 k0, k1, v0, v1;
@@ -690,13 +698,16 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   }
 }
 
-// delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]   (one wave per token row; 64 d per head = 8 lanes x 8)
+// delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]   (one wave per token row; 64 d per head = 8 lanes x 8).
+// grid = (ceil(S / 4), B): row s of sequence b, which starts at seq_start[b] (or b * S) and has seq_len[b] (or S) rows.
 __global__ __launch_bounds__(256) void attn_delta_rows(const bf16_t* __restrict__ d_o, long ld_d, const bf16_t* __restrict__ o,
-                                                       long ld_o, float* __restrict__ delta, int B, int S, int nh) {
+                                                       long ld_o, float* __restrict__ delta, int B, int S, int nh,
+                                                       const int* __restrict__ seq_start, const int* __restrict__ seq_len) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)B * S) return;
-  const int b = (int)(row / S), s = (int)(row - (long)b * S);
+  const int b = blockIdx.y, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int len = seq_len ? seq_len[b] : S;
+  if (s >= len) return;
+  const long row = (seq_start ? (long)seq_start[b] : (long)b * S) + s;
   const int nchunks = nh * 8;  // 8-element chunks per row
   for (int c = lane; c < nchunks; c += 64) {
     const u32x4 x = *(const u32x4*)(d_o + row * ld_d + c * 8);
@@ -733,7 +744,8 @@ void vt_attn_bwd_set_waves(int w) { g_attn_bwd_waves = (w == 4) ? 4 : 8; }
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
                               long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream,
-                              const DropCfg* drop = nullptr) {
+                              const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr,
+                              long rows_total = 0) {
   if (mask_additive == 2) return VT_ERR_UNSUPPORTED;   // per-query masks: forward / probabilities only
   if (!qkv || !dctx || !ctx || !lse || !delta_ws || !dqkv) return VT_ERR_NULL;
   if (head_size != 64) return VT_ERR_UNSUPPORTED;
@@ -749,15 +761,18 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
       return VT_ERR_HIP;
     attr_set = true;
   }
-  const long rows = (long)B * S;
-  hipLaunchKernelGGL(attn_delta_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, (const bf16_t*)dctx, ld_d,
-                     (const bf16_t*)ctx, ld_ctx, delta_ws, B, S, nh);
+  if ((seq_start == nullptr) != (seq_len == nullptr)) return VT_ERR_NULL;
+  if (seq_start && (mask || rows_total <= 0)) return VT_ERR_UNSUPPORTED;   // compacted rows carry no masked keys
+  const long rows = seq_start ? rows_total : (long)B * S;
+  hipLaunchKernelGGL(attn_delta_rows, dim3((unsigned)((S + 3) / 4), B), dim3(256), 0, stream, (const bf16_t*)dctx, ld_d,
+                     (const bf16_t*)ctx, ld_ctx, delta_ws, B, S, nh, seq_start, seq_len);
   AttnBwdArgs a;
   a.qkv = (const bf16_t*)qkv; a.dctx = (const bf16_t*)dctx; a.mask = mask; a.mask_additive = mask_additive;
   a.lse = lse; a.delta = delta_ws; a.dqkv = (bf16_t*)dqkv;
   a.dq32 = nkb > 1 ? dq32_ws : nullptr;
   if (nkb > 1 && hipMemsetAsync(dq32_ws, 0, (size_t)rows * nh * 64 * sizeof(float), stream) != hipSuccess) return VT_ERR_HIP;
   a.ld_qkv = ld_qkv; a.ld_d = ld_d; a.ld_dqkv = ld_dqkv; a.B = B; a.S = S; a.nh = nh;
+  a.seq_start = seq_start; a.seq_len = seq_len;
   a.scale = 1.0f / sqrtf((float)head_size);
   if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
   if (g_attn_bwd_waves == 4) {

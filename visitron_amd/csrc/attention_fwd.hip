@@ -35,6 +35,10 @@ struct AttnArgs {
   float scale;              // 1 / sqrt(head_size)
   DropCfg drop;             // dropout on the attention probabilities (oscar/modeling_bert.py:62); per (b,h) the
                             // seed is hash32(drop.seed, b*nh+h) and the element index is q * S + key
+  // compacted rows (training without the padding rows): sequence b holds seq_len[b] <= S rows starting at row
+  // seq_start[b]; lse keeps its [B, nh, S] layout.  Null: every sequence has S rows, sequence b starts at row b * S.
+  const int* seq_start;
+  const int* seq_len;
 };
 
 #define LOG2E 1.4426950408889634f
@@ -60,11 +64,14 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h2 = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
-  const int S = a.S, H = a.nh * 64;
+  const int Smax = a.S, H = a.nh * 64;
+  const int S = a.seq_len ? a.seq_len[b] : a.S;                       // this sequence's rows
+  const long row0 = a.seq_start ? (long)a.seq_start[b] : (long)b * a.S;
+  if ((int)blockIdx.x * 256 >= S) return;                             // uniform: a query block past a short sequence
   const int q0 = blockIdx.x * 256 + wave * 32;
   const bool wave_active = q0 < S;  // wave-uniform
 
-  const bf16_t* base = a.qkv + (long)b * S * a.ld_qkv + head * 64;
+  const bf16_t* base = a.qkv + row0 * a.ld_qkv + head * 64;
 
   // Q fragments: B operand, lane (r, h2) holds Q[q0+r][16*ds + 8*h2 .. +7]
   bf16x8 qf[4];
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
   const uint32_t q_elem = (uint32_t)(q0 + r) * (uint32_t)S;
-  const float* mrow3 = (a.mask && a.mask_additive == 2) ? a.mask + ((long)b * S + ((q0 + r) < S ? (q0 + r) : S - 1)) * S : nullptr;
+  const float* mrow3 = (a.mask && a.mask_additive == 2) ? a.mask + ((long)b * Smax + ((q0 + r) < S ? (q0 + r) : S - 1)) * Smax : nullptr;
 
   // lane-constant LDS offsets
   const int k_row_off = r * 128;                       // + kt*4096
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
       if (key < S) {
         float add = 0.f;
         if (a.mask && a.mask_additive != 2) {
-          const float mval = a.mask[(long)b * S + key];
+          const float mval = a.mask[(long)b * Smax + key];
           add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
         }
         bias = add;
@@ -208,9 +215,9 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
   const int q = q0 + r;
   if (q >= S) return;
   float inv = 1.0f / l_tot;
-  if (a.lse && h2 == 0) a.lse[((long)b * a.nh + head) * S + q] = m_run + __builtin_amdgcn_logf(l_tot) * 0.6931471805599453f;
+  if (a.lse && h2 == 0) a.lse[((long)b * a.nh + head) * Smax + q] = m_run + __builtin_amdgcn_logf(l_tot) * 0.6931471805599453f;
   if (a.head_scale) inv *= a.head_scale[head];
-  bf16_t* op = a.ctx + ((long)b * S + q) * a.ld_ctx + head * 64 + 16 * h2;
+  bf16_t* op = a.ctx + (row0 + q) * a.ld_ctx + head * 64 + 16 * h2;
   u32x4 w0, w1, w2, w3;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
 
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                               long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream,
-                              const DropCfg* drop = nullptr) {
+                              const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr) {
   if (!qkv || !ctx) return VT_ERR_NULL;
   if (head_size != 64) return VT_ERR_UNSUPPORTED;
   if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
@@ -244,6 +251,9 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   a.ld_qkv = ld_qkv; a.ld_ctx = ld_ctx; a.B = B; a.S = S; a.nh = nh;
   a.scale = 1.0f / sqrtf((float)head_size);
   if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
+  if ((seq_start == nullptr) != (seq_len == nullptr)) return VT_ERR_NULL;
+  if (seq_start && mask) return VT_ERR_UNSUPPORTED;   // compacted rows carry no masked keys
+  a.seq_start = seq_start; a.seq_len = seq_len;
   dim3 grid((S + 255) / 256, nh, B);
   hipLaunchKernelGGL(attention_fwd_d64, grid, dim3(512), ATT_LDS_BYTES, stream, a);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
@@ -294,7 +304,7 @@ int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask,
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = nullptr;
   a.lse = const_cast<float*>(lse);
-  a.ld_qkv = ld_qkv; a.ld_ctx = 0; a.B = B; a.S = S; a.nh = nh;
+  a.ld_qkv = ld_qkv; a.ld_ctx = 0; a.B = B; a.S = S; a.nh = nh; a.seq_start = nullptr; a.seq_len = nullptr;
   a.scale = 1.0f / sqrtf((float)head_size);
   a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f;
   hipLaunchKernelGGL(attention_probs_d64, dim3(S, nh, B), dim3(256), 0, stream, a, probs);

@@ -9,7 +9,8 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
                               long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream,
-                              const DropCfg* drop = nullptr);
+                              const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr,
+                              long rows_total = 0);
 int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
                               hipStream_t stream, void* dx2 = nullptr, long lddx2 = 0, const DropCfg* drop = nullptr);
@@ -32,7 +33,7 @@ int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask,
                                 const float* lse, float* probs, int B, int S, int nh, int head_size, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                               long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream,
-                              const DropCfg* drop = nullptr);
+                              const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr);
 int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
                           float* mean, float* rstd, int M, int H, float eps, int grp_rows, int grp_stride,
                           hipStream_t stream);
@@ -120,6 +121,17 @@ int vt_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int
   const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_attention_bwd_dispatch(qkv, ld_qkv, dctx, ld_d, ctx, ld_ctx, mask, mask_additive, lse, delta_ws, dqkv,
                                    ld_dqkv, dq32_ws, B, S, nh, head_size, (hipStream_t)stream, &d);
+}
+
+int vt_attention_bwd_seq_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
+                              int64_t ld_ctx, const float* lse, float* delta_ws, void* dqkv, int64_t ld_dqkv,
+                              float* dq32_ws, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
+                              uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, int64_t rows,
+                              vt_stream_t stream) {
+  if (!seq_start || !seq_len) return VT_ERR_NULL;
+  const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
+  return vt_attention_bwd_dispatch(qkv, ld_qkv, dctx, ld_d, ctx, ld_ctx, nullptr, 0, lse, delta_ws, dqkv, ld_dqkv, dq32_ws,
+                                   B, S, nh, head_size, (hipStream_t)stream, &d, seq_start, seq_len, rows);
 }
 
 int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* gamma, void* dx,
@@ -225,6 +237,15 @@ int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, in
                                    (hipStream_t)stream, &d);
 }
 
+int vt_attention_fwd_seq_bf16(const void* qkv, int64_t ld_qkv, const float* head_scale, void* ctx, int64_t ld_ctx,
+                              float* lse, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
+                              uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, vt_stream_t stream) {
+  if (!seq_start || !seq_len) return VT_ERR_NULL;
+  const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
+  return vt_attention_fwd_dispatch(qkv, ld_qkv, nullptr, 0, head_scale, ctx, ld_ctx, lse, B, S, nh, head_size,
+                                   (hipStream_t)stream, &d, seq_start, seq_len);
+}
+
 int vt_attention_probs_f32(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive, const float* head_scale,
                            const float* lse, float* probs, int B, int S, int nh, int head_size, vt_stream_t stream) {
   return vt_attention_probs_dispatch(qkv, ld_qkv, mask, mask_additive, head_scale, lse, probs, B, S, nh, head_size,
@@ -273,13 +294,18 @@ int vt_wgrad_bf16(const vt_wgrad_problem* problems, int nprob, int M, vt_stream_
 // layer = CaptionBertLayer.forward (:112-124) as 7 launches on one stream:
 //   qkv GEMM -> fused attention -> out-proj GEMM(+bias+residual) -> LayerNorm
 //   -> FFN-up GEMM(+bias+GELU) -> FFN-down GEMM(+bias+residual) -> LayerNorm
-int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers, const void* x,
-                            const float* mask, int mask_additive, const float* head_scale, int B, int S, int H, int nh,
-                            int I, float ln_eps, float p_hidden, float p_attn, uint64_t drop_seed, vt_stream_t stream_) {
+}  // extern "C"
+
+// rows != 0: the activations hold `rows` compacted token rows (no padding rows), sequence b = rows seq_start[b] ..
+// seq_start[b] + seq_len[b]; every key of a sequence is attended (no mask).  rows == 0: B * S rows, sequence b at b * S.
+static int encoder_forward_impl(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers, const void* x,
+                                const float* mask, int mask_additive, const float* head_scale, int B, int S, int H, int nh,
+                                int I, float ln_eps, float p_hidden, float p_attn, uint64_t drop_seed, hipStream_t stream,
+                                long rows, const int* seq_start, const int* seq_len) {
   if (!layers || !acts || !x) return VT_ERR_NULL;
   if (num_layers <= 0 || B <= 0 || S <= 0 || nh <= 0 || H != nh * 64 || (H % 64) || (I % 64)) return VT_ERR_BAD_SHAPE;
-  hipStream_t stream = (hipStream_t)stream_;
-  const int M = B * S;
+  if (rows && (!seq_start || !seq_len || mask || rows < 0 || rows > (long)B * S)) return VT_ERR_BAD_SHAPE;
+  const int M = rows ? (int)rows : B * S;
   const void* cur = x;
   for (int l = 0; l < num_layers; ++l) {
     const vt_layer_weights& w = layers[l];
@@ -292,7 +318,7 @@ int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts*
     const DropCfg d_so = vt_make_drop(p_hidden, drop_seed, VT_SITE_SELFOUT(l));
     const DropCfg d_out = vt_make_drop(p_hidden, drop_seed, VT_SITE_OUT(l));
     rc = vt_attention_fwd_dispatch(a.qkv, 3L * H, mask, mask_additive, head_scale ? head_scale + (long)l * nh : nullptr, a.ctx, H,
-                                   a.lse, B, S, nh, 64, stream, &d_att);
+                                   a.lse, B, S, nh, 64, stream, &d_att, rows ? seq_start : nullptr, rows ? seq_len : nullptr);
     if (rc) return rc;
     rc = vt_gemm_dispatch(a.ctx, H, w.w_ao, H, w.b_ao, cur, H, a.attn_pre, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream, nullptr, 0, &d_so);
     if (rc) return rc;
@@ -308,6 +334,24 @@ int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts*
     cur = a.out;
   }
   return VT_OK;
+}
+
+extern "C" {
+
+int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers, const void* x,
+                            const float* mask, int mask_additive, const float* head_scale, int B, int S, int H, int nh,
+                            int I, float ln_eps, float p_hidden, float p_attn, uint64_t drop_seed, vt_stream_t stream) {
+  return encoder_forward_impl(layers, acts, num_layers, x, mask, mask_additive, head_scale, B, S, H, nh, I, ln_eps, p_hidden,
+                              p_attn, drop_seed, (hipStream_t)stream, 0, nullptr, nullptr);
+}
+
+int vt_encoder_forward_seq_bf16(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers, const void* x,
+                                const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps, float p_hidden,
+                                float p_attn, uint64_t drop_seed, int64_t rows, const int32_t* seq_start,
+                                const int32_t* seq_len, vt_stream_t stream) {
+  if (rows <= 0) return VT_ERR_BAD_SHAPE;
+  return encoder_forward_impl(layers, acts, num_layers, x, nullptr, 0, head_scale, B, S, H, nh, I, ln_eps, p_hidden, p_attn,
+                              drop_seed, (hipStream_t)stream, (long)rows, seq_start, seq_len);
 }
 
 // Backward of CaptionBertEncoder (oscar/modeling_bert.py:140-169) = the reverse layer loop; per layer
@@ -344,8 +388,10 @@ static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_
                                  const float* mask, int mask_additive, void* g, const vt_bwd_workspace* ws_a,
                                  const vt_bwd_workspace* ws_b, int B, int S, int H, int nh, int I, float ln_eps,
                                  int accumulate, float p_hidden, float p_attn, uint64_t drop_seed, int layer0,
-                                 hipStream_t stream, hipStream_t side) {
+                                 hipStream_t stream, hipStream_t side, long rows = 0, const int* seq_start = nullptr,
+                                 const int* seq_len = nullptr) {
   if (!layers || !layers_t || !acts || !grads || !x || !g || !ws_a) return VT_ERR_NULL;
+  if (rows && (!seq_start || !seq_len || mask || rows < 0 || rows > (long)B * S)) return VT_ERR_BAD_SHAPE;
   const bool overlap = ws_b != nullptr && side != nullptr && side != stream;
   for (int k = 0; k < (overlap ? 2 : 1); ++k) {
     const vt_bwd_workspace* ws = k ? ws_b : ws_a;
@@ -357,7 +403,7 @@ static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_
   hipEvent_t* ev_in = overlap ? bwd_events(0) : nullptr;    // E[l]: layer l's wgrad operands are complete (main)
   hipEvent_t* ev_done = overlap ? bwd_events(1) : nullptr;  // F[l]: layer l's wgrad has finished (side)
   if (overlap && (!ev_in || !ev_done)) return VT_ERR_HIP;
-  const int M = B * S;
+  const int M = rows ? (int)rows : B * S;
   for (int l = num_layers - 1; l >= 0; --l) {
     const vt_layer_weights& w = layers[l];
     const vt_layer_weights_t& wt = layers_t[l];
@@ -394,7 +440,8 @@ static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_
     rc = vt_gemm_dispatch(g_pre2_dn, H, wt.wt_ao, H, nullptr, nullptr, 0, ws->g_ctx, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream);
     if (rc) return rc;
     rc = vt_attention_bwd_dispatch(a.qkv, 3L * H, ws->g_ctx, H, a.ctx, H, mask, mask_additive, a.lse, ws->delta, ws->g_qkv,
-                                   3L * H, ws->dq32, B, S, nh, 64, stream, &d_att);
+                                   3L * H, ws->dq32, B, S, nh, 64, stream, &d_att, rows ? seq_start : nullptr,
+                                   rows ? seq_len : nullptr, rows);
     if (rc) return rc;
     // through the packed q|k|v projection, plus the residual branch: dL/d(layer input) -> g
     rc = vt_gemm_dispatch(ws->g_qkv, 3L * H, wt.wt_qkv, 3L * H, nullptr, ws->g_pre2, H, g, H, M, H, 3 * H, VT_ACT_NONE, 0, 0, 0, stream);
@@ -449,6 +496,18 @@ int vt_encoder_backward_overlap_bf16(const vt_layer_weights* layers, const vt_la
   return encoder_backward_impl(layers, layers_t, acts, grads, num_layers, x, mask, mask_additive, g, ws, ws_b, B, S, H, nh,
                                I, ln_eps, accumulate, p_hidden, p_attn, drop_seed, layer0, (hipStream_t)stream,
                                (hipStream_t)side_stream);
+}
+
+int vt_encoder_backward_seq_bf16(const vt_layer_weights* layers, const vt_layer_weights_t* layers_t,
+                                 const vt_layer_acts* acts, const vt_layer_grads* grads, int num_layers, const void* x,
+                                 void* g, const vt_bwd_workspace* ws, const vt_bwd_workspace* ws_b, int B, int S, int H,
+                                 int nh, int I, float ln_eps, int accumulate, float p_hidden, float p_attn,
+                                 uint64_t drop_seed, int layer0, int64_t rows, const int32_t* seq_start,
+                                 const int32_t* seq_len, vt_stream_t stream, vt_stream_t side_stream) {
+  if (rows <= 0) return VT_ERR_BAD_SHAPE;
+  return encoder_backward_impl(layers, layers_t, acts, grads, num_layers, x, nullptr, 0, g, ws, ws_b, B, S, H, nh, I, ln_eps,
+                               accumulate, p_hidden, p_attn, drop_seed, layer0, (hipStream_t)stream,
+                               (hipStream_t)side_stream, (long)rows, seq_start, seq_len);
 }
 
 }  // extern "C"

@@ -712,6 +712,16 @@ void vt_gemm_tune_set(int M, int N, int K, int act, int variant) {
 static int gemm_pick_variant(int M, int N, int K, int act) {
   for (int i = 0; i < g_ntune; ++i)
     if (g_tune[i].M == M && g_tune[i].N == N && g_tune[i].K == K && g_tune[i].act == act) return g_tune[i].variant;
+  // a row count the tuner has not seen (compacted batches change it every step): the entry of the same (N, K, act)
+  // whose M is nearest, within 25 %
+  int best = -1;
+  long best_d = 0;
+  for (int i = 0; i < g_ntune; ++i)
+    if (g_tune[i].N == N && g_tune[i].K == K && g_tune[i].act == act) {
+      const long d = g_tune[i].M > M ? g_tune[i].M - M : M - g_tune[i].M;
+      if (4 * d <= g_tune[i].M && (best < 0 || d < best_d)) { best = i; best_d = d; }
+    }
+  if (best >= 0) return g_tune[best].variant;
   // heuristic: wave-quantisation efficiency x measured relative rate of each tile
   auto eff = [](long tiles, int slots) { const double w = (double)tiles / slots; return w / (double)((long)(w + 0.999)); };
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);

@@ -241,11 +241,42 @@ def _mask_mode(mask, mask_additive, B, S):
     return 1 if mask_additive else 0
 
 
-def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None, out=None, lse=None, drop=NO_DROP):
-    """qkv [B*S, 3*nh*64] bf16, mask fp32 [B,S] -> context [B*S, nh*64] bf16."""
+class SeqLayout(object):
+    """Compacted token rows (a batch without its padding rows): sequence b = rows start[b] .. start[b] + length[b] of
+    every activation; `rows` real rows in all, at most S per sequence.  index = the kept rows' positions in the padded
+    [B*S] order (int64), inverse[padded position] = compact row or -1."""
+
+    def __init__(self, keep):
+        assert keep.dim() == 2 and keep.dtype == torch.bool
+        B, S = keep.shape
+        lens = keep.sum(1)
+        self.B, self.S = B, S
+        self.length = lens.to(torch.int32).contiguous()
+        self.start = (torch.cumsum(lens, 0) - lens).to(torch.int32).contiguous()
+        flat = keep.reshape(-1)
+        self.index = torch.nonzero(flat).flatten()
+        self.rows = int(self.index.numel())                     # host sync (the step has one for the labels anyway)
+        inv = torch.cumsum(flat.to(torch.int64), 0) - 1
+        self.inverse = torch.where(flat, inv, torch.full_like(inv, -1))
+
+
+def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None, out=None, lse=None, drop=NO_DROP,
+                  seq=None):
+    """qkv [B*S, 3*nh*64] bf16, mask fp32 [B,S] -> context [B*S, nh*64] bf16.  seq (SeqLayout): compacted rows, no
+    mask."""
     _require_hip(qkv, mask, head_scale, out, lse)
     assert qkv.dtype == BF16
     H = nh * 64
+    if seq is not None:
+        assert mask is None and seq.B == B and seq.S == S and qkv.shape[0] >= seq.rows
+        if out is None:
+            out = torch.empty((seq.rows, H), dtype=BF16, device=qkv.device)
+        with _timed("attention_fwd_d64", 4.0 * B * nh * S * S * 64, 2.0 * seq.rows * 4 * H):
+            rc = _lib.load().vt_attention_fwd_seq_bf16(
+                _ptr(qkv), qkv.stride(0), _ptr(head_scale), _ptr(out), out.stride(0), _ptr(lse), B, S, nh, 64,
+                float(drop[0]), int(drop[1]), int(drop[2]), _ptr(seq.start), _ptr(seq.length), _stream())
+        _lib.check(rc, "vt_attention_fwd_seq_bf16")
+        return out
     if out is None:
         out = torch.empty((B * S, H), dtype=BF16, device=qkv.device)
     mode = _mask_mode(mask, mask_additive, B, S)
@@ -320,16 +351,26 @@ def pack_concat(s0, s1, kpad, out=None):
 
 
 def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False, out=None, delta_ws=None, dq32_ws=None,
-                  drop=NO_DROP):
-    """Gradient of attention_fwd w.r.t. the packed qkv: returns dqkv [B*S, 3*nh*64] bf16."""
+                  drop=NO_DROP, seq=None):
+    """Gradient of attention_fwd w.r.t. the packed qkv: returns dqkv [B*S, 3*nh*64] bf16 (seq: compacted rows)."""
     _require_hip(qkv, dctx, ctx, lse, mask, out)
     H = nh * 64
+    nrows = B * S if seq is None else seq.rows
     if out is None:
-        out = torch.empty((B * S, 3 * H), dtype=BF16, device=qkv.device)
+        out = torch.empty((nrows, 3 * H), dtype=BF16, device=qkv.device)
     if delta_ws is None:
         delta_ws = torch.empty((B, nh, S), dtype=torch.float32, device=qkv.device)
     if dq32_ws is None and S > 256:
-        dq32_ws = torch.empty((B * S, H), dtype=torch.float32, device=qkv.device)
+        dq32_ws = torch.empty((nrows, H), dtype=torch.float32, device=qkv.device)
+    if seq is not None:
+        assert mask is None and seq.B == B and seq.S == S
+        with _timed("attention_bwd_d64", 10.0 * B * nh * S * S * 64, 2.0 * nrows * 9 * H):
+            rc = _lib.load().vt_attention_bwd_seq_bf16(
+                _ptr(qkv), qkv.stride(0), _ptr(dctx), dctx.stride(0), _ptr(ctx), ctx.stride(0), _ptr(lse), _ptr(delta_ws),
+                _ptr(out), out.stride(0), _ptr(dq32_ws), B, S, nh, 64, float(drop[0]), int(drop[1]), int(drop[2]),
+                _ptr(seq.start), _ptr(seq.length), seq.rows, _stream())
+        _lib.check(rc, "vt_attention_bwd_seq_bf16")
+        return out
     with _timed("attention_bwd_d64", 10.0 * B * nh * S * S * 64, 2.0 * B * S * 9 * H):
         rc = _lib.load().vt_attention_bwd_bf16(
             _ptr(qkv), qkv.stride(0), _ptr(dctx), dctx.stride(0), _ptr(ctx), ctx.stride(0), _ptr(mask),
@@ -485,10 +526,20 @@ def dgelu_mul(g, h, out=None):
 
 def encoder_backward(layer_weights, layer_weights_t, layer_acts, layer_grads, x, mask, mask_additive, g, ws,
                      B, S, H, nh, I, eps, accumulate=False, p_hidden=0.0, p_attn=0.0, drop_seed=0, layer0=0,
-                     ws_b=None, side_stream=None):
+                     ws_b=None, side_stream=None, seq=None):
     """Reverse layer loop in C; g [B*S,H] bf16 is updated in place to dL/dx.  With a second workspace set and a side
     stream (torch.cuda.Stream) the weight gradients of a layer run beside the next layer's dgrad chain."""
     _require_hip(x, mask, g)
+    if seq is not None:
+        assert mask is None
+        rc = _lib.load().vt_encoder_backward_seq_bf16(
+            layer_weights, layer_weights_t, layer_acts, layer_grads, len(layer_weights), _ptr(x), _ptr(g),
+            ctypes.byref(ws), None if ws_b is None else ctypes.byref(ws_b), B, S, H, nh, I, float(eps),
+            1 if accumulate else 0, float(p_hidden), float(p_attn), int(drop_seed), int(layer0), seq.rows,
+            _ptr(seq.start), _ptr(seq.length), _stream(),
+            None if side_stream is None else ctypes.c_void_p(side_stream.cuda_stream))
+        _lib.check(rc, "vt_encoder_backward_seq_bf16")
+        return
     if ws_b is not None and side_stream is not None:
         rc = _lib.load().vt_encoder_backward_overlap_bf16(
             layer_weights, layer_weights_t, layer_acts, layer_grads, len(layer_weights), _ptr(x), _ptr(mask),
@@ -532,11 +583,19 @@ def wgrad(problems, M):
 
 
 def encoder_forward(layer_weights, layer_acts, x, mask, mask_additive, head_scale, B, S, H, nh, I, eps,
-                    p_hidden=0.0, p_attn=0.0, drop_seed=0):
+                    p_hidden=0.0, p_attn=0.0, drop_seed=0, seq=None):
     """Run the layer loop in C.  layer_weights / layer_acts: ctypes arrays built by the caller
-    (``visitron_amd.modeling`` keeps them alive together with the tensors they point into)."""
+    (``visitron_amd.modeling`` keeps them alive together with the tensors they point into).  seq (SeqLayout): x and
+    the activations hold the compacted rows, no mask."""
     _require_hip(x, mask, head_scale)
     L = len(layer_weights)
+    if seq is not None:
+        assert mask is None and seq.B == B and seq.S == S
+        rc = _lib.load().vt_encoder_forward_seq_bf16(
+            layer_weights, layer_acts, L, _ptr(x), _ptr(head_scale), B, S, H, nh, I, float(eps), float(p_hidden),
+            float(p_attn), int(drop_seed), seq.rows, _ptr(seq.start), _ptr(seq.length), _stream())
+        _lib.check(rc, "vt_encoder_forward_seq_bf16")
+        return
     rc = _lib.load().vt_encoder_forward_bf16(
         layer_weights, layer_acts, L, _ptr(x), _ptr(mask), _mask_mode(mask, mask_additive, B, S), _ptr(head_scale),
         B, S, H, nh, I, float(eps), float(p_hidden), float(p_attn), int(drop_seed), _stream())
