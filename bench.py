@@ -218,6 +218,10 @@ def main():
                 "parallelism": ("dp%d (flat-slab gradient all-reduce over RCCL)" if train else "dp%d (replicas, no collective)") % world,
                 "weights": "random init N(0,0.02), seed 0",
                 "dropout": a.dropout if train else 0.0,
+                # training computes the real rows only: positions with attention mask 0 (text tails, missing regions;
+                # 12.5 % of this synthetic batch, as in the reference's data) are read by nothing in the step -- same
+                # losses and gradients as the padded run (tests/test_gpu_train.py); VT_COMPACT_ROWS=0 computes them all
+                "token_rows_per_gpu": {"padded": a.batch * S, "computed": (engine.last_rows if train else a.batch * S)},
             },
             "encoder_flops_per_seq_fwd": f_enc,
             "mfma_frac_whole_step": round((3 if train else 1) * f_enc * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),

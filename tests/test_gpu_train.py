@@ -263,6 +263,7 @@ def test_dropout_training_matches_oracle_with_same_masks(dev, p_h, p_a):
 
     cfg = _dropout_cfg(p_h, p_a)
     ref, prod, eng = _engine_pair(cfg, 5, dev)
+    eng.compact_rows = False      # the injected masks are generated in the padded geometry (element = row * N + col)
     B, T, R = 3, 20, 17
     b = make_batch(cfg, B, text_len=T, region_len=R, seed=21)
     got = eng.forward_backward({k: v.to(dev) for k, v in b.items()})
@@ -327,6 +328,7 @@ def test_img_layernorm_training_matches_oracle(dev, p_h):
     cfg = _dropout_cfg(p_h, 0.0)
     cfg.use_img_layernorm, cfg.img_layer_norm_eps = 1, 1e-12
     ref, prod, eng = _engine_pair(cfg, 9, dev)
+    eng.compact_rows = False      # (as above: injected masks use the padded geometry)
     assert "bert.LayerNorm.weight" in dict(prod.named_parameters())
     B, T, R = 3, 20, 17
     b = make_batch(cfg, B, text_len=T, region_len=R, seed=31)
@@ -521,3 +523,53 @@ def test_wgrad_overlap_equals_single_stream(dev):
             got, ref_g = torch.nan_to_num(eng.flat.g, nan=0.0), torch.nan_to_num(want, nan=0.0)
             assert bool((torch.isnan(eng.flat.g) == torch.isnan(want)).all()) or not bool(torch.isnan(want).any())
             assert float((got - ref_g).abs().max()) <= 1e-5 * float(ref_g.abs().max()), (L, chunked)
+
+
+
+@pytest.mark.parametrize("chunked", [False, True])
+def test_compacted_rows_equal_padded_run(dev, chunked):
+    """The step on the real rows only (padding rows dropped from every row-wise kernel, vt_encoder_*_seq_bf16) against
+    the padded run of the same engine: the 7-tuple and every gradient.  Also: the oracle agrees, the row count shrank,
+    and a batch whose labels sit on a masked position falls back to the padded path."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config(num_hidden_layers=3)
+    ref, prod, eng = _engine_pair(cfg, 51, dev, lr=0.0)
+    b = make_batch(cfg, 5, text_len=24, region_len=12, seed=13)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    kw = dict(comm=dict(layers_per_chunk=2, launch=lambda rng: None, done=[])) if chunked else {}
+    eng.compact_rows = False
+    want = [float(v) for v in eng.forward_backward(bd, **kw)]
+    assert eng.last_rows == 5 * 36
+    g_want = torch.nan_to_num(eng.flat.g.clone(), nan=0.0)
+    eng.compact_rows = True
+    eng.flat.g.fill_(float("nan"))
+    if chunked:
+        kw = dict(comm=dict(layers_per_chunk=2, launch=lambda rng: None, done=[]))
+    got = [float(v) for v in eng.forward_backward(bd, **kw)]
+    torch.cuda.synchronize()
+    assert eng.last_rows == int(b["attention_mask"].sum()) < 5 * 36
+    for i in range(7):
+        assert abs(got[i] - want[i]) < (2e-3 if i < 4 else 1e-6), (i, got[i], want[i])
+    g_got = torch.nan_to_num(eng.flat.g, nan=0.0)
+    for n, p in prod.named_parameters():
+        o, cnt, _ = eng.flat.off[n]
+        a_, b_ = g_got[o:o + cnt], g_want[o:o + cnt]
+        # (absolute floor: the attention key biases have an exactly-zero true gradient, both runs hold rounding noise)
+        assert float((a_ - b_).norm()) <= 2e-2 * float(b_.norm()) + 1e-4 * cnt ** 0.5, n
+    # and against the oracle
+    wl = ref(**b)
+    wl[0].backward()
+    assert abs(got[0] - float(wl[0])) < 5e-2
+    wg = dict(ref.named_parameters())
+    bad = {n: _rel(p.grad, wg[n].grad) for n, p in prod.named_parameters()}
+    bad = {n: e for n, e in bad.items() if e > 0.08}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    # a supervised label on a masked position: the padded path is taken
+    if not chunked:
+        c = {k: v.clone() for k, v in bd.items()}
+        c["attention_mask"][0, 5] = 0
+        c["labels"][0, 5] = 7
+        eng.forward_backward(c)
+        assert eng.last_rows == 5 * 36

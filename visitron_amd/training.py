@@ -116,7 +116,9 @@ class _TrainBuffers(object):
             for k, v in d.items():
                 setattr(self.acts[i], k, v.data_ptr())
         self.x0 = mk(H)
+        self.x0c = mk(H)      # compacted copy of x0 (real rows only), the encoder's input in the compact path
         self.g = mk(H)
+        self.g_pad = mk(H)    # dL/dx0 scattered back to the padded row order for the embedding / region backward
         self.g_seq32 = torch.empty((M, H), dtype=torch.float32, device=dev)
         self.ws_t = dict(g_pre=mk(H), g_pre2=mk(H), g_mid=mk(I), g_ctx=mk(H), g_qkv=mk(3 * H),
                          g_pre_d=mk(H), g_pre2_d=mk(H),   # dropout-masked copies (hidden dropout > 0)
@@ -175,6 +177,10 @@ class PretrainEngine(object):
         # persistent kernel (its workgroups queue behind the wgrad's and still do a full share each); with a second
         # process on the same GPU it lost a lot, and beside RCCL's kernels it could not be measured here.
         self.overlap_wgrad = os.environ.get("VT_OVERLAP_WGRAD", "0") != "0"
+        # the training step on the real rows only (no padding rows; vt_encoder_*_seq_bf16): same losses and gradients
+        # as the padded run (tests/test_gpu_train.py); VT_COMPACT_ROWS=0 or the attribute turns it off
+        self.compact_rows = os.environ.get("VT_COMPACT_ROWS", "1") != "0"
+        self.last_rows = None
         self._side_stream = None
         self._build_tables()
 
@@ -329,6 +335,25 @@ class PretrainEngine(object):
             raise RuntimeError("attention_mask must be [batch, text+region]")
         tt, pos_ids = _i64(batch.get("token_type_ids")), _i64(batch.get("position_ids"))
         bufs = self._buffers(B, S)
+        # rows nothing in the step reads: positions with attention mask 0.  As keys they weigh exactly 0, so their
+        # hidden states reach no loss and their gradient is exactly 0 -- drop them from every row-wise kernel.  Needs a
+        # 0/1 mask, the [CLS] position and every supervised position kept; otherwise the padded path below.
+        lay = None
+        if self.compact_rows and mask is not None:
+            keep = mask != 0
+            cand = ops.SeqLayout(keep)
+            bad = ((mask != 0) & (mask != 1)).any() | (~keep[:, 0]).any()
+            if Ml:
+                bad = bad | (cand.inverse.index_select(0, idx_w) < 0).any()
+            if Mt:
+                bad = bad | (cand.inverse.index_select(0, idx_t) < 0).any()
+            if cand.rows < M and not bool(bad):
+                lay = cand
+        Mr = M if lay is None else lay.rows
+        self.last_rows = Mr
+        rows_w = idx_w if lay is None else lay.inverse.index_select(0, idx_w)   # supervised rows in the layout in use
+        rows_t = idx_t if lay is None else lay.inverse.index_select(0, idx_t)
+        cls_rows = (torch.arange(B, device=dev) * S) if lay is None else lay.start.to(torch.int64)
         emb = m.bert.embeddings
         eps = emb.LayerNorm.variance_epsilon
         # dropout (nn.Dropout follows the module's training flag): same (p, seed) in forward and backward
@@ -362,13 +387,24 @@ class PretrainEngine(object):
                 img_pre = None
                 ops.linear(a_img, self.w_img, self.b_img, out=x0[T:], ldc=H, grp_rows=R, grp_stride=S,
                            drop=(p_h, seed, ops.SITE_IMG))
+        x_enc, enc_mask = x0, mask
+        if lay is not None:
+            x_enc, enc_mask = bufs.x0c[:Mr], None
+            torch.index_select(x0, 0, lay.index, out=x_enc)
         if ops.profiling():
-            self._encoder_forward_unrolled(bufs, x0, mask, B, S, p_h, p_a, seed)
+            self._encoder_forward_unrolled(bufs, x_enc, enc_mask, B, S, p_h, p_a, seed, lay)
         else:
-            ops.encoder_forward(self.w_tab, bufs.acts, x0, mask, False, None, B, S, H, nh, I, cfg.layer_norm_eps, **dp_kw)
-        seq = bufs.layers[-1]["out"]
-        pooled = ops.linear(seq, self._mirror(m.bert.pooler.dense.weight), m.bert.pooler.dense.bias.detach(),
-                            act=ACT_TANH, out_f32=True, M=B, lda=S * H)
+            ops.encoder_forward(self.w_tab, bufs.acts, x_enc, enc_mask, False, None, B, S, H, nh, I, cfg.layer_norm_eps,
+                                seq=lay, **dp_kw)
+        seq = bufs.layers[-1]["out"][:Mr]
+        if lay is None:
+            cls_seq = None
+            pooled = ops.linear(seq, self._mirror(m.bert.pooler.dense.weight), m.bert.pooler.dense.bias.detach(),
+                                act=ACT_TANH, out_f32=True, M=B, lda=S * H)
+        else:
+            cls_seq = seq.index_select(0, cls_rows)
+            pooled = ops.linear(cls_seq, self._mirror(m.bert.pooler.dense.weight), m.bert.pooler.dense.bias.detach(),
+                                act=ACT_TANH, out_f32=True)
         pooled_bf = pooled.to(BF16)
 
         # heads on supervised rows only
@@ -376,7 +412,7 @@ class PretrainEngine(object):
         pr = m.mlmhead.predictions
         zero = torch.zeros((), dtype=torch.float32, device=dev)
         if Ml > 0:
-            seq_w = seq.index_select(0, idx_w)
+            seq_w = seq.index_select(0, rows_w)
             y_w = lab.index_select(0, idx_w)
             h_t = torch.empty((Ml, H), dtype=BF16, device=dev)
             t1 = ops.linear(seq_w, self._mirror(pr.transform.dense.weight), pr.transform.dense.bias.detach(), act=ACT_GELU,
@@ -395,7 +431,7 @@ class PretrainEngine(object):
             words_acc = zero / zero
         lin_tok = m.token_head[0]
         if Mt > 0:
-            seq_t = seq.index_select(0, idx_t)
+            seq_t = seq.index_select(0, rows_t)
             y_t = tl.index_select(0, idx_t)
             lt = torch.empty((Mt, self.Cp), dtype=torch.float32, device=dev)
             ops.linear(seq_t, self._mirror(lin_tok.weight), lin_tok.bias.detach(), out=lt, out_f32=True)
@@ -426,7 +462,7 @@ class PretrainEngine(object):
         # ---------------- backward ----------------
         gs = float(grad_scale)
         acc = bool(accumulate)
-        g32 = bufs.g_seq32
+        g32 = bufs.g_seq32[:Mr]
         g32.zero_()
         wg = lambda dy, x, dw, db: dict(dy=dy, x=x, dw=dw, db=db, accumulate=acc)
         dec_w_is_tied = pr.decoder.weight is emb.word_embeddings.weight
@@ -445,10 +481,10 @@ class PretrainEngine(object):
                                      ws=bufs.ws_t["ln_partial"], accumulate=acc)
             g_ht = ops.dgelu_mul(g_t1, h_t)
             ops.wgrad([wg(g_ht, seq_w, self._grad(pr.transform.dense.weight), self._grad(pr.transform.dense.bias))], Ml)
-            g32.index_add_(0, idx_w, ops.linear(g_ht, self.head_t["tr"]).float())
+            g32.index_add_(0, rows_w, ops.linear(g_ht, self.head_t["tr"]).float())
         if Mt > 0:
             ops.wgrad([wg(dlt[:, :C], seq_t, self._grad(lin_tok.weight), self._grad(lin_tok.bias))], Mt)
-            g32.index_add_(0, idx_t, ops.linear(dlt, self.head_t["tok"]).float())
+            g32.index_add_(0, rows_t, ops.linear(dlt, self.head_t["tok"]).float())
         if next_action is not None:
             da = torch.exp(logp_a)
             da.scatter_add_(1, next_action.clamp(min=0)[:, None], torch.full((B, 1), -1.0, device=dev))
@@ -461,20 +497,21 @@ class PretrainEngine(object):
                           self._grad(m.next_action.linear.bias))], B)
             g_pooled = ops.linear(dla_bf, self.head_t["act"], out_f32=True)
             g_z = (g_pooled * (1.0 - pooled * pooled)).to(BF16)
-            ops.wgrad([dict(dy=g_z, x=seq.view(B, S * H)[:, :H], dw=self._grad(m.bert.pooler.dense.weight),
-                            db=self._grad(m.bert.pooler.dense.bias), accumulate=acc)], B)
-            g32.view(B, S, H)[:, 0].add_(ops.linear(g_z, self.head_t["pool"]).float())
+            ops.wgrad([dict(dy=g_z, x=seq.view(B, S * H)[:, :H] if lay is None else cls_seq,
+                            dw=self._grad(m.bert.pooler.dense.weight), db=self._grad(m.bert.pooler.dense.bias),
+                            accumulate=acc)], B)
+            g32.index_add_(0, cls_rows, ops.linear(g_z, self.head_t["pool"]).float())
         elif not acc:
             for prm in (m.next_action.linear.weight, m.next_action.linear.bias, m.bert.pooler.dense.weight,
                         m.bert.pooler.dense.bias):
                 self._grad(prm).zero_()
-        g = bufs.g
+        g = bufs.g[:Mr]
         g.copy_(g32)
         if ops.profiling():
-            self._encoder_backward_unrolled(bufs, x0, mask, g, B, S, acc, p_h, p_a, seed)
+            self._encoder_backward_unrolled(bufs, x_enc, enc_mask, g, B, S, acc, p_h, p_a, seed, lay)
         elif comm is None:
-            ops.encoder_backward(self.w_tab, self.wt_tab, bufs.acts, self.g_tab, x0, mask, False, g, bufs.ws, B, S, H, nh,
-                                 I, cfg.layer_norm_eps, accumulate=acc, **dp_kw, **self._overlap_kw(bufs))
+            ops.encoder_backward(self.w_tab, self.wt_tab, bufs.acts, self.g_tab, x_enc, enc_mask, False, g, bufs.ws, B, S,
+                                 H, nh, I, cfg.layer_norm_eps, accumulate=acc, seq=lay, **dp_kw, **self._overlap_kw(bufs))
         else:
             # data-parallel: backward in layer chunks (last layers first); as soon as a chunk's kernels are
             # enqueued its gradient ranges are all-reduced on the communicator's stream, under the backward
@@ -485,15 +522,19 @@ class PretrainEngine(object):
                 lo = max(0, hi - step)
                 n = hi - lo
                 sub = lambda arr, typ: (typ * n).from_address(ctypes.addressof(arr) + lo * ctypes.sizeof(typ))
-                x_in = x0 if lo == 0 else bufs.layers[lo - 1]["out"]
+                x_in = x_enc if lo == 0 else bufs.layers[lo - 1]["out"]
                 ops.encoder_backward(sub(self.w_tab, _lib.LayerWeights), sub(self.wt_tab, _lib.LayerWeightsT),
-                                     sub(bufs.acts, _lib.LayerActs), sub(self.g_tab, _lib.LayerGrads), x_in, mask, False, g,
-                                     bufs.ws, B, S, H, nh, I, cfg.layer_norm_eps, accumulate=acc, layer0=lo, **dp_kw,
-                                     **self._overlap_kw(bufs))
+                                     sub(bufs.acts, _lib.LayerActs), sub(self.g_tab, _lib.LayerGrads), x_in, enc_mask, False,
+                                     g, bufs.ws, B, S, H, nh, I, cfg.layer_norm_eps, accumulate=acc, layer0=lo, seq=lay,
+                                     **dp_kw, **self._overlap_kw(bufs))
                 rng = [(self.layer_ranges[lo][k][0], self.layer_ranges[hi - 1][k][1]) for k in (0, 1)]
                 comm["launch"](rng)
                 comm["done"].extend(rng)
                 hi = lo
+        if lay is not None:   # dL/dx0 back in the padded row order (zero at the padding rows, as in the padded run)
+            g_c, g = g, bufs.g_pad
+            g.zero_()
+            g.index_copy_(0, lay.index, g_c)
         # embeddings: text rows
         de = ops.embed_layernorm_bwd(ids, tt, pos_ids, emb.word_embeddings.weight.detach(),
                                      emb.position_embeddings.weight.detach(), emb.token_type_embeddings.weight.detach(),
@@ -538,13 +579,16 @@ class PretrainEngine(object):
         return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
 
     # ---- the launch sequences of vt_encoder_forward/backward_bf16 issued op by op (bench.py's per-kernel timing)
-    def _encoder_forward_unrolled(self, bufs, x0, mask, B, S, p_h=0.0, p_a=0.0, seed=0):
+    def _encoder_forward_unrolled(self, bufs, x0, mask, B, S, p_h=0.0, p_a=0.0, seed=0, lay=None):
         cfg = self.cfg
         nh, eps = cfg.num_attention_heads, cfg.layer_norm_eps
         cur = x0
+        n = x0.shape[0]
         for l, ((t, _), a) in enumerate(zip(self._keep, bufs.layers)):
+            a = {k: (v if k == "lse" else v[:n]) for k, v in a.items()}   # the rows in use (all, or the compacted ones)
             ops.linear(cur, t["w_qkv"], t["b_qkv"], out=a["qkv"])
-            ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, out=a["ctx"], lse=a["lse"], drop=(p_a, seed, ops.site_attn(l)))
+            ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, out=a["ctx"], lse=a["lse"], drop=(p_a, seed, ops.site_attn(l)),
+                              seq=lay)
             ops.linear(a["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=a["attn_pre"], drop=(p_h, seed, ops.site_selfout(l)))
             ops.layernorm(a["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=a["attn_out"])
             ops.linear(a["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=a["mid"], pre_act_out=a["mid_pre"])
@@ -561,13 +605,15 @@ class PretrainEngine(object):
             self._side_stream = torch.cuda.Stream(device=self.flat.p.device)
         return dict(ws_b=bufs.ws_b, side_stream=self._side_stream)
 
-    def _encoder_backward_unrolled(self, bufs, x0, mask, g, B, S, acc, p_h=0.0, p_a=0.0, seed=0):
+    def _encoder_backward_unrolled(self, bufs, x0, mask, g, B, S, acc, p_h=0.0, p_a=0.0, seed=0, lay=None):
         cfg = self.cfg
-        nh, eps, M = cfg.num_attention_heads, cfg.layer_norm_eps, B * S
-        w = bufs.ws_t
+        nh, eps, M = cfg.num_attention_heads, cfg.layer_norm_eps, x0.shape[0]
+        rowed = ("g_pre", "g_pre2", "g_mid", "g_ctx", "g_qkv", "g_pre_d", "g_pre2_d", "dq32")
+        w = {k: (v[:M] if k in rowed else v) for k, v in bufs.ws_t.items()}
         for l in range(cfg.num_hidden_layers - 1, -1, -1):
             (t, gr), a, (_, wt) = self._keep[l], bufs.layers[l], self.wt[l]
-            x_in = x0 if l == 0 else bufs.layers[l - 1]["out"]
+            a = {k: (v if k == "lse" else v[:M]) for k, v in a.items()}
+            x_in = x0 if l == 0 else bufs.layers[l - 1]["out"][:M]
             hd = p_h > 0.0   # with hidden dropout the dense outputs' gradients are the masked copies
             g_pre_dn, g_pre2_dn = (w["g_pre_d"], w["g_pre2_d"]) if hd else (w["g_pre"], w["g_pre2"])
             ops.layernorm_bwd(a["out_pre"], g, t["ln2_g"], eps, gr["d_ln2_g"], gr["d_ln2_b"], dx=w["g_pre"],
@@ -580,7 +626,7 @@ class PretrainEngine(object):
                               drop=(p_h, seed, ops.site_selfout(l)))
             ops.linear(g_pre2_dn, wt["wt_ao"], out=w["g_ctx"])
             ops.attention_bwd(a["qkv"], w["g_ctx"], a["ctx"], a["lse"], B, S, nh, mask=mask, out=w["g_qkv"],
-                              delta_ws=w["delta"], dq32_ws=w.get("dq32"), drop=(p_a, seed, ops.site_attn(l)))
+                              delta_ws=w["delta"], dq32_ws=w.get("dq32"), drop=(p_a, seed, ops.site_attn(l)), seq=lay)
             ops.linear(w["g_qkv"], wt["wt_qkv"], residual=w["g_pre2"], out=g)
             ops.wgrad([dict(dy=w["g_mid"], x=a["attn_out"], dw=gr["d_w_in"], db=gr["d_b_in"], accumulate=acc),
                        dict(dy=g_pre_dn, x=a["mid"], dw=gr["d_w_out"], db=gr["d_b_out"], accumulate=acc),
