@@ -181,6 +181,7 @@ class PretrainEngine(object):
         # as the padded run (tests/test_gpu_train.py); VT_COMPACT_ROWS=0 or the attribute turns it off
         self.compact_rows = os.environ.get("VT_COMPACT_ROWS", "1") != "0"
         self.last_rows = None
+        self._tuned_rows = set()
         self._side_stream = None
         self._build_tables()
 
@@ -351,6 +352,13 @@ class PretrainEngine(object):
                 lay = cand
         Mr = M if lay is None else lay.rows
         self.last_rows = Mr
+        if lay is not None:
+            # the tile quantisation changes with the row count: tune once per 2048-row bucket (the library then takes
+            # the nearest tuned M); a bucket is tuned at its upper edge
+            bucket = round_up(Mr, 2048)
+            if bucket not in self._tuned_rows and bucket < M:
+                ops.autotune_encoder_shapes(bucket, H, I, training=True, device=dev)
+                self._tuned_rows.add(bucket)
         rows_w = idx_w if lay is None else lay.inverse.index_select(0, idx_w)   # supervised rows in the layout in use
         rows_t = idx_t if lay is None else lay.inverse.index_select(0, idx_t)
         cls_rows = (torch.arange(B, device=dev) * S) if lay is None else lay.start.to(torch.int64)
