@@ -140,6 +140,30 @@ def main():
     value = world * a.batch * a.steps / elapsed
     f_enc = enc_flops_per_seq(S, cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size)
 
+    # the same K steps with every padded row computed (the reference's own amount of work per step): reported beside
+    # `value`, not part of the timed region above
+    value_all_rows = None
+    if train and engine.compact_rows and engine.last_rows is not None and engine.last_rows < a.batch * S \
+            and not a.no_fwd_rate:
+        rows_computed = engine.last_rows
+        engine.compact_rows = False
+        for _ in range(2):
+            step()
+        sync_all()
+        t2 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t2
+        if dist is not None:
+            t = torch.tensor([el2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        value_all_rows = world * a.batch * a.steps / el2
+        engine.compact_rows = True
+        step()                      # back on the default path (and its row count) for what follows
+        sync_all()
+
     # forward-only rate in the same process (train mode): not part of the timed region above
     fwd_value = None
     if train and not a.no_fwd_rate:
@@ -177,10 +201,10 @@ def main():
             # HBM bytes per launch of the same kernels: not measurable from inside this process; taken from the
             # committed PMC passes of this command (profiles/README.md), null when that file is absent
             traffic, traffic_src = None, None
-            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "train_b256_pmc_hbm_traffic_v5.json")
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "train_b256_pmc_hbm_traffic_v6.json")
             if train and a.batch == 256 and os.path.exists(tp):
                 tj = json.load(open(tp))
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01/train_b256_pmc_hbm_traffic_v5.json"
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01/train_b256_pmc_hbm_traffic_v6.json"
             roofline = {
                 "kernel": "gemm_nt_bf16 (NT GEMM family; per shape the autotuner picks among the persistent 256x256-tile "
                           "kernel with 128x128 wave tiles / AGPR accumulators and the older 128x128 .. 256x256 tiles)",
@@ -225,6 +249,7 @@ def main():
             },
             "encoder_flops_per_seq_fwd": f_enc,
             "mfma_frac_whole_step": round((3 if train else 1) * f_enc * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "value_all_padded_rows_computed": None if value_all_rows is None else round(value_all_rows, 2),
             "fwd_samples_per_sec": None if fwd_value is None else round(fwd_value, 2),
             "mfma_frac_whole_forward": (None if (train and fwd_value is None) else
                                         round(f_enc * (fwd_value if train else value) / world / (PEAK_BF16_TFLOPS * 1e12), 4)),
