@@ -15,7 +15,9 @@ def _engine_pair(cfg, seed, dev, std=0.05, **kw):
 
     ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=seed, device=dev, weight_std=std)
     prod.train()
-    return ref, prod, PretrainEngine(prod, **kw)
+    eng = PretrainEngine(prod, **kw)
+    eng.compact_min_rows = 0     # the tests' small batches also take the real-rows-only path (default: >= 16384 rows)
+    return ref, prod, eng
 
 
 def _rel(a, b):
@@ -536,6 +538,7 @@ def test_compacted_rows_equal_padded_run(dev, chunked):
 
     cfg = mini_config(num_hidden_layers=3)
     ref, prod, eng = _engine_pair(cfg, 51, dev, lr=0.0)
+    eng.compact_min_rows = 0                    # (the default only compacts batches of >= 16384 token rows)
     b = make_batch(cfg, 5, text_len=24, region_len=12, seed=13)
     bd = {k: v.to(dev) for k, v in b.items()}
     kw = dict(comm=dict(layers_per_chunk=2, launch=lambda rng: None, done=[])) if chunked else {}

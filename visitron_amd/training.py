@@ -182,6 +182,9 @@ class PretrainEngine(object):
         self.compact_rows = os.environ.get("VT_COMPACT_ROWS", "1") != "0"
         self.last_rows = None
         self._tuned_rows = set()
+        # below this many (padded) token rows the layout's own launches and host sync cost more than the rows saved
+        # (B=36: 3 036 against 3 352 samples/s; B=64 x 656 and B=256 x 228: +6 %)
+        self.compact_min_rows = 16384
         self._side_stream = None
         self._build_tables()
 
@@ -340,7 +343,7 @@ class PretrainEngine(object):
         # hidden states reach no loss and their gradient is exactly 0 -- drop them from every row-wise kernel.  Needs a
         # 0/1 mask, the [CLS] position and every supervised position kept; otherwise the padded path below.
         lay = None
-        if self.compact_rows and mask is not None:
+        if self.compact_rows and mask is not None and M >= self.compact_min_rows:
             keep = mask != 0
             cand = ops.SeqLayout(keep)
             bad = ((mask != 0) & (mask != 1)).any() | (~keep[:, 0]).any()
