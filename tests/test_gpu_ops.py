@@ -747,3 +747,36 @@ def test_attention_dropout_on_compacted_rows_matches_autograd(dev):
         assert maxabs(ctx[off:off + n], o.detach()) < 3e-2
         assert maxabs(dq[off:off + n], x.grad) < 3e-2 * (1 + float(x.grad.abs().max()))
         off += n
+
+
+@pytest.mark.parametrize("act,res,pre,drop_p", [(0, True, False, 0.1), (1, False, True, 0.0), (3, True, False, 0.0), (0, False, False, 0.0)])
+def test_linear_tail_rows_launch(dev, act, res, pre, drop_p):
+    """The persistent GEMM's half-empty last round handed to the 128x128-tile kernel (two launches over disjoint row
+    ranges, the dropout seed shifted by the row offset): same values as the single launch, identical dropout mask."""
+    from visitron_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(act * 10 + int(res))
+    M, N, K = 256 * 200 - 37, 768, 768          # 600 tiles: two full rounds on 256 CUs + 88
+    a = _rand((M, K), g).to(dev, BF16)
+    w = _rand((N, K), g, 0.05).to(dev, BF16)
+    b = _rand((N,), g).to(dev)
+    r = _rand((M, N), g).to(dev, BF16) if (res or act == 3) else None
+    drop = (drop_p, 4242, ops.site_out(1)) if drop_p else ops.NO_DROP
+    lib = _lib.load()
+    lib.vt_gemm_tune(M, N, K, act, 16)
+    outs = []
+    for mode in (-2, -1):
+        lib.vt_debug_set_gemm_variant(mode)
+        c2 = torch.empty((M, N), dtype=BF16, device=dev) if pre else None
+        out = ops.linear(a, w, b, residual=r, act=act, pre_act_out=c2, drop=drop)
+        outs.append((out, c2))
+    lib.vt_debug_set_gemm_variant(-1)
+    torch.cuda.synchronize()
+    (o0, p0), (o1, p1) = outs
+    keep0, keep1 = (o0.float() != (r.float() if (res and act != 3) else 0)), (o1.float() != (r.float() if (res and act != 3) else 0))
+    if drop_p:
+        assert torch.equal(keep0, keep1)                      # the same elements were dropped in both runs
+    assert maxabs(o0, o1) <= 2e-2 * (1 + float(o0.float().abs().max()))
+    assert float((o0.float() - o1.float()).abs().mean()) < 2e-3
+    if pre:
+        assert maxabs(p0, p1) <= 2e-2

@@ -697,7 +697,13 @@ int vt_gemm_v9_launch(const GemmArgs& g, int act, int out_f32, hipStream_t strea
 static void* g_gemm_trace = nullptr;
 void vt_gemm_set_trace(void* p) { g_gemm_trace = p; }
 static int g_gemm_variant = -1;  // -1: table / heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
-void vt_gemm_set_variant(int v) { g_gemm_variant = v; }
+static int g_gemm_tail_split = 1;   // the persistent kernel's half-empty last round goes to the 128x128-tile kernel
+// v >= 0: force a variant; -1: automatic; -2: automatic without the tail launch (A/B hook)
+void vt_gemm_set_variant(int v) {
+  if (v == -2) { g_gemm_tail_split = 0; g_gemm_variant = -1; return; }
+  if (v == -1) g_gemm_tail_split = 1;
+  g_gemm_variant = v;
+}
 
 // Shape -> variant table filled by the host-side autotuner (visitron_amd.ops.autotune_linear) before
 // the shapes are used; read-only afterwards.  Exact-match lookup; misses fall back to the heuristic.
@@ -801,14 +807,51 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   const int variant = g_gemm_variant >= 0 ? g_gemm_variant : gemm_pick_variant(M, N, K, act);
-  switch (act * 2 + (out_f32 ? 1 : 0)) {
-    case 0: return launch_gemm<ACT_NONE, false>(g, variant, stream);
-    case 1: return launch_gemm<ACT_NONE, true>(g, variant, stream);
-    case 2: return launch_gemm<ACT_GELU, false>(g, variant, stream);
-    case 3: return launch_gemm<ACT_GELU, true>(g, variant, stream);
-    case 4: return launch_gemm<ACT_TANH, false>(g, variant, stream);
-    case 5: return launch_gemm<ACT_TANH, true>(g, variant, stream);
-    case 6: return launch_gemm<ACT_MUL, false>(g, variant, stream);
-    default: return VT_ERR_UNSUPPORTED;
+  auto launch = [&](const GemmArgs& ga, int v) {
+    switch (act * 2 + (out_f32 ? 1 : 0)) {
+      case 0: return launch_gemm<ACT_NONE, false>(ga, v, stream);
+      case 1: return launch_gemm<ACT_NONE, true>(ga, v, stream);
+      case 2: return launch_gemm<ACT_GELU, false>(ga, v, stream);
+      case 3: return launch_gemm<ACT_GELU, true>(ga, v, stream);
+      case 4: return launch_gemm<ACT_TANH, false>(ga, v, stream);
+      case 5: return launch_gemm<ACT_TANH, true>(ga, v, stream);
+      case 6: return launch_gemm<ACT_MUL, false>(ga, v, stream);
+      default: return VT_ERR_UNSUPPORTED;
+    }
+  };
+  // Tail rows of the persistent kernel.  T = 256x256 tiles over `cus` CUs: F full rounds and a last round with R tiles.
+  // When that last round is at most half full, its rows go to the 128x128-tile kernel instead (two workgroups per
+  // CU: R * 4 <= 2 * cus small tiles = one round of 0.58 of the big tile's time); the persistent kernel keeps the rows
+  // of the F full rounds.  Dropout: element index = m * N + n and the hash is linear in (index/2 + seed), so the row
+  // offset of the second launch is a seed offset.  Not when a variant is forced (tuning) or rows are remapped.
+  if (variant == 16 && g_gemm_variant < 0 && g_gemm_tail_split && grp_rows == 0 && (N & 1) == 0) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      hipDeviceProp_t pr;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+    }
+    const long tn = (N + 255) / 256, tm = (M + 255) / 256, T = tm * tn;
+    if (cus > 0 && T > cus) {
+      const long F = T / cus, Rt = T - F * cus;
+      const long m1 = (F * cus) / tn;           // row tiles of the full rounds
+      const long M1 = m1 * 256;
+      if (Rt > 0 && 2 * Rt <= cus && M1 > 0 && M1 < M) {
+        GemmArgs g1 = g, g2 = g;
+        g1.M = (int)M1;
+        g1.tiles_m = (int)((M1 + GEMM_BM - 1) / GEMM_BM);
+        g2.M = (int)(M - M1);
+        g2.tiles_m = (g2.M + GEMM_BM - 1) / GEMM_BM;
+        g2.A = g.A + M1 * lda;
+        if (g.R) g2.R = g.R + M1 * ldr;
+        g2.C = out_f32 ? (void*)((float*)C + M1 * ldc) : (void*)((bf16_t*)C + M1 * ldc);
+        if (g.C2) g2.C2 = g.C2 + M1 * ldc2;
+        g2.drop.seed = g.drop.seed + (uint32_t)((M1 * N) >> 1);
+        const int rc = launch(g1, 16);
+        if (rc) return rc;
+        return launch(g2, 1);
+      }
+    }
   }
+  return launch(g, variant);
 }

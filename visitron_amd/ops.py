@@ -129,9 +129,13 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
 GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16)
 
 
+# -1: shape table / heuristic; -2: the same without the tail launch (VT_GEMM_TAIL_SPLIT=0, A/B runs)
+AUTO_VARIANT = -2 if os.environ.get("VT_GEMM_TAIL_SPLIT") == "0" else -1
+
+
 def set_gemm_variant(v):
     """Tuning/test hook: force one GEMM kernel variant (-1: shape table / heuristic)."""
-    _lib.load().vt_debug_set_gemm_variant(int(v))
+    _lib.load().vt_debug_set_gemm_variant(int(AUTO_VARIANT if v == -1 else v))
 # The persistent kernel (16) launches one workgroup per CU and needs every CU to itself (512 registers per wave, 132 KiB
 # of LDS): a collective running beside it on a few CUs makes the workgroups mapped to those CUs wait for a whole kernel
 # time.  Data-parallel training (gradient all-reduce overlapped with the backward) therefore tunes without it; the
@@ -181,7 +185,7 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
                 M, N, K, act, int(r is not None), int(pre_act), v, t / reps * 1e3, 2.0 * M * N * K / (t / reps * 1e-3) * 1e-12))
         if t < best_t:
             best, best_t = v, t
-    lib.vt_debug_set_gemm_variant(-1)
+    lib.vt_debug_set_gemm_variant(AUTO_VARIANT)
     lib.vt_gemm_tune(M, N, K, act, best)
     _tuned[key] = best
     _tune_file_store(key, best)
