@@ -38,7 +38,7 @@ typedef void* vt_stream_t; /* hipStream_t */
 const char* vt_error_string(int code);
 /* ABI version of this header; bumped on any signature change. */
 int vt_abi_version(void);
-/* Tuning hook (benchmarks only): force the GEMM kernel variant, -1 = built-in choice, -2 = built-in choice without the
+/* Tuning hook (benchmarks only): force the GEMM kernel variant, -1 = built-in choice, -2 = built-in choice plus the
  * tail launch (the persistent kernel's half-empty last round of tiles handed to the 128x128-tile kernel).  Process-global. */
 void vt_debug_set_gemm_variant(int variant);
 /* Debug: device buffer (>= 64 * 8 B per workgroup) that the persistent GEMM fills with phase timestamps; NULL = off. */

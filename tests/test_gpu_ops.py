@@ -765,7 +765,7 @@ def test_linear_tail_rows_launch(dev, act, res, pre, drop_p):
     lib = _lib.load()
     lib.vt_gemm_tune(M, N, K, act, 16)
     outs = []
-    for mode in (-2, -1):
+    for mode in (-1, -2):          # single launch, then with the tail launch
         lib.vt_debug_set_gemm_variant(mode)
         c2 = torch.empty((M, N), dtype=BF16, device=dev) if pre else None
         out = ops.linear(a, w, b, residual=r, act=act, pre_act_out=c2, drop=drop)

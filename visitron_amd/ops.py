@@ -129,8 +129,8 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
 GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16)
 
 
-# -1: shape table / heuristic; -2: the same without the tail launch (VT_GEMM_TAIL_SPLIT=0, A/B runs)
-AUTO_VARIANT = -2 if os.environ.get("VT_GEMM_TAIL_SPLIT") == "0" else -1
+# -1: shape table / heuristic; -2: the same plus the tail launch of the persistent kernel's last round (VT_GEMM_TAIL_SPLIT=1)
+AUTO_VARIANT = -2 if os.environ.get("VT_GEMM_TAIL_SPLIT") == "1" else -1
 
 
 def set_gemm_variant(v):
