@@ -156,11 +156,11 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
         lib.vt_gemm_tune(M, N, K, act, int(saved))
         _tuned[key] = int(saved)
         return _tuned[key]
-    g = torch.Generator(device="cpu").manual_seed(M + N + K)
-    a = torch.randn(M, K, generator=g).to(device, BF16)
-    w = (torch.randn(N, K, generator=g) * 0.03).to(device, BF16)
+    g = torch.Generator(device=device).manual_seed(M + N + K)   # on the device: a CPU draw of M x 3072 values costs seconds
+    a = torch.randn(M, K, generator=g, device=device).to(BF16)
+    w = (torch.randn(N, K, generator=g, device=device) * 0.03).to(BF16)
     b = torch.zeros(N, device=device)
-    r = torch.randn(M, N, generator=g).to(device, BF16) if (residual or act == ACT_MUL) else None
+    r = torch.randn(M, N, generator=g, device=device).to(BF16) if (residual or act == ACT_MUL) else None
     out = torch.empty((M, N), dtype=BF16, device=device)
     pre = torch.empty((M, N), dtype=BF16, device=device) if pre_act else None
     best, best_t = GEMM_CANDIDATES[0], float("inf")
