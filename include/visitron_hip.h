@@ -208,6 +208,12 @@ int vt_lstm_sequence_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float
                          const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
                          int B, int hs, int T, int reverse, vt_stream_t stream);
 
+/* vt_lstm_sequence_f32 over COMPACTED input projections: xproj holds only the rows below each sequence's length, row of
+ * (b, t) = row_start[b] + t (row stride ldx_row) -- what pack_padded_sequence feeds the LSTM (agent_models.py:285-287). */
+int vt_lstm_sequence_rows_f32(const float* xproj, int64_t ldx_row, const int32_t* row_start, float* h2_0, float* h2_1,
+                              float* c, const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b,
+                              int64_t lds_t, int B, int hs, int T, int reverse, vt_stream_t stream);
+
 /* out[M,N] (fp32) = act([x0 | x1] . W^T + bias) for a handful of rows: the dense layers of the decoder step
  * (AttnDecoderLSTM.forward, agent_models.py:406-425; SoftDotAttention.linear_in / linear_out :336, :354-355 with its
  * torch.cat folded in).  x0 [M,K0], x1 [M,K1] (optional) fp32 with K0, K1 multiples of 4; W bf16 [N, Kpad] zero-padded

@@ -83,6 +83,8 @@ SIGNATURES = {
                                      c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_skinny_linear_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_lstm_sequence_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_softdot_attention_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          c_int, c_int, c_void_p]),
     "vt_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -172,19 +172,22 @@ int vt_lstm_step_f32(const float* xproj, int64_t ldx, const float* h_prev, float
   LstmStepArgs a;
   a.xproj = xproj; a.ldx = ldx; a.h_prev = h_prev; a.h_out = h_out; a.c = c; a.w_hh = (const bf16_t*)w_hh;
   a.lengths = lengths; a.seq_out = seq_out; a.ld_seq = ld_seq; a.B = B; a.hs = hs; a.t = t;
+  a.xrow_start = nullptr; a.ldx_row = 0;
   return vt_lstm_step_dispatch(a, (hipStream_t)stream);
 }
 
-int vt_lstm_sequence_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float* h2_0, float* h2_1, float* c,
-                         const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
-                         int B, int hs, int T, int reverse, vt_stream_t stream) {
+static int lstm_sequence_impl(const float* xproj, int64_t ldx_b, int64_t ldx_t, float* h2_0, float* h2_1, float* c,
+                              const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
+                              int B, int hs, int T, int reverse, vt_stream_t stream, const int32_t* xrow_start) {
   if (!xproj || !h2_0 || !h2_1 || !c || !w_hh) return VT_ERR_NULL;
   if (T <= 0) return VT_ERR_BAD_SHAPE;
+  if (xrow_start && !lengths) return VT_ERR_NULL;   // compacted rows exist only below a sequence's length
   float* hb[2] = {h2_0, h2_1};
   for (int i = 0; i < T; ++i) {
     const int t = reverse ? T - 1 - i : i;
     LstmStepArgs a;
-    a.xproj = xproj + (int64_t)t * ldx_t; a.ldx = ldx_b; a.h_prev = hb[i & 1]; a.h_out = hb[(i + 1) & 1]; a.c = c;
+    a.xrow_start = xrow_start; a.ldx_row = ldx_t;
+    a.xproj = xrow_start ? xproj : xproj + (int64_t)t * ldx_t; a.ldx = ldx_b; a.h_prev = hb[i & 1]; a.h_out = hb[(i + 1) & 1]; a.c = c;
     a.w_hh = (const bf16_t*)w_hh; a.lengths = lengths; a.seq_out = seq_out ? seq_out + (int64_t)t * lds_t : nullptr;
     a.ld_seq = lds_b; a.B = B; a.hs = hs; a.t = t;
     const int rc = vt_lstm_step_dispatch(a, (hipStream_t)stream);
@@ -196,6 +199,21 @@ int vt_lstm_sequence_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float
       return VT_ERR_HIP;
   }
   return VT_OK;
+}
+
+int vt_lstm_sequence_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float* h2_0, float* h2_1, float* c,
+                         const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
+                         int B, int hs, int T, int reverse, vt_stream_t stream) {
+  return lstm_sequence_impl(xproj, ldx_b, ldx_t, h2_0, h2_1, c, w_hh, lengths, seq_out, lds_b, lds_t, B, hs, T, reverse,
+                            stream, nullptr);
+}
+
+int vt_lstm_sequence_rows_f32(const float* xproj, int64_t ldx_row, const int32_t* row_start, float* h2_0, float* h2_1,
+                              float* c, const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b,
+                              int64_t lds_t, int B, int hs, int T, int reverse, vt_stream_t stream) {
+  if (!row_start) return VT_ERR_NULL;
+  return lstm_sequence_impl(xproj, 0, ldx_row, h2_0, h2_1, c, w_hh, lengths, seq_out, lds_b, lds_t, B, hs, T, reverse,
+                            stream, row_start);
 }
 
 int vt_skinny_linear_f32(const float* x0, int64_t ld0, int K0, const float* x1, int64_t ld1, int K1, const void* w,

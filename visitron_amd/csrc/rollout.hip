@@ -60,16 +60,18 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
   const int r = wave;
   const int hid = h0 + 4 * (lane >> 4) + r;
   if (!bvalid) return;
+  const long e = (long)brow * hs + hid;
+  const bool active = a.lengths == nullptr || a.t < a.lengths[brow];
   float gate[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    float s = a.xproj[(long)brow * a.ldx + (long)g * hs + hid];
+    // (a row past its length has no input projection in the compacted layout: nothing is read for it)
+    const long xr = a.xrow_start ? ((long)a.xrow_start[brow] + a.t) * a.ldx_row : (long)brow * a.ldx;
+    float s = active ? a.xproj[xr + (long)g * hs + hid] : 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) s += ((const float*)&part[w][g][lane])[r];
     gate[g] = s;
   }
-  const long e = (long)brow * hs + hid;
-  const bool active = a.lengths == nullptr || a.t < a.lengths[brow];
   if (active) {
     const float cn = sigmoidf_(gate[1]) * a.c[e] + sigmoidf_(gate[0]) * tanhf_(gate[2]);
     const float hn = sigmoidf_(gate[3]) * tanhf_(cn);

@@ -11,6 +11,8 @@ struct LstmStepArgs {
   const int* lengths;                // [B] or null (all rows active)
   float* seq_out; long ld_seq;       // optional: row b at seq_out + b * ld_seq (already offset to position t), hs wide
   int B, hs, t;
+  const int* xrow_start;             // optional (compacted xproj rows): row of (b, t) = xrow_start[b] + t, xproj then
+  long ldx_row;                      // points at row 0 and ldx_row is the row stride (ldx unused)
 };
 
 struct SoftDotArgs {

@@ -515,8 +515,11 @@ class CaptionBertEncoder(nn.Module):
         return ws
 
     # ---- fused run --------------------------------------------------------------------
-    def run(self, x_bf16, B, S, mask_f32, mask_additive, head_scale=None, history=None):
-        """x_bf16 [B*S,H] -> list of per-layer outputs (len L if output_hidden_states else 1 shared)."""
+    def run(self, x_bf16, B, S, mask_f32, mask_additive, head_scale=None, history=None, seq=None):
+        """x_bf16 [B*S,H] -> list of per-layer outputs (len L if output_hidden_states else 1 shared).  seq (ops.SeqLayout):
+        x_bf16 holds the compacted rows [seq.rows, H] (no masked positions) and so do the outputs' first seq.rows rows."""
+        if seq is not None and (history is not None or self.output_attentions or mask_f32 is not None or ops.profiling()):
+            raise NotImplementedError("compacted rows are served by the fused layer loop only")
         if self._hidden != self._heads * 64:
             raise NotImplementedError("the fused encoder serves head size 64 (hidden = 64 * heads)")
         for layer in self.layer:
@@ -538,7 +541,7 @@ class CaptionBertEncoder(nn.Module):
         if ops.profiling():  # bench.py's per-kernel timing: the same launches, issued one by one
             return self._run_unrolled(pk, ws, x_bf16, B, S, mask_f32, mask_additive, head_scale)
         ops.encoder_forward(pk.table, ws["table"], x_bf16, mask_f32, mask_additive, head_scale, B, S,
-                            self._hidden, self._heads, self._inter, self._eps)
+                            self._hidden, self._heads, self._inter, self._eps, seq=seq)
         return ws["outs"]
 
     def _run_unrolled(self, pk, ws, x, B, S, mask, mask_additive, head_scale, probs=None, history=None):
@@ -652,8 +655,12 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
         return self._img_pack
 
     def run_trunk(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, head_mask=None,
-                  img_feats=None, img_location_embeddings=None, encoder_history_states=None):
-        """Internal: returns (per-layer bf16 outputs list, pooled fp32 [B,H], embedding bf16, B, S)."""
+                  img_feats=None, img_location_embeddings=None, encoder_history_states=None, keep=None):
+        """Internal: returns (per-layer bf16 outputs list, pooled fp32 [B,H], embedding bf16, B, S).
+        keep (bool [B,S], optional): the caller only reads the positions marked True and vouches that the others are the
+        masked ones (OscarEncoder: the padding behind each instruction) -- the encoder then runs on those rows alone
+        (compacted, ops.SeqLayout in self._last_layout; position 0 of every sequence must be kept) and the outputs'
+        first layout.rows rows are the kept positions in order; attention_mask is not consulted."""
         ops._require_hip(input_ids)
         dev = input_ids.device
         B, T = input_ids.shape
@@ -700,6 +707,21 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
             if self.use_img_layernorm:
                 ops.layernorm(x[T:], _f32(self.LayerNorm.weight), _f32(self.LayerNorm.bias),
                               self.LayerNorm.variance_epsilon, out=x[T:], M=B * R, grp_rows=R, grp_stride=S)
+        self._last_layout = None
+        if keep is not None:
+            if encoder_history_states is not None or self.encoder.output_attentions or self.encoder.output_hidden_states:
+                raise NotImplementedError("compacted rows: plain forward only")
+            lay = ops.SeqLayout(keep.to(device=dev, dtype=torch.bool))
+            self._last_layout = lay
+            xc = x.index_select(0, lay.index)
+            # the row count decides the tile quantisation: tune once per 2048-row bucket (nearest tuned M is used)
+            ops.autotune_encoder_shapes(round_up(lay.rows, 2048), H, self.config.intermediate_size, training=False,
+                                        device=dev)
+            outs = self.encoder.run(xc, B, S, None, False, hs, seq=lay)
+            cls = outs[-1][:lay.rows].index_select(0, lay.start.to(torch.int64))
+            pooled = self.pooler.pooled(cls, B, 1)
+            _check_index_error(self.embeddings)
+            return outs, pooled, x, B, S
         outs = self.encoder.run(x, B, S, mask_f32, mask_is_additive, hs, history=encoder_history_states)
         pooled = self.pooler.pooled(outs[-1], B, S)
         _check_index_error(self.embeddings)

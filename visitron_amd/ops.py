@@ -692,3 +692,24 @@ def skinny_linear(x0, w_pad, bias=None, x1=None, act=ACT_NONE):
             _ptr(bias), _ptr(out), out.stride(0), M, N, Kpad, int(act), _stream())
     _lib.check(rc, "vt_skinny_linear_f32")
     return out
+
+
+def lstm_sequence_rows(xproj, row_start, h2, c, w_hh, T, lengths, seq_out=None, reverse=False):
+    """lstm_sequence over compacted input projections: xproj fp32 [rows, 4*hs] holds only the positions below each
+    sequence's length, row of (b, t) = row_start[b] + t (int32 [B]); lengths int32 [B] is required."""
+    _require_hip(xproj, row_start, h2[0], h2[1], c, w_hh, lengths, seq_out)
+    B, hs = c.shape
+    assert xproj.dtype == torch.float32 and xproj.dim() == 2 and xproj.shape[1] == 4 * hs and xproj.stride(1) == 1
+    assert row_start.dtype == torch.int32 and row_start.shape == (B,) and lengths.dtype == torch.int32 and lengths.shape == (B,)
+    assert w_hh.dtype == BF16 and w_hh.shape == (4 * hs, hs) and w_hh.is_contiguous()
+    for s_ in (h2[0], h2[1], c):
+        assert s_.dtype == torch.float32 and s_.shape == (B, hs) and s_.is_contiguous()
+    if seq_out is not None:
+        assert seq_out.dtype == torch.float32 and seq_out.shape == (B, T, hs) and seq_out.stride(2) == 1
+    with _timed("lstm_step", 2.0 * T * B * 4 * hs * hs, T * (2.0 * 4 * hs * hs + 4.0 * B * hs * 8)):
+        rc = _lib.load().vt_lstm_sequence_rows_f32(
+            _ptr(xproj), xproj.stride(0), _ptr(row_start), _ptr(h2[0]), _ptr(h2[1]), _ptr(c), _ptr(w_hh), _ptr(lengths),
+            _ptr(seq_out), 0 if seq_out is None else seq_out.stride(0), 0 if seq_out is None else seq_out.stride(1),
+            B, hs, int(T), 1 if reverse else 0, _stream())
+    _lib.check(rc, "vt_lstm_sequence_rows_f32")
+    return h2[0]

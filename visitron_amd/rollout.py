@@ -162,6 +162,7 @@ class OscarEncoder(nn.Module):
         self.encoder_lstm2decoder_ht = nn.Linear(hidden_size * self.num_directions, decoder_hidden_size)
         self.encoder_lstm2decoder_ct = nn.Linear(hidden_size * self.num_directions, decoder_hidden_size)
         self._pk = _Packed()
+        self.compact_rows = True    # run the trunk on the positions below `lengths` only (when the mask agrees)
 
     def _weights(self):
         L = self.lstm
@@ -191,12 +192,6 @@ class OscarEncoder(nn.Module):
         att_mask = ~mask                                               # :267 (uint8 masks: 254/255, the trunk keeps that)
         B, S = inputs.shape
         H = self.transformer_hidden_size
-        if hasattr(self.bert, "run_trunk"):                            # the bf16 rows, without the fp32 round trip
-            outs, _, _, _, _ = self.bert.run_trunk(inputs, token_type_ids, att_mask, position_ids)
-            seq = outs[-1]
-        else:
-            seq = self.bert(inputs, token_type_ids=token_type_ids, attention_mask=att_mask,
-                            position_ids=position_ids)[0].detach().reshape(B * S, H).to(BF16).contiguous()
         lens = torch.as_tensor(lengths).to("cpu", torch.int64)
         if lens.numel() != B or int(lens.min()) <= 0 or int(lens.max()) > S:
             raise RuntimeError("lengths must hold one value in 1..%d per sequence" % S)
@@ -205,17 +200,39 @@ class OscarEncoder(nn.Module):
         T = int(lens.max())
         dev = inputs.device
         lens_dev = lens.to(dev, torch.int32)
+        # Only the first lengths[b] positions of a sequence are read below (pack_padded_sequence, :286).  When those are
+        # exactly the unmasked ones (mask = 1 on padding, agent.py:181) the trunk runs on them alone: compacted rows,
+        # no masked keys -- the same values at the positions that are read.
+        lay = None
+        if self.compact_rows and hasattr(self.bert, "run_trunk") and mask.shape == (B, S) and not ops.profiling():
+            keep = torch.arange(S, device=dev)[None, :] < lens_dev[:, None]
+            if bool(((mask != 0) == ~keep).all()):
+                outs, _, _, _, _ = self.bert.run_trunk(inputs, token_type_ids, None, position_ids, keep=keep)
+                lay = self.bert._last_layout
+                seq = outs[-1][:lay.rows]
+        if lay is not None:
+            pass
+        elif hasattr(self.bert, "run_trunk"):                          # the bf16 rows, without the fp32 round trip
+            outs, _, _, _, _ = self.bert.run_trunk(inputs, token_type_ids, att_mask, position_ids)
+            seq = outs[-1]
+        else:
+            seq = self.bert(inputs, token_type_ids=token_type_ids, attention_mask=att_mask,
+                            position_ids=position_ids)[0].detach().reshape(B * S, H).to(BF16).contiguous()
         w = self._weights()
         hs, D = self.hidden_size, self.num_directions
         ctx = torch.empty((B, T, D * hs), dtype=torch.float32, device=dev)
         finals = []
         for d, (w_ih, b, w_hh) in enumerate(w["dirs"]):
-            xproj = torch.empty((B * S, 4 * hs), dtype=torch.float32, device=dev)
+            xproj = torch.empty((seq.shape[0], 4 * hs), dtype=torch.float32, device=dev)
             ops.linear(seq, w_ih, b, out=xproj, out_f32=True)
             h2 = (torch.zeros((B, hs), dtype=torch.float32, device=dev), torch.empty((B, hs), dtype=torch.float32, device=dev))
             c = torch.zeros((B, hs), dtype=torch.float32, device=dev)                      # init_state :238-254
-            ops.lstm_sequence(xproj.view(B, S, 4 * hs), h2, c, w_hh, T, lens_dev, ctx[:, :, d * hs:(d + 1) * hs],
-                              reverse=(d == 1))
+            if lay is None:
+                ops.lstm_sequence(xproj.view(B, S, 4 * hs), h2, c, w_hh, T, lens_dev, ctx[:, :, d * hs:(d + 1) * hs],
+                                  reverse=(d == 1))
+            else:
+                ops.lstm_sequence_rows(xproj, lay.start, h2, c, w_hh, T, lens_dev, ctx[:, :, d * hs:(d + 1) * hs],
+                                       reverse=(d == 1))
             finals.append((h2[0], c))
         if D == 2:                                                     # :289-294: (reverse, forward) order
             h_t = torch.cat((finals[1][0], finals[0][0]), 1)
