@@ -143,9 +143,8 @@ def main():
     # the same K steps with every padded row computed (the reference's own amount of work per step): reported beside
     # `value`, not part of the timed region above
     value_all_rows = None
-    if train and engine.compact_rows and engine.last_rows is not None and engine.last_rows < a.batch * S \
-            and not a.no_fwd_rate:
-        rows_computed = engine.last_rows
+    # (the condition must not depend on a rank's own batch: every rank runs the same number of collective steps)
+    if train and engine.compact_rows and a.batch * S >= engine.compact_min_rows and not a.no_fwd_rate:
         engine.compact_rows = False
         for _ in range(2):
             step()
