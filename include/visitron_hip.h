@@ -9,7 +9,11 @@
  *   - "bf16" buffers hold raw bfloat16 bits (uint16_t); fp32 accumulation everywhere;
  *   - nothing is allocated, freed or synchronised here: the caller owns every buffer (workspace
  *     included) and the work is enqueued on `stream` (0 = the null stream);
- *   - re-entrant: no global mutable state besides one-time kernel attribute setup;
+ *   - re-entrant: callable from several host threads, each on its own current device and stream (the reference's
+ *     multi-gpu-dp mode, torch.nn.DataParallel, pretrain.py:93-94).  What the host side remembers between calls --
+ *     the autotuner's shape table (vt_gemm_tune), the compute-unit count, one-time kernel attribute setup -- is kept
+ *     per device behind a mutex / atomics.  The vt_debug_* hooks (forced kernel variants, trace buffer) are
+ *     process-global switches for benchmarks and tests, not for concurrent production use;
  *   - return 0 (VT_OK) or a negative VT_ERR_* code; vt_error_string() names it.
  */
 #ifndef VISITRON_HIP_H
@@ -46,8 +50,8 @@ void vt_debug_set_gemm_trace(void* buf);
 /* Tuning/test hook for vt_wgrad_bf16: 0 automatic (persistent stream-K kernel where N, K are multiples of 256),
    128 / 256 force the one-tile-per-workgroup kernel with that n-tile width, -8 never the persistent kernel. */
 void vt_debug_set_wgrad_kernel(int mode);
-/* Autotuner result: use kernel `variant` for linear layers of exactly this shape and activation (filled by
- * the host before the shape is used; process-global, read-only afterwards). */
+/* Autotuner result: on the calling thread's CURRENT DEVICE use kernel `variant` for linear layers of exactly this
+ * shape and activation (filled by the host before the shape is used; one table per device, mutex-guarded). */
 void vt_gemm_tune(int M, int N, int K, int act, int variant);
 /* Tuning hook: 4 or 8 waves per workgroup in the attention backward (default 8). Process-global. */
 void vt_debug_set_attn_bwd_waves(int waves);
@@ -261,6 +265,11 @@ typedef struct vt_wgrad_problem {
   int accumulate; /* 0: overwrite, 1: add into dW / db */
 } vt_wgrad_problem;
 int vt_wgrad_bf16(const vt_wgrad_problem* problems, int nprob, int M, vt_stream_t stream);
+/* The persistent weight-gradient kernel adds a tile's partial sums in ticket order behind a BOUNDED wait (a grid must
+ * always drain).  *host_count = how many workgroups of the current device ran out of that wait since the last call
+ * (then cleared); non-zero means some dW of an earlier launch is unreliable.  Blocking (copies 4 bytes device -> host):
+ * call it where the host synchronises anyway, e.g. once per training step. */
+int vt_wgrad_turn_timeouts(unsigned* host_count);
 
 /* ---- whole encoder stack: CaptionBertEncoder.forward, oscar/modeling_bert.py:140-169 ---------- */
 typedef struct vt_layer_weights {

@@ -1,0 +1,61 @@
+"""One rank of tests/test_gpu_round2.py::test_engine_under_two_ranks_matches_single_rank_accumulation (launched by
+torch.distributed.run, two ranks sharing cuda:0, gloo collectives): PretrainEngine.train_step with world_size 2 --
+the overlapped chunked backward + bucketed all-reduce of the flat gradient slab + fused AdamW -- on this rank's
+shard; dumps the all-reduced gradients, the updated weights, the 7-tuple and the rank-averaged metrics."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", 0)             # both ranks on the one GPU of the test box
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="gloo")
+    from visitron_amd import ops
+    from visitron_amd.config import mini_config
+    from visitron_amd.distributed import all_reduce_metrics
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import deterministic_state_dict, make_batch
+    from visitron_amd.training import PretrainEngine
+
+    ops.force_gemm_variant(1)                 # one kernel variant everywhere: the comparison is then order-exact
+    ops.set_wgrad_kernel(-8)
+    cfg = mini_config(num_hidden_layers=4)
+    m = PreTrainOscar(cfg)
+    m.load_state_dict(deterministic_state_dict(m, seed=5))
+    m.tie_weights()
+    m = m.to(dev).eval()
+    eng = PretrainEngine(m, lr=1e-3, weight_decay=0.05, schedule="constant", warmup_steps=0, bucket_mb=0.05)
+    eng.compact_min_rows = 0
+    assert eng.world == world == 2
+    shard = {k: v.to(dev) for k, v in make_batch(cfg, 3, text_len=20, region_len=10, seed=100 + rank).items()}
+    # the step, with the gradients captured between the all-reduce and AdamW
+    captured = {}
+    step = eng.optimizer_step
+
+    def spy(grad_scale=1.0):
+        torch.cuda.synchronize()
+        captured["g"] = eng.flat.g.detach().cpu().clone()
+        captured["scale"] = grad_scale
+        return step(grad_scale=grad_scale)
+
+    eng.optimizer_step = spy
+    out = eng.train_step(shard, overlap=True, layers_per_chunk=2)
+    torch.cuda.synchronize()
+    assert abs(captured["scale"] - 1.0 / world) < 1e-12
+    metrics = all_reduce_metrics([v if torch.is_tensor(v) else torch.tensor(float(v), device=dev) for v in out])
+    torch.save({"g": captured["g"], "p": eng.flat.p.detach().cpu(), "out": [float(v) for v in out],
+                "metrics": [float(v) for v in metrics]}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

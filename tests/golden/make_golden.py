@@ -86,6 +86,25 @@ def base():
     print("base 7-tuple", out7)
 
 
+def base_long():
+    """BASELINE configs[4] shape: 512 text + 144 region tokens (S = 656), base config, B = 2."""
+    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    b = make_batch(cfg, 2, text_len=512, region_len=144, seed=77)
+    m, seq, pooled, scores, tokp, act, out7, grads = run(cfg, b, seed=0, weight_std=0.03)
+    names = sorted(grads)
+    np.savez_compressed(
+        os.path.join(HERE, "base_cfg4.npz"),
+        in_input_ids=b["input_ids"].numpy(), in_attention_mask=b["attention_mask"].numpy(),
+        sequence_output_slice=seq[:, ::41, ::31].numpy(), sequence_output_absmax=np.array([float(seq.abs().max())]),
+        pooled_output=pooled.numpy(), prediction_scores_slice=scores[:, ::41, ::1009].numpy(),
+        prediction_scores_absmax=np.array([float(scores.abs().max())]), action_scores=act.numpy(),
+        tuple7=np.array(out7, dtype=np.float64),
+        grad_names=np.array(names), grad_norms=np.array([float(grads[n].norm()) for n in names]),
+    )
+    print("base S=656 7-tuple", out7)
+
+
 if __name__ == "__main__":
-    mini()
-    base()
+    which = sys.argv[1:] or ["mini", "base", "base_long"]
+    for w in which:
+        {"mini": mini, "base": base, "base_long": base_long}[w]()

@@ -22,6 +22,31 @@ def maxabs(a, b):
     return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
 
 
+_MEASURED = []
+
+
+def check_close(name, got, want, bound, kind="maxabs"):
+    """Assert |got - want| <= bound and RECORD the measured error: every parity test prints `PARITY name measured bound`
+    (run pytest with -s, or read tests' session summary written by conftest) so that a bound can be audited against
+    what the kernels actually deliver.  kind: "maxabs" (absolute) or "rel_l2" (||got - want|| / ||want||)."""
+    g, w = torch.as_tensor(got).detach().float().cpu(), torch.as_tensor(want).detach().float().cpu()
+    g = g.reshape(w.shape)
+    if kind == "maxabs":
+        err = float((g - w).abs().max()) if w.numel() else 0.0
+    elif kind == "rel_l2":
+        err = float((g - w).norm() / (w.norm() + 1e-30))
+    else:
+        raise ValueError(kind)
+    _MEASURED.append((name, kind, err, float(bound)))
+    print("PARITY %-58s %-7s measured %.3e  bound %.3e" % (name, kind, err, bound))
+    assert err <= bound, "%s: %s error %.4e exceeds the bound %.4e" % (name, kind, err, bound)
+    return err
+
+
+def measured():
+    return list(_MEASURED)
+
+
 class FixedMaskDropout(torch.nn.Module):
     """nn.Dropout with the keep-mask given instead of drawn: x * keep / (1 - p)."""
 
@@ -33,9 +58,15 @@ class FixedMaskDropout(torch.nn.Module):
         return x * self.keep.view_as(x) / (1.0 - self.p)
 
 
-def inject_dropout_masks(ref, p_hidden, p_attn, seed, B, T, R, device="cuda:0"):
+def inject_dropout_masks(ref, p_hidden, p_attn, seed, B, T, R, device="cuda:0", layout=None):
     """Replace every nn.Dropout of the oracle model by a FixedMaskDropout holding the keep-mask the HIP
-    kernels derive from (seed, site, element index) — read back through vt_debug_dropout_mask."""
+    kernels derive from (seed, site, element index) — read back through vt_debug_dropout_mask.
+
+    layout (ops.SeqLayout, the engine's `last_layout`): the step ran on the compacted rows (padding rows dropped).  The
+    encoder's row-wise sites then index their elements by COMPACT row (row_c * H + col) and the attention site by
+    sequence-relative (query, key) with the sequence's own length as the row pitch; the masks are scattered back to the
+    padded [B, S] geometry the oracle computes in (positions the step never computed keep 1: nothing reads them).  The
+    embedding and image sites are applied before the compaction and stay in the padded geometry."""
     from visitron_amd import ops
 
     cfg = ref.config
@@ -51,14 +82,35 @@ def inject_dropout_masks(ref, p_hidden, p_attn, seed, B, T, R, device="cuda:0"):
             parent = getattr(parent, q)
         setattr(parent, parts[-1], mod)
 
+    if layout is not None:
+        index = layout.index.cpu()
+        start, length = layout.start.cpu().tolist(), layout.length.cpu().tolist()
+        pos = [(index[start[b]:start[b] + length[b]] - b * S) for b in range(B)]   # padded positions of b's kept rows
+
+    def rows_site(site):
+        if layout is None:
+            return keep(B * S * H, p_hidden, site).view(B, S, H)
+        full = torch.ones(B * S, H, dtype=torch.uint8)
+        full[index] = keep(layout.rows * H, p_hidden, site).view(layout.rows, H)
+        return full.view(B, S, H)
+
+    def attn_site(site):
+        if layout is None:
+            return torch.stack([keep(S * S, p_attn, site, head=i).view(S, S) for i in range(B * nh)]).view(B, nh, S, S)
+        full = torch.ones(B, nh, S, S, dtype=torch.uint8)
+        for b in range(B):
+            n = length[b]
+            for h in range(nh):
+                blk = keep(n * n, p_attn, site, head=b * nh + h).view(n, n)
+                full[b, h][pos[b][:, None], pos[b][None, :]] = blk
+        return full
+
     setmod("bert.embeddings.dropout", FixedMaskDropout(keep(B * T * H, p_hidden, ops.SITE_EMB).view(B, T, H), p_hidden))
     if R:
         setmod("bert.dropout", FixedMaskDropout(keep(B * R * H, p_hidden, ops.SITE_IMG).view(B, R, H), p_hidden))
     for l in range(cfg.num_hidden_layers):
         pre = "bert.encoder.layer.%d." % l
-        att = torch.stack([keep(S * S, p_attn, ops.site_attn(l), head=i).view(S, S) for i in range(B * nh)])
-        setmod(pre + "attention.self.dropout", FixedMaskDropout(att.view(B, nh, S, S), p_attn))
-        setmod(pre + "attention.output.dropout",
-               FixedMaskDropout(keep(B * S * H, p_hidden, ops.site_selfout(l)).view(B, S, H), p_hidden))
-        setmod(pre + "output.dropout", FixedMaskDropout(keep(B * S * H, p_hidden, ops.site_out(l)).view(B, S, H), p_hidden))
+        setmod(pre + "attention.self.dropout", FixedMaskDropout(attn_site(ops.site_attn(l)), p_attn))
+        setmod(pre + "attention.output.dropout", FixedMaskDropout(rows_site(ops.site_selfout(l)), p_hidden))
+        setmod(pre + "output.dropout", FixedMaskDropout(rows_site(ops.site_out(l)), p_hidden))
     return ref

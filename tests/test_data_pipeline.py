@@ -16,6 +16,14 @@ def test_location_embedding_table_matches_reference_construction():
 
 
 def test_mask_tokens_and_assembly_match_per_item_restatement():
+    check_against_per_item_restatement("cpu")
+
+
+def check_against_per_item_restatement(device):
+    """visitron_amd.data on `device` against oracle/data.py item by item, on shared random draws.  Integer outputs
+    (ids, labels, attention mask, token labels, next action) must be EQUAL; the float outputs are gathers of the inputs
+    / of the location table, so they must be equal too (the table to fp32 rounding of sin / cos)."""
+    dev = torch.device(device)
     g = torch.Generator().manual_seed(5)
     B, T, V, R_in, D, R = 6, 24, 997, 30, 11, 20
     special_ids, pad_id, mask_id = {0, 101, 102, 103}, 0, 103
@@ -32,13 +40,20 @@ def test_mask_tokens_and_assembly_match_per_item_restatement():
     draws = (torch.rand(B, T, generator=g), torch.rand(B, T, generator=g), torch.rand(B, T, generator=g),
              torch.randint(V, (B, T), generator=g))
     for tc in (None, token_classes):
-        got_in, got_lab, got_att = vdata.mask_tokens(ids, special, pad_id, mask_id, V, 0.15, token_classes=tc, draws=draws)
+        d = lambda t: t.to(dev)
+        got_in, got_lab, got_att = vdata.mask_tokens(d(ids), d(special), pad_id, mask_id, V, 0.15,
+                                                     token_classes=None if tc is None else d(tc),
+                                                     draws=tuple(d(x) for x in draws))
         counts = torch.tensor([30, 20, 25, 5, 0, 19])            # > R, == R, between, short, empty, R - 1
         feats = torch.rand(B, R_in, D, generator=g)
         view_ids = torch.randint(0, 36, (B, R_in), generator=g)
         cur = torch.randint(0, 36, (B,), generator=g)
         nxt = torch.randint(0, 36, (B,), generator=g)
-        batch = vdata.assemble_batch(got_in, got_lab, got_att, feats, counts, view_ids, cur, nxt, R, token_classes=tc)
+        batch = vdata.assemble_batch(got_in, got_lab, got_att, d(feats), d(counts), d(view_ids), d(cur), d(nxt), R,
+                                     token_classes=None if tc is None else d(tc))
+        assert all(v is None or v.device.type == dev.type for v in batch.values())
+        batch = {k: (None if v is None else v.cpu()) for k, v in batch.items()}
+        got_in, got_lab, got_att = got_in.cpu(), got_lab.cpu(), got_att.cpu()
         for b in range(B):
             w_in, w_lab, w_att = odata.mask_tokens_item(ids[b], special_ids, pad_id, mask_id, 0.15, None if tc is None else tc[b],
                                                         draws[0][b], draws[1][b], draws[2][b], draws[3][b])
@@ -48,8 +63,8 @@ def test_mask_tokens_and_assembly_match_per_item_restatement():
                                               int(nxt[b]), R, token_classes=None if tc is None else tc[b])
             assert torch.equal(batch["labels"][b], want["labels"])
             assert torch.equal(batch["attention_mask"][b], want["attention_mask"].long())
-            assert torch.allclose(batch["img_feats"][b], want["img_feats"])
-            assert torch.allclose(batch["img_location_embeddings"][b], want["img_location_embeddings"], atol=1e-6)
+            assert torch.equal(batch["img_feats"][b], want["img_feats"])
+            assert torch.allclose(batch["img_location_embeddings"][b], want["img_location_embeddings"], atol=1e-6, rtol=0)
             if tc is not None:
                 assert torch.equal(batch["token_labels"][b], want["token_labels"])
             assert int(batch["next_action"][b]) == want["next_action"]

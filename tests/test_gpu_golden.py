@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import check_close
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = 5e-2  # bf16 path tolerance, BASELINE.json north_star
@@ -32,14 +34,13 @@ def test_mini_fixture(dev):
                                                  img_feats=b["img_feats"], img_location_embeddings=b["img_location_embeddings"])
         scores, tokp, act = m.head_outputs(outs[-1], pooled)
         out7 = m(**b)
-    d = lambda t, ref: float(np.abs(t.float().cpu().numpy().reshape(ref.shape) - ref).max())
-    assert d(outs[-1], g["sequence_output"]) < TOL
-    assert d(pooled, g["pooled_output"]) < TOL
-    assert d(scores, g["prediction_scores"]) < TOL
-    assert d(tokp, g["token_probs"]) < TOL
-    assert d(act, g["action_scores"]) < TOL
+    check_close("golden mini sequence_output", outs[-1], g["sequence_output"], TOL)
+    check_close("golden mini pooled_output", pooled, g["pooled_output"], TOL)
+    check_close("golden mini prediction_scores", scores, g["prediction_scores"], TOL)
+    check_close("golden mini token_probs", tokp, g["token_probs"], TOL)
+    check_close("golden mini action_scores", act, g["action_scores"], TOL)
     for i in range(4):
-        assert abs(float(out7[i]) - g["tuple7"][i]) < TOL
+        check_close("golden mini tuple7[%d]" % i, float(out7[i]), float(g["tuple7"][i]), TOL)
 
 
 def test_base_cfg1_fixture(dev):
@@ -58,10 +59,10 @@ def test_base_cfg1_fixture(dev):
         scores, tokp, act = m.head_outputs(outs[-1], pooled)
         out7 = m(**b)
     seq = outs[-1].float().cpu().view(B, S, -1)
-    assert float(np.abs(seq[:, ::19, ::31].numpy() - g["sequence_output_slice"]).max()) < 2 * TOL
-    assert float(np.abs(pooled.cpu().numpy() - g["pooled_output"]).max()) < TOL
-    sc = scores.float().cpu().view(B, S, -1)[:, ::23, ::1009].numpy()
-    assert float(np.abs(sc - g["prediction_scores_slice"]).max()) < TOL * float(g["prediction_scores_absmax"][0])
-    assert float(np.abs(act.cpu().numpy() - g["action_scores"]).max()) < TOL
+    check_close("golden base cfg1 sequence_output slice", seq[:, ::19, ::31], g["sequence_output_slice"], TOL)
+    check_close("golden base cfg1 pooled_output", pooled, g["pooled_output"], TOL)
+    check_close("golden base cfg1 prediction_scores slice", scores.float().cpu().view(B, S, -1)[:, ::23, ::1009],
+                g["prediction_scores_slice"], TOL)
+    check_close("golden base cfg1 action_scores", act, g["action_scores"], TOL)
     for i in range(4):
-        assert abs(float(out7[i]) - g["tuple7"][i]) < TOL * max(1.0, abs(g["tuple7"][i]))
+        check_close("golden base cfg1 tuple7[%d]" % i, float(out7[i]), float(g["tuple7"][i]), TOL)

@@ -88,6 +88,26 @@ def test_base_cfg1_fixture_reproduced_by_oracle():
     np.testing.assert_allclose([float(x) for x in out7], g["tuple7"], atol=5e-4)
 
 
+def test_base_cfg4_fixture_reproduced_by_oracle():
+    """BASELINE configs[4] shape (512 text + 144 regions): forward only here (the fixture's gradient norms come from
+    tests/golden/make_golden.py base_long)."""
+    from visitron_amd.config import BertConfig
+    from visitron_amd.synth import make_batch
+
+    g = np.load(os.path.join(GOLD, "base_cfg4.npz"))
+    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    b = make_batch(cfg, 2, text_len=512, region_len=144, seed=77)
+    assert np.array_equal(g["in_input_ids"], b["input_ids"].numpy())
+    assert np.array_equal(g["in_attention_mask"], b["attention_mask"].numpy())
+    m = _oracle(cfg, 0, 0.03)
+    with torch.no_grad():
+        seq, pooled = m.bert(**{k: b[k] for k in TRUNK_KEYS})[:2]
+        scores, _, act = m.heads(seq, pooled)
+    np.testing.assert_allclose(seq[:, ::41, ::31].numpy(), g["sequence_output_slice"], atol=1e-4)
+    np.testing.assert_allclose(scores[:, ::41, ::1009].numpy(), g["prediction_scores_slice"], atol=5e-4)
+    np.testing.assert_allclose(act.numpy(), g["action_scores"], atol=1e-4)
+
+
 def test_crosscheck_report_is_green():
     with open(os.path.join(GOLD, "hf_crosscheck.json")) as f:
         r = json.load(f)

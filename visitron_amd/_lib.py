@@ -121,6 +121,7 @@ SIGNATURES = {
                                    c_void_p, c_float, c_uint64, c_void_p]),
     "vt_pack_concat_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "vt_wgrad_bf16": (c_int, [ctypes.POINTER(WgradProblem), c_int, c_int, c_void_p]),
+    "vt_wgrad_turn_timeouts": (c_int, [ctypes.POINTER(ctypes.c_uint)]),
     "vt_encoder_forward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerActs), c_int, c_void_p,
                                         c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                         c_float, c_float, c_uint64, c_void_p]),

@@ -755,12 +755,8 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
   if ((ld_qkv % 8) || (ld_d % 8) || (ld_ctx % 8) || (ld_dqkv % 8)) return VT_ERR_BAD_ALIGN;
   if (((uintptr_t)qkv | (uintptr_t)dctx | (uintptr_t)ctx | (uintptr_t)dqkv) & 15) return VT_ERR_BAD_ALIGN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attention_bwd_d64, hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_BYTES) != hipSuccess)
-      return VT_ERR_HIP;
-    attr_set = true;
-  }
+  static VtLdsAttrOnce attr4;
+  if (!attr4.set((const void*)attention_bwd_d64, AB_LDS_BYTES)) return VT_ERR_HIP;
   if ((seq_start == nullptr) != (seq_len == nullptr)) return VT_ERR_NULL;
   if (seq_start && (mask || rows_total <= 0)) return VT_ERR_UNSUPPORTED;   // compacted rows carry no masked keys
   const long rows = seq_start ? rows_total : (long)B * S;
@@ -778,12 +774,8 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   if (g_attn_bwd_waves == 4) {
     hipLaunchKernelGGL(attention_bwd_d64, dim3(nh, B, nkb), dim3(256), AB_LDS_BYTES, stream, a);
   } else {
-    static bool attr8 = false;
-    if (!attr8) {
-      if (hipFuncSetAttribute((const void*)attention_bwd_d64_w8, hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_BYTES) != hipSuccess)
-        return VT_ERR_HIP;
-      attr8 = true;
-    }
+    static VtLdsAttrOnce attr8;
+    if (!attr8.set((const void*)attention_bwd_d64_w8, AB_LDS_BYTES)) return VT_ERR_HIP;
     hipLaunchKernelGGL(attention_bwd_d64_w8, dim3(nh, B, nkb), dim3(512), AB_LDS_BYTES, stream, a);
   }
   if (nkb > 1) {

@@ -240,12 +240,8 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
   if ((ld_qkv % 8) || (ld_ctx % 8) || ld_qkv < 3L * nh * 64 || ld_ctx < (long)nh * 64) return VT_ERR_BAD_ALIGN;
   if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return VT_ERR_BAD_ALIGN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attention_fwd_d64, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES) != hipSuccess)
-      return VT_ERR_HIP;
-    attr_set = true;
-  }
+  static VtLdsAttrOnce attr;
+  if (!attr.set((const void*)attention_fwd_d64, ATT_LDS_BYTES)) return VT_ERR_HIP;
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = (bf16_t*)ctx; a.lse = lse;
   a.ld_qkv = ld_qkv; a.ld_ctx = ld_ctx; a.B = B; a.S = S; a.nh = nh;

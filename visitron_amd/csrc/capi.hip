@@ -50,6 +50,7 @@ void vt_gemm_set_variant(int v);
 void vt_gemm_set_trace(void* p);
 void vt_wgrad_set_tile(int tn);
 void vt_wgrad_v8_enable(int on);
+int vt_wgrad_v8_timeouts(unsigned* out);
 void vt_gemm_tune_set(int M, int N, int K, int act, int variant);
 void vt_attn_bwd_set_waves(int w);
 
@@ -74,7 +75,7 @@ const char* vt_error_string(int code) {
   }
 }
 
-int vt_abi_version(void) { return 2; }
+int vt_abi_version(void) { return 3; }
 
 void vt_debug_set_gemm_variant(int variant) { vt_gemm_set_variant(variant); }
 void vt_debug_set_gemm_trace(void* buf) { vt_gemm_set_trace(buf); }
@@ -289,6 +290,11 @@ int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_
 int vt_pack_concat_bf16(const float* s0, int d0, const float* s1, int d1, void* out, int kpad, int64_t rows,
                         vt_stream_t stream) {
   return vt_pack_concat_dispatch(s0, d0, s1, d1, out, kpad, rows, (hipStream_t)stream);
+}
+
+int vt_wgrad_turn_timeouts(unsigned* host_count) {
+  if (!host_count) return VT_ERR_NULL;
+  return vt_wgrad_v8_timeouts(host_count);
 }
 
 int vt_wgrad_bf16(const vt_wgrad_problem* problems, int nprob, int M, vt_stream_t stream) {

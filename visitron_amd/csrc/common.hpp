@@ -1,5 +1,6 @@
 // Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  wave = 64 lanes.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -210,6 +211,42 @@ __host__ __forceinline__ DropCfg vt_make_drop(float p, uint64_t step_seed, uint3
 #define VT_SITE_OUT(l) (8u * (l) + 2u)
 #define VT_SITE_EMB 0xE0u
 #define VT_SITE_IMG 0xE1u
+
+// ---- per-device host-side state ---------------------------------------------------------------------------
+// One process may drive several GPUs from several threads (torch.nn.DataParallel, pretrain.py:93-94): everything the
+// host side remembers between calls is kept PER DEVICE (the calling thread's current device) and behind atomics.
+#define VT_MAX_DEVICES 64
+inline int vt_current_device() {
+  int d = 0;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < VT_MAX_DEVICES) ? d : -1;
+}
+// compute units of the current device (0 on error)
+inline int vt_device_cus() {
+  static std::atomic<int> cus[VT_MAX_DEVICES];
+  const int d = vt_current_device();
+  if (d < 0) return 0;
+  int c = cus[d].load(std::memory_order_relaxed);
+  if (!c) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) != hipSuccess) return 0;
+    c = p.multiProcessorCount;
+    cus[d].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel call site, device): function attributes belong to
+// the device's copy of the code object, so a process-wide "done" flag would skip the second GPU.
+struct VtLdsAttrOnce {
+  std::atomic<bool> done[VT_MAX_DEVICES];
+  bool set(const void* kern, int bytes) {
+    const int d = vt_current_device();
+    if (d < 0) return false;
+    if (done[d].load(std::memory_order_acquire)) return true;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done[d].store(true, std::memory_order_release);
+    return true;
+  }
+};
 
 // error codes of the C ABI (include/visitron_hip.h)
 #define VT_OK 0

@@ -24,7 +24,8 @@
 //   * block ids are remapped so that the tiles sharing an activation row-panel run on one XCD
 //     (one L2).
 // This file holds the 2-waves-per-SIMD kernels (v2, v4, v5, v6 below) and the dispatcher / shape table; the
-// one-wave-per-SIMD 256x256 kernels with AGPR accumulators are in gemm_v7.hip (variants 15, 16) and gemm_v9.hip (17).
+// one-wave-per-SIMD 256x256 kernels with AGPR accumulators are in gemm_v7.hip (variants 15, 16).
+#include <mutex>
 #include "gemm_common.hpp"
 
 // ================================================================================================
@@ -690,10 +691,9 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_bf16_v6(GemmArgs g) {
 // variant: 1 = 128x128 tile, 4 waves, BK 64, 2-stage ring (v2); 14 = the same tile with 8 waves of 32x64 (v6);
 //          9 / 10 = 256x192 / 256x256 tile, 8 waves (v4); 11 = 256x256, BK 32, 4-stage ring, phased (v5);
 //          15 / 16 = 256x256 tile, 4 waves of 128x128 with AGPR accumulators, one tile per workgroup / persistent
-//          (gemm_v7.hip); 17 = the persistent kernel on 32x32x16 MFMAs (gemm_v9.hip).
+//          (gemm_v7.hip).
 int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip
 int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip (persistent)
-int vt_gemm_v9_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v9.hip (persistent, 32x32x16 MFMAs)
 static void* g_gemm_trace = nullptr;
 void vt_gemm_set_trace(void* p) { g_gemm_trace = p; }
 static int g_gemm_variant = -1;  // -1: table / heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
@@ -707,15 +707,27 @@ void vt_gemm_set_variant(int v) {
 
 // Shape -> variant table filled by the host-side autotuner (visitron_amd.ops.autotune_linear) before
 // the shapes are used; read-only afterwards.  Exact-match lookup; misses fall back to the heuristic.
+// One table PER DEVICE (the calling thread's current device), guarded by a mutex: threads driving different GPUs of one
+// process (torch.nn.DataParallel) tune and look up independently.
 struct TuneEntry { int M, N, K, act, variant; };
-static TuneEntry g_tune[256];
-static int g_ntune = 0;
+struct TuneTable { TuneEntry e[256]; int n; };
+static TuneTable g_tune_dev[VT_MAX_DEVICES];
+static std::mutex g_tune_mu;
 void vt_gemm_tune_set(int M, int N, int K, int act, int variant) {
+  const int dev = vt_current_device();
+  if (dev < 0) return;
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  TuneEntry* g_tune = g_tune_dev[dev].e;
+  int& g_ntune = g_tune_dev[dev].n;
   for (int i = 0; i < g_ntune; ++i)
     if (g_tune[i].M == M && g_tune[i].N == N && g_tune[i].K == K && g_tune[i].act == act) { g_tune[i].variant = variant; return; }
   if (g_ntune < 256) g_tune[g_ntune++] = TuneEntry{M, N, K, act, variant};
 }
 static int gemm_pick_variant(int M, int N, int K, int act) {
+  const int dev = vt_current_device();
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  const TuneEntry* g_tune = g_tune_dev[dev < 0 ? 0 : dev].e;
+  const int g_ntune = dev < 0 ? 0 : g_tune_dev[dev].n;
   for (int i = 0; i < g_ntune; ++i)
     if (g_tune[i].M == M && g_tune[i].N == N && g_tune[i].K == K && g_tune[i].act == act) return g_tune[i].variant;
   // a row count the tuner has not seen (compacted batches change it every step): the entry of the same (N, K, act)
@@ -781,7 +793,6 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
     }
     case 15: return vt_gemm_v7_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
     case 16: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
-    case 17: return vt_gemm_v9_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
     default: return VT_ERR_UNSUPPORTED;
   }
 }
@@ -825,12 +836,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   // of the F full rounds.  Dropout: element index = m * N + n and the hash is linear in (index/2 + seed), so the row
   // offset of the second launch is a seed offset.  Not when a variant is forced (tuning) or rows are remapped.
   if (variant == 16 && g_gemm_variant < 0 && g_gemm_tail_split && grp_rows == 0 && (N & 1) == 0) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t pr;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
-    }
+    const int cus = vt_device_cus();
     const long tn = (N + 255) / 256, tm = (M + 255) / 256, T = tm * tn;
     if (cus > 0 && T > cus) {
       const long F = T / cus, Rt = T - F * cus;

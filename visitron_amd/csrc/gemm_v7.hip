@@ -530,13 +530,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
 }
 
 static int v8_grid(int tiles) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
-    cus = p.multiProcessorCount;
-  }
+  const int cus = vt_device_cus();   // of the calling thread's current device
+  if (cus <= 0) return -1;
   return tiles < cus ? tiles : cus;
 }
 

@@ -465,8 +465,24 @@ class _PackedEncoder(object):
         self.tensors, self.table = keep, table
 
 
-def _param_key(module):
-    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+# Packed bf16 weight copies (encoder layers, region projection, rollout modules) are cached and keyed on each
+# parameter's (storage address, version) PLUS this process-wide generation.  Writers that change parameter values
+# without bumping ``_version`` -- the fused AdamW kernel (raw pointers into the flat slab) and torch optimizers that
+# update through ``p.data`` (the reference's pytorch-transformers AdamW does) -- are covered by the generation: the
+# training engine bumps it after every optimizer step and the autograd bridge before every training forward (an
+# external optimizer is expected to step after it).  Code that edits ``p.data`` by hand between two inference calls
+# must call ``invalidate_packed_weights()`` itself.
+_WEIGHTS_GEN = [0]
+
+
+def invalidate_packed_weights():
+    """Drop every cached packed-weight copy in this process (they are rebuilt on the next forward)."""
+    _WEIGHTS_GEN[0] += 1
+
+
+def _param_key(module_or_params):
+    ps = module_or_params.parameters() if isinstance(module_or_params, nn.Module) else module_or_params
+    return (_WEIGHTS_GEN[0],) + tuple((p.data_ptr(), p._version) for p in ps)
 
 
 class CaptionBertEncoder(nn.Module):
@@ -642,7 +658,7 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
     def _packed_img(self):
         """[H, Kpad] bf16 = [img_embedding.weight | location_embeds.weight | 0], bias = b_img + b_loc."""
         ps = (self.img_embedding.weight, self.img_embedding.bias, self.location_embeds.weight, self.location_embeds.bias)
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        key = _param_key(ps)
         if self._img_pack is None or key != self._img_pack_key:
             D = self.img_dim
             kpad = round_up(D + 128, 64)
@@ -788,54 +804,58 @@ class PreTrainOscar(BertPreTrainedModel):
             return self.bert(input_ids, position_ids=position_ids, token_type_ids=token_type_ids,
                              attention_mask=attention_mask, head_mask=head_mask, img_feats=img_feats,
                              img_location_embeddings=img_location_embeddings)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        batch = dict(input_ids=input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask, labels=labels,
+                     token_labels=token_labels, position_ids=position_ids, img_feats=img_feats,
+                     img_location_embeddings=img_location_embeddings, next_action=next_action)
+        batch = {k: v for k, v in batch.items() if v is not None}
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if wants_grad and self.training:
             # training: HIP forward + backward, bridged to autograd so that `loss.backward()` and any torch
             # optimizer / DistributedDataParallel wrapper work as in the reference's loop
             if head_mask is not None:
                 raise NotImplementedError("head_mask is not supported by the HIP training path")
-            from .training import autograd_forward
-
-            batch = dict(input_ids=input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask, labels=labels,
-                         token_labels=token_labels, position_ids=position_ids, img_feats=img_feats,
-                         img_location_embeddings=img_location_embeddings, next_action=next_action)
             if token_labels is None:
                 raise NameError("token_prediction")  # the reference leaves it unbound (encoder.py:400)
-            return autograd_forward(self, {k: v for k, v in batch.items() if v is not None})
+            from .training import autograd_forward
+
+            return autograd_forward(self, batch)
         outs, pooled, _, B, S = self.bert.run_trunk(
             input_ids, token_type_ids, attention_mask, position_ids, head_mask, img_feats, img_location_embeddings)
         prediction_scores, token_prob, action_scores = self.head_outputs(outs[-1], pooled)
         V, C = self.config.vocab_size, self.config.detector_classes
 
-        token_loss = 0
-        if token_labels is not None:
-            token_prediction = token_prob.view(B, S, C)
-            token_loss = self.criterion(token_prob.reshape(-1, C), token_labels.view(-1))
-        mask_loss = self.criterion(prediction_scores.reshape(-1, V), labels.view(-1))
-        next_loss = 0
-        if next_action is not None:
-            next_loss = self.criterion(action_scores, next_action)
+        # losses: encoder.py:379-396 (every criterion ignores label -1; an absent label set contributes the int 0)
+        if token_labels is None:
+            raise NameError("token_prediction")  # the reference leaves it unbound (encoder.py:400)
+        token_loss = self.criterion(token_prob, token_labels.reshape(-1))
+        mask_loss = self.criterion(prediction_scores, labels.reshape(-1))
+        next_loss = self.criterion(action_scores, next_action) if next_action is not None else 0
         loss = mask_loss + next_loss + token_loss
+        # accuracies: encoder.py:398-431
+        words_accuracy = _supervised_accuracy(prediction_scores, labels)
+        token_accuracy = _supervised_accuracy(token_prob, token_labels)
+        action_accuracy = 0
+        if next_action is not None:   # divides by the whole batch, ignored (-1) actions included (encoder.py:418-421)
+            action_accuracy = (action_scores.argmax(1) == next_action).sum().float() / action_scores.shape[0]
+        if wants_grad and head_mask is None:
+            # eval mode with grad enabled (the reference's val() never wraps its loop in no_grad): the values above stand;
+            # the backward pass is prepared only if someone calls it
+            from .training import lazy_autograd_loss
 
-        predicted_action = torch.argmax(action_scores, dim=1)
-        predicted_words = torch.argmax(prediction_scores.view(B, S, -1), dim=2)
-        token_prediction = torch.argmax(token_prediction, dim=2)  # NameError if token_labels is None, as the reference
-
-        predicted_words[labels == -1] = -1
-        ignored_words_no = torch.sum(labels == -1)
-        words_left = ((labels.shape[0] * labels.shape[1]) - ignored_words_no).type(torch.float)
-        words_accuracy = (torch.sum(predicted_words == labels) - ignored_words_no) / words_left
-
-        if next_action is not None:
-            action_accuracy = torch.sum(predicted_action == next_action).type(torch.float) / predicted_action.shape[0]
-        else:
-            action_accuracy = 0
-
-        token_prediction[token_labels == -1] = -1
-        ignored_tokens_no = torch.sum(token_labels == -1)
-        tokens_left = ((token_prediction.shape[0] * token_prediction.shape[1]) - ignored_tokens_no).type(torch.float)
-        token_accuracy = (torch.sum(token_prediction == token_labels).type(torch.float) - ignored_tokens_no) / tokens_left
-
+            loss = lazy_autograd_loss(self, batch, loss)
         return (loss, mask_loss, next_loss, token_loss, words_accuracy, action_accuracy, token_accuracy)
+
+
+def _supervised_accuracy(scores, labels):
+    """Fraction of the positions with a label (!= -1) whose argmax over the class axis equals it; 0-d fp32 tensor.
+
+    The reference reaches the same number by overwriting the prediction with -1 wherever the label is -1, counting ALL
+    equal positions and subtracting the ignored count again (encoder.py:402-431); with no labelled position both forms
+    are 0/0 = NaN."""
+    y = labels.reshape(-1)
+    have = y != -1
+    hits = ((scores.reshape(y.numel(), -1).argmax(1) == y) & have).sum()
+    return hits.float() / have.sum().float()
 
 
 # tasks/viewpoint_select/model_utils.py:15-26 -- the registry the reference's loader indexes by name.

@@ -124,8 +124,7 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
 
 
 # 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring), 256x256 with 128x128 wave tiles
-# and AGPR accumulators (15: one tile per workgroup, 16: persistent).  Variant 17 (the persistent kernel on 32x32x16
-# MFMAs, gemm_v9.hip) measured level with 16 on the plain shapes and slower with epilogues: not a candidate.
+# and AGPR accumulators (15: one tile per workgroup, 16: persistent).
 GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16)
 
 
@@ -142,12 +141,23 @@ def set_gemm_variant(v):
 # one-tile-per-workgroup form of the same kernel (15) is within 3-5 % and simply queues its tiles.
 PERSISTENT_GEMM_OK = True
 _tuned = {}
+_forced_variant = None
+
+
+def force_gemm_variant(v):
+    """Test hook: every linear() takes kernel variant `v` and the autotuner stands down (None: back to automatic).
+    With one variant everywhere two processes run the same summation order, so their results can be compared exactly."""
+    global _forced_variant
+    _forced_variant = None if v is None else int(v)
+    _lib.load().vt_debug_set_gemm_variant(AUTO_VARIANT if v is None else int(v))
 
 
 def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device="cuda", reps=8):
     """Time the GEMM kernel variants on one shape (random data, HIP events) and register the fastest in the
     library's shape table.  Synchronises; call it before the timed region / graph capture."""
     key = (M, N, K, act)
+    if _forced_variant is not None:
+        return _forced_variant
     if key in _tuned:
         return _tuned[key]
     lib = _lib.load()
@@ -584,6 +594,14 @@ def wgrad(problems, M):
     with _timed("gemm_wgrad_tn_bf16", flops, 0.0):
         rc = _lib.load().vt_wgrad_bf16(arr, len(problems), M, _stream())
     _lib.check(rc, "vt_wgrad_bf16")
+
+
+def wgrad_turn_timeouts():
+    """Workgroups of the persistent weight-gradient kernel that ran out of their bounded wait for a dW tile since the last
+    call (0 in a healthy run).  Blocking 4-byte read-back: call it where the host synchronises anyway."""
+    n = ctypes.c_uint(0)
+    _lib.check(_lib.load().vt_wgrad_turn_timeouts(ctypes.byref(n)), "vt_wgrad_turn_timeouts")
+    return int(n.value)
 
 
 def encoder_forward(layer_weights, layer_acts, x, mask, mask_additive, head_scale, B, S, H, nh, I, eps,

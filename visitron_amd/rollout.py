@@ -30,7 +30,9 @@ class _Packed(object):
         self._key, self._val = None, None
 
     def get(self, params, build):
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        from .modeling import _param_key   # (address, version) per parameter + the process-wide weights generation
+
+        key = _param_key(params)
         if key != self._key:
             self._val, self._key = build(), key
         return self._val

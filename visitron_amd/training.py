@@ -25,7 +25,7 @@ import os
 import torch.nn.functional as F
 
 from . import _lib, ops
-from .modeling import PreTrainOscar, _i64
+from .modeling import PreTrainOscar, _i64, invalidate_packed_weights
 from .ops import ACT_MUL, ACT_GELU, ACT_NONE, ACT_TANH, BF16, round_up
 
 ALIGN = 64  # elements; keeps every parameter view 256-byte aligned inside the slabs
@@ -181,6 +181,7 @@ class PretrainEngine(object):
         # as the padded run (tests/test_gpu_train.py); VT_COMPACT_ROWS=0 or the attribute turns it off
         self.compact_rows = os.environ.get("VT_COMPACT_ROWS", "1") != "0"
         self.last_rows = None
+        self.last_layout = None
         self._tuned_rows = set()
         # below this many (padded) token rows the layout's own launches and host sync cost more than the rows saved
         # (B=36: 3 036 against 3 352 samples/s; B=64 x 656 and B=256 x 228: +6 %)
@@ -326,19 +327,44 @@ class PretrainEngine(object):
         S, H, I, nh, L = T + R, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
         M = B * S
         labels, token_labels, next_action = batch["labels"], batch["token_labels"], batch.get("next_action")
-        # supervised-row compaction first: torch.nonzero synchronises with the host, and here the GPU is
-        # idle anyway (start of the step) instead of between the encoder and the heads
-        lab = labels.reshape(-1)
-        idx_w = torch.nonzero(lab != -1).flatten()
-        tl = token_labels.reshape(-1)
-        idx_t = torch.nonzero(tl != -1).flatten()
-        Ml, Mt = int(idx_w.numel()), int(idx_t.numel())
         am = batch.get("attention_mask")
         mask = None if am is None else am.to(torch.float32).contiguous()
         if mask is not None and mask.shape != (B, S):
             raise RuntimeError("attention_mask must be [batch, text+region]")
         tt, pos_ids = _i64(batch.get("token_type_ids")), _i64(batch.get("position_ids"))
         bufs = self._buffers(B, S)
+        emb = m.bert.embeddings
+        eps = emb.LayerNorm.variance_epsilon
+        # dropout (nn.Dropout follows the module's training flag): same (p, seed) in forward and backward
+        p_h = float(cfg.hidden_dropout_prob) if m.training else 0.0
+        p_a = float(cfg.attention_probs_dropout_prob) if m.training else 0.0
+        seed = (self.drop_seed_base + self.fb_count) & 0xFFFFFFFFFFFFFFFF
+        self.fb_count += 1
+        self.last_drop_seed = seed
+        dp_kw = dict(p_hidden=p_h, p_attn=p_a, drop_seed=seed)
+        # the text embeddings go first: their out-of-range flag is then ready when the host synchronises below
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.embed_layernorm(ids, tt, pos_ids, emb.word_embeddings.weight.detach(), emb.position_embeddings.weight.detach(),
+                            emb.token_type_embeddings.weight.detach(), emb.LayerNorm.weight.detach(),
+                            emb.LayerNorm.bias.detach(), eps, bufs.x0, S, err_flag=err, drop=(p_h, seed, ops.SITE_EMB))
+        # supervised-row compaction: torch.nonzero synchronises with the host, and here the GPU is all but idle
+        # (start of the step) instead of between the encoder and the heads
+        lab = labels.reshape(-1)
+        idx_w = torch.nonzero(lab != -1).flatten()
+        tl = token_labels.reshape(-1)
+        idx_t = torch.nonzero(tl != -1).flatten()
+        Ml, Mt = int(idx_w.numel()), int(idx_t.numel())
+        # out-of-range input_ids / position_ids / token_type_ids: the reference's embedding lookup raises IndexError.
+        # Checked before anything indexes the gradient tables with those ids (no extra wait: the nonzero calls above
+        # have already drained the stream).
+        if int(err.item()) != 0:
+            raise IndexError("index out of range in BertEmbeddings (input_ids / position_ids / token_type_ids)")
+        # the previous step's weight gradients: a workgroup of the persistent wgrad kernel that gave up its bounded wait
+        # for a dW tile added out of turn (never seen; a preempted / shared GPU could do it) -- fail loudly
+        late = ops.wgrad_turn_timeouts()
+        if late:
+            raise RuntimeError("vt_wgrad_bf16: %d workgroup(s) ran out of their turn wait in an earlier launch; the weight "
+                               "gradients of that step are unreliable" % late)
         # rows nothing in the step reads: positions with attention mask 0.  As keys they weigh exactly 0, so their
         # hidden states reach no loss and their gradient is exactly 0 -- drop them from every row-wise kernel.  Needs a
         # 0/1 mask, the [CLS] position and every supervised position kept; otherwise the padded path below.
@@ -355,6 +381,7 @@ class PretrainEngine(object):
                 lay = cand
         Mr = M if lay is None else lay.rows
         self.last_rows = Mr
+        self.last_layout = lay
         if lay is not None:
             # the tile quantisation changes with the row count: tune once per 2048-row bucket (the library then takes
             # the nearest tuned M); a bucket is tuned at its upper edge
@@ -365,22 +392,9 @@ class PretrainEngine(object):
         rows_w = idx_w if lay is None else lay.inverse.index_select(0, idx_w)   # supervised rows in the layout in use
         rows_t = idx_t if lay is None else lay.inverse.index_select(0, idx_t)
         cls_rows = (torch.arange(B, device=dev) * S) if lay is None else lay.start.to(torch.int64)
-        emb = m.bert.embeddings
-        eps = emb.LayerNorm.variance_epsilon
-        # dropout (nn.Dropout follows the module's training flag): same (p, seed) in forward and backward
-        p_h = float(cfg.hidden_dropout_prob) if m.training else 0.0
-        p_a = float(cfg.attention_probs_dropout_prob) if m.training else 0.0
-        seed = (self.drop_seed_base + self.fb_count) & 0xFFFFFFFFFFFFFFFF
-        self.fb_count += 1
-        self.last_drop_seed = seed
-        dp_kw = dict(p_hidden=p_h, p_attn=p_a, drop_seed=seed)
 
         # ---------------- forward ----------------
         x0 = bufs.x0
-        err = torch.zeros(1, dtype=torch.int32, device=dev)
-        ops.embed_layernorm(ids, tt, pos_ids, emb.word_embeddings.weight.detach(), emb.position_embeddings.weight.detach(),
-                            emb.token_type_embeddings.weight.detach(), emb.LayerNorm.weight.detach(),
-                            emb.LayerNorm.bias.detach(), eps, x0, S, err_flag=err, drop=(p_h, seed, ops.SITE_EMB))
         a_img = None
         if img is not None:
             a_img = ops.pack_concat(img.reshape(B * R, -1).float().contiguous(),
@@ -493,9 +507,18 @@ class PretrainEngine(object):
             g_ht = ops.dgelu_mul(g_t1, h_t)
             ops.wgrad([wg(g_ht, seq_w, self._grad(pr.transform.dense.weight), self._grad(pr.transform.dense.bias))], Ml)
             g32.index_add_(0, rows_w, ops.linear(g_ht, self.head_t["tr"]).float())
+        elif not acc:
+            # no supervised MLM row (the loss is NaN, as the reference's): the head's gradients must not keep the
+            # previous step's values (the tied decoder weight / bias were zeroed above)
+            for prm in (pr.transform.dense.weight, pr.transform.dense.bias, pr.transform.LayerNorm.weight,
+                        pr.transform.LayerNorm.bias, pr.bias) + (() if dec_w_is_tied else (pr.decoder.weight,)):
+                self._grad(prm).zero_()
         if Mt > 0:
             ops.wgrad([wg(dlt[:, :C], seq_t, self._grad(lin_tok.weight), self._grad(lin_tok.bias))], Mt)
             g32.index_add_(0, rows_t, ops.linear(dlt, self.head_t["tok"]).float())
+        elif not acc:
+            self._grad(lin_tok.weight).zero_()
+            self._grad(lin_tok.bias).zero_()
         if next_action is not None:
             da = torch.exp(logp_a)
             da.scatter_add_(1, next_action.clamp(min=0)[:, None], torch.full((B, 1), -1.0, device=dev))
@@ -586,7 +609,6 @@ class PretrainEngine(object):
                 gi.add_(self.dw_img[:, :D]); gl.add_(self.dw_img[:, D:D + 128]); gbi.add_(self.db_img); gbl.add_(self.db_img)
             else:
                 gi.copy_(self.dw_img[:, :D]); gl.copy_(self.dw_img[:, D:D + 128]); gbi.copy_(self.db_img); gbl.copy_(self.db_img)
-        self._last_err = err
         return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
 
     # ---- the launch sequences of vt_encoder_forward/backward_bf16 issued op by op (bench.py's per-kernel timing)
@@ -665,6 +687,9 @@ class PretrainEngine(object):
         self.sched_step += 1
         f.mark_fresh()
         self._wt_dirty = True
+        # the fused kernel wrote the slab through raw pointers: no parameter's _version moved, so the packed bf16
+        # copies the inference path caches (encoder layers, region projection, rollout modules) are told explicitly
+        invalidate_packed_weights()
 
     def all_reduce_grads(self):
         """Sum the flat gradient slab over the data-parallel group in fixed-size buckets (no overlap)."""
@@ -720,14 +745,60 @@ class _LossWithGrads(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
-def autograd_forward(model, batch):
-    """PreTrainOscar.forward in training mode with grad enabled: returns the 7-tuple whose first element
-    back-propagates into the model's parameters."""
+class _LossLazyGrads(torch.autograd.Function):
+    """eval-mode forward with grad enabled (the reference's val(), pretrain.py:291,469-481, calls model(**batch) in
+    eval() with no torch.no_grad): the values come from the inference path; the engine (its slabs and saved
+    activations) is built and the HIP forward + backward run only IF `.backward()` is actually called -- dropout is
+    the identity in eval mode, so the recomputation sees the same function."""
+
+    @staticmethod
+    def forward(ctx, model, batch, loss, *params):
+        ctx.model, ctx.batch = model, batch
+        ctx.params = params
+        return loss.detach().clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model = ctx.model
+        eng = _bridge_engine(model)
+        was = model.training
+        model.eval()
+        try:
+            eng.forward_backward(ctx.batch)
+        finally:
+            model.train(was)
+        f = eng.flat
+        return (None, None, None) + tuple(f.view(f.g, eng._name_of(p)) * grad_out for p in ctx.params)
+
+
+def _bridge_engine(model):
+    """The engine behind the autograd bridge (parameters stay the model's own: attach_grads=False).  An external torch
+    optimizer owns the update there, and optimizers that write through `p.data` (the reference's pytorch-transformers
+    AdamW: `p.data.addcdiv_`, `p.data.add_`) do not move `p._version` -- so nothing can tell whether the fp32 slab
+    changed since the last call.  The bf16 mirror (one fused cast of the slab) and the transposed copies are therefore
+    rebuilt on EVERY bridged forward, and the inference-side packed copies are invalidated."""
     eng = getattr(model, "_vt_engine", None)
     if eng is None or eng.flat.p.device != next(model.parameters()).device:
         eng = PretrainEngine(model, attach_grads=False)
         object.__setattr__(model, "_vt_engine", eng)
+    else:
+        eng.flat.refresh_mirror()
+        eng._wt_dirty = True
+    invalidate_packed_weights()
+    return eng
+
+
+def autograd_forward(model, batch):
+    """PreTrainOscar.forward in training mode with grad enabled: returns the 7-tuple whose first element
+    back-propagates into the model's parameters."""
+    eng = _bridge_engine(model)
     out = eng.forward_backward(batch)
     params = [p for p in model.parameters() if p.requires_grad]
     loss = _LossWithGrads.apply(eng, out[0], *params)
     return (loss,) + tuple(out[1:])
+
+
+def lazy_autograd_loss(model, batch, loss):
+    """The inference path's loss made differentiable on demand (eval mode, grad enabled)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    return _LossLazyGrads.apply(model, batch, loss, *params)
