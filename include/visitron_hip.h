@@ -271,6 +271,39 @@ int vt_wgrad_bf16(const vt_wgrad_problem* problems, int nprob, int M, vt_stream_
  * call it where the host synchronises anyway, e.g. once per training step. */
 int vt_wgrad_turn_timeouts(unsigned* host_count);
 
+/* ---- fp32 parity path -------------------------------------------------------------------------------------------
+ * The reference computes in fp32 (tasks/viewpoint_select/encoder.py:238-240; no AMP anywhere) and north_star asks for
+ * logits within 1e-3 of it.  These entry points keep every operand, activation and accumulation in fp32 (matrix
+ * products on the exact-fp32 MFMA, v_mfma_f32_32x32x2_f32); visitron_amd.set_precision(model, "fp32") routes a
+ * model's forward through them.  A correctness mode: plainly tiled, not tuned.
+ *
+ * vt_linear_f32: out = act(alpha * a . op(w) + bias) (+ residual), fp32 everywhere.  a [M, K] (row stride lda);
+ *   w_is_kn == 0: w is nn.Linear.weight [N, K] (oscar/modeling_bert.py:43-45, :94, :119, :120; encoder.py:277-279, :296,
+ *   :377-391); w_is_kn == 1: w is [K, N].  act: VT_ACT_NONE / VT_ACT_GELU (erf) / VT_ACT_TANH.  grp_rows / grp_stride: output
+ *   row remap as in vt_linear_bf16_ex.  Any K (tails are zero-filled); 16-byte loads when bases / strides allow. */
+int vt_linear_f32(const float* a, int64_t lda, const float* w, int64_t ldw, int w_is_kn, const float* bias,
+                  const float* residual, int64_t ldr, float* out, int64_t ldc, int M, int N, int K, int act, float alpha,
+                  int grp_rows, int grp_stride, vt_stream_t stream);
+/* The same product batched over (batch, head) with element strides per operand: torch.matmul(q, k^T) and
+ * torch.matmul(probs, v) of oscar/modeling_bert.py:52,68 straight on the packed [B*S, 3H] projection buffer. */
+int vt_bmm_f32(const float* a, int64_t lda, int64_t a_stride_b, int64_t a_stride_h, const float* w, int64_t ldw,
+               int64_t w_stride_b, int64_t w_stride_h, int w_is_kn, float* out, int64_t ldc, int64_t c_stride_b,
+               int64_t c_stride_h, int M, int N, int K, float alpha, int batch, int heads, vt_stream_t stream);
+/* In place on x [rows, cols] fp32: x * scale + mask -> Softmax(dim=-1) -> * head_scale (oscar/modeling_bert.py:53-66).
+ * Row r = (b * nh + h) * S + q.  mask_mode: -1 none; 0 raw mask [B, cols] -> (1 - m) * -10000 (encoder.py:238-241);
+ * 1 additive [B, cols]; 2 additive per query [B, S, cols].  With nh = S = 1 and no mask: a plain row softmax (the token
+ * head's nn.Softmax, encoder.py:323-326). */
+int vt_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int cols, float scale, const float* mask, int mask_mode,
+                        const float* head_scale, int nh, int S, vt_stream_t stream);
+/* BertLayerNorm over fp32 or bf16 rows into fp32 or bf16 rows (statistics in fp32).  H % 4 == 0, H <= 4096. */
+int vt_layernorm_rows(const void* x, int64_t ldx, int x_is_f32, void* y, int64_t ldy, int y_is_f32, const float* gamma,
+                      const float* beta, int64_t M, int H, float eps, int grp_rows, int grp_stride, vt_stream_t stream);
+/* BertEmbeddings (encoder.py:267-269) with fp32 output rows b*S + t; arguments as vt_embed_layernorm. */
+int vt_embed_layernorm_f32(const int64_t* input_ids, const int64_t* token_type_ids, const int64_t* position_ids,
+                           const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+                           float* out, int64_t ld_out, int B, int T, int S, int H, int n_word, int n_pos, int n_type,
+                           float eps, int* err_flag, vt_stream_t stream);
+
 /* ---- whole encoder stack: CaptionBertEncoder.forward, oscar/modeling_bert.py:140-169 ---------- */
 typedef struct vt_layer_weights {
   const void* w_qkv;  const float* b_qkv;   /* [3H,H] bf16 = query|key|value weights, [3H] */

@@ -122,6 +122,17 @@ SIGNATURES = {
     "vt_pack_concat_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "vt_wgrad_bf16": (c_int, [ctypes.POINTER(WgradProblem), c_int, c_int, c_void_p]),
     "vt_wgrad_turn_timeouts": (c_int, [ctypes.POINTER(ctypes.c_uint)]),
+    "vt_linear_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                              c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "vt_bmm_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p,
+                           c_int64, c_int64, c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "vt_softmax_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_int, c_void_p, c_int, c_int,
+                                    c_void_p]),
+    "vt_layernorm_rows": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int,
+                                  c_float, c_int, c_int, c_void_p]),
+    "vt_embed_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                       c_void_p, c_void_p]),
     "vt_encoder_forward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerActs), c_int, c_void_p,
                                         c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                         c_float, c_float, c_uint64, c_void_p]),

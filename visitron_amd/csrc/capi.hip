@@ -292,6 +292,54 @@ int vt_pack_concat_bf16(const float* s0, int d0, const float* s1, int d1, void* 
   return vt_pack_concat_dispatch(s0, d0, s1, d1, out, kpad, rows, (hipStream_t)stream);
 }
 
+// ---- fp32 parity path (fp32_path.hip) ----------------------------------------------------------------------------
+int vt_gemm_f32_dispatch(const float* A, long lda, long sA_b, long sA_h, const float* W, long ldw, long sW_b, long sW_h,
+                         int w_is_kn, const float* bias, const float* R, long ldr, float* C, long ldc, long sC_b, long sC_h,
+                         int M, int N, int K, int act, float alpha, int batch, int heads, int grp_rows, int grp_stride,
+                         hipStream_t stream);
+int vt_softmax_rows_f32_dispatch(float* x, long ld, long rows, int cols, float scale, const float* mask, int mask_mode,
+                                 const float* head_scale, int nh, int S, hipStream_t stream);
+int vt_layernorm_f32_dispatch(const void* x, long ldx, int x_is_f32, void* y, long ldy, int y_is_f32, const float* gamma,
+                              const float* beta, long M, int H, float eps, int grp_rows, int grp_stride, hipStream_t stream);
+int vt_embed_layernorm_f32_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
+                                    const float* pos, const float* type, const float* gamma, const float* beta, float* y,
+                                    long ldy, int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
+                                    int* err_flag, hipStream_t stream);
+
+int vt_linear_f32(const float* a, int64_t lda, const float* w, int64_t ldw, int w_is_kn, const float* bias,
+                  const float* residual, int64_t ldr, float* out, int64_t ldc, int M, int N, int K, int act, float alpha,
+                  int grp_rows, int grp_stride, vt_stream_t stream) {
+  return vt_gemm_f32_dispatch(a, lda, 0, 0, w, ldw, 0, 0, w_is_kn, bias, residual, ldr, out, ldc, 0, 0, M, N, K, act, alpha,
+                              1, 1, grp_rows, grp_stride, (hipStream_t)stream);
+}
+
+int vt_bmm_f32(const float* a, int64_t lda, int64_t a_stride_b, int64_t a_stride_h, const float* w, int64_t ldw,
+               int64_t w_stride_b, int64_t w_stride_h, int w_is_kn, float* out, int64_t ldc, int64_t c_stride_b,
+               int64_t c_stride_h, int M, int N, int K, float alpha, int batch, int heads, vt_stream_t stream) {
+  return vt_gemm_f32_dispatch(a, lda, a_stride_b, a_stride_h, w, ldw, w_stride_b, w_stride_h, w_is_kn, nullptr, nullptr, 0,
+                              out, ldc, c_stride_b, c_stride_h, M, N, K, VT_ACT_NONE, alpha, batch, heads, 0, 0,
+                              (hipStream_t)stream);
+}
+
+int vt_softmax_rows_f32(float* x, int64_t ld, int64_t rows, int cols, float scale, const float* mask, int mask_mode,
+                        const float* head_scale, int nh, int S, vt_stream_t stream) {
+  return vt_softmax_rows_f32_dispatch(x, ld, rows, cols, scale, mask, mask_mode, head_scale, nh, S, (hipStream_t)stream);
+}
+
+int vt_layernorm_rows(const void* x, int64_t ldx, int x_is_f32, void* y, int64_t ldy, int y_is_f32, const float* gamma,
+                      const float* beta, int64_t M, int H, float eps, int grp_rows, int grp_stride, vt_stream_t stream) {
+  return vt_layernorm_f32_dispatch(x, ldx, x_is_f32, y, ldy, y_is_f32, gamma, beta, M, H, eps, grp_rows, grp_stride,
+                                   (hipStream_t)stream);
+}
+
+int vt_embed_layernorm_f32(const int64_t* input_ids, const int64_t* token_type_ids, const int64_t* position_ids,
+                           const float* word, const float* pos, const float* type, const float* gamma, const float* beta,
+                           float* out, int64_t ld_out, int B, int T, int S, int H, int n_word, int n_pos, int n_type,
+                           float eps, int* err_flag, vt_stream_t stream) {
+  return vt_embed_layernorm_f32_dispatch(input_ids, token_type_ids, position_ids, word, pos, type, gamma, beta, out, ld_out,
+                                         B, T, S, H, n_word, n_pos, n_type, eps, err_flag, (hipStream_t)stream);
+}
+
 int vt_wgrad_turn_timeouts(unsigned* host_count) {
   if (!host_count) return VT_ERR_NULL;
   return vt_wgrad_v8_timeouts(host_count);

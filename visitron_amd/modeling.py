@@ -480,6 +480,26 @@ def invalidate_packed_weights():
     _WEIGHTS_GEN[0] += 1
 
 
+PRECISIONS = ("bf16", "fp32")
+
+
+def set_precision(model, precision):
+    """Select the arithmetic of `model`'s HIP forward: "bf16" (default: bf16 operands on the bf16 matrix cores, fp32
+    accumulation -- the performance path, within 5e-2 of the fp32 reference) or "fp32" (every operand, activation and
+    accumulation in fp32 on the fp32 matrix cores -- the parity path, within 1e-3 of the reference, which computes in
+    fp32 itself: tasks/viewpoint_select/encoder.py:238-240).  "fp32" serves inference at encoder / trunk / model level;
+    training stays on the bf16 kernels."""
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % (PRECISIONS,))
+    for m in model.modules():
+        object.__setattr__(m, "_vt_precision", precision)
+    return model
+
+
+def _is_fp32(module):
+    return getattr(module, "_vt_precision", "bf16") == "fp32"
+
+
 def _param_key(module_or_params):
     ps = module_or_params.parameters() if isinstance(module_or_params, nn.Module) else module_or_params
     return (_WEIGHTS_GEN[0],) + tuple((p.data_ptr(), p._version) for p in ps)
@@ -498,6 +518,9 @@ class CaptionBertEncoder(nn.Module):
         self._packed = None
         self._packed_key = None
         self._ws = {}
+        self._final_f32 = None
+        # inference: the last layer's pre-LayerNorm sums and its output also in fp32 (see run()); VT_PRECISE_FINAL=0: off
+        self.precise_final = os.environ.get("VT_PRECISE_FINAL", "1") != "0"
 
     # ---- cached state -----------------------------------------------------------------
     def packed(self):
@@ -544,6 +567,7 @@ class CaptionBertEncoder(nn.Module):
         pk = self.packed()
         ws = self._workspace(B * S, B, x_bf16.device, self.output_hidden_states)
         self._last_attentions = None
+        self._final_f32 = None
         if history is not None:   # encoder_history_states: layer i attends over cat([history[i], hidden], 1) (:148-155)
             probs = [] if self.output_attentions else None
             outs = self._run_unrolled(pk, ws, x_bf16, B, S, mask_f32, mask_additive, head_scale, probs, history)
@@ -556,8 +580,38 @@ class CaptionBertEncoder(nn.Module):
             return outs
         if ops.profiling():  # bench.py's per-kernel timing: the same launches, issued one by one
             return self._run_unrolled(pk, ws, x_bf16, B, S, mask_f32, mask_additive, head_scale)
-        ops.encoder_forward(pk.table, ws["table"], x_bf16, mask_f32, mask_additive, head_scale, B, S,
-                            self._hidden, self._heads, self._inter, self._eps, seq=seq)
+        L = len(self.layer)
+        if seq is not None or not self.precise_final:
+            ops.encoder_forward(pk.table, ws["table"], x_bf16, mask_f32, mask_additive, head_scale, B, S,
+                                self._hidden, self._heads, self._inter, self._eps, seq=seq)
+            return ws["outs"]
+        # The hidden states this call returns are handed to the caller in fp32.  Layers 0 .. L-2 run in the C loop; the
+        # last layer is issued here with its two pre-LayerNorm sums kept in fp32 and its LayerNorm written twice from
+        # them -- bf16 for the heads / pooler GEMMs, fp32 for the caller -- so the returned tensor is not rounded to
+        # bf16 once before the last LayerNorm and once after it.
+        if L > 1:
+            n = L - 1
+            sub = lambda arr, typ: (typ * n).from_address(ctypes.addressof(arr))
+            hs = None if head_scale is None else head_scale[:n].contiguous()
+            ops.encoder_forward(sub(pk.table, _lib.LayerWeights), sub(ws["table"], _lib.LayerActs), x_bf16, mask_f32,
+                                mask_additive, hs, B, S, self._hidden, self._heads, self._inter, self._eps)
+        cur = ws["outs"][L - 2] if L > 1 else x_bf16
+        t, sh, eps = pk.tensors[L - 1], ws["shared"], self._eps
+        M = B * S
+        if "pre32" not in ws:
+            ws["pre32"] = torch.empty((M, self._hidden), dtype=torch.float32, device=x_bf16.device)
+            ws["final32"] = torch.empty((M, self._hidden), dtype=torch.float32, device=x_bf16.device)
+        hs_l = None if head_scale is None else head_scale[L - 1].contiguous()
+        ops.linear(cur, t["w_qkv"], t["b_qkv"], out=sh["qkv"])
+        ops.attention_fwd(sh["qkv"], B, S, self._heads, mask=mask_f32, mask_additive=mask_additive, head_scale=hs_l,
+                          out=sh["ctx"])
+        ops.linear(sh["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=ws["pre32"], out_f32=True)
+        ops.layernorm_rows(ws["pre32"], t["ln1_g"], t["ln1_b"], eps, out=sh["attn_out"])
+        ops.linear(sh["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=sh["mid"])
+        ops.linear(sh["mid"], t["w_out"], t["b_out"], residual=sh["attn_out"], out=ws["pre32"], out_f32=True)
+        ops.layernorm_rows(ws["pre32"], t["ln2_g"], t["ln2_b"], eps, out=ws["outs"][L - 1])
+        ops.layernorm_rows(ws["pre32"], t["ln2_g"], t["ln2_b"], eps, out=ws["final32"])
+        self._final_f32 = ws["final32"]
         return ws["outs"]
 
     def _run_unrolled(self, pk, ws, x, B, S, mask, mask_additive, head_scale, probs=None, history=None):
@@ -590,16 +644,62 @@ class CaptionBertEncoder(nn.Module):
             cur = out
         return ws["outs"]
 
+    def run_f32(self, x, B, S, mask_f32, mask_additive, head_scale=None, history=None):
+        """The layer loop in fp32 (set_precision(model, "fp32")): x fp32 [B*S, H] -> list of the L layer outputs (fp32);
+        per-layer attention probabilities land in self._last_attentions when output_attentions is set."""
+        if self._hidden != self._heads * 64:
+            raise NotImplementedError("the fp32 path serves head size 64 (hidden = 64 * heads)")
+        nh, H, eps = self._heads, self._hidden, self._eps
+        probs_all = [] if self.output_attentions else None
+        outs, cur = [], x
+        f = _f32
+        for i, layer in enumerate(self.layer):
+            att, so = layer.attention.self, layer.attention.output
+            w_qkv = torch.cat([att.query.weight, att.key.weight, att.value.weight], 0).detach().float().contiguous()
+            b_qkv = torch.cat([att.query.bias, att.key.bias, att.value.bias], 0).detach().float().contiguous()
+            hs_i = None if head_scale is None else head_scale[i].contiguous()
+            Sh, xs = 0, cur
+            if history is not None:   # :37-41, :148-155: keys / values over cat([history_i, hidden], 1)
+                Sh = history[i].shape[1]
+                xs = torch.cat([history[i].detach().float(), cur.view(B, S, H)], 1).reshape(B * (Sh + S), H).contiguous()
+            St = Sh + S
+            qkv = ops.linear_f32(xs, w_qkv, b_qkv)
+            ctx, p_i = ops.attention_f32(qkv, B, St, nh, mask=mask_f32, mask_additive=mask_additive, head_scale=hs_i,
+                                         want_probs=probs_all is not None)
+            if Sh:
+                ctx = ctx.view(B, St, H)[:, Sh:].reshape(B * S, H).contiguous()
+                if p_i is not None:
+                    p_i = p_i[:, :, Sh:, :].contiguous()
+            if probs_all is not None:
+                probs_all.append(p_i)
+            pre = ops.linear_f32(ctx, f(so.dense.weight), f(so.dense.bias), residual=cur)
+            a_out = ops.layernorm_rows(pre, f(so.LayerNorm.weight), f(so.LayerNorm.bias), eps)
+            mid = ops.linear_f32(a_out, f(layer.intermediate.dense.weight), f(layer.intermediate.dense.bias), act=ACT_GELU)
+            pre2 = ops.linear_f32(mid, f(layer.output.dense.weight), f(layer.output.dense.bias), residual=a_out)
+            cur = ops.layernorm_rows(pre2, f(layer.output.LayerNorm.weight), f(layer.output.LayerNorm.bias), eps)
+            outs.append(cur)
+        self._last_attentions = probs_all
+        return outs
+
     def forward(self, hidden_states, attention_mask, head_mask=None, encoder_history_states=None):
         """oscar/modeling_bert.py:140-169.  attention_mask is the ADDITIVE extended mask [B,1,1,S]."""
         B, S, H = hidden_states.shape
-        x = _as_bf16_2d(hidden_states)
         Sh = 0 if encoder_history_states is None else encoder_history_states[0].shape[1]
         mask = _additive_mask_2d(attention_mask, B, Sh + S) if attention_mask is not None else None
         hs = _head_scale(head_mask, len(self.layer), self._heads, hidden_states.device)
-        outs = self.run(x, B, S, mask, True, hs, history=encoder_history_states)
+        if _is_fp32(self):
+            ops._require_hip(hidden_states)
+            outs = self.run_f32(hidden_states.detach().reshape(B * S, H).float().contiguous(), B, S, mask, True, hs,
+                                history=encoder_history_states)
+            if not self.output_hidden_states:
+                outs = outs[-1:]
+        else:
+            outs = self.run(_as_bf16_2d(hidden_states), B, S, mask, True, hs, history=encoder_history_states)
         dt = hidden_states.dtype
-        last = outs[-1].view(B, S, H).to(dt)
+        if not _is_fp32(self) and self._final_f32 is not None:   # (a copy: the fp32 buffer is rewritten by the next call)
+            last = self._final_f32.view(B, S, H).to(dt, copy=True)
+        else:
+            last = outs[-1].view(B, S, H).to(dt)
         outputs = (last,)
         if self.output_hidden_states:
             outputs = outputs + ((hidden_states,) + tuple(o.view(B, S, H).to(dt) for o in outs[:-1]) + (last,),)
@@ -710,6 +810,11 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                 raise NotImplementedError
         hs = _head_scale(head_mask, self.config.num_hidden_layers, self.config.num_attention_heads, dev)
 
+        if _is_fp32(self):
+            if keep is not None:
+                raise NotImplementedError("compacted rows are served by the bf16 path")
+            return self._run_trunk_f32(input_ids, token_type_ids, position_ids, img_feats, img_location_embeddings,
+                                       encoder_history_states, mask_f32, mask_is_additive, hs, B, T, R, S, H)
         x = torch.empty((B * S, H), dtype=BF16, device=dev)
         self.embeddings.write_rows(x, S, input_ids, token_type_ids, position_ids)  # rows b*S + [0,T)
         if img_feats is not None:
@@ -743,13 +848,46 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
         _check_index_error(self.embeddings)
         return outs, pooled, x, B, S
 
+    def _run_trunk_f32(self, input_ids, token_type_ids, position_ids, img_feats, img_location_embeddings, history,
+                       mask_f32, mask_is_additive, hs, B, T, R, S, H):
+        """encoder.py:204-303 with every tensor in fp32 (set_precision(model, "fp32")); same return as run_trunk."""
+        dev = input_ids.device
+        emb = self.embeddings
+        x = torch.empty((B * S, H), dtype=torch.float32, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.embed_layernorm_f32(_i64(input_ids), _i64(token_type_ids), _i64(position_ids), _f32(emb.word_embeddings.weight),
+                                _f32(emb.position_embeddings.weight), _f32(emb.token_type_embeddings.weight),
+                                _f32(emb.LayerNorm.weight), _f32(emb.LayerNorm.bias), emb.LayerNorm.variance_epsilon, x, S,
+                                err_flag=err)
+        emb._last_err = err
+        if img_feats is not None:
+            # img_embedding(img_feats) + location_embeds(loc) (:277-279) as ONE product over the K-concatenated operands,
+            # written straight into rows b*S + T + r (the torch.cat of :287)
+            a = torch.cat([img_feats.reshape(B * R, -1).float(), img_location_embeddings.reshape(B * R, -1).float()], 1)
+            w = torch.cat([_f32(self.img_embedding.weight), _f32(self.location_embeds.weight)], 1).contiguous()
+            b = _f32(self.img_embedding.bias) + _f32(self.location_embeds.bias)
+            ops.linear_f32(a.contiguous(), w, b, out=x[T:], ldc=H, grp_rows=R, grp_stride=S)
+            if self.use_img_layernorm:
+                ops.layernorm_rows(x[T:], _f32(self.LayerNorm.weight), _f32(self.LayerNorm.bias),
+                                   self.LayerNorm.variance_epsilon, out=x[T:], M=B * R, grp_rows=R, grp_stride=S)
+        self._last_layout = None
+        outs = self.encoder.run_f32(x, B, S, mask_f32, mask_is_additive, hs, history=history)
+        pooled = ops.linear_f32(outs[-1], _f32(self.pooler.dense.weight), _f32(self.pooler.dense.bias), act=ACT_TANH,
+                                M=B, lda=S * H)
+        _check_index_error(emb)
+        if not self.encoder.output_hidden_states:
+            outs = outs[-1:]
+        return outs, pooled, x, B, S
+
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, head_mask=None,
                 img_feats=None, img_location_embeddings=None, encoder_history_states=None):
         outs, pooled, x, B, S = self.run_trunk(input_ids, token_type_ids, attention_mask, position_ids, head_mask,
                                                img_feats, img_location_embeddings, encoder_history_states)
         dt = next(self.parameters()).dtype
         H = self.config.hidden_size
-        sequence_output = outs[-1].view(B, S, H).to(dt)
+        f32 = None if _is_fp32(self) else self.encoder._final_f32
+        # (the fp32 copy lives in the encoder's workspace and is rewritten by the next call: hand out a copy)
+        sequence_output = outs[-1].view(B, S, H).to(dt) if f32 is None else f32.view(B, S, H).to(dt, copy=True)
         outputs = (sequence_output, pooled.to(dt))
         if self.encoder.output_hidden_states:
             hidden = (x.view(B, S, H).to(dt),) + tuple(o.view(B, S, H).to(dt) for o in outs[:-1]) + (sequence_output,)
@@ -788,6 +926,8 @@ class PreTrainOscar(BertPreTrainedModel):
 
     def head_outputs(self, seq_bf16, pooled_f32):
         """(prediction_scores [M,V] fp32, token probabilities [M,C] fp32, action log-probs [B,A] fp32)."""
+        if _is_fp32(self):
+            return self._head_outputs_f32(seq_bf16, pooled_f32)
         scores = self.mlmhead.scores(seq_bf16)
         lin = self.token_head[0]
         C = lin.weight.shape[0]
@@ -796,6 +936,18 @@ class PreTrainOscar(BertPreTrainedModel):
         token_prob = torch.softmax(buf[:, :C], dim=-1)
         action = self.next_action(pooled_f32)
         return scores, token_prob, action
+
+    def _head_outputs_f32(self, seq, pooled):
+        """The three heads in fp32 (encoder.py:377-391): seq fp32 [M, H], pooled fp32 [B, H]."""
+        p = self.mlmhead.predictions
+        t = ops.linear_f32(seq, _f32(p.transform.dense.weight), _f32(p.transform.dense.bias), act=ACT_GELU)
+        t = ops.layernorm_rows(t, _f32(p.transform.LayerNorm.weight), _f32(p.transform.LayerNorm.bias),
+                               p.transform.LayerNorm.variance_epsilon)
+        scores = ops.linear_f32(t, _f32(p.decoder.weight), _f32(p.bias))
+        lin = self.token_head[0]
+        token_prob = ops.softmax_rows_f32(ops.linear_f32(seq, _f32(lin.weight), _f32(lin.bias)))
+        act = ops.linear_f32(pooled, _f32(self.next_action.linear.weight), _f32(self.next_action.linear.bias))
+        return scores, token_prob, torch.log_softmax(act, dim=-1)
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, labels=None, token_labels=None,
                 position_ids=None, head_mask=None, img_feats=None, img_location_embeddings=None, next_action=None,
@@ -809,6 +961,8 @@ class PreTrainOscar(BertPreTrainedModel):
                      img_location_embeddings=img_location_embeddings, next_action=next_action)
         batch = {k: v for k, v in batch.items() if v is not None}
         wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if wants_grad and _is_fp32(self):
+            raise NotImplementedError('precision "fp32" serves inference (torch.no_grad()); training runs on the bf16 kernels')
         if wants_grad and self.training:
             # training: HIP forward + backward, bridged to autograd so that `loss.backward()` and any torch
             # optimizer / DistributedDataParallel wrapper work as in the reference's loop

@@ -731,3 +731,95 @@ def lstm_sequence_rows(xproj, row_start, h2, c, w_hh, T, lengths, seq_out=None, 
             B, hs, int(T), 1 if reverse else 0, _stream())
     _lib.check(rc, "vt_lstm_sequence_rows_f32")
     return h2[0]
+
+
+# ---- fp32 parity path (csrc/fp32_path.hip): every operand, activation and accumulation in fp32 -----------------------
+def _f32ok(*ts):
+    for t in ts:
+        assert t is None or (t.dtype == torch.float32 and t.stride(-1) == 1), "fp32 path: contiguous-row fp32 tensors"
+
+
+def linear_f32(a, w, bias=None, residual=None, act=ACT_NONE, out=None, w_is_kn=False, alpha=1.0, grp_rows=0, grp_stride=0,
+               M=None, lda=None, ldc=None):
+    """out = act(alpha * a @ w.T + bias) (+ residual) in fp32 on the fp32 matrix cores.  a [M,K] (row stride lda),
+    w [N,K] (nn.Linear.weight) or [K,N] with w_is_kn."""
+    _require_hip(a, w, bias, residual, out)
+    _f32ok(a, w, bias, residual, out)
+    K = a.shape[-1]
+    N = w.shape[1] if w_is_kn else w.shape[0]
+    assert (w.shape[0] if w_is_kn else w.shape[1]) == K
+    if M is None:
+        M = a.shape[0]
+    if lda is None:
+        lda = a.stride(0)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if ldc is None:
+        ldc = out.stride(0)
+    with _timed("gemm_f32", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)):
+        rc = _lib.load().vt_linear_f32(_ptr(a), lda, _ptr(w), w.stride(0), 1 if w_is_kn else 0, _ptr(bias), _ptr(residual),
+                                       0 if residual is None else residual.stride(0), _ptr(out), ldc, M, N, K, int(act),
+                                       float(alpha), grp_rows, grp_stride, _stream())
+    _lib.check(rc, "vt_linear_f32")
+    return out
+
+
+def attention_f32(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None, want_probs=False):
+    """oscar/modeling_bert.py:47-72 in fp32 on the packed projection qkv fp32 [B*S, 3*nh*64]: scores = q k^T (one batched
+    product), / sqrt(64) + mask, softmax, * head_mask (one row kernel, in place), context = probs v (one batched product).
+    -> (ctx fp32 [B*S, nh*64], probs fp32 [B, nh, S, S] or None)."""
+    _require_hip(qkv, mask, head_scale)
+    _f32ok(qkv, mask, head_scale)
+    H = nh * 64
+    ld = qkv.stride(0)
+    lib = _lib.load()
+    probs = torch.empty((B, nh, S, S), dtype=torch.float32, device=qkv.device)
+    q, k, v = qkv, qkv[:, H:], qkv[:, 2 * H:]
+    rc = lib.vt_bmm_f32(_ptr(q), ld, S * ld, 64, _ptr(k), ld, S * ld, 64, 0, _ptr(probs), S, nh * S * S, S * S, S, S, 64, 1.0,
+                        B, nh, _stream())
+    _lib.check(rc, "vt_bmm_f32 (q k^T)")
+    mode = -1 if mask is None else _mask_mode(mask, mask_additive, B, S)
+    rc = lib.vt_softmax_rows_f32(_ptr(probs), S, B * nh * S, S, 0.125, _ptr(mask), mode, _ptr(head_scale), nh, S, _stream())
+    _lib.check(rc, "vt_softmax_rows_f32")
+    ctx = torch.empty((B * S, H), dtype=torch.float32, device=qkv.device)
+    rc = lib.vt_bmm_f32(_ptr(probs), S, nh * S * S, S * S, _ptr(v), ld, S * ld, 64, 1, _ptr(ctx), H, S * H, 64, S, 64, S, 1.0,
+                        B, nh, _stream())
+    _lib.check(rc, "vt_bmm_f32 (probs v)")
+    return ctx, (probs if want_probs else None)
+
+
+def softmax_rows_f32(x):
+    """In-place softmax over the last dim of a 2-D fp32 tensor (the token head's nn.Softmax, encoder.py:323-326)."""
+    _require_hip(x)
+    _f32ok(x)
+    rc = _lib.load().vt_softmax_rows_f32(_ptr(x), x.stride(0), x.shape[0], x.shape[1], 1.0, None, -1, None, 1, 1, _stream())
+    _lib.check(rc, "vt_softmax_rows_f32")
+    return x
+
+
+def layernorm_rows(x, gamma, beta, eps, out=None, out_f32=None, M=None, grp_rows=0, grp_stride=0):
+    """BertLayerNorm over fp32 or bf16 rows into fp32 or bf16 rows (default: the input's type)."""
+    _require_hip(x, gamma, beta, out)
+    assert x.dtype in (torch.float32, BF16) and x.stride(-1) == 1
+    if out is None:
+        want32 = (x.dtype == torch.float32) if out_f32 is None else bool(out_f32)
+        out = torch.empty(x.shape, dtype=torch.float32 if want32 else BF16, device=x.device)
+    if M is None:
+        M = x.shape[0]
+    rc = _lib.load().vt_layernorm_rows(_ptr(x), x.stride(0), 1 if x.dtype == torch.float32 else 0, _ptr(out), out.stride(0),
+                                       1 if out.dtype == torch.float32 else 0, _ptr(gamma), _ptr(beta), M, gamma.numel(),
+                                       float(eps), grp_rows, grp_stride, _stream())
+    _lib.check(rc, "vt_layernorm_rows")
+    return out
+
+
+def embed_layernorm_f32(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, eps, out, S, err_flag=None):
+    """BertEmbeddings with fp32 output: rows b*S + t (t < T) of ``out`` [B*S, H] fp32."""
+    _require_hip(ids, word, out)
+    _f32ok(word, pos, typ, gamma, beta, out)
+    B, T = ids.shape
+    rc = _lib.load().vt_embed_layernorm_f32(_ptr(ids), _ptr(type_ids), _ptr(pos_ids), _ptr(word), _ptr(pos), _ptr(typ),
+                                            _ptr(gamma), _ptr(beta), _ptr(out), out.stride(0), B, T, S, word.shape[1],
+                                            word.shape[0], pos.shape[0], typ.shape[0], float(eps), _ptr(err_flag), _stream())
+    _lib.check(rc, "vt_embed_layernorm_f32")
+    return out
