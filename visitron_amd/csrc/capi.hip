@@ -51,6 +51,19 @@ void vt_gemm_set_trace(void* p);
 void vt_wgrad_set_tile(int tn);
 void vt_wgrad_v8_enable(int on);
 int vt_wgrad_v8_timeouts(unsigned* out);
+int vt_gemm_f32_dispatch(const float* A, long lda, long sA_b, long sA_h, const float* W, long ldw, long sW_b, long sW_h,
+                         int w_is_kn, const float* bias, const float* R, long ldr, float* C, long ldc, long sC_b, long sC_h,
+                         int M, int N, int K, int act, float alpha, int batch, int heads, int grp_rows, int grp_stride,
+                         hipStream_t stream);
+int vt_softmax_rows_f32_dispatch(float* x, long ld, long rows, int cols, float scale, const float* mask, int mask_mode,
+                                 const float* head_scale, int nh, int S, hipStream_t stream);
+int vt_layernorm_f32_dispatch(const void* x, long ldx, int x_is_f32, void* y, long ldy, int y_is_f32, const float* gamma,
+                              const float* beta, long M, int H, float eps, int grp_rows, int grp_stride, hipStream_t stream);
+int vt_embed_layernorm_f32_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
+                                    const float* pos, const float* type, const float* gamma, const float* beta, float* y,
+                                    long ldy, int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
+                                    int* err_flag, hipStream_t stream);
+
 void vt_gemm_tune_set(int M, int N, int K, int act, int variant);
 void vt_attn_bwd_set_waves(int w);
 
@@ -293,19 +306,6 @@ int vt_pack_concat_bf16(const float* s0, int d0, const float* s1, int d1, void* 
 }
 
 // ---- fp32 parity path (fp32_path.hip) ----------------------------------------------------------------------------
-int vt_gemm_f32_dispatch(const float* A, long lda, long sA_b, long sA_h, const float* W, long ldw, long sW_b, long sW_h,
-                         int w_is_kn, const float* bias, const float* R, long ldr, float* C, long ldc, long sC_b, long sC_h,
-                         int M, int N, int K, int act, float alpha, int batch, int heads, int grp_rows, int grp_stride,
-                         hipStream_t stream);
-int vt_softmax_rows_f32_dispatch(float* x, long ld, long rows, int cols, float scale, const float* mask, int mask_mode,
-                                 const float* head_scale, int nh, int S, hipStream_t stream);
-int vt_layernorm_f32_dispatch(const void* x, long ldx, int x_is_f32, void* y, long ldy, int y_is_f32, const float* gamma,
-                              const float* beta, long M, int H, float eps, int grp_rows, int grp_stride, hipStream_t stream);
-int vt_embed_layernorm_f32_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
-                                    const float* pos, const float* type, const float* gamma, const float* beta, float* y,
-                                    long ldy, int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
-                                    int* err_flag, hipStream_t stream);
-
 int vt_linear_f32(const float* a, int64_t lda, const float* w, int64_t ldw, int w_is_kn, const float* bias,
                   const float* residual, int64_t ldr, float* out, int64_t ldc, int M, int N, int K, int act, float alpha,
                   int grp_rows, int grp_stride, vt_stream_t stream) {
