@@ -95,6 +95,7 @@ def main():
     global torch
     import torch
 
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -160,9 +161,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def note(msg):
+        if rank == 0:
+            print("[bench] %s (t=%.1f s)" % (msg, time.perf_counter() - t_start), file=sys.stderr, flush=True)
+
+    note("model built")
     for _ in range(a.warmup):
         step()
     sync_all()
+    note("warm-up done")
     # HIP events around every step, on the stream the kernels are launched on (torch's current stream: the library is
     # handed torch.cuda.current_stream() with every call) -> median / p10 / p90 per step; `value` is the wall clock over
     # the whole region between the two barrier + synchronize brackets
@@ -183,6 +190,7 @@ def main():
 
     ms_per_step = elapsed / a.steps * 1e3
     value = world * a.batch * a.steps / elapsed
+    note("timed region done: %.3f ms/step" % ms_per_step)
     f_enc = enc_flops_per_seq(S, cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size)
 
     # the same K steps with every padded row computed (the reference's own amount of work per step): reported beside
@@ -226,6 +234,7 @@ def main():
         fwd_value = world * a.batch * a.steps / fwd_elapsed
         sync_all()
 
+    note("side measurements done")
     # ---- live per-kernel timing (HIP events on the launch stream), outside the timed region ----
     roofline = None
     kernels = None
@@ -264,6 +273,7 @@ def main():
     if train and engine.last_layout is not None:
         f_exec = 3 * enc_flops_rows(engine.last_layout.length.tolist(), cfg.hidden_size, cfg.num_hidden_layers,
                                     cfg.intermediate_size)
+    note("kernel timing done")
     cpu_baseline = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         gpu_out = None
@@ -360,7 +370,24 @@ def run_cpu_baseline(cfg, T, R, train, gpu_out=None):
         usable = len(os.sched_getaffinity(0))
     except Exception:
         usable = logical
-    threads = usable          # every core this process may run on (no cap); torch CPU ops pick their own parallelism
+    # the container's CPU share (cgroup quota): a GPU box hands one GPU's share of the host cores to this process, and
+    # more threads than that share only fight over it (a first attempt with one thread per visible core did not finish)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(round(float(q) / float(per))))
+    except Exception:
+        try:   # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, int(round(q / per)))
+        except Exception:
+            pass
+    # no visible quota: torch's CPU GEMMs at these sizes stop scaling around 32 threads (round 1: 32 threads finished
+    # 14 steps in 12 s; one thread per visible core of the GPU host did not finish a step in minutes)
+    threads = min(usable, quota) if quota else min(usable, 32)
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     points = []
@@ -377,12 +404,16 @@ def run_cpu_baseline(cfg, T, R, train, gpu_out=None):
             else:
                 with torch.no_grad():
                     model(**b)
+        tw = time.perf_counter()
         it()  # warm-up
+        tw = time.perf_counter() - tw
+        print("[bench] cpu baseline B=%d: warm-up iteration %.1f s (%d threads)" % (B, tw, threads), file=sys.stderr, flush=True)
         n, t0 = 0, time.perf_counter()
-        while n < 2 or (time.perf_counter() - t0 < budget_s and n < 50):
+        while n < 1 or (time.perf_counter() - t0 < budget_s and n < 50):
             it()
             n += 1
         dt = time.perf_counter() - t0
+        print("[bench] cpu baseline B=%d: %d iterations in %.1f s" % (B, n, dt), file=sys.stderr, flush=True)
         points.append({"batch": B, "value": round(B * n / dt, 3), "iterations": n, "seconds": round(dt, 1)})
     what = ("oracle fp32 pretrain step (fwd + bwd + AdamW, torch CPU ops)" if train else
             "oracle fp32 trunk forward (torch CPU ops)")
@@ -391,7 +422,7 @@ def run_cpu_baseline(cfg, T, R, train, gpu_out=None):
         "value": best["value"], "unit": "samples/s", "cores": threads, "kind": "port",
         "sample": "%s, S=%d: %s" % (what, T + R, "; ".join("B=%d: %d iterations in %.1f s = %.3f samples/s" % (
             p_["batch"], p_["iterations"], p_["seconds"], p_["value"]) for p_ in points)),
-        "points": points, "host_logical_cpus": logical, "host_usable_cpus": usable,
+        "points": points, "host_logical_cpus": logical, "host_usable_cpus": usable, "cgroup_cpu_quota": quota,
     }
     if gpu_out is not None:
         ref = OraclePreTrain(cfg).eval()
