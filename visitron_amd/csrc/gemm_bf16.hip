@@ -691,9 +691,10 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_bf16_v6(GemmArgs g) {
 // variant: 1 = 128x128 tile, 4 waves, BK 64, 2-stage ring (v2); 14 = the same tile with 8 waves of 32x64 (v6);
 //          9 / 10 = 256x192 / 256x256 tile, 8 waves (v4); 11 = 256x256, BK 32, 4-stage ring, phased (v5);
 //          15 / 16 = 256x256 tile, 4 waves of 128x128 with AGPR accumulators, one tile per workgroup / persistent
-//          (gemm_v7.hip).
+//          (gemm_v7.hip); 18 / 19 = the persistent kernel on 224- / 192-row tiles (fewer, better balanced rounds when the
+//          256-row tiling leaves the last round mostly empty).
 int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip
-int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip (persistent)
+int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn);  // gemm_v7.hip (persistent; tile height 32 * mtn)
 static void* g_gemm_trace = nullptr;
 void vt_gemm_set_trace(void* p) { g_gemm_trace = p; }
 static int g_gemm_variant = -1;  // -1: table / heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
@@ -792,7 +793,9 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
       return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
     }
     case 15: return vt_gemm_v7_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
-    case 16: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
+    case 16: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 8);
+    case 18: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 7);   // the persistent kernel on 224-row tiles
+    case 19: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 6);   // ... on 192-row tiles
     default: return VT_ERR_UNSUPPORTED;
   }
 }

@@ -23,11 +23,15 @@
 #define V7_STAGE 65536
 #define V7_LDS_BYTES (2 * V7_STAGE + 4096)   // two operand stages + 1 KiB per wave: the tile's bias values
 #define V7_WOFF 32768
+// MTN = row blocks (of 16) per wave: 8 (tile height 256), 7 (224) or 6 (192).  The stream keeps its 64 slots per phase;
+// with MTN < 8 the MFMAs of the missing row blocks (and their fragment reads) simply are not emitted.
 #define V7_MFMA(S, i)                                                                                             \
+  if (((i) & 7) < MTN)                                                                                            \
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[(i) & 7][(i) >> 3]) : "v"(wf[S][(i) >> 3]), \
                "v"(xf[S][(i) & 7]))
 // first K-step of a tile: C = 0 (an inline constant), so the 256 accumulator registers need no zeroing pass
 #define V7_MFMA0(S, i)                                                                                            \
+  if (((i) & 7) < MTN)                                                                                            \
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[(i) & 7][(i) >> 3]) : "v"(wf[S][(i) >> 3]), \
                "v"(xf[S][(i) & 7]))
 #define V7_LDSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
@@ -73,7 +77,7 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
       asm volatile("" : "+a"(acc[MT][4 * (NH) + t]));   /* stays in AGPRs until its slab's turn */         \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) v[4 * t + e] = acc[MT][4 * (NH) + t][e] + bv[4 * t + e]; \
     }                                                                                                     \
-    const int so_row = 128 * wm + 16 * (MT);                                                              \
+    const int so_row = 16 * MTN * wm + 16 * (MT);                                                         \
     if (has_c2) {   /* saved for the backward pass: the activation's derivative (GELU) or the pre-activation */ \
       float d2[16];                                                                                       \
       _Pragma("unroll") for (int i = 0; i < 16; i += 4) {                                                 \
@@ -105,7 +109,7 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
          stores issued since -> counted wait (VMEM retires in order).  With C2 stores in the stream as well (not a  \
          combination the encoder uses) simply drain. */                                                            \
       if (has_c2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NH) == 0 ? 14 + 2 * (MT) : 30 - 2 * (MT)) : "memory"); \
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NH) == 0 ? 2 * (MTN - 1) + 2 * (MT) : 4 * MTN - 2 - 2 * (MT)) : "memory"); \
       asm volatile("" : "+v"(rq[MT][0]), "+v"(rq[MT][1]));                                                \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
         const u32x4 q0 = rq[MT][0], q1 = rq[MT][1];                                                       \
@@ -128,11 +132,11 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
     v7_buf_store16_o16(o1, rs_c, vo_c, so_row * ldc_b + ec * 2);                                          \
   }
 
-template <int ACT, bool HAS_R>
+template <int ACT, bool HAS_R, int MTN>
 __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)[8][8], int lane, int wave, int m0, int n0, unsigned lds0) {
   const int wm = wave >> 1, wn = wave & 1;
   const unsigned bias_slot = lds0 + 2 * V7_STAGE + wave * 1024;   // this wave's copy of the tile's 256 bias values
-  const int rows = g.M - m0 < 256 ? g.M - m0 : 256;
+  const int rows = g.M - m0 < 32 * MTN ? g.M - m0 : 32 * MTN;
   const int ldc_b = (int)g.ldc * 2, ldc2_b = (int)g.ldc2 * 2, ldr_b = (int)g.ldr * 2;
   // rows past M fall outside num_records: their loads read zeros, their stores are dropped
   const u32x4 rs_c = v7_rsrc((const bf16_t*)g.C + (long)m0 * g.ldc, (unsigned)rows * ldc_b);
@@ -150,9 +154,9 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
     const int ec = n0 + ecr;                                                                              \
     if (ec < g.N) {   /* N % 64 == 0 (host-checked): the 64 columns are all valid */                      \
       if (HAS_R && (NH) == 0) {                                                                           \
-        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                   \
-          v7_buf_load16(rq[q][0], rs_r, vo_r, (128 * wm + 16 * q) * ldr_b + ec * 2);                      \
-          v7_buf_load16_o16(rq[q][1], rs_r, vo_r, (128 * wm + 16 * q) * ldr_b + ec * 2);                  \
+        _Pragma("unroll") for (int q = 0; q < MTN; ++q) {                                                 \
+          v7_buf_load16(rq[q][0], rs_r, vo_r, (16 * MTN * wm + 16 * q) * ldr_b + ec * 2);                 \
+          v7_buf_load16_o16(rq[q][1], rs_r, vo_r, (16 * MTN * wm + 16 * q) * ldr_b + ec * 2);             \
         }                                                                                                 \
       }                                                                                                   \
       u32x4 bq[4];                                                                                        \
@@ -167,7 +171,9 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
         _Pragma("unroll") for (int e = 0; e < 4; ++e) bv[4 * i + e] = __uint_as_float(bq[i][e]);          \
       }                                                                                                   \
       V7_SLAB(0, NH) V7_SLAB(1, NH) V7_SLAB(2, NH) V7_SLAB(3, NH)                                         \
-      V7_SLAB(4, NH) V7_SLAB(5, NH) V7_SLAB(6, NH) V7_SLAB(7, NH)                                         \
+      V7_SLAB(4, NH) V7_SLAB(5, NH)                                                                       \
+      if (MTN > 6) V7_SLAB(6, NH)                                                                         \
+      if (MTN > 7) V7_SLAB(7, NH)                                                                         \
     }                                                                                                     \
   }
   V7_HALF(0)
@@ -211,7 +217,7 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
     asm volatile("" : "+v"(vx[0]), "+v"(vx[1]), "+v"(vw[0]), "+v"(vw[1]));                                \
     _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
       MFMA_A(0, i);                                                                                        \
-      if (i < 16 && (i & 1)) V7_LDSR(xf[1][i >> 1], xa1, (i >> 1) * 2048);                                 \
+      if (i < 16 && (i & 1) && (i >> 1) < MTN) V7_LDSR(xf[1][i >> 1], xa1, (i >> 1) * 2048);               \
       if (i == 20) {                                                                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
         __builtin_amdgcn_s_barrier();                                                                      \
@@ -234,7 +240,7 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
       }                                                                                                    \
       if (i >= 26 && i < 58 && !(i & 1)) {                                                                 \
         const int j = (i - 26) >> 1;                                                                       \
-        if (j < 8) V7_LDSR(xf[0][j], xn0, j * 2048);                                                       \
+        if (j < 8) { if (j < MTN) V7_LDSR(xf[0][j], xn0, j * 2048); }                                      \
         else V7_LDSR(wf[0][j - 8], wn0, (j - 8) * 2048);                                                   \
       }                                                                                                    \
       if (i == 31) V7_DMA_W(rw, dst, 5);                                                                   \
@@ -248,6 +254,7 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
 #define V7_TR nullptr
 template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R>
 __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
+  constexpr int MTN = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      V7_LDSR(xf[0][i], xa0, i * 2048);
+      if (i < MTN) V7_LDSR(xf[0][i], xa0, i * 2048);
       V7_LDSR(wf[0][i], wa0, i * 2048);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   // plain register epilogue, slab by slab
 #define V7_EPILOGUE()                                                                                     \
   if (EPI_LDS) {                                                                                          \
-    v7_epilogue_fast<ACT, HAS_R>(g, acc, lane, wave, m0, n0, lds0);                                       \
+    v7_epilogue_fast<ACT, HAS_R, MTN>(g, acc, lane, wave, m0, n0, lds0);                                  \
   } else {                                                                                                \
     _Pragma("unroll 1") for (int h = 0; h < 16; ++h) {                                                    \
       f32x4 a[4];                                                                                         \
@@ -392,8 +399,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
 // on one L2 are neighbours.
 #undef V7_TR
 #define V7_TR tr
-template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R>
+// MTN (row blocks of 16 per wave, 8 / 7 / 6 = tile height TH 256 / 224 / 192): with ~200 row tiles of 256 the
+// three column tiles of the N = 768 shapes make 600 tiles = 2.34 rounds on 256 CUs, paid as 3; 224-row tiles make 681 =
+// 2.66 rounds of tiles that are 7/8 the work -- the same 3 rounds, 12.5 % fewer MFMAs.  The host picks per shape.
+template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R, int MTN = 8>
 __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
+  constexpr int TH = 32 * MTN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
     const int rows_left = g.tiles_m - band * 8;
     const int band_h = rows_left < 8 ? rows_left : 8;
     const int bn = within / band_h;
-    m0 = (band * 8 + (within - bn * band_h)) * 256;
+    m0 = (band * 8 + (within - bn * band_h)) * TH;
     n0 = bn * 256;
   };
 
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned fr = (lane & 15) * 128 + ((((unsigned)lane >> 4) ^ (((unsigned)lane & 15) >> 1)) << 4);
-  unsigned xa0 = lds0 + wm * 16384 + fr, xa1 = xa0 ^ 64;
+  unsigned xa0 = lds0 + wm * (MTN * 2048) + fr, xa1 = xa0 ^ 64;
   unsigned wa0 = lds0 + V7_WOFF + wn * 16384 + fr, wa1 = wa0 ^ 64;
   unsigned dst = wave * 8192;
 
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
       int m0, n0;
       tile_origin(cur_t, m0, n0);
       if (dbg_same) { m0 = 0; n0 = 0; }
-      const int rows_x = g.M - m0 < 256 ? g.M - m0 : 256;
+      const int rows_x = g.M - m0 < TH ? g.M - m0 : TH;
       const int rows_w = g.N - n0 < 256 ? g.N - n0 : 256;
       cur_x = (const char*)(g.A + (long)m0 * g.lda);
       cur_w = (const char*)(g.W + (long)n0 * g.ldw);
@@ -499,7 +510,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      V7_LDSR(xf[0][i], xa0, i * 2048);
+      if (i < MTN) V7_LDSR(xf[0][i], xa0, i * 2048);
       V7_LDSR(wf[0][i], wa0, i * 2048);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -536,19 +547,27 @@ static int v8_grid(int tiles) {
 }
 
 template <int ACT, bool OUT_F32>
-static int launch_v8(const GemmArgs& g, hipStream_t stream) {
+static int launch_v8(const GemmArgs& g, hipStream_t stream, int mtn) {
   GemmArgs g8 = g;
-  g8.tiles_m = (g.M + 255) / 256;
   g8.tiles_n = (g.N + 255) / 256;
   if ((g.K & 63) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31)) return VT_ERR_UNSUPPORTED;
-  const int grid = v8_grid(g8.tiles_m * g8.tiles_n);
-  if (grid <= 0) return VT_ERR_HIP;
-  // bf16 output with whole 64-column slabs goes through the LDS-transposed (coalesced) epilogue
   // bf16 output in whole 64-column slabs without row remap: the straight-line epilogue, specialised on the residual
   const bool fast = !OUT_F32 && (g.N & 63) == 0 && g.grp_rows == 0;
   if (ACT == ACT_MUL && !g.R) return VT_ERR_NULL;
-  auto kern = !fast ? gemm_nt_bf16_v8<ACT, OUT_F32, false, false>
-                    : ((g.R || ACT == ACT_MUL) ? gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, true> : gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL>);
+  if (!fast || OUT_F32 || ACT == ACT_TANH) mtn = 8;   // the shorter tiles exist for the encoder's own (bf16, fast-epilogue) shapes
+  const int th = 32 * mtn;
+  g8.tiles_m = (g.M + th - 1) / th;
+  const int grid = v8_grid(g8.tiles_m * g8.tiles_n);
+  if (grid <= 0) return VT_ERR_HIP;
+  const bool has_r = g.R || ACT == ACT_MUL;
+  void (*kern)(GemmArgs) = nullptr;
+  if (!fast) kern = gemm_nt_bf16_v8<ACT, OUT_F32, false, false>;
+  else if (mtn == 8) kern = has_r ? gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, true> : gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL>;
+  else if (mtn == 7) kern = has_r ? gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, true, (OUT_F32 || ACT == ACT_TANH) ? 8 : 7>
+                                  : gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL, (OUT_F32 || ACT == ACT_TANH) ? 8 : 7>;
+  else if (mtn == 6) kern = has_r ? gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, true, (OUT_F32 || ACT == ACT_TANH) ? 8 : 6>
+                                  : gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL, (OUT_F32 || ACT == ACT_TANH) ? 8 : 6>;
+  else return VT_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES) != hipSuccess) return VT_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), V7_LDS_BYTES, stream, g8);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
@@ -570,19 +589,19 @@ static int launch_v7(const GemmArgs& g, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
-int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream) {
+int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn) {
 #ifdef V7_ONE
-  return launch_v8<ACT_NONE, false>(g, stream);
+  return launch_v8<ACT_NONE, false>(g, stream, mtn);
 #else
   switch (act * 2 + (out_f32 ? 1 : 0)) {
-    case 0: return launch_v8<ACT_NONE, false>(g, stream);
-    case 1: return launch_v8<ACT_NONE, true>(g, stream);
-    case 2: return launch_v8<ACT_GELU, false>(g, stream);
-    case 3: return launch_v8<ACT_GELU, true>(g, stream);
-    case 4: return launch_v8<ACT_TANH, false>(g, stream);
-    case 5: return launch_v8<ACT_TANH, true>(g, stream);
-    case 6: return launch_v8<ACT_MUL, false>(g, stream);
-    case 7: return launch_v8<ACT_MUL, true>(g, stream);
+    case 0: return launch_v8<ACT_NONE, false>(g, stream, mtn);
+    case 1: return launch_v8<ACT_NONE, true>(g, stream, mtn);
+    case 2: return launch_v8<ACT_GELU, false>(g, stream, mtn);
+    case 3: return launch_v8<ACT_GELU, true>(g, stream, mtn);
+    case 4: return launch_v8<ACT_TANH, false>(g, stream, mtn);
+    case 5: return launch_v8<ACT_TANH, true>(g, stream, mtn);
+    case 6: return launch_v8<ACT_MUL, false>(g, stream, mtn);
+    case 7: return launch_v8<ACT_MUL, true>(g, stream, mtn);
     default: return VT_ERR_UNSUPPORTED;
   }
 #endif

@@ -124,8 +124,9 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
 
 
 # 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring), 256x256 with 128x128 wave tiles
-# and AGPR accumulators (15: one tile per workgroup, 16: persistent).
-GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16)
+# and AGPR accumulators (15: one tile per workgroup, 16: persistent; 18 / 19: the persistent kernel on 224- / 192-row tiles,
+# which balance the rounds over the 256 CUs when the 256-row tiling leaves the last round mostly empty).
+GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16, 18, 19)
 
 
 # -1: shape table / heuristic; -2: the same plus the tail launch of the persistent kernel's last round (VT_GEMM_TAIL_SPLIT=1)
@@ -140,6 +141,7 @@ def set_gemm_variant(v):
 # time.  Data-parallel training (gradient all-reduce overlapped with the backward) therefore tunes without it; the
 # one-tile-per-workgroup form of the same kernel (15) is within 3-5 % and simply queues its tiles.
 PERSISTENT_GEMM_OK = True
+PERSISTENT_VARIANTS = (16, 18, 19)
 _tuned = {}
 _forced_variant = None
 
@@ -162,7 +164,7 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
         return _tuned[key]
     lib = _lib.load()
     saved = _tune_file_table().get("%d,%d,%d,%d" % key)
-    if saved is not None and (saved != 16 or PERSISTENT_GEMM_OK):   # VT_TUNE_FILE: a previous run's choices
+    if saved is not None and (saved not in PERSISTENT_VARIANTS or PERSISTENT_GEMM_OK):   # VT_TUNE_FILE: a previous run's choices
         lib.vt_gemm_tune(M, N, K, act, int(saved))
         _tuned[key] = int(saved)
         return _tuned[key]
@@ -175,7 +177,7 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
     pre = torch.empty((M, N), dtype=BF16, device=device) if pre_act else None
     best, best_t = GEMM_CANDIDATES[0], float("inf")
     for v in GEMM_CANDIDATES:
-        if v == 16 and not PERSISTENT_GEMM_OK:
+        if v in PERSISTENT_VARIANTS and not PERSISTENT_GEMM_OK:
             continue
         lib.vt_debug_set_gemm_variant(v)
         try:
