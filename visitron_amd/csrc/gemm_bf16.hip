@@ -691,7 +691,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_bf16_v6(GemmArgs g) {
 // variant: 1 = 128x128 tile, 4 waves, BK 64, 2-stage ring (v2); 14 = the same tile with 8 waves of 32x64 (v6);
 //          9 / 10 = 256x192 / 256x256 tile, 8 waves (v4); 11 = 256x256, BK 32, 4-stage ring, phased (v5);
 //          15 / 16 = 256x256 tile, 4 waves of 128x128 with AGPR accumulators, one tile per workgroup / persistent
-//          (gemm_v7.hip); 18 / 19 = the persistent kernel on 224- / 192-row tiles (fewer, better balanced rounds when the
+//          (gemm_v7.hip); 18 .. 21 = the persistent kernel on 224- / 192- / 160- / 128-row tiles (fewer, better balanced rounds when the
 //          256-row tiling leaves the last round mostly empty).
 int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip
 int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn);  // gemm_v7.hip (persistent; tile height 32 * mtn)
@@ -796,6 +796,8 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
     case 16: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 8);
     case 18: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 7);   // the persistent kernel on 224-row tiles
     case 19: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 6);   // ... on 192-row tiles
+    case 20: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 5);   // ... on 160-row tiles
+    case 21: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 4);   // ... on 128-row tiles (small batches)
     default: return VT_ERR_UNSUPPORTED;
   }
 }

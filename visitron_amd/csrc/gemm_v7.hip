@@ -23,7 +23,7 @@
 #define V7_STAGE 65536
 #define V7_LDS_BYTES (2 * V7_STAGE + 4096)   // two operand stages + 1 KiB per wave: the tile's bias values
 #define V7_WOFF 32768
-// MTN = row blocks (of 16) per wave: 8 (tile height 256), 7 (224) or 6 (192).  The stream keeps its 64 slots per phase;
+// MTN = row blocks (of 16) per wave: 8 (tile height 256) down to 4 (128).  The stream keeps its 64 slots per phase;
 // with MTN < 8 the MFMAs of the missing row blocks (and their fragment reads) simply are not emitted.
 #define V7_MFMA(S, i)                                                                                             \
   if (((i) & 7) < MTN)                                                                                            \
@@ -171,7 +171,8 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
         _Pragma("unroll") for (int e = 0; e < 4; ++e) bv[4 * i + e] = __uint_as_float(bq[i][e]);          \
       }                                                                                                   \
       V7_SLAB(0, NH) V7_SLAB(1, NH) V7_SLAB(2, NH) V7_SLAB(3, NH)                                         \
-      V7_SLAB(4, NH) V7_SLAB(5, NH)                                                                       \
+      if (MTN > 4) V7_SLAB(4, NH)                                                                         \
+      if (MTN > 5) V7_SLAB(5, NH)                                                                         \
       if (MTN > 6) V7_SLAB(6, NH)                                                                         \
       if (MTN > 7) V7_SLAB(7, NH)                                                                         \
     }                                                                                                     \
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
 // on one L2 are neighbours.
 #undef V7_TR
 #define V7_TR tr
-// MTN (row blocks of 16 per wave, 8 / 7 / 6 = tile height TH 256 / 224 / 192): with ~200 row tiles of 256 the
+// MTN (row blocks of 16 per wave, 8 .. 4 = tile height TH 256 .. 128): with ~200 row tiles of 256 the
 // three column tiles of the N = 768 shapes make 600 tiles = 2.34 rounds on 256 CUs, paid as 3; 224-row tiles make 681 =
 // 2.66 rounds of tiles that are 7/8 the work -- the same 3 rounds, 12.5 % fewer MFMAs.  The host picks per shape.
 template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R, int MTN = 8>
@@ -563,10 +564,11 @@ static int launch_v8(const GemmArgs& g, hipStream_t stream, int mtn) {
   void (*kern)(GemmArgs) = nullptr;
   if (!fast) kern = gemm_nt_bf16_v8<ACT, OUT_F32, false, false>;
   else if (mtn == 8) kern = has_r ? gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, true> : gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL>;
-  else if (mtn == 7) kern = has_r ? gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, true, (OUT_F32 || ACT == ACT_TANH) ? 8 : 7>
-                                  : gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL, (OUT_F32 || ACT == ACT_TANH) ? 8 : 7>;
-  else if (mtn == 6) kern = has_r ? gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, true, (OUT_F32 || ACT == ACT_TANH) ? 8 : 6>
-                                  : gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL, (OUT_F32 || ACT == ACT_TANH) ? 8 : 6>;
+#define V8_PICK(MT)                                                                                                  \
+  else if (mtn == MT) kern = has_r ? gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, true, (OUT_F32 || ACT == ACT_TANH) ? 8 : MT>   \
+                                   : gemm_nt_bf16_v8<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL, (OUT_F32 || ACT == ACT_TANH) ? 8 : MT>;
+  V8_PICK(7) V8_PICK(6) V8_PICK(5) V8_PICK(4)
+#undef V8_PICK
   else return VT_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES) != hipSuccess) return VT_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), V7_LDS_BYTES, stream, g8);
