@@ -332,6 +332,8 @@ def main():
             "mfma_frac_whole_forward": (None if (train and fwd_value is None) else
                                         round(f_enc * (fwd_value if train else value) / world / (PEAK_BF16_TFLOPS * 1e12), 4)),
             "roofline": roofline,
+            # the autotuner's pick per (M, N, K, act) -- kernel variant numbers as in csrc/gemm_bf16.hip
+            "gemm_variants": {"%d,%d,%d,%d" % k: v for k, v in sorted(ops._tuned.items())},
             "device": device_info(dev),
             "cpu_baseline": cpu_baseline,
             "kernels_ms_per_step": None if kernels is None else {

@@ -86,8 +86,9 @@ __device__ __forceinline__ void attn_bwd_keep16(const DropCfg& dr, uint32_t qbas
       const uint32_t hm = vt_hash_fin(x0 + (uint32_t)(((2 * j) & 3) + 8 * ((2 * j) >> 2)) * qstep);   // element 2j + par
       const uint32_t hp = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);   // the neighbour's: element 2j + 1 - par
       const uint32_t h0 = odd ? hp : hm, h1 = odd ? hm : hp;
-      keep[2 * j] = ((h0 >> fsh) & 0xffffu) >= dr.thresh;
-      keep[2 * j + 1] = ((h1 >> fsh) & 0xffffu) >= dr.thresh;
+      // this key's field moved to the high half: one shift (by 16 or 0), one compare
+      keep[2 * j] = vt_keep_hi(h0 << (16u - fsh), dr.thresh);
+      keep[2 * j + 1] = vt_keep_hi(h1 << (16u - fsh), dr.thresh);
     }
   } else {
 #pragma unroll
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   const int nslices = (S + 31) >> 5;
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
+  const float ds_scale = a.scale * dr.scale;   // 1 / sqrt(d) times dropout's 1 / (1-p) (1 when off)
   const int kcount = (S - kb0) < 256 ? (S - kb0) : 256;
   const int nkt = (kcount + 31) >> 5;  // 32-key steps of this key block for dQ
 
@@ -281,11 +283,14 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
           const float p = __builtin_amdgcn_exp2f((s - lse4[g4][e]) * LOG2E);
           float dpv = dpacc[i], pv = p;
           if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
-            dpv = keep[i] ? dpv * dr.scale : 0.f;
-            pv = keep[i] ? p * dr.scale : 0.f;
+            dpv = keep[i] ? dpv : 0.f;
+            pv = keep[i] ? p : 0.f;
           }
+          // dropout's uniform 1 / (1-p) is not applied per element: dV takes it once at the end, and in
+          // dS = P (mask dP / (1-p) - delta) / 8 it moves outside the bracket: ds_scale = 1 / (8 (1-p)), the row constant arrives
+          // as delta (1-p) (attn_delta_rows)
           pacc[i] = pv;
-          sacc[i] = p * (dpv - del4[g4][e]) * a.scale;  // dS' (scale folded in)
+          sacc[i] = p * (dpv - del4[g4][e]) * ds_scale;  // dS' (scales folded in)
         }
       // dV^T += dO^T P ; dK^T += Q^T dS'   (k = q, 2 steps of 16)
 #pragma unroll
@@ -388,8 +393,8 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
       for (int i = 0; i < 4; ++i) {
         k0[i] = pack_bf16x2(dk[dt][kt][2 * i], dk[dt][kt][2 * i + 1]);
         k1[i] = pack_bf16x2(dk[dt][kt][8 + 2 * i], dk[dt][kt][8 + 2 * i + 1]);
-        v0[i] = pack_bf16x2(dv[dt][kt][2 * i], dv[dt][kt][2 * i + 1]);
-        v1[i] = pack_bf16x2(dv[dt][kt][8 + 2 * i], dv[dt][kt][8 + 2 * i + 1]);
+        v0[i] = pack_bf16x2(dv[dt][kt][2 * i] * dr.scale, dv[dt][kt][2 * i + 1] * dr.scale);
+        v1[i] = pack_bf16x2(dv[dt][kt][8 + 2 * i] * dr.scale, dv[dt][kt][8 + 2 * i + 1] * dr.scale);
       }
       ((u32x4*)(orow + H + 32 * dt))[0] = k0;
       ((u32x4*)(orow + H + 32 * dt))[1] = k1;
@@ -421,6 +426,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   const int nslices = (S + 31) >> 5;
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
+  const float ds_scale = a.scale * dr.scale;   // 1 / sqrt(d) times dropout's 1 / (1-p) (1 when off)
   const int kcount = (S - kb0) < 256 ? (S - kb0) : 256;
   const int nkt = (kcount + 31) >> 5;  // 32-key steps of this key block for dQ
 
@@ -584,11 +590,14 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
           const float p = __builtin_amdgcn_exp2f((s - lse4_g[e]) * LOG2E);
           float dpv = dpacc[i], pv = p;
           if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
-            dpv = keep[i] ? dpv * dr.scale : 0.f;
-            pv = keep[i] ? p * dr.scale : 0.f;
+            dpv = keep[i] ? dpv : 0.f;
+            pv = keep[i] ? p : 0.f;
           }
+          // dropout's uniform 1 / (1-p) is not applied per element: dV takes it once at the end, and in
+          // dS = P (mask dP / (1-p) - delta) / 8 it moves outside the bracket: ds_scale = 1 / (8 (1-p)), the row constant arrives
+          // as delta (1-p) (attn_delta_rows)
           pacc[i] = pv;
-          sacc[i] = p * (dpv - del4_g[e]) * a.scale;  // dS' (scale folded in)
+          sacc[i] = p * (dpv - del4_g[e]) * ds_scale;  // dS' (scales folded in)
         }
       }
       // dV^T += dO^T P ; dK^T += Q^T dS'   (k = q, 2 steps of 16)
@@ -687,8 +696,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       for (int i = 0; i < 4; ++i) {
         k0[i] = pack_bf16x2(dk[dt][kt][2 * i], dk[dt][kt][2 * i + 1]);
         k1[i] = pack_bf16x2(dk[dt][kt][8 + 2 * i], dk[dt][kt][8 + 2 * i + 1]);
-        v0[i] = pack_bf16x2(dv[dt][kt][2 * i], dv[dt][kt][2 * i + 1]);
-        v1[i] = pack_bf16x2(dv[dt][kt][8 + 2 * i], dv[dt][kt][8 + 2 * i + 1]);
+        v0[i] = pack_bf16x2(dv[dt][kt][2 * i] * dr.scale, dv[dt][kt][2 * i + 1] * dr.scale);
+        v1[i] = pack_bf16x2(dv[dt][kt][8 + 2 * i] * dr.scale, dv[dt][kt][8 + 2 * i + 1] * dr.scale);
       }
       ((u32x4*)(orow + H + 32 * dt))[0] = k0;
       ((u32x4*)(orow + H + 32 * dt))[1] = k1;
@@ -698,11 +707,12 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   }
 }
 
-// delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]   (one wave per token row; 64 d per head = 8 lanes x 8).
+// delta[b,h,s] = mul * sum_d dO[b,s,h,d] * O[b,s,h,d]   (one wave per token row; 64 d per head = 8 lanes x 8).
 // grid = (ceil(S / 4), B): row s of sequence b, which starts at seq_start[b] (or b * S) and has seq_len[b] (or S) rows.
 __global__ __launch_bounds__(256) void attn_delta_rows(const bf16_t* __restrict__ d_o, long ld_d, const bf16_t* __restrict__ o,
                                                        long ld_o, float* __restrict__ delta, int B, int S, int nh,
-                                                       const int* __restrict__ seq_start, const int* __restrict__ seq_len) {
+                                                       const int* __restrict__ seq_start, const int* __restrict__ seq_len,
+                                                       float mul) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.y, s = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int len = seq_len ? seq_len[b] : S;
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(256) void attn_delta_rows(const bf16_t* __restrict_
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
-    if ((c & 7) == 0) delta[((long)b * nh + (c >> 3)) * S + s] = acc;
+    if ((c & 7) == 0) delta[((long)b * nh + (c >> 3)) * S + s] = acc * mul;   // mul = 1 - p (see the backward's dS)
   }
 }
 
@@ -761,7 +771,8 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   if (seq_start && (mask || rows_total <= 0)) return VT_ERR_UNSUPPORTED;   // compacted rows carry no masked keys
   const long rows = seq_start ? rows_total : (long)B * S;
   hipLaunchKernelGGL(attn_delta_rows, dim3((unsigned)((S + 3) / 4), B), dim3(256), 0, stream, (const bf16_t*)dctx, ld_d,
-                     (const bf16_t*)ctx, ld_ctx, delta_ws, B, S, nh, seq_start, seq_len);
+                     (const bf16_t*)ctx, ld_ctx, delta_ws, B, S, nh, seq_start, seq_len,
+                     (drop && drop->thresh) ? 1.0f / drop->scale : 1.0f);
   AttnBwdArgs a;
   a.qkv = (const bf16_t*)qkv; a.dctx = (const bf16_t*)dctx; a.mask = mask; a.mask_additive = mask_additive;
   a.lse = lse; a.delta = delta_ws; a.dqkv = (bf16_t*)dqkv;

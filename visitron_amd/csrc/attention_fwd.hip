@@ -193,8 +193,8 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
               bool k0, k1;
               if ((S & 1) == 0) vt_keep2_pre(dr, xb + (uint32_t)(((i & 3) + 8 * (i >> 2)) >> 1) * VT_HASH_C1, k0, k1);
               else { k0 = vt_keep(dr, e); k1 = vt_keep(dr, e + 1); }
-              sacc[i] = k0 ? sacc[i] * dr.scale : 0.f;
-              sacc[i + 1] = k1 ? sacc[i + 1] * dr.scale : 0.f;
+              sacc[i] = k0 ? sacc[i] : 0.f;          // the 1 / (1 - p) factor is uniform: applied once to O below
+              sacc[i + 1] = k1 ? sacc[i + 1] : 0.f;
             }
           }
 #pragma unroll
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
   const int q = q0 + r;
   if (q >= S) return;
   float inv = 1.0f / l_tot;
+  if (dr.thresh) inv *= dr.scale;   // dropout's 1 / (1 - p)
   if (a.lse && h2 == 0) a.lse[((long)b * a.nh + head) * Smax + q] = m_run + __builtin_amdgcn_logf(l_tot) * 0.6931471805599453f;
   if (a.head_scale) inv *= a.head_scale[head];
   bf16_t* op = a.ctx + (row0 + q) * a.ld_ctx + head * 64 + 16 * h2;

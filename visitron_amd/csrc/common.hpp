@@ -142,8 +142,10 @@ __device__ __forceinline__ float wave_max(float v) {
 // One 32-bit hash serves TWO neighbouring elements: keep(element i) = 16 bits of hash32(site_seed, i >> 1) (low half
 // for even i, high half for odd i) >= p * 2^16; kept values are scaled by 1/(1-p).  Nothing is stored: the backward
 // kernels recompute the same mask from (seed, index).  site_seed mixes the step seed with a site id (layer, which
-// dropout), see vt_site_seed.  The hash is two multiply / xor-shift rounds (v_mul_lo_u32 is a quarter-rate
-// instruction and the epilogues that apply dropout have nothing to overlap it with).
+// dropout), see vt_site_seed.  The hash is two multiply / xor-shift rounds; the first multiply is linear in the index
+// (amortised over a run, see vt_hash_pre) and the second is a 24-bit multiply: v_mul_u32_u24 issues at the full rate,
+// v_mul_lo_u32 at a quarter of it, and the attention kernels -- VALU-bound, half of it this hash -- have nothing to
+// overlap it with.  (Keep rate, 16-bit uniformity and lag correlations measured equal to the 32-bit-multiply finisher's.)
 struct DropCfg {
   uint32_t thresh;   // p * 2^16, 0 = no dropout
   uint32_t seed;     // site seed
@@ -155,26 +157,32 @@ struct DropCfg {
 #define VT_HASH_C1 0x9E3779B1u
 __host__ __device__ __forceinline__ uint32_t vt_hash_pre(uint32_t seed, uint32_t idx) { return (idx + seed) * VT_HASH_C1; }
 __host__ __device__ __forceinline__ uint32_t vt_hash_fin(uint32_t x) {
-  x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13; x ^= x << 7; x ^= x >> 17;
+  x ^= x >> 15;
+  x = (x & 0xffffffu) * 0x85EBCBu;   // low 32 bits of a 24 x 24-bit product
+  x ^= x >> 16;
   return x;
 }
+// the two 16-bit fields of a hash word against the threshold, without extracting them: the high field decides
+// h >= thresh << 16 on the whole word, the low field the same after a shift
+__host__ __device__ __forceinline__ bool vt_keep_lo(uint32_t h, uint32_t thresh) { return (h << 16) >= (thresh << 16); }
+__host__ __device__ __forceinline__ bool vt_keep_hi(uint32_t h, uint32_t thresh) { return h >= (thresh << 16); }
 __host__ __device__ __forceinline__ uint32_t vt_hash32(uint32_t seed, uint32_t idx) { return vt_hash_fin(vt_hash_pre(seed, idx)); }
 __host__ __device__ __forceinline__ bool vt_keep(const DropCfg& d, uint32_t idx) {
   const uint32_t h = vt_hash32(d.seed, idx >> 1);
-  return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= d.thresh;
+  return (idx & 1u) ? vt_keep_hi(h, d.thresh) : vt_keep_lo(h, d.thresh);
 }
 // elements idx (even) and idx + 1 from one hash
 __host__ __device__ __forceinline__ void vt_keep2(const DropCfg& d, uint32_t idx_even, bool& k0, bool& k1) {
   const uint32_t h = vt_hash32(d.seed, idx_even >> 1);
-  k0 = (h & 0xffffu) >= d.thresh;
-  k1 = (h >> 16) >= d.thresh;
+  k0 = vt_keep_lo(h, d.thresh);
+  k1 = vt_keep_hi(h, d.thresh);
 }
 // v[0..N) *= keep / (1-p) for N consecutive elements starting at e0 (N even); pairs share a hash when e0 is even
 // the two keep flags of the pair whose pre-multiplied index is x (see vt_hash_pre)
 __host__ __device__ __forceinline__ void vt_keep2_pre(const DropCfg& d, uint32_t x, bool& k0, bool& k1) {
   const uint32_t h = vt_hash_fin(x);
-  k0 = (h & 0xffffu) >= d.thresh;
-  k1 = (h >> 16) >= d.thresh;
+  k0 = vt_keep_lo(h, d.thresh);
+  k1 = vt_keep_hi(h, d.thresh);
 }
 template <int N>
 __device__ __forceinline__ void vt_drop_run(const DropCfg& d, uint32_t e0, float (&v)[N]) {
