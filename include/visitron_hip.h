@@ -174,18 +174,25 @@ int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const in
 int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                   float step_size, float b1, float b2, float eps, float wd, float grad_scale,
                   vt_stream_t stream);
+/* The same with the gradients given as bf16: the data-parallel step all-reduces a bf16 copy of the gradient slab (half
+ * the bytes of the reference's fp32 DDP buckets, pretrain.py:96-102,191, over xGMI); moments and master weights stay fp32. */
+int vt_adamw_flat_g16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16, int64_t n, float lr, float step_size,
+                      float b1, float b2, float eps, float wd, float grad_scale, vt_stream_t stream);
+/* dst_bf16[i] = bf16(src[i] * scale), n % 8 == 0: the communication copy of a gradient-slab range. */
+int vt_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, float scale, vt_stream_t stream);
 
 /* Fused softmax cross-entropy rows for the MLM head (tasks/viewpoint_select/encoder.py:387-389, argmax
  * :399, and the criterion's backward): loss_row[r] = logsumexp(z[r, :V]) - z[r, y[r]], amax[r] =
  * argmax(z[r, :V]) (first index on ties), dz[r, :Vpad] = bf16((softmax(z[r]) - onehot(y[r])) * scale),
- * columns V..Vpad-1 zero.  z fp32 [rows, ldz], labels must be valid (0 <= y < V). */
+ * columns V..Vpad-1 zero.  z fp32 [rows, ldz], labels must be valid (0 <= y < V).  dz == NULL: loss and argmax only
+ * (the inference path: the reference's 7-tuple needs nothing else of the 30522-wide logits). */
 int vt_ce_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz,
                        int64_t lddz, int64_t rows, int V, int Vpad, float scale, vt_stream_t stream);
 
 /* The masked-region-token head's loss (tasks/viewpoint_select/encoder.py:323-326, 380-385): token_head ends in a
  * Softmax and the criterion applies log-softmax again.  Per supervised row of logits z [rows, V] (V <= 2048):
  * loss_row = logsumexp(softmax(z)) - softmax(z)[y], amax = argmax, dz (bf16 [rows, Vpad], zero past V) =
- * d(scale * loss_row)/dz. */
+ * d(scale * loss_row)/dz (dz == NULL: loss and argmax only). */
 int vt_ce_double_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* loss_row, int64_t* amax,
                               void* dz, int64_t lddz, int64_t rows, int V, int Vpad, float scale,
                               vt_stream_t stream);

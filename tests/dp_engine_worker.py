@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    out_dir = sys.argv[1]
+    out_dir, comm_dtype = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda", 0)             # both ranks on the one GPU of the test box
     torch.cuda.set_device(dev)
@@ -32,7 +32,9 @@ def main():
     m.load_state_dict(deterministic_state_dict(m, seed=5))
     m.tie_weights()
     m = m.to(dev).eval()
-    eng = PretrainEngine(m, lr=1e-3, weight_decay=0.05, schedule="constant", warmup_steps=0, bucket_mb=0.05)
+    eng = PretrainEngine(m, lr=1e-3, weight_decay=0.05, schedule="constant", warmup_steps=0, bucket_mb=0.05,
+                         grad_comm_dtype=comm_dtype)
+    assert (eng.g16 is not None) == (comm_dtype == "bf16")
     eng.compact_min_rows = 0
     assert eng.world == world == 2
     shard = {k: v.to(dev) for k, v in make_batch(cfg, 3, text_len=20, region_len=10, seed=100 + rank).items()}
@@ -40,11 +42,12 @@ def main():
     captured = {}
     step = eng.optimizer_step
 
-    def spy(grad_scale=1.0):
+    def spy(grad_scale=1.0, grads=None):
         torch.cuda.synchronize()
-        captured["g"] = eng.flat.g.detach().cpu().clone()
+        assert (grads is not None) == (comm_dtype == "bf16")      # AdamW is handed the reduced bf16 copy
+        captured["g"] = (eng.flat.g if grads is None else grads).detach().float().cpu().clone()
         captured["scale"] = grad_scale
-        return step(grad_scale=grad_scale)
+        return step(grad_scale=grad_scale, grads=grads)
 
     eng.optimizer_step = spy
     out = eng.train_step(shard, overlap=True, layers_per_chunk=2)

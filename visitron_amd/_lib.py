@@ -73,6 +73,9 @@ SIGNATURES = {
                                         c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_uint64, c_void_p]),
     "vt_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                               c_float, c_float, c_float, c_float, c_void_p]),
+    "vt_adamw_flat_g16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                                  c_float, c_float, c_float, c_float, c_void_p]),
+    "vt_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "vt_ce_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                    c_int, c_float, c_void_p]),
     "vt_ce_double_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,

@@ -27,8 +27,9 @@ int vt_ce_double_softmax_dispatch(const float* z, long ldz, const int64_t* y, fl
 int vt_ce_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, long lddz,
                            long rows, int V, int Vpad, float scale, hipStream_t stream);
 int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, int C, hipStream_t stream);
-int vt_adamw_dispatch(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float step_size, float b1,
-                      float b2, float eps, float wd, float grad_scale, hipStream_t stream);
+int vt_adamw_dispatch(float* p, const void* g, int g_is_bf16, float* m, float* v, void* p_bf16, long n, float lr,
+                      float step_size, float b1, float b2, float eps, float wd, float grad_scale, hipStream_t stream);
+int vt_cast_scale_dispatch(const float* x, void* y, long n, float scale, hipStream_t stream);
 int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale,
                                 const float* lse, float* probs, int B, int S, int nh, int head_size, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
@@ -168,7 +169,16 @@ int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const in
 
 int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float step_size, float b1,
                   float b2, float eps, float wd, float grad_scale, vt_stream_t stream) {
-  return vt_adamw_dispatch(p, g, m, v, p_bf16, n, lr, step_size, b1, b2, eps, wd, grad_scale, (hipStream_t)stream);
+  return vt_adamw_dispatch(p, g, 0, m, v, p_bf16, n, lr, step_size, b1, b2, eps, wd, grad_scale, (hipStream_t)stream);
+}
+
+int vt_adamw_flat_g16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16, int64_t n, float lr, float step_size,
+                      float b1, float b2, float eps, float wd, float grad_scale, vt_stream_t stream) {
+  return vt_adamw_dispatch(p, g_bf16, 1, m, v, p_bf16, n, lr, step_size, b1, b2, eps, wd, grad_scale, (hipStream_t)stream);
+}
+
+int vt_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, float scale, vt_stream_t stream) {
+  return vt_cast_scale_dispatch(src, dst_bf16, n, scale, (hipStream_t)stream);
 }
 
 int vt_ce_softmax_rows(const float* z, int64_t ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, int64_t lddz,

@@ -642,14 +642,23 @@ int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids,
 // with step_size = lr * sqrt(1-b2^t) / (1-b1^t) computed on the host (eps is added to the UN-corrected
 // sqrt(v); the decoupled decay uses the already-moved p).  Also refreshes the bf16 working copy the
 // GEMMs read.  grad_scale multiplies g first (1/world_size for the data-parallel mean).
-__global__ __launch_bounds__(256) void adamw_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// G16: the gradients arrive as bf16 (the data-parallel all-reduce ran on a bf16 copy of the slab: half the bytes over
+// xGMI); moments and master weights stay fp32.
+template <bool G16>
+__global__ __launch_bounds__(256) void adamw_flat(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n4, float lr,
                                                   float step_size, float b1, float b2, float eps, float wd,
                                                   float grad_scale) {
   const long stride = (long)gridDim.x * 256;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     f32x4 pv = ((f32x4*)p)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
-    const f32x4 gv = ((const f32x4*)g)[i];
+    f32x4 gv;
+    if (G16) {
+      const u32x2 w = ((const u32x2*)g)[i];
+      gv = (f32x4){bf16lo(w[0]), bf16hi(w[0]), bf16lo(w[1]), bf16hi(w[1])};
+    } else {
+      gv = ((const f32x4*)g)[i];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gg = gv[k] * grad_scale;
@@ -671,16 +680,43 @@ __global__ __launch_bounds__(256) void adamw_flat(float* __restrict__ p, const f
   }
 }
 
-int vt_adamw_dispatch(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float step_size, float b1,
-                      float b2, float eps, float wd, float grad_scale, hipStream_t stream) {
+int vt_adamw_dispatch(float* p, const void* g, int g_is_bf16, float* m, float* v, void* p_bf16, long n, float lr,
+                      float step_size, float b1, float b2, float eps, float wd, float grad_scale, hipStream_t stream) {
   if (!p || !g || !m || !v) return VT_ERR_NULL;
   if (n <= 0 || (n % 4)) return VT_ERR_BAD_SHAPE;
-  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)p_bf16 & 7)) return VT_ERR_BAD_ALIGN;
+  if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)g & (g_is_bf16 ? 7 : 15)) || ((uintptr_t)p_bf16 & 7)) return VT_ERR_BAD_ALIGN;
   const long n4 = n / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(adamw_flat, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n4, lr, step_size,
-                     b1, b2, eps, wd, grad_scale);
+  if (g_is_bf16)
+    hipLaunchKernelGGL(adamw_flat<true>, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n4, lr,
+                       step_size, b1, b2, eps, wd, grad_scale);
+  else
+    hipLaunchKernelGGL(adamw_flat<false>, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n4, lr,
+                       step_size, b1, b2, eps, wd, grad_scale);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// y = bf16(x * scale), flat: the communication copy of a gradient-slab range (half the all-reduce bytes)
+__global__ __launch_bounds__(256) void cast_scale_f32_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, long n8, float scale) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+    const f32x4 a = ((const f32x4*)x)[2 * i], b = ((const f32x4*)x)[2 * i + 1];
+    u32x4 o;
+    o[0] = pack_bf16x2(a[0] * scale, a[1] * scale); o[1] = pack_bf16x2(a[2] * scale, a[3] * scale);
+    o[2] = pack_bf16x2(b[0] * scale, b[1] * scale); o[3] = pack_bf16x2(b[2] * scale, b[3] * scale);
+    ((u32x4*)y)[i] = o;
+  }
+}
+
+int vt_cast_scale_dispatch(const float* x, void* y, long n, float scale, hipStream_t stream) {
+  if (!x || !y) return VT_ERR_NULL;
+  if (n <= 0 || (n % 8)) return VT_ERR_BAD_SHAPE;
+  if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return VT_ERR_BAD_ALIGN;
+  const long n8 = n / 8;
+  long blocks = (n8 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(cast_scale_f32_bf16, dim3((unsigned)blocks), dim3(256), 0, stream, x, (bf16_t*)y, n8, scale);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
@@ -851,7 +887,8 @@ __global__ __launch_bounds__(256) void ce_softmax_rows(const float* __restrict__
     loss_row[row] = lse - zp[label];
     amax[row] = bi;
   }
-  // pass 2: gradient row
+  // pass 2: gradient row (skipped when the caller wants the loss and the argmax only: dz == nullptr)
+  if (!dz) return;
   bf16_t* dp = dz + row * lddz;
   for (int c = tid * 8; c < Vpad; c += 2048) {
     float g[8];
@@ -875,7 +912,8 @@ __global__ __launch_bounds__(256) void ce_softmax_rows(const float* __restrict__
 
 int vt_ce_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, long lddz,
                            long rows, int V, int Vpad, float scale, hipStream_t stream) {
-  if (!z || !y || !loss_row || !amax || !dz) return VT_ERR_NULL;
+  if (!z || !y || !loss_row || !amax) return VT_ERR_NULL;
+  if (!dz) { Vpad = (V + 7) / 8 * 8; lddz = Vpad; }   // no gradient row wanted
   if (rows <= 0 || V <= 0 || Vpad < V || (Vpad % 8) || lddz < Vpad) return VT_ERR_BAD_SHAPE;
   if ((ldz % 4) || (lddz % 8) || (((uintptr_t)z | (uintptr_t)dz) & 15)) return VT_ERR_BAD_ALIGN;
   hipLaunchKernelGGL(ce_softmax_rows, dim3((unsigned)rows), dim3(256), 0, stream, z, ldz, y, loss_row, amax, (bf16_t*)dz, lddz,
@@ -961,6 +999,7 @@ __global__ __launch_bounds__(256) void ce_double_softmax_rows(const float* __res
     amax[row] = bi;
   }
   const float dot = t / s2 - py;   // sum_i (softmax(p)_i - onehot_i) p_i
+  if (!dz) return;                 // loss and argmax only
   bf16_t* dp = dz + row * lddz;
   if (c0 < Vpad) {
     float gz[8];
@@ -978,7 +1017,8 @@ __global__ __launch_bounds__(256) void ce_double_softmax_rows(const float* __res
 
 int vt_ce_double_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, long lddz,
                                   long rows, int V, int Vpad, float scale, hipStream_t stream) {
-  if (!z || !y || !loss_row || !amax || !dz) return VT_ERR_NULL;
+  if (!z || !y || !loss_row || !amax) return VT_ERR_NULL;
+  if (!dz) { Vpad = (V + 7) / 8 * 8; lddz = Vpad; }   // no gradient row wanted
   if (rows <= 0 || V <= 0 || Vpad < V || (Vpad % 8) || lddz < Vpad) return VT_ERR_BAD_SHAPE;
   if (Vpad > 2048) return VT_ERR_UNSUPPORTED;   // the row is held in registers: 256 threads x 8 classes
   if ((lddz % 8) || ((uintptr_t)dz & 15)) return VT_ERR_BAD_ALIGN;

@@ -933,9 +933,60 @@ class PreTrainOscar(BertPreTrainedModel):
         C = lin.weight.shape[0]
         buf = torch.empty((seq_bf16.shape[0], round_up(C, 4)), dtype=torch.float32, device=seq_bf16.device)
         ops.linear(seq_bf16, _bf16(lin.weight), _f32(lin.bias), out=buf, out_f32=True)
-        token_prob = torch.softmax(buf[:, :C], dim=-1)
+        token_prob = ops.softmax_rows_f32(buf[:, :C])   # token_head's nn.Softmax (encoder.py:323-326), in place
         action = self.next_action(pooled_f32)
         return scores, token_prob, action
+
+    LOSS_ROWS_PER_CHUNK = 8192   # labelled rows per decoder GEMM + fused CE launch (1 GB of fp32 logits at a time)
+
+    def _mlm_loss_on_labelled_rows(self, seq_bf16, labels):
+        """(mean CE over the positions with a label, their argmax accuracy) of the MLM head -- encoder.py:377, 387-389,
+        402-413 -- from the labelled rows only, chunked: transform GEMM (+GELU), LayerNorm, decoder GEMM, fused
+        log-sum-exp / argmax (vt_ce_softmax_rows without its gradient output).  No labelled row: NaN, as the criterion."""
+        y_all = labels.reshape(-1)
+        idx = torch.nonzero(y_all != -1).flatten()
+        n = int(idx.numel())
+        dev = seq_bf16.device
+        if n == 0:
+            nan = torch.full((), float("nan"), dtype=torch.float32, device=dev)
+            return nan, nan.clone()
+        p = self.mlmhead.predictions
+        V = p.decoder.weight.shape[0]
+        _check_targets(y_all, V)
+        w_tr, w_dec = _bf16(p.transform.dense.weight), _bf16(p.decoder.weight)
+        loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
+        hits = torch.zeros((), dtype=torch.int64, device=dev)
+        for s0 in range(0, n, self.LOSS_ROWS_PER_CHUNK):
+            rows = idx[s0:s0 + self.LOSS_ROWS_PER_CHUNK]
+            y = y_all.index_select(0, rows)
+            t = ops.linear(seq_bf16.index_select(0, rows), w_tr, _f32(p.transform.dense.bias), act=ACT_GELU)
+            t = ops.layernorm(t, _f32(p.transform.LayerNorm.weight), _f32(p.transform.LayerNorm.bias),
+                              p.transform.LayerNorm.variance_epsilon, out=t)
+            z = torch.empty((rows.numel(), round_up(V, 4)), dtype=torch.float32, device=dev)
+            ops.linear(t, w_dec, _f32(p.bias), out=z, out_f32=True)
+            loss_rows, amax = ops.ce_softmax_rows(z, y, V, None, 1.0)
+            loss_sum += loss_rows.sum()
+            hits += (amax == y).sum()
+        return loss_sum / n, hits.float() / n
+
+    def _token_loss_on_labelled_rows(self, seq_bf16, token_labels):
+        """The masked-region-token head (encoder.py:323-326, 380-385, 423-431): Linear + Softmax, then CrossEntropy on
+        the probabilities -- loss and argmax of the labelled rows from vt_ce_double_softmax_rows."""
+        y_all = token_labels.reshape(-1)
+        idx = torch.nonzero(y_all != -1).flatten()
+        n = int(idx.numel())
+        dev = seq_bf16.device
+        if n == 0:
+            nan = torch.full((), float("nan"), dtype=torch.float32, device=dev)
+            return nan, nan.clone()
+        lin = self.token_head[0]
+        C = lin.weight.shape[0]
+        _check_targets(y_all, C)
+        y = y_all.index_select(0, idx)
+        z = torch.empty((n, round_up(C, 4)), dtype=torch.float32, device=dev)
+        ops.linear(seq_bf16.index_select(0, idx), _bf16(lin.weight), _f32(lin.bias), out=z, out_f32=True)
+        loss_rows, amax = ops.ce_double_softmax_rows(z, y, C, None, 1.0)
+        return loss_rows.mean(), (amax == y).sum().float() / n
 
     def _head_outputs_f32(self, seq, pooled):
         """The three heads in fp32 (encoder.py:377-391): seq fp32 [M, H], pooled fp32 [B, H]."""
@@ -975,19 +1026,25 @@ class PreTrainOscar(BertPreTrainedModel):
             return autograd_forward(self, batch)
         outs, pooled, _, B, S = self.bert.run_trunk(
             input_ids, token_type_ids, attention_mask, position_ids, head_mask, img_feats, img_location_embeddings)
-        prediction_scores, token_prob, action_scores = self.head_outputs(outs[-1], pooled)
-        V, C = self.config.vocab_size, self.config.detector_classes
-
-        # losses: encoder.py:379-396 (every criterion ignores label -1; an absent label set contributes the int 0)
         if token_labels is None:
             raise NameError("token_prediction")  # the reference leaves it unbound (encoder.py:400)
-        token_loss = self.criterion(token_prob, token_labels.reshape(-1))
-        mask_loss = self.criterion(prediction_scores, labels.reshape(-1))
+        if _is_fp32(self):
+            # fp32 parity path: every row, exactly the reference's sequence of ops (encoder.py:377-431)
+            prediction_scores, token_prob, action_scores = self.head_outputs(outs[-1], pooled)
+            token_loss = self.criterion(token_prob, token_labels.reshape(-1))
+            mask_loss = self.criterion(prediction_scores, labels.reshape(-1))
+            words_accuracy = _supervised_accuracy(prediction_scores, labels)
+            token_accuracy = _supervised_accuracy(token_prob, token_labels)
+        else:
+            # The 7-tuple reads the 30522-wide MLM logits and the 1601-wide token probabilities only at the positions
+            # that carry a label: every criterion ignores -1 (encoder.py:321) and the accuracies drop those positions
+            # (:402-431).  So the two wide heads run on the labelled rows alone and their logits go straight into the
+            # fused loss + argmax kernels -- [B, S, 30522] fp32 (7 GB at B = 256) is never written.
+            mask_loss, words_accuracy = self._mlm_loss_on_labelled_rows(outs[-1], labels)
+            token_loss, token_accuracy = self._token_loss_on_labelled_rows(outs[-1], token_labels)
+            action_scores = self.next_action(pooled)
         next_loss = self.criterion(action_scores, next_action) if next_action is not None else 0
         loss = mask_loss + next_loss + token_loss
-        # accuracies: encoder.py:398-431
-        words_accuracy = _supervised_accuracy(prediction_scores, labels)
-        token_accuracy = _supervised_accuracy(token_prob, token_labels)
         action_accuracy = 0
         if next_action is not None:   # divides by the whole batch, ignored (-1) actions included (encoder.py:418-421)
             action_accuracy = (action_scores.argmax(1) == next_action).sum().float() / action_scores.shape[0]
@@ -998,6 +1055,12 @@ class PreTrainOscar(BertPreTrainedModel):
 
             loss = lazy_autograd_loss(self, batch, loss)
         return (loss, mask_loss, next_loss, token_loss, words_accuracy, action_accuracy, token_accuracy)
+
+
+def _check_targets(y, n_classes):
+    """CrossEntropyLoss raises on a target outside [0, classes) other than ignore_index; the fused kernels index with it."""
+    if bool(((y >= n_classes) | (y < -1)).any()):
+        raise IndexError("Target out of bounds for a criterion with %d classes (ignore_index = -1)" % n_classes)
 
 
 def _supervised_accuracy(scores, labels):

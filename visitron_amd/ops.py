@@ -435,39 +435,53 @@ def embed_layernorm_bwd(ids, type_ids, pos_ids, word, pos, typ, gamma, eps, g, S
 
 
 def adamw_flat(p, g, m, v, p_bf16, lr, step_size, b1, b2, eps, wd, grad_scale=1.0):
-    """In-place AdamW (pytorch-transformers rule) over flat fp32 slabs; refreshes the bf16 mirror."""
+    """In-place AdamW (pytorch-transformers rule) over flat fp32 slabs; refreshes the bf16 mirror.  g: fp32, or bf16 (the
+    all-reduced communication copy of the gradient slab)."""
     _require_hip(p, g, m, v, p_bf16)
     n = p.numel()
-    with _timed("adamw_flat", 0.0, n * (28.0 + (2.0 if p_bf16 is not None else 0.0))):
-        rc = _lib.load().vt_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), n, float(lr), float(step_size),
-                                       float(b1), float(b2), float(eps), float(wd), float(grad_scale), _stream())
+    g16 = g.dtype == BF16
+    fn = _lib.load().vt_adamw_flat_g16 if g16 else _lib.load().vt_adamw_flat
+    with _timed("adamw_flat", 0.0, n * ((26.0 if g16 else 28.0) + (2.0 if p_bf16 is not None else 0.0))):
+        rc = fn(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), n, float(lr), float(step_size), float(b1), float(b2),
+                float(eps), float(wd), float(grad_scale), _stream())
     _lib.check(rc, "vt_adamw_flat")
+
+
+def cast_to_bf16(src, dst, scale=1.0):
+    """dst (bf16, flat) = src (fp32, flat) * scale; element counts a multiple of 8."""
+    _require_hip(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype == BF16 and src.numel() == dst.numel()
+    rc = _lib.load().vt_cast_f32_to_bf16(_ptr(src), _ptr(dst), src.numel(), float(scale), _stream())
+    _lib.check(rc, "vt_cast_f32_to_bf16")
+    return dst
 
 
 def ce_softmax_rows(z, y, V, dz, scale):
     """Fused CE over logits z fp32 [rows, >=V] with labels y: returns (loss_row fp32 [rows], argmax int64 [rows])
-    and fills dz bf16 [rows, Vpad] with (softmax - onehot) * scale."""
+    and fills dz bf16 [rows, Vpad] with (softmax - onehot) * scale (dz None: loss and argmax only)."""
     _require_hip(z, y, dz)
     rows = z.shape[0]
     loss = torch.empty(rows, dtype=torch.float32, device=z.device)
     amax = torch.empty(rows, dtype=torch.int64, device=z.device)
-    with _timed("ce_softmax_rows", 0.0, rows * (8.0 * V + 2.0 * dz.shape[1])):
-        rc = _lib.load().vt_ce_softmax_rows(_ptr(z), z.stride(0), _ptr(y), _ptr(loss), _ptr(amax), _ptr(dz), dz.stride(0),
-                                            rows, V, dz.shape[1], float(scale), _stream())
+    vpad, lddz = (round_up(V, 8), round_up(V, 8)) if dz is None else (dz.shape[1], dz.stride(0))
+    with _timed("ce_softmax_rows", 0.0, rows * ((8.0 if dz is not None else 4.0) * V + (2.0 * vpad if dz is not None else 0.0))):
+        rc = _lib.load().vt_ce_softmax_rows(_ptr(z), z.stride(0), _ptr(y), _ptr(loss), _ptr(amax), _ptr(dz), lddz,
+                                            rows, V, vpad, float(scale), _stream())
     _lib.check(rc, "vt_ce_softmax_rows")
     return loss, amax
 
 
 def ce_double_softmax_rows(z, y, V, dz, scale):
     """The token head's loss (Linear + Softmax, then CrossEntropy = a second log-softmax): returns (loss_row, argmax)
-    and fills dz bf16 [rows, Vpad] with d(scale * loss_row)/dz."""
+    and fills dz bf16 [rows, Vpad] with d(scale * loss_row)/dz (dz None: loss and argmax only)."""
     _require_hip(z, y, dz)
     rows = z.shape[0]
     loss = torch.empty(rows, dtype=torch.float32, device=z.device)
     amax = torch.empty(rows, dtype=torch.int64, device=z.device)
-    with _timed("ce_softmax_rows", 0.0, rows * (4.0 * V + 2.0 * dz.shape[1])):
+    vpad, lddz = (round_up(V, 8), round_up(V, 8)) if dz is None else (dz.shape[1], dz.stride(0))
+    with _timed("ce_softmax_rows", 0.0, rows * (4.0 * V + (2.0 * vpad if dz is not None else 0.0))):
         rc = _lib.load().vt_ce_double_softmax_rows(_ptr(z), z.stride(0), _ptr(y), _ptr(loss), _ptr(amax), _ptr(dz),
-                                                   dz.stride(0), rows, V, dz.shape[1], float(scale), _stream())
+                                                   lddz, rows, V, vpad, float(scale), _stream())
     _lib.check(rc, "vt_ce_double_softmax_rows")
     return loss, amax
 

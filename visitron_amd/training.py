@@ -142,7 +142,7 @@ class _TrainBuffers(object):
 class PretrainEngine(object):
     def __init__(self, model, lr=5e-5, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999), correct_bias=True,
                  schedule="linear", warmup_steps=0, t_total=20000, process_group=None, bucket_mb=64,
-                 loss_scale_by_world=True, attach_grads=True):
+                 loss_scale_by_world=True, attach_grads=True, grad_comm_dtype=None):
         assert isinstance(model, PreTrainOscar)
         cfg = model.config
         if cfg.hidden_size != 64 * cfg.num_attention_heads:
@@ -162,6 +162,19 @@ class PretrainEngine(object):
             self.world = torch.distributed.get_world_size(process_group)
         self.bucket_elems = int(bucket_mb * 1024 * 1024 // 4)
         self.loss_scale_by_world = loss_scale_by_world
+        # data-parallel gradient exchange: the reference's DDP moves 452 MB of fp32 buckets per step (pretrain.py:96-102);
+        # here each range of the fp32 gradient slab is cast to a bf16 communication copy as soon as its backward kernels
+        # are enqueued, THAT is all-reduced (226 MB: on xGMI a ring is bound per link), and the fused
+        # AdamW reads the reduced bf16 gradients into its fp32 moments.  VT_GRAD_COMM=fp32 / grad_comm_dtype="fp32": the
+        # fp32 slab itself is all-reduced.
+        if grad_comm_dtype is None:
+            grad_comm_dtype = os.environ.get("VT_GRAD_COMM", "bf16")
+        if grad_comm_dtype not in ("bf16", "fp32"):
+            raise ValueError("grad_comm_dtype must be 'bf16' or 'fp32'")
+        self.grad_comm_dtype = grad_comm_dtype
+        self.g16 = None
+        if self.world > 1 and grad_comm_dtype == "bf16":
+            self.g16 = torch.zeros(self.flat.total, dtype=BF16, device=self.flat.p.device)
         self._bufs = {}
         self._tables = None
         # dropout: masks come from a counter-based hash of (seed, site, element); the seed of a
@@ -561,7 +574,9 @@ class PretrainEngine(object):
                                      sub(bufs.acts, _lib.LayerActs), sub(self.g_tab, _lib.LayerGrads), x_in, enc_mask, False,
                                      g, bufs.ws, B, S, H, nh, I, cfg.layer_norm_eps, accumulate=acc, layer0=lo, seq=lay,
                                      **dp_kw, **self._overlap_kw(bufs))
-                rng = [(self.layer_ranges[lo][k][0], self.layer_ranges[hi - 1][k][1]) for k in (0, 1)]
+                # (range ends rounded up to the slab's alignment granule: the padding belongs to no parameter)
+                rng = [(self.layer_ranges[lo][k][0], min(round_up(self.layer_ranges[hi - 1][k][1], ALIGN), f.total))
+                       for k in (0, 1)]
                 comm["launch"](rng)
                 comm["done"].extend(rng)
                 hi = lo
@@ -667,7 +682,7 @@ class PretrainEngine(object):
                        dict(dy=g_pre2_dn, x=a["ctx"], dw=gr["d_w_ao"], db=gr["d_b_ao"], accumulate=acc)], M)
 
     # ------------------------------------------------------------------------------ optimizer
-    def optimizer_step(self, grad_scale=1.0):
+    def optimizer_step(self, grad_scale=1.0, grads=None):
         """AdamW.step() + scheduler.step() (pretrain.py:192-193) as two fused launches (decay / no-decay)."""
         f = self.flat
         self.step_count += 1
@@ -678,11 +693,12 @@ class PretrainEngine(object):
         if self.correct_bias:
             step_size = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
         nd = f.n_decay
+        g = f.g if grads is None else grads   # fp32 slab, or the all-reduced bf16 communication copy
         if nd > 0:
-            ops.adamw_flat(f.p[:nd], f.g[:nd], f.m[:nd], f.v[:nd], f.mirror[:nd], lr, step_size, b1, b2, self.eps, self.wd,
+            ops.adamw_flat(f.p[:nd], g[:nd], f.m[:nd], f.v[:nd], f.mirror[:nd], lr, step_size, b1, b2, self.eps, self.wd,
                            grad_scale)
         if f.total > nd:
-            ops.adamw_flat(f.p[nd:], f.g[nd:], f.m[nd:], f.v[nd:], f.mirror[nd:], lr, step_size, b1, b2, self.eps, 0.0,
+            ops.adamw_flat(f.p[nd:], g[nd:], f.m[nd:], f.v[nd:], f.mirror[nd:], lr, step_size, b1, b2, self.eps, 0.0,
                            grad_scale)
         self.sched_step += 1
         f.mark_fresh()
@@ -697,7 +713,11 @@ class PretrainEngine(object):
             return
         from .distributed import all_reduce_flat
 
-        all_reduce_flat(self.flat.g, self.bucket_elems, self.pg)
+        if self.g16 is not None:
+            ops.cast_to_bf16(self.flat.g, self.g16)
+            all_reduce_flat(self.g16, 2 * self.bucket_elems, self.pg)
+        else:
+            all_reduce_flat(self.flat.g, self.bucket_elems, self.pg)
 
     def train_step(self, batch, overlap=True, layers_per_chunk=3, _force_comm=None):
         """zero_grad -> forward -> backward -> gradient all-reduce -> AdamW -> schedule, as pretrain.py:150-193.
@@ -713,13 +733,24 @@ class PretrainEngine(object):
             from .distributed import all_reduce_ranges, complement_ranges
 
             handles = []
-            launch = _force_comm or (lambda rng: all_reduce_ranges(self.flat.g, rng, self.bucket_elems, self.pg, handles))
+
+            def reduce_ranges(rng):
+                if self.g16 is None:
+                    all_reduce_ranges(self.flat.g, rng, self.bucket_elems, self.pg, handles)
+                    return
+                for s_, e_ in rng:   # bf16 communication copy of the range, then its all-reduce (same byte size per bucket)
+                    if e_ > s_:
+                        ops.cast_to_bf16(self.flat.g[s_:e_], self.g16[s_:e_])
+                all_reduce_ranges(self.g16, rng, 2 * self.bucket_elems, self.pg, handles)
+
+            launch = _force_comm or reduce_ranges
             comm = dict(layers_per_chunk=layers_per_chunk, launch=launch, done=[])
             out = self.forward_backward(batch, grad_scale=scale, comm=comm)
             launch(complement_ranges(self.flat.total, comm["done"]))  # embeddings, region projection, heads
             for h in handles:
                 h.wait()
-        self.optimizer_step(grad_scale=1.0 / ws)  # DDP's mean over ranks
+        use16 = self.g16 is not None and _force_comm is None
+        self.optimizer_step(grad_scale=1.0 / ws, grads=self.g16 if use16 else None)  # DDP's mean over ranks
         return out
 
 
