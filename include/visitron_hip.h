@@ -311,6 +311,27 @@ int vt_embed_layernorm_f32(const int64_t* input_ids, const int64_t* token_type_i
                            float* out, int64_t ld_out, int B, int T, int S, int H, int n_word, int n_pos, int n_type,
                            float eps, int* err_flag, vt_stream_t stream);
 
+/* ---- pretrain input preparation on the device ---------------------------------------------------
+ * PretrainDataset._mask_tokens (tasks/viewpoint_select/data_loader_pretrain.py:549-613) over n = B*T tokens: BERT's
+ * 15 % / 80-10-10 rule with the random draws handed in (u_* uniform [0,1) fp32, random_words int64), forced masking of
+ * the token-class positions (token_classes != -1; NULL when masked_token_prediction is off), special tokens never
+ * masked (special_mask uint8), attention_mask = id != pad_id.  Outputs int64 [n]. */
+int vt_mask_tokens(const int64_t* input_ids, const uint8_t* special_mask, const int64_t* token_classes, const float* u_mask,
+                   const float* u_replace, const float* u_random, const int64_t* random_words, int64_t* out_ids,
+                   int64_t* labels, int64_t* attention_mask, int64_t n, int64_t pad_id, int64_t mask_id,
+                   float mlm_probability, vt_stream_t stream);
+/* The tail of PretrainDataset._preprocess_item (data_loader_pretrain.py:627-633, 654-712) for a batch: items keep their
+ * LAST R region rows of region_counts[b] (<= R_in) or are zero-padded to R with attention mask 0; loc_out rows are
+ * _static_loc_embeddings[current_view[b]][region_view_ids[b, row]] (loc_table fp32 [36, 36, 128], :25-49); labels /
+ * token labels get -1 on every region position; the text parts [B, T] are copied in front.  Outputs: feats_out
+ * [B, R, D], loc_out [B, R, 128] fp32; labels_out / mask_out / token_labels_out int64 [B, T + R] (token labels NULL
+ * together with text_token_classes). */
+int vt_assemble_regions(const float* img_feats, const int64_t* region_counts, const int64_t* region_view_ids,
+                        const int64_t* current_view, const float* loc_table, const int64_t* text_labels,
+                        const int64_t* text_mask, const int64_t* text_token_classes, float* feats_out, float* loc_out,
+                        int64_t* labels_out, int64_t* mask_out, int64_t* token_labels_out, int B, int T, int R, int R_in,
+                        int D, vt_stream_t stream);
+
 /* ---- whole encoder stack: CaptionBertEncoder.forward, oscar/modeling_bert.py:140-169 ---------- */
 typedef struct vt_layer_weights {
   const void* w_qkv;  const float* b_qkv;   /* [3H,H] bf16 = query|key|value weights, [3H] */

@@ -30,6 +30,15 @@ int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, 
 int vt_adamw_dispatch(float* p, const void* g, int g_is_bf16, float* m, float* v, void* p_bf16, long n, float lr,
                       float step_size, float b1, float b2, float eps, float wd, float grad_scale, hipStream_t stream);
 int vt_cast_scale_dispatch(const float* x, void* y, long n, float scale, hipStream_t stream);
+int vt_mask_tokens_dispatch(const int64_t* ids, const uint8_t* special, const int64_t* token_classes, const float* u_mask,
+                            const float* u_replace, const float* u_random, const int64_t* random_words, int64_t* out_ids,
+                            int64_t* labels, int64_t* attention_mask, long n, int64_t pad_id, int64_t mask_id,
+                            float mlm_probability, hipStream_t stream);
+int vt_assemble_regions_dispatch(const float* img_feats, const int64_t* region_counts, const int64_t* region_view_ids,
+                                 const int64_t* current_view, const float* loc_table, const int64_t* text_labels,
+                                 const int64_t* text_mask, const int64_t* text_token_classes, float* feats_out, float* loc_out,
+                                 int64_t* labels_out, int64_t* mask_out, int64_t* token_labels_out, int B, int T, int R,
+                                 int R_in, int D, hipStream_t stream);
 int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale,
                                 const float* lse, float* probs, int B, int S, int nh, int head_size, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
@@ -175,6 +184,24 @@ int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, in
 int vt_adamw_flat_g16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16, int64_t n, float lr, float step_size,
                       float b1, float b2, float eps, float wd, float grad_scale, vt_stream_t stream) {
   return vt_adamw_dispatch(p, g_bf16, 1, m, v, p_bf16, n, lr, step_size, b1, b2, eps, wd, grad_scale, (hipStream_t)stream);
+}
+
+int vt_mask_tokens(const int64_t* input_ids, const uint8_t* special_mask, const int64_t* token_classes, const float* u_mask,
+                   const float* u_replace, const float* u_random, const int64_t* random_words, int64_t* out_ids,
+                   int64_t* labels, int64_t* attention_mask, int64_t n, int64_t pad_id, int64_t mask_id,
+                   float mlm_probability, vt_stream_t stream) {
+  return vt_mask_tokens_dispatch(input_ids, special_mask, token_classes, u_mask, u_replace, u_random, random_words, out_ids,
+                                 labels, attention_mask, n, pad_id, mask_id, mlm_probability, (hipStream_t)stream);
+}
+
+int vt_assemble_regions(const float* img_feats, const int64_t* region_counts, const int64_t* region_view_ids,
+                        const int64_t* current_view, const float* loc_table, const int64_t* text_labels,
+                        const int64_t* text_mask, const int64_t* text_token_classes, float* feats_out, float* loc_out,
+                        int64_t* labels_out, int64_t* mask_out, int64_t* token_labels_out, int B, int T, int R, int R_in,
+                        int D, vt_stream_t stream) {
+  return vt_assemble_regions_dispatch(img_feats, region_counts, region_view_ids, current_view, loc_table, text_labels,
+                                      text_mask, text_token_classes, feats_out, loc_out, labels_out, mask_out,
+                                      token_labels_out, B, T, R, R_in, D, (hipStream_t)stream);
 }
 
 int vt_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, float scale, vt_stream_t stream) {

@@ -6,7 +6,12 @@ region padding / truncation and the label / attention-mask assembly.
 
 Random draws are taken from a torch.Generator (or passed in, which is how the tests pin this against
 oracle/data.py): the reference's stream of torch.bernoulli / torch.randint calls per item is not reproduced, the
-distribution is."""
+distribution is.
+
+HIP tensors go through the library's two kernels (csrc/datapipe.hip: vt_mask_tokens, vt_assemble_regions -- the whole
+batch in two launches, outputs bit-exact against oracle/data.py); host tensors (dataset workers, the CPU tests) take
+the same steps as torch tensor ops."""
+import ctypes
 import math
 
 import torch
@@ -53,6 +58,9 @@ def mask_tokens(inputs, special_mask, pad_id, mask_id, vocab_size, mlm_probabili
         random_words = torch.randint(vocab_size, inputs.shape, generator=generator, device=dev, dtype=torch.long)
     else:
         u_mask, u_replace, u_random, random_words = draws
+    if inputs.is_cuda:
+        return _mask_tokens_hip(inputs, special_mask, pad_id, mask_id, mlm_probability, token_classes, u_mask, u_replace,
+                                u_random, random_words)
     labels = inputs.clone()
     prob = torch.full(inputs.shape, float(mlm_probability), device=dev).masked_fill(special_mask, 0.0)
     masked = u_mask < prob                                    # torch.bernoulli(probability_matrix)
@@ -74,6 +82,56 @@ def mask_tokens(inputs, special_mask, pad_id, mask_id, vocab_size, mlm_probabili
     return out, labels, attention_mask
 
 
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _i64c(t):
+    return t if (t.dtype == torch.int64 and t.is_contiguous()) else t.to(torch.int64).contiguous()
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+
+def _mask_tokens_hip(inputs, special_mask, pad_id, mask_id, mlm_probability, token_classes, u_mask, u_replace, u_random,
+                     random_words):
+    from . import _lib
+
+    ids = _i64c(inputs)
+    sp = special_mask.to(torch.bool).contiguous().view(torch.uint8)
+    tc = None if token_classes is None else _i64c(token_classes)
+    out, labels, att = torch.empty_like(ids), torch.empty_like(ids), torch.empty_like(ids)
+    rc = _lib.load().vt_mask_tokens(_p(ids), _p(sp), _p(tc), _p(_f32c(u_mask)), _p(_f32c(u_replace)), _p(_f32c(u_random)),
+                                    _p(_i64c(random_words)), _p(out), _p(labels), _p(att), ids.numel(), int(pad_id),
+                                    int(mask_id), float(mlm_probability),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "vt_mask_tokens")
+    return out, labels, att.to(torch.bool)
+
+
+def _assemble_batch_hip(input_ids, labels, text_attention_mask, img_feats, region_counts, region_view_ids,
+                        current_view_index, next_action, R, token_classes, no_action_grounding):
+    from . import _lib
+
+    B, R_in, D = img_feats.shape
+    T = input_ids.shape[1]
+    dev = img_feats.device
+    feats = torch.empty((B, R, D), dtype=torch.float32, device=dev)
+    loc = torch.empty((B, R, 128), dtype=torch.float32, device=dev)
+    lab = torch.empty((B, T + R), dtype=torch.int64, device=dev)
+    att = torch.empty((B, T + R), dtype=torch.int64, device=dev)
+    tok = None if token_classes is None else torch.empty((B, T + R), dtype=torch.int64, device=dev)
+    tc = None if token_classes is None else _i64c(token_classes)
+    rc = _lib.load().vt_assemble_regions(
+        _p(_f32c(img_feats)), _p(_i64c(region_counts)), _p(_i64c(region_view_ids)), _p(_i64c(current_view_index)),
+        _p(loc_embedding_table(dev)), _p(_i64c(labels)), _p(_i64c(text_attention_mask)), _p(tc), _p(feats), _p(loc), _p(lab),
+        _p(att), _p(tok), B, T, R, R_in, D, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "vt_assemble_regions")
+    return dict(input_ids=input_ids, labels=lab, attention_mask=att, img_feats=feats, img_location_embeddings=loc,
+                next_action=torch.full_like(next_action, -1) if no_action_grounding else next_action, token_labels=tok)
+
+
 def assemble_batch(input_ids, labels, text_attention_mask, img_feats, region_counts, region_view_ids, current_view_index,
                    next_action, max_img_seq_length, token_classes=None, no_action_grounding=False):
     """The tail of PretrainDataset._preprocess_item (data_loader_pretrain.py:654-712) for a batch whose region rows are
@@ -84,6 +142,9 @@ def assemble_batch(input_ids, labels, text_attention_mask, img_feats, region_cou
     B, R_in, D = img_feats.shape
     R = int(max_img_seq_length)
     dev = img_feats.device
+    if img_feats.is_cuda:
+        return _assemble_batch_hip(input_ids, labels, text_attention_mask, img_feats, region_counts, region_view_ids,
+                                   current_view_index, next_action, R, token_classes, no_action_grounding)
     loc = region_location_embeddings(current_view_index, region_view_ids)
     n = region_counts.clamp(max=R_in)
     start = (n - R).clamp(min=0)                                # first kept row of every item
