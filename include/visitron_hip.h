@@ -178,6 +178,10 @@ int vt_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, in
  * the bytes of the reference's fp32 DDP buckets, pretrain.py:96-102,191, over xGMI); moments and master weights stay fp32. */
 int vt_adamw_flat_g16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16, int64_t n, float lr, float step_size,
                       float b1, float b2, float eps, float wd, float grad_scale, vt_stream_t stream);
+/* out[r, 64 h + d] = x[r, 64 h + d] * head_scale[h] (bf16 rows of nh * 64 columns): the reference's head_mask
+ * (oscar/modeling_bert.py:65-66) on a context tensor or, on the way back, on its gradient (training path). */
+int vt_scale_heads_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int nh, const float* head_scale,
+                        vt_stream_t stream);
 /* dst_bf16[i] = bf16(src[i] * scale), n % 8 == 0: the communication copy of a gradient-slab range. */
 int vt_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, float scale, vt_stream_t stream);
 

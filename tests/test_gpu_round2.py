@@ -407,3 +407,56 @@ def test_eval_tuple_from_labelled_rows_in_chunks(dev):
     c["labels"][0, 3] = cfg.vocab_size
     with torch.no_grad(), pytest.raises(IndexError):
         prod(**_to(c, dev))
+
+
+# ------------------------------------------------------------------------------------------------
+# training with head_mask and with 3-D (per-query) attention masks (oscar/modeling_bert.py:65-66; encoder.py:226-229,
+# 248-265): losses and every gradient against the oracle's autograd
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("what", ["head_mask", "mask3d", "both_with_dropout"])
+def test_training_with_head_mask_and_per_query_masks(dev, what):
+    from helpers import inject_dropout_masks
+    from oracle.modeling import PreTrainOscar as OModel
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import make_batch
+    from visitron_amd.training import PretrainEngine
+
+    p = 0.1 if what == "both_with_dropout" else 0.0
+    cfg = mini_config(num_hidden_layers=3, hidden_dropout_prob=p, attention_probs_dropout_prob=p)
+    ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=23, device=dev)
+    prod.train()
+    eng = PretrainEngine(prod)
+    eng.compact_min_rows = 0
+    B, T, R = 3, 22, 9
+    S = T + R
+    b = make_batch(cfg, B, text_len=T, region_len=R, seed=15)
+    g = torch.Generator().manual_seed(5)
+    hm = None
+    if what != "mask3d":
+        hm = torch.tensor([[1.0, 0.5], [0.0, 1.0], [1.5, 0.25]])           # [layers, heads]
+    if what != "head_mask":
+        m3 = (torch.rand(B, S, S, generator=g) > 0.25).float() * b["attention_mask"][:, None, :].float()
+        m3[:, :, 0] = 1.0
+        b["attention_mask"] = m3
+    got = eng.forward_backward(_to(b, dev), head_mask=None if hm is None else hm.to(dev))
+    torch.cuda.synchronize()
+    assert eng.last_layout is None                                        # these forms keep the padded rows
+    ref.train()
+    if p > 0:
+        inject_dropout_masks(ref, p, p, eng.last_drop_seed, B, T, R, device=dev)
+    want = ref(**b, head_mask=hm)
+    want[0].backward()
+    for i in range(4):
+        check_close("train %s tuple[%d]" % (what, i), float(got[i]), float(want[i]), 5e-2)
+    wg = dict(ref.named_parameters())
+    errs = {n: _rel(p_.grad, wg[n].grad) for n, p_ in prod.named_parameters()}
+    worst = max(errs, key=errs.get)
+    check_close("train %s grads worst rel-L2 (%s)" % (what, worst), errs[worst], 0.0, 0.08)
+    # ... and through the module's own forward (the autograd bridge)
+    if what == "head_mask":
+        prod.zero_grad()
+        out = prod(**_to(b, dev), head_mask=hm.to(dev))
+        out[0].backward()
+        errs = {n: _rel(p_.grad, wg[n].grad) for n, p_ in prod.named_parameters()}
+        assert max(errs.values()) < 0.08, max(errs, key=errs.get)

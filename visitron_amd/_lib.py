@@ -76,6 +76,7 @@ SIGNATURES = {
     "vt_adamw_flat_g16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                   c_float, c_float, c_float, c_float, c_void_p]),
     "vt_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "vt_scale_heads_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "vt_mask_tokens": (c_int, [c_void_p] * 10 + [c_int64, c_int64, c_int64, c_float, c_void_p]),
     "vt_assemble_regions": (c_int, [c_void_p] * 13 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_ce_softmax_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,

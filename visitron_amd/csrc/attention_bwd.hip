@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   // ---- this wave's K and V fragments (B operands; lane = key) and its key biases ----
   bf16x8 kf[2][4], vf[2][4];
   float kbias[2];
+  const float* mq3[2];
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
     const int key = kb0 + 64 * wave + 32 * kt + r;
@@ -172,12 +173,15 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
     float add = -INFINITY;
     if (key < S) {
       add = 0.f;
-      if (a.mask) {
+      if (a.mask && a.mask_additive != 2) {
         const float mval = a.mask[(long)b * Smax + key];
         add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
       }
     }
     kbias[kt] = add;
+    // mask_additive == 2: an additive bias per (query, key) [B, S, S] (the reference's 3-D attention masks,
+    // encoder.py:228-229): this lane's key column; the query row is added per element below
+    mq3[kt] = (a.mask && a.mask_additive == 2) ? a.mask + (long)b * Smax * Smax + kr : nullptr;
   }
 
   f32x16 dv[2][2], dk[2][2];  // [d-tile][key-tile]: lane = key, reg <-> d = 32dt + 16h2 + reg
@@ -279,7 +283,11 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g4 + e;
-          const float s = fmaf(sacc[i], a.scale, kbias[kt]);
+          float s = fmaf(sacc[i], a.scale, kbias[kt]);
+          if (mq3[kt]) {   // per-query bias row of element i's query (clamped: rows past S carry dO = 0)
+            const int qi = sl * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+            s += mq3[kt][(long)(qi < S ? qi : S - 1) * Smax];
+          }
           const float p = __builtin_amdgcn_exp2f((s - lse4[g4][e]) * LOG2E);
           float dpv = dpacc[i], pv = p;
           if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
@@ -468,6 +476,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   // ---- this wave's K and V fragments (B operands; lane = key) and its key biases ----
   bf16x8 kf[1][4], vf[1][4];
   float kbias[1];
+  const float* mq3[1];
 #pragma unroll
   for (int kt = 0; kt < 1; ++kt) {
     const int key = kb0 + 32 * wave + r;
@@ -482,12 +491,15 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
     float add = -INFINITY;
     if (key < S) {
       add = 0.f;
-      if (a.mask) {
+      if (a.mask && a.mask_additive != 2) {
         const float mval = a.mask[(long)b * Smax + key];
         add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
       }
     }
     kbias[kt] = add;
+    // mask_additive == 2: an additive bias per (query, key) [B, S, S] (the reference's 3-D attention masks,
+    // encoder.py:228-229): this lane's key column; the query row is added per element below
+    mq3[kt] = (a.mask && a.mask_additive == 2) ? a.mask + (long)b * Smax * Smax + kr : nullptr;
   }
 
   f32x16 dv[2][1], dk[2][1];  // [d-tile][key-tile]: lane = key, reg <-> d = 32dt + 16h2 + reg
@@ -586,7 +598,11 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g4 + e;
-          const float s = fmaf(sacc[i], a.scale, kbias[kt]);
+          float s = fmaf(sacc[i], a.scale, kbias[kt]);
+          if (mq3[kt]) {   // per-query bias row of element i's query (clamped: rows past S carry dO = 0)
+            const int qi = sl * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+            s += mq3[kt][(long)(qi < S ? qi : S - 1) * Smax];
+          }
           const float p = __builtin_amdgcn_exp2f((s - lse4_g[e]) * LOG2E);
           float dpv = dpacc[i], pv = p;
           if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
@@ -756,7 +772,7 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
                               long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream,
                               const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr,
                               long rows_total = 0) {
-  if (mask_additive == 2) return VT_ERR_UNSUPPORTED;   // per-query masks: forward / probabilities only
+  if (mask_additive == 2 && (!mask || seq_start)) return VT_ERR_NULL;   // per-query bias [B, S, S]
   if (!qkv || !dctx || !ctx || !lse || !delta_ws || !dqkv) return VT_ERR_NULL;
   if (head_size != 64) return VT_ERR_UNSUPPORTED;
   const int nkb = (S + 255) / 256;

@@ -30,6 +30,7 @@ int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, 
 int vt_adamw_dispatch(float* p, const void* g, int g_is_bf16, float* m, float* v, void* p_bf16, long n, float lr,
                       float step_size, float b1, float b2, float eps, float wd, float grad_scale, hipStream_t stream);
 int vt_cast_scale_dispatch(const float* x, void* y, long n, float scale, hipStream_t stream);
+int vt_scale_heads_dispatch(const void* x, long ldx, void* out, long ldo, long rows, int nh, const float* scale, hipStream_t stream);
 int vt_mask_tokens_dispatch(const int64_t* ids, const uint8_t* special, const int64_t* token_classes, const float* u_mask,
                             const float* u_replace, const float* u_random, const int64_t* random_words, int64_t* out_ids,
                             int64_t* labels, int64_t* attention_mask, long n, int64_t pad_id, int64_t mask_id,
@@ -202,6 +203,11 @@ int vt_assemble_regions(const float* img_feats, const int64_t* region_counts, co
   return vt_assemble_regions_dispatch(img_feats, region_counts, region_view_ids, current_view, loc_table, text_labels,
                                       text_mask, text_token_classes, feats_out, loc_out, labels_out, mask_out,
                                       token_labels_out, B, T, R, R_in, D, (hipStream_t)stream);
+}
+
+int vt_scale_heads_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int nh, const float* head_scale,
+                        vt_stream_t stream) {
+  return vt_scale_heads_dispatch(x, ldx, out, ldo, rows, nh, head_scale, (hipStream_t)stream);
 }
 
 int vt_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, float scale, vt_stream_t stream) {

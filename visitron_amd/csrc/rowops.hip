@@ -697,6 +697,34 @@ int vt_adamw_dispatch(float* p, const void* g, int g_is_bf16, float* m, float* v
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
+// out[r, 64 h + d] = x[r, 64 h + d] * scale[h]: head_mask applied to a context tensor (oscar/modeling_bert.py:65-66 scales
+// the probabilities of head h, i.e. that head's 64 context columns) -- the training path's forward copy and its
+// gradient's way back.  One thread = 8 columns.
+__global__ __launch_bounds__(256) void scale_heads_bf16(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ out, long ldo,
+                                                        long rows, int nh, const float* __restrict__ scale) {
+  const int cpr = nh * 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cpr) return;
+  const long row = i / cpr;
+  const int c = (int)(i - row * cpr);
+  const float sc = scale[c >> 3];
+  const u32x4 v = *(const u32x4*)(x + row * ldx + c * 8);
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(bf16lo(v[k]) * sc, bf16hi(v[k]) * sc);
+  *(u32x4*)(out + row * ldo + c * 8) = o;
+}
+
+int vt_scale_heads_dispatch(const void* x, long ldx, void* out, long ldo, long rows, int nh, const float* scale, hipStream_t stream) {
+  if (!x || !out || !scale) return VT_ERR_NULL;
+  if (rows <= 0 || nh <= 0) return VT_ERR_BAD_SHAPE;
+  if ((ldx % 8) || (ldo % 8) || (((uintptr_t)x | (uintptr_t)out) & 15)) return VT_ERR_BAD_ALIGN;
+  const long n = rows * nh * 8;
+  hipLaunchKernelGGL(scale_heads_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx,
+                     (bf16_t*)out, ldo, rows, nh, scale);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
 // y = bf16(x * scale), flat: the communication copy of a gradient-slab range (half the all-reduce bytes)
 __global__ __launch_bounds__(256) void cast_scale_f32_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, long n8, float scale) {
   const long stride = (long)gridDim.x * 256;

@@ -1017,13 +1017,11 @@ class PreTrainOscar(BertPreTrainedModel):
         if wants_grad and self.training:
             # training: HIP forward + backward, bridged to autograd so that `loss.backward()` and any torch
             # optimizer / DistributedDataParallel wrapper work as in the reference's loop
-            if head_mask is not None:
-                raise NotImplementedError("head_mask is not supported by the HIP training path")
             if token_labels is None:
                 raise NameError("token_prediction")  # the reference leaves it unbound (encoder.py:400)
             from .training import autograd_forward
 
-            return autograd_forward(self, batch)
+            return autograd_forward(self, batch, head_mask=head_mask)
         outs, pooled, _, B, S = self.bert.run_trunk(
             input_ids, token_type_ids, attention_mask, position_ids, head_mask, img_feats, img_location_embeddings)
         if token_labels is None:
@@ -1048,12 +1046,12 @@ class PreTrainOscar(BertPreTrainedModel):
         action_accuracy = 0
         if next_action is not None:   # divides by the whole batch, ignored (-1) actions included (encoder.py:418-421)
             action_accuracy = (action_scores.argmax(1) == next_action).sum().float() / action_scores.shape[0]
-        if wants_grad and head_mask is None:
+        if wants_grad:
             # eval mode with grad enabled (the reference's val() never wraps its loop in no_grad): the values above stand;
             # the backward pass is prepared only if someone calls it
             from .training import lazy_autograd_loss
 
-            loss = lazy_autograd_loss(self, batch, loss)
+            loss = lazy_autograd_loss(self, batch, loss, head_mask=head_mask)
         return (loss, mask_loss, next_loss, token_loss, words_accuracy, action_accuracy, token_accuracy)
 
 

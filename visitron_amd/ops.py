@@ -390,7 +390,7 @@ def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False,
     with _timed("attention_bwd_d64", 10.0 * B * nh * S * S * 64, 2.0 * B * S * 9 * H):
         rc = _lib.load().vt_attention_bwd_bf16(
             _ptr(qkv), qkv.stride(0), _ptr(dctx), dctx.stride(0), _ptr(ctx), ctx.stride(0), _ptr(mask),
-            1 if mask_additive else 0, _ptr(lse), _ptr(delta_ws), _ptr(out), out.stride(0), _ptr(dq32_ws), B, S, nh, 64,
+            _mask_mode(mask, mask_additive, B, S), _ptr(lse), _ptr(delta_ws), _ptr(out), out.stride(0), _ptr(dq32_ws), B, S, nh, 64,
             float(drop[0]), int(drop[1]), int(drop[2]), _stream())
     _lib.check(rc, "vt_attention_bwd_bf16")
     return out
@@ -445,6 +445,20 @@ def adamw_flat(p, g, m, v, p_bf16, lr, step_size, b1, b2, eps, wd, grad_scale=1.
         rc = fn(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), n, float(lr), float(step_size), float(b1), float(b2),
                 float(eps), float(wd), float(grad_scale), _stream())
     _lib.check(rc, "vt_adamw_flat")
+
+
+def scale_heads(x, head_scale, out=None):
+    """out[r, 64 h + d] = x[r, 64 h + d] * head_scale[h] (bf16 [rows, nh * 64]; head_scale fp32 [nh])."""
+    _require_hip(x, head_scale, out)
+    assert x.dtype == BF16 and x.stride(1) == 1 and head_scale.dtype == torch.float32 and head_scale.is_contiguous()
+    nh = head_scale.numel()
+    assert x.shape[1] == nh * 64
+    if out is None:
+        out = torch.empty_like(x)
+    rc = _lib.load().vt_scale_heads_bf16(_ptr(x), x.stride(0), _ptr(out), out.stride(0), x.shape[0], nh, _ptr(head_scale),
+                                         _stream())
+    _lib.check(rc, "vt_scale_heads_bf16")
+    return out
 
 
 def cast_to_bf16(src, dst, scale=1.0):
@@ -573,14 +587,14 @@ def encoder_backward(layer_weights, layer_weights_t, layer_acts, layer_grads, x,
     if ws_b is not None and side_stream is not None:
         rc = _lib.load().vt_encoder_backward_overlap_bf16(
             layer_weights, layer_weights_t, layer_acts, layer_grads, len(layer_weights), _ptr(x), _ptr(mask),
-            1 if mask_additive else 0, _ptr(g), ctypes.byref(ws), ctypes.byref(ws_b), B, S, H, nh, I, float(eps),
+            _mask_mode(mask, mask_additive, B, S), _ptr(g), ctypes.byref(ws), ctypes.byref(ws_b), B, S, H, nh, I, float(eps),
             1 if accumulate else 0, float(p_hidden), float(p_attn), int(drop_seed), int(layer0), _stream(),
             ctypes.c_void_p(side_stream.cuda_stream))
         _lib.check(rc, "vt_encoder_backward_overlap_bf16")
         return
     rc = _lib.load().vt_encoder_backward_bf16(
         layer_weights, layer_weights_t, layer_acts, layer_grads, len(layer_weights), _ptr(x), _ptr(mask),
-        1 if mask_additive else 0, _ptr(g), ctypes.byref(ws), B, S, H, nh, I, float(eps), 1 if accumulate else 0,
+        _mask_mode(mask, mask_additive, B, S), _ptr(g), ctypes.byref(ws), B, S, H, nh, I, float(eps), 1 if accumulate else 0,
         float(p_hidden), float(p_attn), int(drop_seed), int(layer0), _stream())
     _lib.check(rc, "vt_encoder_backward_bf16")
 

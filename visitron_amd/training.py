@@ -115,6 +115,8 @@ class _TrainBuffers(object):
             self.layers.append(d)
             for k, v in d.items():
                 setattr(self.acts[i], k, v.data_ptr())
+        self._mk, self._ctx_raw = mk, {}
+        self._H = H
         self.x0 = mk(H)
         self.x0c = mk(H)      # compacted copy of x0 (real rows only), the encoder's input in the compact path
         self.g = mk(H)
@@ -137,6 +139,16 @@ class _TrainBuffers(object):
         self.ws_b = _lib.BwdWorkspace()
         for k, v in self.ws_t_b.items():
             setattr(self.ws_b, k, v.data_ptr())
+
+
+def _ctx_raw(self, layer):
+    """Per-layer buffer for the attention kernel's unscaled context (head_mask in training), allocated on first use."""
+    if layer not in self._ctx_raw:
+        self._ctx_raw[layer] = self._mk(self._H)
+    return self._ctx_raw[layer]
+
+
+_TrainBuffers.ctx_raw = _ctx_raw
 
 
 class PretrainEngine(object):
@@ -326,9 +338,12 @@ class PretrainEngine(object):
         return max(0.0, float(self.t_total - s) / float(max(1.0, self.t_total - self.warmup_steps)))
 
     # ------------------------------------------------------------------------------ forward + backward
-    def forward_backward(self, batch, grad_scale=1.0, accumulate=False, comm=None):
+    def forward_backward(self, batch, grad_scale=1.0, accumulate=False, comm=None, head_mask=None):
         """One forward + backward; gradients of `grad_scale * loss` land in the flat slab (p.grad).
-        Returns the reference's 7-tuple (0-d fp32 tensors)."""
+        Returns the reference's 7-tuple (0-d fp32 tensors).  attention_mask: [B, S] (any numeric values, the reference's
+        (1 - m) * -10000 arithmetic) or the reference's 3-D form [B, S, S] (encoder.py:228-229); head_mask as the
+        reference takes it (encoder.py:248-265; the layer loop then runs op by op: the head scaling sits between the
+        attention kernel and the output projection in both directions)."""
         m, cfg, f = self.model, self.cfg, self.flat
         self.refresh_derived_weights()
         f.reattach_grads()
@@ -342,8 +357,18 @@ class PretrainEngine(object):
         labels, token_labels, next_action = batch["labels"], batch["token_labels"], batch.get("next_action")
         am = batch.get("attention_mask")
         mask = None if am is None else am.to(torch.float32).contiguous()
-        if mask is not None and mask.shape != (B, S):
+        mask_additive = False
+        if mask is not None and mask.dim() == 3:   # per-query mask -> additive bias [B, S, S] (encoder.py:228-229, :238-241)
+            if mask.shape != (B, S, S):
+                raise RuntimeError("3-D attention_mask must be [batch, text+region, text+region]")
+            mask = ((1.0 - mask) * -10000.0).contiguous()
+            mask_additive = True
+        elif mask is not None and mask.shape != (B, S):
             raise RuntimeError("attention_mask must be [batch, text+region]")
+        from .modeling import _head_scale
+        hs = _head_scale(head_mask, cfg.num_hidden_layers, cfg.num_attention_heads, ids.device)
+        if hs is not None and comm is not None:
+            raise NotImplementedError("head_mask together with the chunked data-parallel backward")
         tt, pos_ids = _i64(batch.get("token_type_ids")), _i64(batch.get("position_ids"))
         bufs = self._buffers(B, S)
         emb = m.bert.embeddings
@@ -382,7 +407,7 @@ class PretrainEngine(object):
         # hidden states reach no loss and their gradient is exactly 0 -- drop them from every row-wise kernel.  Needs a
         # 0/1 mask, the [CLS] position and every supervised position kept; otherwise the padded path below.
         lay = None
-        if self.compact_rows and mask is not None and M >= self.compact_min_rows:
+        if self.compact_rows and mask is not None and mask.dim() == 2 and hs is None and M >= self.compact_min_rows:
             keep = mask != 0
             cand = ops.SeqLayout(keep)
             bad = ((mask != 0) & (mask != 1)).any() | (~keep[:, 0]).any()
@@ -429,11 +454,11 @@ class PretrainEngine(object):
         if lay is not None:
             x_enc, enc_mask = bufs.x0c[:Mr], None
             torch.index_select(x0, 0, lay.index, out=x_enc)
-        if ops.profiling():
-            self._encoder_forward_unrolled(bufs, x_enc, enc_mask, B, S, p_h, p_a, seed, lay)
+        if ops.profiling() or hs is not None:
+            self._encoder_forward_unrolled(bufs, x_enc, enc_mask, B, S, p_h, p_a, seed, lay, mask_additive, hs)
         else:
-            ops.encoder_forward(self.w_tab, bufs.acts, x_enc, enc_mask, False, None, B, S, H, nh, I, cfg.layer_norm_eps,
-                                seq=lay, **dp_kw)
+            ops.encoder_forward(self.w_tab, bufs.acts, x_enc, enc_mask, mask_additive, None, B, S, H, nh, I,
+                                cfg.layer_norm_eps, seq=lay, **dp_kw)
         seq = bufs.layers[-1]["out"][:Mr]
         if lay is None:
             cls_seq = None
@@ -554,10 +579,10 @@ class PretrainEngine(object):
                 self._grad(prm).zero_()
         g = bufs.g[:Mr]
         g.copy_(g32)
-        if ops.profiling():
-            self._encoder_backward_unrolled(bufs, x_enc, enc_mask, g, B, S, acc, p_h, p_a, seed, lay)
+        if ops.profiling() or hs is not None:
+            self._encoder_backward_unrolled(bufs, x_enc, enc_mask, g, B, S, acc, p_h, p_a, seed, lay, mask_additive, hs)
         elif comm is None:
-            ops.encoder_backward(self.w_tab, self.wt_tab, bufs.acts, self.g_tab, x_enc, enc_mask, False, g, bufs.ws, B, S,
+            ops.encoder_backward(self.w_tab, self.wt_tab, bufs.acts, self.g_tab, x_enc, enc_mask, mask_additive, g, bufs.ws, B, S,
                                  H, nh, I, cfg.layer_norm_eps, accumulate=acc, seq=lay, **dp_kw, **self._overlap_kw(bufs))
         else:
             # data-parallel: backward in layer chunks (last layers first); as soon as a chunk's kernels are
@@ -571,7 +596,7 @@ class PretrainEngine(object):
                 sub = lambda arr, typ: (typ * n).from_address(ctypes.addressof(arr) + lo * ctypes.sizeof(typ))
                 x_in = x_enc if lo == 0 else bufs.layers[lo - 1]["out"]
                 ops.encoder_backward(sub(self.w_tab, _lib.LayerWeights), sub(self.wt_tab, _lib.LayerWeightsT),
-                                     sub(bufs.acts, _lib.LayerActs), sub(self.g_tab, _lib.LayerGrads), x_in, enc_mask, False,
+                                     sub(bufs.acts, _lib.LayerActs), sub(self.g_tab, _lib.LayerGrads), x_in, enc_mask, mask_additive,
                                      g, bufs.ws, B, S, H, nh, I, cfg.layer_norm_eps, accumulate=acc, layer0=lo, seq=lay,
                                      **dp_kw, **self._overlap_kw(bufs))
                 # (range ends rounded up to the slab's alignment granule: the padding belongs to no parameter)
@@ -627,7 +652,8 @@ class PretrainEngine(object):
         return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
 
     # ---- the launch sequences of vt_encoder_forward/backward_bf16 issued op by op (bench.py's per-kernel timing)
-    def _encoder_forward_unrolled(self, bufs, x0, mask, B, S, p_h=0.0, p_a=0.0, seed=0, lay=None):
+    def _encoder_forward_unrolled(self, bufs, x0, mask, B, S, p_h=0.0, p_a=0.0, seed=0, lay=None, mask_additive=False,
+                                  hs=None):
         cfg = self.cfg
         nh, eps = cfg.num_attention_heads, cfg.layer_norm_eps
         cur = x0
@@ -635,8 +661,16 @@ class PretrainEngine(object):
         for l, ((t, _), a) in enumerate(zip(self._keep, bufs.layers)):
             a = {k: (v if k == "lse" else v[:n]) for k, v in a.items()}   # the rows in use (all, or the compacted ones)
             ops.linear(cur, t["w_qkv"], t["b_qkv"], out=a["qkv"])
-            ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, out=a["ctx"], lse=a["lse"], drop=(p_a, seed, ops.site_attn(l)),
-                              seq=lay)
+            if hs is None:
+                ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, mask_additive=mask_additive, out=a["ctx"], lse=a["lse"],
+                                  drop=(p_a, seed, ops.site_attn(l)), seq=lay)
+            else:
+                # head_mask (oscar/modeling_bert.py:65-66): the attention kernel's own context is kept for the backward
+                # (ctx_raw), its per-head scaled copy is what the output projection sees
+                raw = bufs.ctx_raw(l)[:n]
+                ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, mask_additive=mask_additive, out=raw, lse=a["lse"],
+                                  drop=(p_a, seed, ops.site_attn(l)), seq=lay)
+                ops.scale_heads(raw, hs[l].contiguous(), out=a["ctx"])
             ops.linear(a["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=a["attn_pre"], drop=(p_h, seed, ops.site_selfout(l)))
             ops.layernorm(a["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=a["attn_out"])
             ops.linear(a["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=a["mid"], pre_act_out=a["mid_pre"])
@@ -653,7 +687,8 @@ class PretrainEngine(object):
             self._side_stream = torch.cuda.Stream(device=self.flat.p.device)
         return dict(ws_b=bufs.ws_b, side_stream=self._side_stream)
 
-    def _encoder_backward_unrolled(self, bufs, x0, mask, g, B, S, acc, p_h=0.0, p_a=0.0, seed=0, lay=None):
+    def _encoder_backward_unrolled(self, bufs, x0, mask, g, B, S, acc, p_h=0.0, p_a=0.0, seed=0, lay=None,
+                                   mask_additive=False, hs=None):
         cfg = self.cfg
         nh, eps, M = cfg.num_attention_heads, cfg.layer_norm_eps, x0.shape[0]
         rowed = ("g_pre", "g_pre2", "g_mid", "g_ctx", "g_qkv", "g_pre_d", "g_pre2_d", "dq32")
@@ -673,8 +708,13 @@ class PretrainEngine(object):
                               ws=w["ln_partial"], accumulate=acc, dx_dropped=w["g_pre2_d"] if hd else None,
                               drop=(p_h, seed, ops.site_selfout(l)))
             ops.linear(g_pre2_dn, wt["wt_ao"], out=w["g_ctx"])
-            ops.attention_bwd(a["qkv"], w["g_ctx"], a["ctx"], a["lse"], B, S, nh, mask=mask, out=w["g_qkv"],
-                              delta_ws=w["delta"], dq32_ws=w.get("dq32"), drop=(p_a, seed, ops.site_attn(l)), seq=lay)
+            g_ctx, ctx_l = w["g_ctx"], a["ctx"]
+            if hs is not None:   # back through the head scaling: dL/d(raw context) = head_mask * dL/d(scaled context)
+                g_ctx = ops.scale_heads(w["g_ctx"], hs[l].contiguous())
+                ctx_l = bufs.ctx_raw(l)[:M]
+            ops.attention_bwd(a["qkv"], g_ctx, ctx_l, a["lse"], B, S, nh, mask=mask, mask_additive=mask_additive,
+                              out=w["g_qkv"], delta_ws=w["delta"], dq32_ws=w.get("dq32"), drop=(p_a, seed, ops.site_attn(l)),
+                              seq=lay)
             ops.linear(w["g_qkv"], wt["wt_qkv"], residual=w["g_pre2"], out=g)
             ops.wgrad([dict(dy=w["g_mid"], x=a["attn_out"], dw=gr["d_w_in"], db=gr["d_b_in"], accumulate=acc),
                        dict(dy=g_pre_dn, x=a["mid"], dw=gr["d_w_out"], db=gr["d_b_out"], accumulate=acc),
@@ -784,7 +824,8 @@ class _LossLazyGrads(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, batch, loss, *params):
-        ctx.model, ctx.batch = model, batch
+        ctx.model, ctx.batch = model, dict(batch)
+        ctx.head_mask = ctx.batch.pop("__head_mask__", None)
         ctx.params = params
         return loss.detach().clone()
 
@@ -795,7 +836,7 @@ class _LossLazyGrads(torch.autograd.Function):
         was = model.training
         model.eval()
         try:
-            eng.forward_backward(ctx.batch)
+            eng.forward_backward(ctx.batch, head_mask=ctx.head_mask)
         finally:
             model.train(was)
         f = eng.flat
@@ -819,17 +860,19 @@ def _bridge_engine(model):
     return eng
 
 
-def autograd_forward(model, batch):
+def autograd_forward(model, batch, head_mask=None):
     """PreTrainOscar.forward in training mode with grad enabled: returns the 7-tuple whose first element
     back-propagates into the model's parameters."""
     eng = _bridge_engine(model)
-    out = eng.forward_backward(batch)
+    out = eng.forward_backward(batch, head_mask=head_mask)
     params = [p for p in model.parameters() if p.requires_grad]
     loss = _LossWithGrads.apply(eng, out[0], *params)
     return (loss,) + tuple(out[1:])
 
 
-def lazy_autograd_loss(model, batch, loss):
+def lazy_autograd_loss(model, batch, loss, head_mask=None):
     """The inference path's loss made differentiable on demand (eval mode, grad enabled)."""
     params = [p for p in model.parameters() if p.requires_grad]
+    if head_mask is not None:
+        batch = dict(batch, __head_mask__=head_mask)
     return _LossLazyGrads.apply(model, batch, loss, *params)
