@@ -360,11 +360,16 @@ def test_engine_under_two_ranks_matches_single_rank_accumulation(dev, tmp_path, 
         check_close("2-rank engine (bf16 all-reduce): gradient slab, max |error| / max |g|",
                     float((got["g"] - g_sum.cpu()).abs().max()) / gmax, 0.0, 2.0 ** -7)
     assert torch.equal(got["g"], other["g"]), "ranks disagree on the all-reduced gradients"
+    p_before = eng.flat.p.detach().cpu().clone()
     eng.optimizer_step(grad_scale=1.0 / world)
     torch.cuda.synchronize()
-    # (Adam normalises the step: a bf16-rounded gradient moves a weight by at most ~lr * 1e-2 differently)
-    check_close("2-rank engine (%s all-reduce): weights after AdamW vs 1-rank" % comm_dtype, got["p"], eng.flat.p.cpu(),
-                2e-6 if comm_dtype == "fp32" else 3e-5)
+    if comm_dtype == "fp32":
+        check_close("2-rank engine (fp32 all-reduce): weights after AdamW vs 1-rank", got["p"], eng.flat.p.cpu(), 2e-6)
+    else:
+        # Adam's first step is lr * sign-like (m / sqrt(v) = +-1): where a gradient is all but zero its bf16 rounding can
+        # flip the step, so single weights may differ by 2 lr; compared as the update's relative L2
+        check_close("2-rank engine (bf16 all-reduce): AdamW update vs 1-rank, relative L2", got["p"] - p_before,
+                    eng.flat.p.cpu() - p_before, 5e-2, kind="rel_l2")
     assert torch.equal(got["p"], other["p"]), "ranks diverged after the optimizer step"
     for r_, rec in enumerate((got, other)):
         for i in range(4):
