@@ -439,6 +439,8 @@ def run_cpu_baseline(cfg, T, R, train, gpu_out=None):
             "sequence_output": d(gpu_out["sequence_output"], seq), "prediction_scores": d(gpu_out["prediction_scores"], scores),
             "action_scores": d(gpu_out["action_scores"], act),
             "sequence_output_rows_inside_the_full_batch": d(gpu_out["sequence_output_in_full_batch"], seq),
+            "sequence_output_rms": round(float((gpu_out["sequence_output"].reshape(seq.shape) - seq).pow(2).mean().sqrt()), 6),
+            "sequence_output_absmax_of_reference": round(float(seq.abs().max()), 4),
             "tolerance": 5e-2,
         }
     return out
