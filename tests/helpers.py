@@ -25,6 +25,33 @@ def maxabs(a, b):
 _MEASURED = []
 
 
+def _recorded():
+    """tests/golden/parity_measured.json: the error every named check measured on an MI355X when its bound was last
+    reviewed (written from profiles/r02/parity_measured.txt).  A check then passes only below
+    min(stated bound, max(2 x recorded, stated bound / 10)): the stated bound is the contract (north_star's 5e-2 / 1e-3,
+    or what the docstring derives), the recorded value keeps a regression from hiding inside a generous contract, and
+    the floor of a tenth of the bound keeps noise-level errors (which move with the autotuner's kernel choice and the
+    summation order) from failing a healthy run."""
+    global _REC
+    if _REC is None:
+        import json
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_measured.json")
+        _REC = json.load(open(path)) if os.path.exists(path) else {}
+    return _REC
+
+
+_REC = None
+
+
+def effective_bound(name, bound):
+    rec = _recorded().get(name)
+    if rec is None:
+        return bound
+    return min(bound, max(2.0 * rec, 0.1 * bound))
+
+
 def check_close(name, got, want, bound, kind="maxabs"):
     """Assert |got - want| <= bound and RECORD the measured error: every parity test prints `PARITY name measured bound`
     (run pytest with -s, or read tests' session summary written by conftest) so that a bound can be audited against
@@ -37,9 +64,11 @@ def check_close(name, got, want, bound, kind="maxabs"):
         err = float((g - w).norm() / (w.norm() + 1e-30))
     else:
         raise ValueError(kind)
-    _MEASURED.append((name, kind, err, float(bound)))
-    print("PARITY %-58s %-7s measured %.3e  bound %.3e" % (name, kind, err, bound))
-    assert err <= bound, "%s: %s error %.4e exceeds the bound %.4e" % (name, kind, err, bound)
+    stated, bound = float(bound), effective_bound(name, float(bound))
+    _MEASURED.append((name, kind, err, bound))
+    print("PARITY %-58s %-7s measured %.3e  bound %.3e (stated %.1e)" % (name, kind, err, bound, stated))
+    assert err <= bound, "%s: %s error %.4e exceeds the bound %.4e (stated %.1e, tightened by the recorded value)" % (
+        name, kind, err, bound, stated)
     return err
 
 
