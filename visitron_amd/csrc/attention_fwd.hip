@@ -86,7 +86,8 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
   f32x16 o0, o1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;   // running maximum (exp2 domain) and running sum
+  const float scale2 = a.scale * LOG2E;
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
   const uint32_t q_elem = (uint32_t)(q0 + r) * (uint32_t)S;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
           const float mval = a.mask[(long)b * Smax + key];
           add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
         }
-        bias = add;
+        bias = add * LOG2E;   // exp2 domain (see the softmax below)
       }
       ((float*)(smem + ATT_SBIAS))[tid] = bias;
     }
@@ -143,7 +144,9 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
           const bf16x8 kf = *(const bf16x8*)(kp + (((2 * ds + h2) ^ k_swz) << 4));
           sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc, 0, 0, 0);
         }
-        // ---- scale + mask, online softmax (exp2 domain) ----
+        // ---- scale + mask, online softmax in the exp2 domain: s2 = (q.k / sqrt(d) + bias) * log2(e) in ONE fma per
+        // element (scale2 = log2(e) / sqrt(d), the bias row is staged pre-multiplied), p = exp2(s2 - m2).  The kernel is
+        // VALU-bound (profiles/r01/attention_sq_counters.txt): every instruction taken out of this loop shows. ----
         const float* bp = (const float*)(smem + ATT_SBIAS) + kt * 32 + 4 * h2;
         float tmax = -INFINITY;
 #pragma unroll
@@ -153,30 +156,34 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
             const int key0 = kc + kt * 32 + 8 * g4 + 4 * h2;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (key0 + e < S) bv[e] += mrow3[key0 + e];
+              if (key0 + e < S) bv[e] += mrow3[key0 + e] * LOG2E;
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            // same two roundings as the reference's scores / sqrt(d) + mask (the division by 8 is exact)
-            const float s = fmaf(sacc[4 * g4 + e], a.scale, bv[e]);
+            const float s = fmaf(sacc[4 * g4 + e], scale2, bv[e]);
             sacc[4 * g4 + e] = s;
             tmax = fmaxf(tmax, s);
           }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-        m_run = m_new;
+        // the running maximum moves in the first tile or two and then rarely: the rescale of the 32 output registers (and
+        // its exp2) is skipped when no lane's maximum changed (wave-uniform branch; exact: alpha would be 1)
+        if (__builtin_amdgcn_ballot_w64(tmax > m_run) != 0) {
+          const float m_new = fmaxf(m_run, tmax);
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          m_run = m_new;
+          l_run *= alpha;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
         float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f((sacc[i] - m_new) * LOG2E);  // (s - max) is exact
+          const float p = __builtin_amdgcn_exp2f(sacc[i] - m_run);
           sacc[i] = p;
           psum += p;
         }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        l_run += psum;
 
         // ---- O^T += V^T . P^T ----
 #pragma unroll
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
   if (q >= S) return;
   float inv = 1.0f / l_tot;
   if (dr.thresh) inv *= dr.scale;   // dropout's 1 / (1 - p)
-  if (a.lse && h2 == 0) a.lse[((long)b * a.nh + head) * Smax + q] = m_run + __builtin_amdgcn_logf(l_tot) * 0.6931471805599453f;
+  if (a.lse && h2 == 0) a.lse[((long)b * a.nh + head) * Smax + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
   if (a.head_scale) inv *= a.head_scale[head];
   bf16_t* op = a.ctx + (row0 + q) * a.ld_ctx + head * 64 + 16 * h2;
   u32x4 w0, w1, w2, w3;
