@@ -118,7 +118,6 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
   const float ds_scale = a.scale * dr.scale;   // 1 / sqrt(d) times dropout's 1 / (1-p) (1 when off)
-  const float scale2 = a.scale * LOG2E;        // scores straight into the exp2 domain
   const int kcount = (S - kb0) < 256 ? (S - kb0) : 256;
   const int nkt = (kcount + 31) >> 5;  // 32-key steps of this key block for dQ
 
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
     float v = 0.f;
     if (tid < 64) {
       const int qq = sl * 32 + (tid & 31);
-      if (tid < 32) v = qq < S ? lse_p[qq] * LOG2E : INFINITY;  // exp2 domain; +inf => P = 0 for padded queries
+      if (tid < 32) v = qq < S ? lse_p[qq] : INFINITY;  // +inf => P = 0 for padded queries
       else v = qq < S ? del_p[qq] : 0.f;
     }
     return v;
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
         add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
       }
     }
-    kbias[kt] = add * LOG2E;   // exp2 domain: p = exp2(q.k * scale2 + kbias - lse * log2 e)
+    kbias[kt] = add;
     // mask_additive == 2: an additive bias per (query, key) [B, S, S] (the reference's 3-D attention masks,
     // encoder.py:228-229): this lane's key column; the query row is added per element below
     mq3[kt] = (a.mask && a.mask_additive == 2) ? a.mask + (long)b * Smax * Smax + kr : nullptr;
@@ -284,12 +283,12 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g4 + e;
-          float s = fmaf(sacc[i], scale2, kbias[kt]);
+          float s = fmaf(sacc[i], a.scale, kbias[kt]);
           if (mq3[kt]) {   // per-query bias row of element i's query (clamped: rows past S carry dO = 0)
             const int qi = sl * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
-            s = fmaf(mq3[kt][(long)(qi < S ? qi : S - 1) * Smax], LOG2E, s);
+            s += mq3[kt][(long)(qi < S ? qi : S - 1) * Smax];
           }
-          const float p = __builtin_amdgcn_exp2f(s - lse4[g4][e]);
+          const float p = __builtin_amdgcn_exp2f((s - lse4[g4][e]) * LOG2E);
           float dpv = dpacc[i], pv = p;
           if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
             dpv = keep[i] ? dpv : 0.f;
@@ -436,7 +435,6 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
   const float ds_scale = a.scale * dr.scale;   // 1 / sqrt(d) times dropout's 1 / (1-p) (1 when off)
-  const float scale2 = a.scale * LOG2E;        // scores straight into the exp2 domain
   const int kcount = (S - kb0) < 256 ? (S - kb0) : 256;
   const int nkt = (kcount + 31) >> 5;  // 32-key steps of this key block for dQ
 
@@ -455,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
     float v = 0.f;
     if (tid < 64) {
       const int qq = sl * 32 + (tid & 31);
-      if (tid < 32) v = qq < S ? lse_p[qq] * LOG2E : INFINITY;  // exp2 domain; +inf => P = 0 for padded queries
+      if (tid < 32) v = qq < S ? lse_p[qq] : INFINITY;  // +inf => P = 0 for padded queries
       else v = qq < S ? del_p[qq] : 0.f;
     }
     return v;
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
         add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
       }
     }
-    kbias[kt] = add * LOG2E;   // exp2 domain: p = exp2(q.k * scale2 + kbias - lse * log2 e)
+    kbias[kt] = add;
     // mask_additive == 2: an additive bias per (query, key) [B, S, S] (the reference's 3-D attention masks,
     // encoder.py:228-229): this lane's key column; the query row is added per element below
     mq3[kt] = (a.mask && a.mask_additive == 2) ? a.mask + (long)b * Smax * Smax + kr : nullptr;
@@ -600,12 +598,12 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g4 + e;
-          float s = fmaf(sacc[i], scale2, kbias[kt]);
+          float s = fmaf(sacc[i], a.scale, kbias[kt]);
           if (mq3[kt]) {   // per-query bias row of element i's query (clamped: rows past S carry dO = 0)
             const int qi = sl * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
-            s = fmaf(mq3[kt][(long)(qi < S ? qi : S - 1) * Smax], LOG2E, s);
+            s += mq3[kt][(long)(qi < S ? qi : S - 1) * Smax];
           }
-          const float p = __builtin_amdgcn_exp2f(s - lse4_g[e]);
+          const float p = __builtin_amdgcn_exp2f((s - lse4_g[e]) * LOG2E);
           float dpv = dpacc[i], pv = p;
           if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
             dpv = keep[i] ? dpv : 0.f;
