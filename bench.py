@@ -254,10 +254,12 @@ def main():
             # HBM bytes per launch of the same kernels: not measurable from inside this process; taken from the
             # committed PMC passes of this command (profiles/README.md), null when that file is absent
             traffic, traffic_src = None, None
-            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "train_b256_pmc_hbm_traffic_v6.json")
-            if train and a.batch == 256 and os.path.exists(tp):
-                tj = json.load(open(tp))
-                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01/train_b256_pmc_hbm_traffic_v6.json"
+            here = os.path.dirname(os.path.abspath(__file__))
+            for rel in ("profiles/r02/train_b256_pmc_hbm_traffic_v1.json", "profiles/r01/train_b256_pmc_hbm_traffic_v6.json"):
+                tp = os.path.join(here, rel)
+                if train and a.batch == 256 and os.path.exists(tp):
+                    traffic, traffic_src = json.load(open(tp))["hbm_bytes_per_launch"], rel
+                    break
             roofline = {
                 "kernel": "gemm_nt_bf16 (NT GEMM family; per shape the autotuner picks among the persistent 256x256-tile "
                           "kernel with 128x128 wave tiles / AGPR accumulators and the older 128x128 .. 256x256 tiles)",

@@ -75,7 +75,7 @@ def test_base_config_long_dialog_cfg4_forward_backward(dev):
         check_close("base S=656 golden tuple7[%d]" % i, float(got[i]), float(g["tuple7"][i]), 5e-2)
     errs = {n: _rel(p.grad, dict(ref.named_parameters())[n].grad) for n, p in prod.named_parameters()}
     worst = max(errs, key=errs.get)
-    check_close("base S=656 grads worst rel-L2 (%s)" % worst, errs[worst], 0.0, 0.08)
+    check_close("base S=656 grads worst rel-L2 (%s)" % worst, errs[worst], 0.0, 0.035)   # measured 1.6 %
 
 
 # ------------------------------------------------------------------------------------------------
@@ -215,7 +215,7 @@ def test_validation_in_eval_mode_with_grad_enabled_is_forward_only(dev):
     wg = dict(ref.named_parameters())
     errs = {n: _rel(p.grad, wg[n].grad) for n, p in prod.named_parameters()}
     worst = max(errs, key=errs.get)
-    check_close("eval+grad lazy backward grads worst rel-L2 (%s)" % worst, errs[worst], 0.0, 0.08)
+    check_close("eval+grad lazy backward grads worst rel-L2 (%s)" % worst, errs[worst], 0.0, 0.02)   # measured 0.7 - 1.0 %
 
 
 def test_training_step_raises_index_error_and_clears_unsupervised_heads(dev):
@@ -289,10 +289,10 @@ def test_resized_embeddings_untied_decoder_forward_and_training(dev):
     wg = dict(ref.named_parameters())
     errs = {n: _rel(p.grad, wg[n].grad) for n, p in prod.named_parameters()}
     worst = max(errs, key=errs.get)
-    check_close("resized: grads worst rel-L2 (%s)" % worst, errs[worst], 0.0, 0.08)
+    check_close("resized: grads worst rel-L2 (%s)" % worst, errs[worst], 0.0, 0.02)   # measured 0.7 - 1.0 %
     # the untied tables really got their own gradients
-    assert _rel(prod.mlmhead.predictions.decoder.weight.grad, wg["mlmhead.predictions.decoder.weight"].grad) < 0.08
-    assert _rel(prod.bert.embeddings.word_embeddings.weight.grad, wg["bert.embeddings.word_embeddings.weight"].grad) < 0.08
+    assert _rel(prod.mlmhead.predictions.decoder.weight.grad, wg["mlmhead.predictions.decoder.weight"].grad) < 0.02
+    assert _rel(prod.bert.embeddings.word_embeddings.weight.grad, wg["bert.embeddings.word_embeddings.weight"].grad) < 0.02
     eng.optimizer_step()
     torch.cuda.synchronize()
 
@@ -457,11 +457,11 @@ def test_training_with_head_mask_and_per_query_masks(dev, what):
     wg = dict(ref.named_parameters())
     errs = {n: _rel(p_.grad, wg[n].grad) for n, p_ in prod.named_parameters()}
     worst = max(errs, key=errs.get)
-    check_close("train %s grads worst rel-L2 (%s)" % (what, worst), errs[worst], 0.0, 0.08)
+    check_close("train %s grads worst rel-L2 (%s)" % (what, worst), errs[worst], 0.0, 0.02)   # measured 0.7 - 1.0 %
     # ... and through the module's own forward (the autograd bridge)
     if what == "head_mask":
         prod.zero_grad()
         out = prod(**_to(b, dev), head_mask=hm.to(dev))
         out[0].backward()
         errs = {n: _rel(p_.grad, wg[n].grad) for n, p_ in prod.named_parameters()}
-        assert max(errs.values()) < 0.08, max(errs, key=errs.get)
+        assert max(errs.values()) < 0.02, max(errs, key=errs.get)

@@ -28,7 +28,8 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + floor))
 
 
-GRAD_TOL = 0.08   # relative L2 per parameter (bf16 GEMM operands, fp32 accumulation); measured values are printed
+GRAD_TOL = 0.02   # relative L2 per parameter (bf16 GEMM operands, fp32 accumulation); measured on MI355X: worst 0.7 - 1.0 %,
+                  # median 0.5 - 0.7 % (profiles/r02/parity_measured.txt), so 2 % is <= 2.5x the worst case seen
 
 
 def _check_grads(tag, prod, want_grads, bound=GRAD_TOL):
@@ -84,7 +85,7 @@ def test_gradients_match_oracle_mini(dev):
     for n, p in prod.named_parameters():
         assert abs(float(p.grad.norm()) - norms[n]) < 0.08 * norms[n] + 2e-3 * (p.numel() ** 0.5), n
     q0 = dict(prod.named_parameters())["bert.encoder.layer.0.attention.self.query.weight"].grad
-    assert _rel(q0, torch.from_numpy(g["grad_query0"])) < 0.08
+    assert _rel(q0, torch.from_numpy(g["grad_query0"])) < GRAD_TOL
 
 
 def test_padding_row_and_tied_decoder_gradients(dev):
@@ -101,7 +102,7 @@ def test_padding_row_and_tied_decoder_gradients(dev):
     w = ref.bert.embeddings.word_embeddings.weight.grad
     gq = prod.bert.embeddings.word_embeddings.weight.grad
     assert _rel(gq[0], w[0]) < 0.1
-    assert _rel(gq, w) < 0.08
+    assert _rel(gq, w) < GRAD_TOL
 
 
 def test_adamw_step_matches_oracle(dev):
@@ -210,7 +211,7 @@ def test_reference_style_loop_with_torch_optimizer(dev):
             wg = dict(ref.named_parameters())
             for n, p in prod.named_parameters():
                 assert p.grad is not None, n
-                assert _rel(p.grad, wg[n].grad) < 0.08, n
+                assert _rel(p.grad, wg[n].grad) < GRAD_TOL, n
         o_prod.step()
         assert abs(float(loss) - float(lr_)) < 0.15
     # eval / no_grad still takes the inference path
@@ -505,7 +506,7 @@ def test_rccl_all_reduce_path_single_rank(dev):
         wg = dict(ref.named_parameters())
         for n, p in prod2.named_parameters():
             assert p.grad is not None, n
-            assert _rel(p.grad, wg[n].grad) < 0.08, n
+            assert _rel(p.grad, wg[n].grad) < GRAD_TOL, n
     finally:
         dist.destroy_process_group()
 
