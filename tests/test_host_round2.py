@@ -1,0 +1,121 @@
+"""CPU: host logic added in round 2 -- precision switch, weights generation, the tightened parity bounds, the bench's
+own launcher and FLOP counts, and the alignment of the data-parallel gradient ranges (no GPU, no compute calls)."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_set_precision_flags_every_module_and_rejects_unknown_modes():
+    from visitron_amd import set_precision
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar, _is_fp32
+
+    m = PreTrainOscar(mini_config())
+    assert not _is_fp32(m) and not _is_fp32(m.bert.encoder)
+    assert set_precision(m, "fp32") is m
+    assert all(_is_fp32(x) for x in m.modules())
+    set_precision(m, "bf16")
+    assert not any(_is_fp32(x) for x in m.modules())
+    with pytest.raises(ValueError):
+        set_precision(m, "fp16")
+    # training in fp32 mode is refused before any tensor is touched
+    set_precision(m, "fp32").train()
+    ids = torch.zeros(1, 4, dtype=torch.long)
+    with pytest.raises(NotImplementedError):
+        m(ids, labels=ids, token_labels=ids)
+
+
+def test_weights_generation_invalidates_every_cache_key():
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar, _param_key, invalidate_packed_weights
+
+    m = PreTrainOscar(mini_config())
+    k0 = _param_key(m.bert.encoder)
+    assert _param_key(m.bert.encoder) == k0
+    m.bert.pooler.dense.weight.data.add_(1.0)                 # a write through .data: no version bump ...
+    assert _param_key(m.bert.pooler) == _param_key(m.bert.pooler)
+    invalidate_packed_weights()                               # ... so writers of that kind advance the generation
+    assert _param_key(m.bert.encoder) != k0
+    with torch.no_grad():
+        m.bert.encoder.layer[0].output.dense.bias.add_(1.0)   # an ordinary in-place update bumps the version itself
+    assert _param_key(m.bert.encoder)[1:] != k0[1:]
+
+
+def test_effective_parity_bound_rule(tmp_path, monkeypatch):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+
+    monkeypatch.setattr(helpers, "_REC", {"a": 1e-3, "b": 4e-2, "c": 1e-9})
+    assert helpers.effective_bound("a", 5e-2) == pytest.approx(5e-3)      # floor: a tenth of the stated bound
+    assert helpers.effective_bound("b", 5e-2) == pytest.approx(5e-2)      # never above the stated bound
+    assert helpers.effective_bound("c", 1e-3) == pytest.approx(1e-4)
+    assert helpers.effective_bound("unknown", 5e-2) == 5e-2
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "parity_measured.json")))
+    assert len(rec) > 200 and all(v >= 0 for v in rec.values())
+    # the committed table is the one profiles/r02 was written from
+    names = {line.split("  ")[0].strip() for line in open(os.path.join(ROOT, "profiles", "r02", "parity_measured.txt"))
+             if not line.startswith("#")}
+    assert len(names & set(rec)) > 200
+
+
+def test_bench_flop_counts_and_self_launch_command(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    S = 228
+    full = bench.enc_flops_per_seq(S)
+    assert full == 12 * (24 * S * 768 ** 2 + 4 * S * S * 768) == 40646541312
+    assert bench.enc_flops_rows([S] * 7) == pytest.approx(7 * full)
+    assert bench.enc_flops_rows([100, 228]) < 2 * full
+    assert bench._pct([1.0, 2.0, 3.0, 4.0, 5.0], 0.5) == 3.0 and bench._pct([1.0, 3.0], 0.1) == pytest.approx(1.2)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()                                  # must hand over to the launcher before importing torch.cuda
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and os.path.basename(cmd[-5]) == "bench.py"
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+
+
+def test_data_parallel_gradient_ranges_are_aligned_and_tile_the_slab():
+    """The chunked backward hands [start, end) ranges of the gradient slab to the communicator; with the bf16
+    communication copy every range must start and end on a multiple of 8 elements, and the chunk ranges plus their
+    complement must cover the slab exactly once."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.distributed import complement_ranges
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.ops import round_up
+    from visitron_amd.training import ALIGN, PretrainEngine
+
+    for L, step in ((4, 3), (5, 2), (2, 1)):
+        m = PreTrainOscar(mini_config(num_hidden_layers=L))
+        e = PretrainEngine(m, grad_comm_dtype="bf16")
+        assert e.g16 is None and e.world == 1          # the copy exists only with more than one rank
+        f = e.flat
+        done, hi = [], L
+        while hi > 0:
+            lo = max(0, hi - step)
+            done += [(e.layer_ranges[lo][k][0], min(round_up(e.layer_ranges[hi - 1][k][1], ALIGN), f.total)) for k in (0, 1)]
+            hi = lo
+        cover = torch.zeros(f.total, dtype=torch.int32)
+        for s, t in done + complement_ranges(f.total, done):
+            assert s % 8 == 0 and t % 8 == 0 and t > s
+            cover[s:t] += 1
+        assert int(cover.min()) == 1 and int(cover.max()) == 1
+    with pytest.raises(ValueError):
+        PretrainEngine(PreTrainOscar(mini_config()), grad_comm_dtype="fp8")
