@@ -404,32 +404,41 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows(LnBwdArgs a) {
   }
 }
 
-// out[j] (+)= sum_b partial[b][j], j < n  (n = 2H: dgamma | dbeta).  A block owns 32 columns; its 8
-// thread groups each sum every 8th partial row (independent, unrolled loads), then combine through LDS.
+// out[j] (+)= sum_b partial[b][j], j < n  (n = 2H: dgamma | dbeta; n % 4 == 0).  A block owns 16 columns (4 lanes x
+// 16 bytes); its 64 row groups each sum every 64th partial row with independent 16-byte loads (1024 partial rows = 16
+// loads per thread, all in flight), then combine through LDS.  (The first form -- 32 columns x 8 row groups, 128
+// dependent-latency loads per thread on 48 workgroups -- took 12 us per call, as much as the LayerNorm backward itself
+// at a small batch.)
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ partial, int nblocks, int n,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int H,
                                                      int accumulate) {
-  __shared__ float red[8][32];
-  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + cl;
-  float s = 0.f;
+  __shared__ f32x4 red[64][4];
+  const int cg = threadIdx.x & 3, part = threadIdx.x >> 2;
+  const int j = blockIdx.x * 16 + cg * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (j < n) {
     int b = part;
-    for (; b + 24 < nblocks; b += 32) {
-      const float v0 = partial[(long)b * n + j], v1 = partial[(long)(b + 8) * n + j];
-      const float v2 = partial[(long)(b + 16) * n + j], v3 = partial[(long)(b + 24) * n + j];
+    for (; b + 192 < nblocks; b += 256) {
+      const f32x4 v0 = *(const f32x4*)(partial + (long)b * n + j), v1 = *(const f32x4*)(partial + (long)(b + 64) * n + j);
+      const f32x4 v2 = *(const f32x4*)(partial + (long)(b + 128) * n + j), v3 = *(const f32x4*)(partial + (long)(b + 192) * n + j);
       s += (v0 + v1) + (v2 + v3);
     }
-    for (; b < nblocks; b += 8) s += partial[(long)b * n + j];
+    for (; b < nblocks; b += 64) s += *(const f32x4*)(partial + (long)b * n + j);
   }
-  red[part][cl] = s;
+  red[part][cg] = s;
   __syncthreads();
+  for (int h = 32; h > 0; h >>= 1) {   // tree over the 64 row groups: a fixed order, reproducible
+    if (part < h) red[part][cg] += red[part + h][cg];
+    __syncthreads();
+  }
   if (part == 0 && j < n) {
-    float t = 0.f;
+    const f32x4 t = red[0][cg];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
-    float* dst = j < H ? dgamma + j : dbeta + (j - H);
-    *dst = accumulate ? *dst + t : t;
+    for (int k = 0; k < 4; ++k) {
+      const int jj = j + k;
+      float* dst = jj < H ? dgamma + jj : dbeta + (jj - H);
+      *dst = accumulate ? *dst + t[k] : t[k];
+    }
   }
 }
 
@@ -450,7 +459,7 @@ int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy,
   if (nblocks > LN_BWD_MAX_BLOCKS) nblocks = LN_BWD_MAX_BLOCKS;
   if (H <= 512) hipLaunchKernelGGL(layernorm_bwd_rows<1>, dim3(nblocks), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(layernorm_bwd_rows<2>, dim3(nblocks), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 31) / 32), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 15) / 16), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
                      dbeta, H, accumulate);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
@@ -630,7 +639,7 @@ int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids,
   const int nblocks = (int)(nb > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : nb);
   if (H <= 512) hipLaunchKernelGGL(embed_layernorm_bwd<1>, dim3(nblocks), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(embed_layernorm_bwd<2>, dim3(nblocks), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 31) / 32), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
+  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 15) / 16), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
                      dbeta, H, accumulate);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }

@@ -154,7 +154,7 @@ def force_gemm_variant(v):
     _lib.load().vt_debug_set_gemm_variant(AUTO_VARIANT if v is None else int(v))
 
 
-def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device="cuda", reps=8):
+def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device="cuda", reps=8, out_f32=False):
     """Time the GEMM kernel variants on one shape (random data, HIP events) and register the fastest in the
     library's shape table.  Synchronises; call it before the timed region / graph capture."""
     key = (M, N, K, act)
@@ -173,7 +173,7 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
     w = (torch.randn(N, K, generator=g, device=device) * 0.03).to(BF16)
     b = torch.zeros(N, device=device)
     r = torch.randn(M, N, generator=g, device=device).to(BF16) if (residual or act == ACT_MUL) else None
-    out = torch.empty((M, N), dtype=BF16, device=device)
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=device)
     pre = torch.empty((M, N), dtype=BF16, device=device) if pre_act else None
     best, best_t = GEMM_CANDIDATES[0], float("inf")
     for v in GEMM_CANDIDATES:
@@ -182,11 +182,11 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
         lib.vt_debug_set_gemm_variant(v)
         try:
             for _ in range(2):
-                linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre)
+                linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre, out_f32=out_f32)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre)
+                linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre, out_f32=out_f32)
             e1.record()
             torch.cuda.synchronize()
             t = e0.elapsed_time(e1)

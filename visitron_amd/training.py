@@ -427,6 +427,14 @@ class PretrainEngine(object):
             if bucket not in self._tuned_rows and bucket < M:
                 ops.autotune_encoder_shapes(bucket, H, I, training=True, device=dev)
                 self._tuned_rows.add(bucket)
+        # the MLM head's two wide GEMMs ([Ml, 768] x [768, 30528] and back) are tuned like the encoder's, once per bucket of
+        # 512 supervised rows (the row count changes from batch to batch; the library takes the nearest tuned M)
+        if Ml:
+            hb = round_up(Ml, 512)
+            if ("head", hb) not in self._tuned_rows:
+                ops.autotune_linear(hb, self.Vp, H, device=dev, out_f32=True)
+                ops.autotune_linear(hb, H, self.Vp, device=dev)
+                self._tuned_rows.add(("head", hb))
         rows_w = idx_w if lay is None else lay.inverse.index_select(0, idx_w)   # supervised rows in the layout in use
         rows_t = idx_t if lay is None else lay.inverse.index_select(0, idx_t)
         cls_rows = (torch.arange(B, device=dev) * S) if lay is None else lay.start.to(torch.int64)
