@@ -693,7 +693,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_bf16_v6(GemmArgs g) {
 //          15 / 16 = 256x256 tile, 4 waves of 128x128 with AGPR accumulators, one tile per workgroup / persistent
 //          (gemm_v7.hip); 18 .. 21 = the persistent kernel on 224- / 192- / 160- / 128-row tiles (fewer, better balanced rounds when the
 //          256-row tiling leaves the last round mostly empty).
-int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);  // gemm_v7.hip
+int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn);  // gemm_v7.hip (tile height 32 * mtn)
 int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn);  // gemm_v7.hip (persistent; tile height 32 * mtn)
 static void* g_gemm_trace = nullptr;
 void vt_gemm_set_trace(void* p) { g_gemm_trace = p; }
@@ -792,7 +792,9 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
       hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(512), 2 * 32768, stream, g);
       return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
     }
-    case 15: return vt_gemm_v7_launch(g, ACT, OUT_F32 ? 1 : 0, stream);
+    case 15: return vt_gemm_v7_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 8);
+    case 22: return vt_gemm_v7_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 7);   // one tile per workgroup, 224-row tiles
+    case 23: return vt_gemm_v7_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 6);   // ... 192-row tiles (mid-size batches: one fuller round)
     case 16: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 8);
     case 18: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 7);   // the persistent kernel on 224-row tiles
     case 19: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 6);   // ... on 192-row tiles

@@ -253,9 +253,9 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
   }
 
 #define V7_TR nullptr
-template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R>
+template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R, int MTN = 8>
 __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
-  constexpr int MTN = 8;
+  constexpr int TH = 32 * MTN;   // tile height (see gemm_nt_bf16_v8): 256, or 224 / 192 to fill one round better
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -274,11 +274,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   const int band_h = rows_left < 8 ? rows_left : 8;
   const int bn = within / band_h;
   const int bm = band * 8 + (within - bn * band_h);
-  const int m0 = bm * 256, n0 = bn * 256;
+  const int m0 = bm * TH, n0 = bn * 256;
 
   // ---- DMA addressing.  Piece p = wave*8 + i covers LDS rows 8p .. 8p+7 of an operand image (128 B per row);
   // lane -> row 8p + (lane>>3), 16-B chunk (lane&7) ^ swz(row), swz(row) = (4*(i&1) + (lane>>4)) & 7.
-  const int rows_x = g.M - m0 < 256 ? g.M - m0 : 256;
+  const int rows_x = g.M - m0 < TH ? g.M - m0 : TH;
   const int rows_w = g.N - n0 < 256 ? g.N - n0 : 256;
   const bf16_t* xbase = g.A + (long)m0 * g.lda;
   const bf16_t* wbase = g.W + (long)n0 * g.ldw;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   const unsigned fr = (lane & 15) * 128 + ((((unsigned)lane >> 4) ^ (((unsigned)lane & 15) >> 1)) << 4);
   // current-stage addresses of the two k-substeps; toggled (^ V7_STAGE) every K-step.  They are loop-carried on
   // purpose: as long-lived loop invariants the register allocator would park them in scratch.
-  unsigned xa0 = lds0 + wm * 16384 + fr, xa1 = xa0 ^ 64;
+  unsigned xa0 = lds0 + wm * (MTN * 2048) + fr, xa1 = xa0 ^ 64;
   unsigned wa0 = lds0 + V7_WOFF + wn * 16384 + fr, wa1 = wa0 ^ 64;
   unsigned dst = wave * 8192;   // byte offset of this wave's first DMA piece inside the current stage's X image
 
@@ -576,16 +576,25 @@ static int launch_v8(const GemmArgs& g, hipStream_t stream, int mtn) {
 }
 
 template <int ACT, bool OUT_F32>
-static int launch_v7(const GemmArgs& g, hipStream_t stream) {
+static int launch_v7(const GemmArgs& g, hipStream_t stream, int mtn) {
   GemmArgs g7 = g;
-  g7.tiles_m = (g.M + 255) / 256;
   g7.tiles_n = (g.N + 255) / 256;
   // operand panels are addressed with 32-bit byte offsets inside a tile's row panel
   if ((g.K & 63) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31)) return VT_ERR_UNSUPPORTED;
   const bool fast = !OUT_F32 && (g.N & 63) == 0 && g.grp_rows == 0;
   if (ACT == ACT_MUL && !g.R) return VT_ERR_NULL;
-  auto kern = !fast ? gemm_nt_bf16_v7<ACT, OUT_F32, false, false>
-                    : ((g.R || ACT == ACT_MUL) ? gemm_nt_bf16_v7<ACT, OUT_F32, !OUT_F32, true> : gemm_nt_bf16_v7<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL>);
+  if (!fast || OUT_F32 || ACT == ACT_TANH) mtn = 8;
+  g7.tiles_m = (g.M + 32 * mtn - 1) / (32 * mtn);
+  const bool has_r = g.R || ACT == ACT_MUL;
+  void (*kern)(GemmArgs) = nullptr;
+  if (!fast) kern = gemm_nt_bf16_v7<ACT, OUT_F32, false, false>;
+  else if (mtn == 8) kern = has_r ? gemm_nt_bf16_v7<ACT, OUT_F32, !OUT_F32, true> : gemm_nt_bf16_v7<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL>;
+#define V7_PICK(MT)                                                                                                  \
+  else if (mtn == MT) kern = has_r ? gemm_nt_bf16_v7<ACT, OUT_F32, !OUT_F32, true, (OUT_F32 || ACT == ACT_TANH) ? 8 : MT>   \
+                                   : gemm_nt_bf16_v7<ACT, OUT_F32, !OUT_F32, ACT == ACT_MUL, (OUT_F32 || ACT == ACT_TANH) ? 8 : MT>;
+  V7_PICK(7) V7_PICK(6)
+#undef V7_PICK
+  else return VT_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES) != hipSuccess) return VT_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3(g7.tiles_m * g7.tiles_n), dim3(256), V7_LDS_BYTES, stream, g7);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
@@ -609,19 +618,19 @@ int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t strea
 #endif
 }
 
-int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream) {
+int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn) {
 #ifdef V7_ONE
-  return launch_v7<ACT_NONE, false>(g, stream);
+  return launch_v7<ACT_NONE, false>(g, stream, mtn);
 #else
   switch (act * 2 + (out_f32 ? 1 : 0)) {
-    case 0: return launch_v7<ACT_NONE, false>(g, stream);
-    case 1: return launch_v7<ACT_NONE, true>(g, stream);
-    case 2: return launch_v7<ACT_GELU, false>(g, stream);
-    case 3: return launch_v7<ACT_GELU, true>(g, stream);
-    case 4: return launch_v7<ACT_TANH, false>(g, stream);
-    case 5: return launch_v7<ACT_TANH, true>(g, stream);
-    case 6: return launch_v7<ACT_MUL, false>(g, stream);
-    case 7: return launch_v7<ACT_MUL, true>(g, stream);
+    case 0: return launch_v7<ACT_NONE, false>(g, stream, mtn);
+    case 1: return launch_v7<ACT_NONE, true>(g, stream, mtn);
+    case 2: return launch_v7<ACT_GELU, false>(g, stream, mtn);
+    case 3: return launch_v7<ACT_GELU, true>(g, stream, mtn);
+    case 4: return launch_v7<ACT_TANH, false>(g, stream, mtn);
+    case 5: return launch_v7<ACT_TANH, true>(g, stream, mtn);
+    case 6: return launch_v7<ACT_MUL, false>(g, stream, mtn);
+    case 7: return launch_v7<ACT_MUL, true>(g, stream, mtn);
     default: return VT_ERR_UNSUPPORTED;
   }
 #endif
