@@ -72,7 +72,7 @@ def check_close(name, got, want, bound, kind="maxabs"):
     return err
 
 
-def check_bf16_tensor(name, got, want, max_bound, rms_bound, target=5e-2, beyond_frac=2e-5):
+def check_bf16_tensor(name, got, want, max_bound, rms_bound, target=5e-2, beyond_frac=1e-4):
     """A large bf16-path tensor against the fp32 oracle.  north_star's bf16 tolerance is 5e-2 absolute; with bf16
     operands (8-bit mantissas on every weight and activation of 12 layers) the error of the base config is ~1e-2 RMS, so
     the MAXIMUM over 10^5 .. 10^7 elements lands at 5 .. 6 sigma = 4.5e-2 .. 6e-2: recorded as it is.  Asserted: the
