@@ -223,6 +223,19 @@ int vt_lstm_sequence_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float
                          const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
                          int B, int hs, int T, int reverse, vt_stream_t stream);
 
+/* The same recurrence (padded layout: row_start == NULL, xproj row (b, t) at b * ldx_b + t * ldx_t; compacted layout:
+ * row (b, t) at (row_start[b] + t) * ldx_t) as ONE persistent launch: hs / 16 workgroups stay resident for all T steps
+ * with their rows of W_hh and their cell / hidden state in registers and exchange the hidden state per step through `ws`
+ * (write-through stores, one agent-scope arrival counter, bounded polls).  h / c: [B, hs] fp32, initial state in, final
+ * state out.  ws: device scratch of vt_lstm_sequence_persistent_ws_bytes(B, hs) bytes, 16-byte aligned; its first 256
+ * bytes are zeroed by this call; after completion the unsigned word at ws + 4 is non-zero if a workgroup ran out of
+ * its bounded wait (not all workgroups were resident together): h / c are then untouched and the caller falls back to
+ * vt_lstm_sequence_f32.  Returns VT_ERR_UNSUPPORTED outside B <= 64, hs in {128, 256, 512, 1024}: use the step form. */
+int64_t vt_lstm_sequence_persistent_ws_bytes(int B, int hs);
+int vt_lstm_sequence_persistent_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, const int32_t* row_start, float* h,
+                                    float* c, const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b,
+                                    int64_t lds_t, int B, int hs, int T, int reverse, void* ws, int64_t ws_bytes,
+                                    vt_stream_t stream);
 /* vt_lstm_sequence_f32 over COMPACTED input projections: xproj holds only the rows below each sequence's length, row of
  * (b, t) = row_start[b] + t (row stride ldx_row) -- what pack_padded_sequence feeds the LSTM (agent_models.py:285-287). */
 int vt_lstm_sequence_rows_f32(const float* xproj, int64_t ldx_row, const int32_t* row_start, float* h2_0, float* h2_1,

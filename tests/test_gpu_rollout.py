@@ -5,7 +5,7 @@ products: the 5e-2 tolerance of the bf16 path."""
 import pytest
 import torch
 
-from helpers import maxabs, model_pair
+from helpers import check_close, maxabs, model_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -169,3 +169,49 @@ def test_oscar_encoder_matches_oracle(dev, bidir, dec_hidden):
     assert float(got[0][5, 1:].abs().max()) == 0.0            # padded positions are exact zeros
     with pytest.raises(RuntimeError):
         prod(ids.to(dev), torch.tensor([1, 2, 3, 4, 5, 6]), mask.to(dev))      # not sorted in decreasing order
+
+
+@pytest.mark.parametrize("B,hs,S", [(21, 128, 9), (64, 512, 40), (5, 256, 33), (48, 512, 17)])
+def test_persistent_lstm_recurrence_equals_step_launches(dev, B, hs, S):
+    """vt_lstm_sequence_persistent_f32 (one resident launch, W_hh in registers, hidden state exchanged per step through
+    write-through stores and an arrival counter) against the one-launch-per-position form: same arithmetic, so the
+    sequences, the final states and the untouched neighbours must agree to fp32 rounding of a different summation order
+    -- padded and compacted input projections, both directions, ragged lengths, non-zero initial state."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(B + hs + S)
+    w_hh = (torch.randn(4 * hs, hs, generator=g) * (1.5 / hs ** 0.5)).to(torch.bfloat16).to(dev)
+    xp = torch.randn(B, S, 4 * hs, generator=g).to(dev)
+    lens = torch.randint(1, S + 1, (B,), generator=g).sort(descending=True).values.to(torch.int32)
+    lens[0] = S
+    lens_d = lens.to(dev)
+    h0, c0 = (torch.randn(B, hs, generator=g) * 0.5).to(dev), (torch.randn(B, hs, generator=g) * 0.5).to(dev)
+    # compacted copy of the projections: only the rows below each length
+    start = (torch.cumsum(lens, 0) - lens).to(torch.int32)
+    rows = torch.cat([xp[b, : int(lens[b])] for b in range(B)], 0).contiguous()
+    for reverse in (False, True):
+        outs = {}
+        for mode in ("steps", "persistent"):
+            ops.LSTM_PERSISTENT = mode == "persistent"
+            try:
+                for layout in ("padded", "rows"):
+                    h2 = (h0.clone(), torch.empty(B, hs, device=dev))
+                    c = c0.clone()
+                    seq = torch.full((B, S, 2 * hs), 7.0, device=dev)
+                    if layout == "padded":
+                        ops.lstm_sequence(xp, h2, c, w_hh, S, lens_d, seq[:, :, :hs], reverse=reverse)
+                    else:
+                        ops.lstm_sequence_rows(rows, start.to(dev), h2, c, w_hh, S, lens_d, seq[:, :, :hs], reverse=reverse)
+                    torch.cuda.synchronize()
+                    assert float(seq[:, :, hs:].min()) == 7.0
+                    outs[(mode, layout)] = (seq[:, :, :hs].clone(), h2[0].clone(), c.clone())
+            finally:
+                ops.LSTM_PERSISTENT = True
+        for layout in ("padded", "rows"):
+            for k, name in enumerate(("sequence", "final h", "final c")):
+                check_close("persistent LSTM B=%d hs=%d S=%d rev=%d %s %s" % (B, hs, S, reverse, layout, name),
+                            outs[("persistent", layout)][k], outs[("steps", layout)][k], 2e-5)
+        # and the zero padding past each length
+        seqp = outs[("persistent", "padded")][0]
+        for b in range(B):
+            assert float(seqp[b, int(lens[b]):].abs().max() if int(lens[b]) < S else 0.0) == 0.0

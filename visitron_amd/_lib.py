@@ -87,6 +87,10 @@ SIGNATURES = {
                                  c_int, c_int, c_int, c_void_p]),
     "vt_lstm_sequence_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_lstm_sequence_persistent_ws_bytes": (c_int64, [c_int, c_int]),
+    "vt_lstm_sequence_persistent_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64,
+                                                c_void_p]),
     "vt_skinny_linear_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_lstm_sequence_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -30,6 +30,12 @@ int vt_transpose_dispatch(const void* in, long ldi, void* out, long ldo, int R, 
 int vt_adamw_dispatch(float* p, const void* g, int g_is_bf16, float* m, float* v, void* p_bf16, long n, float lr,
                       float step_size, float b1, float b2, float eps, float wd, float grad_scale, hipStream_t stream);
 int vt_cast_scale_dispatch(const float* x, void* y, long n, float scale, hipStream_t stream);
+struct LstmPersistArgs {   // lstm_persistent.hip
+  const float* xproj; long ldx_b, ldx_t; const int* xrow_start; float* h; float* c; const bf16_t* w_hh; const int* lengths;
+  float* seq_out; long lds_b, lds_t; bf16_t* xchg; unsigned* sync; int B, hs, T, reverse;
+};
+int vt_lstm_persistent_dispatch(LstmPersistArgs a, void* ws, long ws_bytes, hipStream_t stream);
+long vt_lstm_persistent_ws_bytes(int B, int hs);
 int vt_scale_heads_dispatch(const void* x, long ldx, void* out, long ldo, long rows, int nh, const float* scale, hipStream_t stream);
 int vt_mask_tokens_dispatch(const int64_t* ids, const uint8_t* special, const int64_t* token_classes, const float* u_mask,
                             const float* u_replace, const float* u_random, const int64_t* random_words, int64_t* out_ids,
@@ -271,6 +277,19 @@ int vt_lstm_sequence_rows_f32(const float* xproj, int64_t ldx_row, const int32_t
   if (!row_start) return VT_ERR_NULL;
   return lstm_sequence_impl(xproj, 0, ldx_row, h2_0, h2_1, c, w_hh, lengths, seq_out, lds_b, lds_t, B, hs, T, reverse,
                             stream, row_start);
+}
+
+int64_t vt_lstm_sequence_persistent_ws_bytes(int B, int hs) { return vt_lstm_persistent_ws_bytes(B, hs); }
+
+int vt_lstm_sequence_persistent_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, const int32_t* row_start, float* h,
+                                    float* c, const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b,
+                                    int64_t lds_t, int B, int hs, int T, int reverse, void* ws, int64_t ws_bytes,
+                                    vt_stream_t stream) {
+  LstmPersistArgs a;
+  a.xproj = xproj; a.ldx_b = ldx_b; a.ldx_t = ldx_t; a.xrow_start = row_start; a.h = h; a.c = c;
+  a.w_hh = (const bf16_t*)w_hh; a.lengths = lengths; a.seq_out = seq_out; a.lds_b = lds_b; a.lds_t = lds_t;
+  a.xchg = nullptr; a.sync = nullptr; a.B = B; a.hs = hs; a.T = T; a.reverse = reverse;
+  return vt_lstm_persistent_dispatch(a, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int vt_skinny_linear_f32(const float* x0, int64_t ld0, int K0, const float* x1, int64_t ld1, int K1, const void* w,

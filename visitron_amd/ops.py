@@ -698,6 +698,36 @@ def softdot_attention(target, context, mask=None, want_weighted=True, want_attn=
     return weighted, attn
 
 
+# The recurrence as ONE persistent launch (csrc/lstm_persistent.hip) where the shape allows (B <= 64, hs in 128 .. 1024):
+# VT_LSTM_PERSISTENT=0 keeps the one-launch-per-position form.  Scratch (exchange buffers + sync words) per (B, hs, device).
+LSTM_PERSISTENT = os.environ.get("VT_LSTM_PERSISTENT", "1") != "0"
+_lstm_ws = {}
+
+
+def _lstm_persistent(xproj, ldx_b, ldx_t, row_start, h, c, w_hh, lengths, seq_out, T, reverse):
+    """-> True if the persistent kernel served the call (h, c, seq_out updated); False: the caller issues the step launches
+    (shape outside the persistent form, or a workgroup ran out of its bounded wait -- h / c are then untouched)."""
+    B, hs = c.shape
+    if not LSTM_PERSISTENT or B > 64 or hs not in (128, 256, 512, 1024):
+        return False
+    lib = _lib.load()
+    key = (B, hs, str(c.device))
+    ws = _lstm_ws.get(key)
+    if ws is None:
+        ws = torch.empty(int(lib.vt_lstm_sequence_persistent_ws_bytes(B, hs)), dtype=torch.uint8, device=c.device)
+        _lstm_ws[key] = ws
+    with _timed("lstm_persistent", 2.0 * T * B * 4 * hs * hs, T * 4.0 * B * hs * 8):
+        rc = lib.vt_lstm_sequence_persistent_f32(
+            _ptr(xproj), ldx_b, ldx_t, _ptr(row_start), _ptr(h), _ptr(c), _ptr(w_hh), _ptr(lengths), _ptr(seq_out),
+            0 if seq_out is None else seq_out.stride(0), 0 if seq_out is None else seq_out.stride(1), B, hs, int(T),
+            1 if reverse else 0, _ptr(ws), ws.numel(), _stream())
+    if rc == -4:   # VT_ERR_UNSUPPORTED
+        return False
+    _lib.check(rc, "vt_lstm_sequence_persistent_f32")
+    # the timeout word (one 4-byte read-back; the recurrence's result is consumed right after anyway)
+    return int(ws[4:8].view(torch.int32).item()) == 0
+
+
 def lstm_sequence(xproj, h2, c, w_hh, T, lengths=None, seq_out=None, reverse=False):
     """One nn.LSTM direction over a padded batch: xproj fp32 [B,S,4*hs] (last dim contiguous), h2 = (h, scratch) two
     fp32 [B,hs] buffers (h: initial state in, final state out), c fp32 [B,hs] in place, seq_out fp32 [B,T,hs] view."""
@@ -712,6 +742,8 @@ def lstm_sequence(xproj, h2, c, w_hh, T, lengths=None, seq_out=None, reverse=Fal
         assert lengths.dtype == torch.int32 and lengths.shape == (B,) and lengths.is_contiguous()
     if seq_out is not None:
         assert seq_out.dtype == torch.float32 and seq_out.shape == (B, T, hs) and seq_out.stride(2) == 1
+    if _lstm_persistent(xproj, xproj.stride(0), xproj.stride(1), None, h2[0], c, w_hh, lengths, seq_out, T, reverse):
+        return h2[0]
     with _timed("lstm_step", 2.0 * T * B * 4 * hs * hs, T * (2.0 * 4 * hs * hs + 4.0 * B * hs * 8)):
         rc = _lib.load().vt_lstm_sequence_f32(
             _ptr(xproj), xproj.stride(0), xproj.stride(1), _ptr(h2[0]), _ptr(h2[1]), _ptr(c), _ptr(w_hh), _ptr(lengths),
@@ -754,6 +786,8 @@ def lstm_sequence_rows(xproj, row_start, h2, c, w_hh, T, lengths, seq_out=None, 
         assert s_.dtype == torch.float32 and s_.shape == (B, hs) and s_.is_contiguous()
     if seq_out is not None:
         assert seq_out.dtype == torch.float32 and seq_out.shape == (B, T, hs) and seq_out.stride(2) == 1
+    if _lstm_persistent(xproj, 0, xproj.stride(0), row_start, h2[0], c, w_hh, lengths, seq_out, T, reverse):
+        return h2[0]
     with _timed("lstm_step", 2.0 * T * B * 4 * hs * hs, T * (2.0 * 4 * hs * hs + 4.0 * B * hs * 8)):
         rc = _lib.load().vt_lstm_sequence_rows_f32(
             _ptr(xproj), xproj.stride(0), _ptr(row_start), _ptr(h2[0]), _ptr(h2[1]), _ptr(c), _ptr(w_hh), _ptr(lengths),
