@@ -180,7 +180,9 @@ def test_persistent_lstm_recurrence_equals_step_launches(dev, B, hs, S):
     from visitron_amd import ops
 
     g = torch.Generator().manual_seed(B + hs + S)
-    w_hh = (torch.randn(4 * hs, hs, generator=g) * (1.5 / hs ** 0.5)).to(torch.bfloat16).to(dev)
+    # (recurrent gain below 1: with a gain of 1.5 the dynamics are chaotic and the two kernels' last-bit differences -- the
+    # compiler contracts c' = f c + i g into fmas differently -- grow to 5e-4 over 40 steps)
+    w_hh = (torch.randn(4 * hs, hs, generator=g) * (0.6 / hs ** 0.5)).to(torch.bfloat16).to(dev)
     xp = torch.randn(B, S, 4 * hs, generator=g).to(dev)
     lens = torch.randint(1, S + 1, (B,), generator=g).sort(descending=True).values.to(torch.int32)
     lens[0] = S
