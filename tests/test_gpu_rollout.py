@@ -209,10 +209,27 @@ def test_persistent_lstm_recurrence_equals_step_launches(dev, B, hs, S):
                     outs[(mode, layout)] = (seq[:, :, :hs].clone(), h2[0].clone(), c.clone())
             finally:
                 ops.LSTM_PERSISTENT = True
+        # the recurrence written out in torch (bf16-rounded hidden state into the recurrent product, as both kernels do)
+        wf = w_hh.float().cpu()
+        h, c = h0.cpu().clone(), c0.cpu().clone()
+        want = torch.zeros(B, S, hs)
+        xc = xp.cpu()
+        for t in (range(S - 1, -1, -1) if reverse else range(S)):
+            gates = xc[:, t] + h.to(torch.bfloat16).float() @ wf.t()
+            i_, f_, g_, o_ = gates.chunk(4, 1)
+            cn = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
+            hn = torch.sigmoid(o_) * torch.tanh(cn)
+            act = (t < lens)[:, None]
+            h, c = torch.where(act, hn, h), torch.where(act, cn, c)
+            want[:, t] = torch.where(act, hn, torch.zeros_like(hn))
         for layout in ("padded", "rows"):
-            for k, name in enumerate(("sequence", "final h", "final c")):
-                check_close("persistent LSTM B=%d hs=%d S=%d rev=%d %s %s" % (B, hs, S, reverse, layout, name),
-                            outs[("persistent", layout)][k], outs[("steps", layout)][k], 2e-5)
+            for k, (name, ref) in enumerate((("sequence", want), ("final h", h), ("final c", c))):
+                tag = "persistent LSTM B=%d hs=%d S=%d rev=%d %s %s" % (B, hs, S, reverse, layout, name)
+                # a last-bit difference in a hidden value can flip its bf16 rounding (2^-9 relative) for the next step: the
+                # two kernels (same arithmetic, different fma contraction) drift apart by 1e-5 .. 1e-4 over tens of steps,
+                # each staying as close to the written-out recurrence as the other
+                check_close(tag + " vs steps", outs[("persistent", layout)][k], outs[("steps", layout)][k], 1e-3)
+                check_close(tag + " vs torch", outs[("persistent", layout)][k], ref, 5e-3)
         # and the zero padding past each length
         seqp = outs[("persistent", "padded")][0]
         for b in range(B):
