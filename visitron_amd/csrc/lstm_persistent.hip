@@ -106,6 +106,17 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmPersistArgs
   bool finished = true;
   for (int i = 0; i < a.T; ++i) {
     const int t = a.reverse ? a.T - 1 - i : i;
+    // this step's input projections do not depend on the exchange: requested before the wait, used after it
+    float xg[NBT][4];
+    bool act[NBT];
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt) {
+      const int b = 16 * bt + (lane & 15);
+      act[bt] = b < a.B && t < len[bt];
+      const long xr = a.xrow_start ? ((long)(act[bt] ? a.xrow_start[b] : 0) + t) * a.ldx_t : (long)b * a.ldx_b + (long)t * a.ldx_t;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xg[bt][g] = act[bt] ? a.xproj[xr + (long)g * hs + hid] : 0.f;
+    }
     // ---- wait until every workgroup has published epoch i + 1 (the state before this step) ----
     if (tid == 0) {
       const unsigned want = (unsigned)(i + 1) * (unsigned)nwg;
@@ -131,25 +142,27 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmPersistArgs
     for (int bt = 0; bt < NBT; ++bt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[bt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 hb[KS][NBT];
+    // (the asm loads below are invisible to the compiler's own vmcnt bookkeeping: nothing of its may be in flight
+    // around them -- drained before, everything drained after; all KS x NBT loads go out together: one round trip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int k = wave * kq + 32 * ks + kl;          // 8 consecutive units: inside one workgroup's 16
-      u32x4 hb[NBT];
-      // (the asm loads below are invisible to the compiler's own vmcnt bookkeeping: nothing of its may be in flight
-      // around them -- drained before, everything drained after)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int bt = 0; bt < NBT; ++bt)
-        hb[bt] = lp_load16_sc1(xb + ((long)(k >> 4) * Bp + 16 * bt + (lane & 15)) * 16 + (k & 15));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        hb[ks][bt] = lp_load16_sc1(xb + ((long)(k >> 4) * Bp + 16 * bt + (lane & 15)) * 16 + (k & 15));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int bt = 0; bt < NBT; ++bt) {
-        asm volatile("" : "+v"(hb[bt]));
+        asm volatile("" : "+v"(hb[ks][bt]));
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          acc[bt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][ks], __builtin_bit_cast(bf16x8, hb[bt]), acc[bt][g], 0, 0, 0);
+          acc[bt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g][ks], __builtin_bit_cast(bf16x8, hb[ks][bt]), acc[bt][g], 0, 0, 0);
       }
-    }
 #pragma unroll
     for (int bt = 0; bt < NBT; ++bt)
 #pragma unroll
@@ -161,14 +174,13 @@ __global__ __launch_bounds__(256, 1) void lstm_persistent_kernel(LstmPersistArgs
     for (int bt = 0; bt < NBT; ++bt) {
       const int b = 16 * bt + (lane & 15);
       if (b >= a.B) continue;
-      const bool active = t < len[bt];
+      const bool active = act[bt];
       float hn = hreg[bt];
       if (active) {
-        const long xr = a.xrow_start ? ((long)a.xrow_start[b] + t) * a.ldx_t : (long)b * a.ldx_b + (long)t * a.ldx_t;
         float gate[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float s = a.xproj[xr + (long)g * hs + hid];
+          float s = xg[bt][g];
 #pragma unroll
           for (int w = 0; w < 4; ++w) s += ((const float*)&part[w][bt][g][lane])[wave];
           gate[g] = s;
