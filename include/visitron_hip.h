@@ -55,9 +55,6 @@ void vt_debug_set_wgrad_kernel(int mode);
 void vt_gemm_tune(int M, int N, int K, int act, int variant);
 /* Tuning hook: 4 or 8 waves per workgroup in the attention backward (default 8). Process-global. */
 void vt_debug_set_attn_bwd_waves(int waves);
-/* Tuning/test hook for vt_attention_fwd_bf16: 0 automatic (4-wave workgroups of 128 queries when 8-wave ones would leave
- * the last round of the launch mostly empty), 4 / 8 forced. */
-void vt_debug_set_attn_fwd_waves(int waves);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R[M,N]);  A, W, R bf16; C bf16 (out_f32 == 0) or
  * fp32.  Replaces every nn.Linear call on the path -- query/key/value oscar/modeling_bert.py:43-45

@@ -182,20 +182,8 @@ def _attention_ref(q, k, v, add_mask):
     return torch.softmax(s, dim=-1) @ v
 
 
-@pytest.mark.parametrize("fwd_waves", [0, 4, 8])
 @pytest.mark.parametrize("B,S,nh", [(2, 228, 12), (3, 37, 2), (1, 300, 4), (2, 656, 2), (1, 128, 1), (2, 1, 2)])
-def test_attention_matches_fp32(dev, B, S, nh, fwd_waves):
-    """fwd_waves: 8-wave workgroups (256 queries), 4-wave ones (128 queries), or the launcher's choice."""
-    from visitron_amd import ops
-
-    ops.set_attn_fwd_waves(fwd_waves)
-    try:
-        _attention_matches_fp32(dev, B, S, nh)
-    finally:
-        ops.set_attn_fwd_waves(0)
-
-
-def _attention_matches_fp32(dev, B, S, nh):
+def test_attention_matches_fp32(dev, B, S, nh):
     from visitron_amd import ops
 
     g = torch.Generator().manual_seed(S)

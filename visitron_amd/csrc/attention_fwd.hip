@@ -57,12 +57,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// NW = waves per workgroup: 8 (256 queries per workgroup) or 4 (128 queries: twice the workgroups, each staging the
-// same K / V) -- the launcher takes 4 when 8-wave workgroups would leave the last round of the two-per-CU schedule
-// mostly empty (B = 64: 768 workgroups on 512 slots = 1.5 rounds paid as 2).
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attention_fwd_d64(AttnArgs a) {
-  constexpr int QB = 32 * NW;   // queries per workgroup
+__global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -72,8 +67,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_d64(AttnArgs a) {
   const int Smax = a.S, H = a.nh * 64;
   const int S = a.seq_len ? a.seq_len[b] : a.S;                       // this sequence's rows
   const long row0 = a.seq_start ? (long)a.seq_start[b] : (long)b * a.S;
-  if ((int)blockIdx.x * QB >= S) return;                              // uniform: a query block past a short sequence
-  const int q0 = blockIdx.x * QB + wave * 32;
+  if ((int)blockIdx.x * 256 >= S) return;                             // uniform: a query block past a short sequence
+  const int q0 = blockIdx.x * 256 + wave * 32;
   const bool wave_active = q0 < S;  // wave-uniform
 
   const bf16_t* base = a.qkv + row0 * a.ld_qkv + head * 64;
@@ -112,7 +107,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_d64(AttnArgs a) {
     if (kc > 0) __syncthreads();  // previous chunk fully consumed
 
     // ---- stage K, V (8-row pieces, one 1-KiB DMA each) and the additive bias ----
-    for (int j = wave; j < ntiles * 4; j += NW) {
+    for (int j = wave; j < ntiles * 4; j += 8) {
       const int row = 8 * j + (lane >> 3);
       int kr = kc + row;
       kr = kr < S ? kr : S - 1;
@@ -121,8 +116,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_d64(AttnArgs a) {
       glds16(src + H + ((cs ^ ((row >> 1) & 7)) << 3), smem + ATT_SK + j * 1024);
       glds16(src + 2 * H + ((cs ^ (((row >> 1) & 1) << 2)) << 3), smem + ATT_SV + j * 1024);
     }
-    for (int tk = tid; tk < ATT_KCHUNK; tk += 64 * NW) {
-      const int key = kc + tk;
+    if (tid < ATT_KCHUNK) {
+      const int key = kc + tid;
       float bias = -INFINITY;
       if (key < S) {
         float add = 0.f;
@@ -132,7 +127,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_d64(AttnArgs a) {
         }
         bias = add * LOG2E;   // exp2 domain (see the softmax below)
       }
-      ((float*)(smem + ATT_SBIAS))[tk] = bias;
+      ((float*)(smem + ATT_SBIAS))[tid] = bias;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -245,9 +240,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_fwd_d64(AttnArgs a) {
   ((u32x4*)(op + 32))[1] = w3;
 }
 
-static int g_attn_fwd_waves = 0;   // tuning hook: 0 automatic, 4 / 8 forced
-void vt_attn_fwd_set_waves(int w) { g_attn_fwd_waves = (w == 4 || w == 8) ? w : 0; }
-
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                               long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream,
                               const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr) {
@@ -256,9 +248,8 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
   if ((ld_qkv % 8) || (ld_ctx % 8) || ld_qkv < 3L * nh * 64 || ld_ctx < (long)nh * 64) return VT_ERR_BAD_ALIGN;
   if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return VT_ERR_BAD_ALIGN;
-  static VtLdsAttrOnce attr8, attr4;
-  if (!attr8.set((const void*)attention_fwd_d64<8>, ATT_LDS_BYTES)) return VT_ERR_HIP;
-  if (!attr4.set((const void*)attention_fwd_d64<4>, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  static VtLdsAttrOnce attr;
+  if (!attr.set((const void*)attention_fwd_d64, ATT_LDS_BYTES)) return VT_ERR_HIP;
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = (bf16_t*)ctx; a.lse = lse;
   a.ld_qkv = ld_qkv; a.ld_ctx = ld_ctx; a.B = B; a.S = S; a.nh = nh;
@@ -267,16 +258,8 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   if ((seq_start == nullptr) != (seq_len == nullptr)) return VT_ERR_NULL;
   if (seq_start && mask) return VT_ERR_UNSUPPORTED;   // compacted rows carry no masked keys
   a.seq_start = seq_start; a.seq_len = seq_len;
-  // two workgroups per CU either way (LDS): rounds of 2 * CUs slots.  8-wave workgroups cost a slot for one unit of
-  // time, 4-wave workgroups half a unit each but there are twice as many (and each stages K / V again: +5 % assumed)
-  const int slots = 2 * (vt_device_cus() > 0 ? vt_device_cus() : 256);
-  const long w8 = (long)((S + 255) / 256) * nh * B, w4 = (long)((S + 127) / 128) * nh * B;
-  const double t8 = (double)((w8 + slots - 1) / slots), t4 = 0.5 * 1.05 * (double)((w4 + slots - 1) / slots);
-  if (t4 < 0.95 * t8 && g_attn_fwd_waves != 8 || g_attn_fwd_waves == 4) {
-    hipLaunchKernelGGL(attention_fwd_d64<4>, dim3((S + 127) / 128, nh, B), dim3(256), ATT_LDS_BYTES, stream, a);
-  } else {
-    hipLaunchKernelGGL(attention_fwd_d64<8>, dim3((S + 255) / 256, nh, B), dim3(512), ATT_LDS_BYTES, stream, a);
-  }
+  dim3 grid((S + 255) / 256, nh, B);
+  hipLaunchKernelGGL(attention_fwd_d64, grid, dim3(512), ATT_LDS_BYTES, stream, a);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 

@@ -83,7 +83,6 @@ int vt_embed_layernorm_f32_dispatch(const int64_t* ids, const int64_t* type_ids,
 
 void vt_gemm_tune_set(int M, int N, int K, int act, int variant);
 void vt_attn_bwd_set_waves(int w);
-void vt_attn_fwd_set_waves(int w);
 
 #include "wgrad_common.hpp"
 int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream);
@@ -117,7 +116,6 @@ void vt_debug_set_wgrad_kernel(int mode) {
 }
 void vt_gemm_tune(int M, int N, int K, int act, int variant) { vt_gemm_tune_set(M, N, K, act, variant); }
 void vt_debug_set_attn_bwd_waves(int waves) { vt_attn_bwd_set_waves(waves); }
-void vt_debug_set_attn_fwd_waves(int waves) { vt_attn_fwd_set_waves(waves); }
 
 int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* R,
                    int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int act, int out_f32, int grp_rows,
@@ -647,4 +645,3 @@ int vt_encoder_backward_seq_bf16(const vt_layer_weights* layers, const vt_layer_
 }
 
 }  // extern "C"
- 

@@ -505,11 +505,6 @@ def set_attn_bwd_waves(waves):
     _lib.load().vt_debug_set_attn_bwd_waves(int(waves))
 
 
-def set_attn_fwd_waves(waves):
-    """Tuning/test hook: 4- or 8-wave attention forward workgroups (0: the launcher decides)."""
-    _lib.load().vt_debug_set_attn_fwd_waves(int(waves))
-
-
 def apply_dropout(x, drop):
     """x *= mask / (1-p) in place (bf16 [rows, cols], element index row * cols + col)."""
     _require_hip(x)
