@@ -465,3 +465,93 @@ def test_training_with_head_mask_and_per_query_masks(dev, what):
         out[0].backward()
         errs = {n: _rel(p_.grad, wg[n].grad) for n, p_ in prod.named_parameters()}
         assert max(errs.values()) < 0.02, max(errs, key=errs.get)
+
+
+# ------------------------------------------------------------------------------------------------
+# ragged and degenerate inputs (encoder.py:215-241; data_loader_pretrain.py:666-690): one position, no regions, a
+# sequence whose mask is zero everywhere (the reference then spreads the softmax evenly: every key carries the same
+# -10000), masks with holes, text at the position table's maximum -- inference and one training step
+# ------------------------------------------------------------------------------------------------
+def _ragged_cases(cfg):
+    from visitron_amd.synth import make_batch
+
+    cases = []
+    b = make_batch(cfg, 1, text_len=1, region_len=0, seed=1, with_labels=False)
+    cases.append(("one_position", b))
+    b = make_batch(cfg, 3, text_len=9, region_len=0, seed=2)
+    cases.append(("text_only", b))
+    b = make_batch(cfg, 4, text_len=14, region_len=6, seed=3)
+    b["attention_mask"][2].zero_()
+    cases.append(("one_sequence_fully_masked", b))
+    b = make_batch(cfg, 3, text_len=14, region_len=6, seed=4)
+    b["attention_mask"][:, 3] = 0
+    b["attention_mask"][1, 10:16] = 0
+    b["attention_mask"][1, 18] = 1
+    cases.append(("masks_with_holes", b))
+    b = make_batch(cfg, 2, text_len=cfg.max_position_embeddings, region_len=5, seed=5)
+    cases.append(("text_at_position_table_maximum", b))
+    b = make_batch(cfg, 2, text_len=10, region_len=4, seed=6)
+    b["attention_mask"] = b["attention_mask"].float() * 0.5 + 0.25          # arbitrary numeric masks are taken literally
+    cases.append(("fractional_mask_values", b))
+    return cases
+
+
+def test_ragged_and_degenerate_inputs_inference(dev):
+    from oracle.modeling import PreTrainOscar as OModel
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+
+    cfg = mini_config()
+    ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=29, device=dev)
+    for name, b in _ragged_cases(cfg):
+        trunk = {k: b[k] for k in TRUNK_KEYS if k in b}
+        with torch.no_grad():
+            want = ref.bert(**trunk)
+            got = prod.bert(**_to(trunk, dev))
+            want7 = ref(**{**b, **trunk}) if "img_feats" in trunk else None
+            got7 = prod(**_to({**b, **trunk}, dev)) if "img_feats" in trunk else None
+        torch.cuda.synchronize()
+        assert got[0].shape == want[0].shape, name
+        check_close("ragged %s sequence_output" % name, got[0], want[0], 5e-2)
+        check_close("ragged %s pooled_output" % name, got[1], want[1], 5e-2)
+        if want7 is not None:
+            for i in range(4):
+                assert _both_nan_or_close(got7[i], want7[i], 5e-2), (name, i, float(got7[i]), float(want7[i]))
+            for i in range(4, 7):
+                assert _both_nan_or_close(got7[i], want7[i], 1e-6), (name, i, float(got7[i]), float(want7[i]))
+
+
+def _both_nan_or_close(a, b, tol):
+    a, b = float(torch.as_tensor(a).detach()), float(torch.as_tensor(b).detach())
+    return (a != a and b != b) or abs(a - b) < tol
+
+
+def test_ragged_and_degenerate_inputs_training_step(dev):
+    from oracle.modeling import PreTrainOscar as OModel
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.training import PretrainEngine
+
+    cfg = mini_config()
+    ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=37, device=dev)
+    prod.train()
+    eng = PretrainEngine(prod)
+    wg = dict(ref.named_parameters())
+    for compact_min in (0, 1 << 30):                                        # compacted rows / padded rows
+        eng.compact_min_rows = compact_min
+        for name, b in _ragged_cases(cfg):
+            if "img_feats" not in b:
+                continue                                                    # PreTrainOscar's callers always pass regions
+            ref.zero_grad()
+            want = ref(**b)
+            want[0].backward()
+            got = eng.forward_backward(_to(b, dev))
+            torch.cuda.synchronize()
+            tag = "ragged train %s%s" % (name, "" if compact_min == 0 else " padded")
+            for i in range(4):
+                assert _both_nan_or_close(got[i], want[i], 5e-2), (tag, i, float(got[i]), float(want[i]))
+            for i in range(4, 7):
+                assert _both_nan_or_close(got[i], want[i], 1e-6), (tag, i, float(got[i]), float(want[i]))
+            errs = {n: _rel(p_.grad, wg[n].grad) for n, p_ in prod.named_parameters()}
+            worst = max(errs, key=errs.get)
+            check_close(tag + " grads worst rel-L2", errs[worst], 0.0, 0.03)
