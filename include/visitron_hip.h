@@ -259,6 +259,51 @@ int vt_softdot_attention_f32(const float* target, const float* context, int64_t 
                              const uint8_t* mask, float* weighted, float* attn, int B, int L, int D, int output_prob,
                              vt_stream_t stream);
 
+/* ---- rollout training: the gradients the reference gets from autograd through nn.LSTM / nn.LSTMCell / torch.bmm +
+ * Softmax when agent.py:493-518 back-propagates the rollout loss through OscarEncoder and AttnDecoderLSTM ---- */
+
+/* vt_lstm_step_f32 that also saves what the backward step needs: sv_gates fp32 [B, 4*hs] (the activated gates i, f, g,
+ * o), sv_c fp32 [B, hs] (the cell state before the step), sv_h bf16 [B, hs] (the hidden state before the step); rows of
+ * an inactive position (t >= lengths[b]) are left untouched.  Any of the three may be NULL. */
+int vt_lstm_step_train_f32(const float* xproj, int64_t ldx, const float* h_prev, float* h_out, float* c, const void* w_hh,
+                           const int32_t* lengths, float* seq_out, int64_t ld_seq, int B, int hs, int t, float* sv_gates,
+                           float* sv_c, void* sv_h, vt_stream_t stream);
+
+/* vt_lstm_sequence_f32 with the saves laid out like the padded sequence: sv_gates [B, S_sv, 4*hs] fp32, sv_c [B, S_sv, hs]
+ * fp32, sv_h [B, S_sv, hs] bf16 (S_sv >= T; the caller zeroes sv_h: it is the X operand of the W_hh gradient GEMM). */
+int vt_lstm_sequence_train_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float* h2_0, float* h2_1, float* c,
+                               const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
+                               int B, int hs, int T, int reverse, float* sv_gates, float* sv_c, void* sv_h, int64_t S_sv,
+                               vt_stream_t stream);
+
+/* One step of back-propagation through time at position t.  dh = d_out[b] (optional, row stride ld_dout) + the gradient
+ * arriving through h: dg_next[b] . W_hh (dg_next = the bf16 gate gradients of position t_next, the step that consumed
+ * h_t; w_hh_t = W_hh transposed, bf16 [hs, 4*hs]) for rows active at t_next, else dh_final[b] (NULL = zeros; also taken
+ * by every row when dg_next is NULL).  dc fp32 [B, hs] in place: in = gradient of the cell state after this step,
+ * out = before it.  dg_out bf16 (row stride ld_dg, 4*hs wide) receives the pre-activation gate gradients, zeros for
+ * rows with t >= lengths[b]; dg_out_f32: optional fp32 copy.  dg_out must not alias dg_next. */
+int vt_lstm_step_bwd_f32(const void* dg_next, int64_t ld_dgn, const void* w_hh_t, const float* dh_final, const float* d_out,
+                         int64_t ld_dout, float* dc, const float* sv_gates, int64_t ld_svg, const float* sv_c,
+                         int64_t ld_svc, void* dg_out, int64_t ld_dg, float* dg_out_f32, int64_t ld_dgf,
+                         const int32_t* lengths, int B, int hs, int t, int t_next, vt_stream_t stream);
+
+/* The T steps of vt_lstm_sequence_train_f32 backwards, T launches from one call.  d_seq_out: gradient of the padded
+ * output (strides ldd_b / ldd_t, optional); dh_final / dc: gradients of the final hidden / cell state ([B, hs]; dc is
+ * the running value afterwards = gradient of the initial cell state); dgates bf16 [B, S_sv, 4*hs], zeroed by the caller
+ * at positions >= T: afterwards dW_hh = dgates^T . sv_h, dW_ih = dgates^T . x and db via vt_wgrad_bf16, dx = dgates . W_ih
+ * via vt_linear_bf16_ex. */
+int vt_lstm_sequence_bwd_f32(const float* d_seq_out, int64_t ldd_b, int64_t ldd_t, const float* dh_final, float* dc,
+                             const void* w_hh_t, const int32_t* lengths, const float* sv_gates, const float* sv_c,
+                             void* dgates, int64_t S_sv, int B, int hs, int T, int reverse, vt_stream_t stream);
+
+/* Gradient of vt_softdot_attention_f32 (autograd through agent_models.py:336-352): d_weighted fp32 [B,D] and / or d_attn
+ * fp32 [B,L] (gradient of the returned probabilities when output_prob != 0, of the returned masked logits otherwise; a
+ * masked key's logit gradient is dropped like masked_fill_ does) -> d_target fp32 [B,D], d_context fp32 [B,L,D]
+ * contiguous (optional).  The probabilities are recomputed from target and context. */
+int vt_softdot_attention_bwd_f32(const float* target, const float* context, int64_t ld_batch, int64_t ld_row,
+                                 const uint8_t* mask, const float* d_weighted, const float* d_attn, float* d_target,
+                                 float* d_context, int B, int L, int D, int output_prob, vt_stream_t stream);
+
 /* out[c, r] = in[r, c] (bf16; R, C multiples of 8): refreshes the transposed weight copies (W^T of every nn.Linear on the
  * path, oscar/modeling_bert.py:43-45,94,119,120) that the
  * dgrad GEMMs consume (vt_layer_weights_t). */

@@ -95,6 +95,18 @@ SIGNATURES = {
                                      c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_lstm_sequence_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_lstm_step_train_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vt_lstm_sequence_train_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                           c_void_p, c_int64, c_void_p]),
+    "vt_lstm_step_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                     c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int,
+                                     c_int, c_void_p]),
+    "vt_lstm_sequence_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_softdot_attention_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_softdot_attention_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          c_int, c_int, c_void_p]),
     "vt_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),

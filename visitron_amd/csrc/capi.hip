@@ -88,6 +88,8 @@ void vt_attn_bwd_set_waves(int w);
 int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream);
 #include "rollout_args.hpp"
 int vt_lstm_step_dispatch(const LstmStepArgs& a, hipStream_t stream);
+int vt_lstm_step_bwd_dispatch(const LstmBwdArgs& a, hipStream_t stream);
+int vt_softdot_bwd_dispatch(const SoftDotBwdArgs& a, hipStream_t stream);
 int vt_softdot_dispatch(const SoftDotArgs& a, hipStream_t stream);
 int vt_skinny_linear_dispatch(const SkinnyArgs& a, hipStream_t stream);
 
@@ -230,21 +232,32 @@ int vt_ce_double_softmax_rows(const float* z, int64_t ldz, const int64_t* y, flo
   return vt_ce_double_softmax_dispatch(z, ldz, y, loss_row, amax, dz, lddz, rows, V, Vpad, scale, (hipStream_t)stream);
 }
 
-int vt_lstm_step_f32(const float* xproj, int64_t ldx, const float* h_prev, float* h_out, float* c, const void* w_hh,
-                     const int32_t* lengths, float* seq_out, int64_t ld_seq, int B, int hs, int t, vt_stream_t stream) {
+int vt_lstm_step_train_f32(const float* xproj, int64_t ldx, const float* h_prev, float* h_out, float* c, const void* w_hh,
+                           const int32_t* lengths, float* seq_out, int64_t ld_seq, int B, int hs, int t, float* sv_gates,
+                           float* sv_c, void* sv_h, vt_stream_t stream) {
   LstmStepArgs a;
   a.xproj = xproj; a.ldx = ldx; a.h_prev = h_prev; a.h_out = h_out; a.c = c; a.w_hh = (const bf16_t*)w_hh;
   a.lengths = lengths; a.seq_out = seq_out; a.ld_seq = ld_seq; a.B = B; a.hs = hs; a.t = t;
   a.xrow_start = nullptr; a.ldx_row = 0;
+  a.sv_gates = sv_gates; a.ld_svg = 4L * hs; a.sv_c = sv_c; a.ld_svc = hs; a.sv_h = (bf16_t*)sv_h; a.ld_svh = hs;
   return vt_lstm_step_dispatch(a, (hipStream_t)stream);
 }
 
+int vt_lstm_step_f32(const float* xproj, int64_t ldx, const float* h_prev, float* h_out, float* c, const void* w_hh,
+                     const int32_t* lengths, float* seq_out, int64_t ld_seq, int B, int hs, int t, vt_stream_t stream) {
+  return vt_lstm_step_train_f32(xproj, ldx, h_prev, h_out, c, w_hh, lengths, seq_out, ld_seq, B, hs, t, nullptr, nullptr,
+                                nullptr, stream);
+}
+
+// sv_*: optional training saves laid out like the padded sequence, [B, S_sv, .] (position t of row b at (b * S_sv + t))
 static int lstm_sequence_impl(const float* xproj, int64_t ldx_b, int64_t ldx_t, float* h2_0, float* h2_1, float* c,
                               const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
-                              int B, int hs, int T, int reverse, vt_stream_t stream, const int32_t* xrow_start) {
+                              int B, int hs, int T, int reverse, vt_stream_t stream, const int32_t* xrow_start,
+                              float* sv_gates = nullptr, float* sv_c = nullptr, void* sv_h = nullptr, int64_t S_sv = 0) {
   if (!xproj || !h2_0 || !h2_1 || !c || !w_hh) return VT_ERR_NULL;
   if (T <= 0) return VT_ERR_BAD_SHAPE;
   if (xrow_start && !lengths) return VT_ERR_NULL;   // compacted rows exist only below a sequence's length
+  if (sv_gates && (!sv_c || !sv_h || S_sv < T)) return VT_ERR_BAD_SHAPE;
   float* hb[2] = {h2_0, h2_1};
   for (int i = 0; i < T; ++i) {
     const int t = reverse ? T - 1 - i : i;
@@ -253,6 +266,9 @@ static int lstm_sequence_impl(const float* xproj, int64_t ldx_b, int64_t ldx_t, 
     a.xproj = xrow_start ? xproj : xproj + (int64_t)t * ldx_t; a.ldx = ldx_b; a.h_prev = hb[i & 1]; a.h_out = hb[(i + 1) & 1]; a.c = c;
     a.w_hh = (const bf16_t*)w_hh; a.lengths = lengths; a.seq_out = seq_out ? seq_out + (int64_t)t * lds_t : nullptr;
     a.ld_seq = lds_b; a.B = B; a.hs = hs; a.t = t;
+    a.sv_gates = sv_gates ? sv_gates + (int64_t)t * 4 * hs : nullptr; a.ld_svg = S_sv * 4 * hs;
+    a.sv_c = sv_gates ? sv_c + (int64_t)t * hs : nullptr; a.ld_svc = S_sv * hs;
+    a.sv_h = sv_gates ? (bf16_t*)sv_h + (int64_t)t * hs : nullptr; a.ld_svh = S_sv * hs;
     const int rc = vt_lstm_step_dispatch(a, (hipStream_t)stream);
     if (rc != VT_OK) return rc;
   }
@@ -269,6 +285,52 @@ int vt_lstm_sequence_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float
                          int B, int hs, int T, int reverse, vt_stream_t stream) {
   return lstm_sequence_impl(xproj, ldx_b, ldx_t, h2_0, h2_1, c, w_hh, lengths, seq_out, lds_b, lds_t, B, hs, T, reverse,
                             stream, nullptr);
+}
+
+int vt_lstm_sequence_train_f32(const float* xproj, int64_t ldx_b, int64_t ldx_t, float* h2_0, float* h2_1, float* c,
+                               const void* w_hh, const int32_t* lengths, float* seq_out, int64_t lds_b, int64_t lds_t,
+                               int B, int hs, int T, int reverse, float* sv_gates, float* sv_c, void* sv_h, int64_t S_sv,
+                               vt_stream_t stream) {
+  if (!sv_gates || !sv_c || !sv_h) return VT_ERR_NULL;
+  return lstm_sequence_impl(xproj, ldx_b, ldx_t, h2_0, h2_1, c, w_hh, lengths, seq_out, lds_b, lds_t, B, hs, T, reverse,
+                            stream, nullptr, sv_gates, sv_c, sv_h, S_sv);
+}
+
+int vt_lstm_step_bwd_f32(const void* dg_next, int64_t ld_dgn, const void* w_hh_t, const float* dh_final, const float* d_out,
+                         int64_t ld_dout, float* dc, const float* sv_gates, int64_t ld_svg, const float* sv_c,
+                         int64_t ld_svc, void* dg_out, int64_t ld_dg, float* dg_out_f32, int64_t ld_dgf,
+                         const int32_t* lengths, int B, int hs, int t, int t_next, vt_stream_t stream) {
+  LstmBwdArgs a;
+  a.dg_next = (const bf16_t*)dg_next; a.ld_dgn = ld_dgn; a.w_hh_t = (const bf16_t*)w_hh_t; a.dh_final = dh_final;
+  a.d_out = d_out; a.ld_dout = ld_dout; a.dc = dc; a.sv_gates = sv_gates; a.ld_svg = ld_svg; a.sv_c = sv_c;
+  a.ld_svc = ld_svc; a.dg_out = (bf16_t*)dg_out; a.ld_dg = ld_dg; a.dg_out_f32 = dg_out_f32; a.ld_dgf = ld_dgf;
+  a.lengths = lengths; a.B = B; a.hs = hs; a.t = t; a.t_next = t_next;
+  return vt_lstm_step_bwd_dispatch(a, (hipStream_t)stream);
+}
+
+// Back-propagation through the T steps of vt_lstm_sequence_train_f32, in the reverse of the order they ran.  d_seq_out
+// [B, ., hs] (strides ldd_b, ldd_t; may be null), dh_final / dc [B, hs] (dc: in = gradient of the final cell state, it is
+// the running value afterwards), saves and dgates [B, S_sv, .]; dgates must arrive zeroed at positions >= T.
+int vt_lstm_sequence_bwd_f32(const float* d_seq_out, int64_t ldd_b, int64_t ldd_t, const float* dh_final, float* dc,
+                             const void* w_hh_t, const int32_t* lengths, const float* sv_gates, const float* sv_c,
+                             void* dgates, int64_t S_sv, int B, int hs, int T, int reverse, vt_stream_t stream) {
+  if (!dc || !w_hh_t || !sv_gates || !sv_c || !dgates) return VT_ERR_NULL;
+  if (T <= 0 || S_sv < T) return VT_ERR_BAD_SHAPE;
+  bf16_t* dg = (bf16_t*)dgates;
+  for (int i = T - 1; i >= 0; --i) {
+    const int t = reverse ? T - 1 - i : i;                     // the forward's i-th step ran position t
+    const int t_next = (i == T - 1) ? -1 : (reverse ? t - 1 : t + 1);
+    LstmBwdArgs a;
+    a.dg_next = t_next < 0 ? nullptr : dg + (int64_t)t_next * 4 * hs; a.ld_dgn = S_sv * 4 * hs;
+    a.w_hh_t = (const bf16_t*)w_hh_t; a.dh_final = dh_final;
+    a.d_out = d_seq_out ? d_seq_out + (int64_t)t * ldd_t : nullptr; a.ld_dout = ldd_b; a.dc = dc;
+    a.sv_gates = sv_gates + (int64_t)t * 4 * hs; a.ld_svg = S_sv * 4 * hs; a.sv_c = sv_c + (int64_t)t * hs; a.ld_svc = S_sv * hs;
+    a.dg_out = dg + (int64_t)t * 4 * hs; a.ld_dg = S_sv * 4 * hs; a.dg_out_f32 = nullptr; a.ld_dgf = 0;
+    a.lengths = lengths; a.B = B; a.hs = hs; a.t = t; a.t_next = t_next;
+    const int rc = vt_lstm_step_bwd_dispatch(a, (hipStream_t)stream);
+    if (rc != VT_OK) return rc;
+  }
+  return VT_OK;
 }
 
 int vt_lstm_sequence_rows_f32(const float* xproj, int64_t ldx_row, const int32_t* row_start, float* h2_0, float* h2_1,
@@ -299,6 +361,16 @@ int vt_skinny_linear_f32(const float* x0, int64_t ld0, int K0, const float* x1, 
   a.x0 = x0; a.ld0 = ld0; a.K0 = K0; a.x1 = x1; a.ld1 = ld1; a.K1 = K1; a.w = (const bf16_t*)w; a.ldw = ldw;
   a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.Kpad = Kpad; a.act = act;
   return vt_skinny_linear_dispatch(a, (hipStream_t)stream);
+}
+
+int vt_softdot_attention_bwd_f32(const float* target, const float* context, int64_t ld_batch, int64_t ld_row,
+                                 const uint8_t* mask, const float* d_weighted, const float* d_attn, float* d_target,
+                                 float* d_context, int B, int L, int D, int output_prob, vt_stream_t stream) {
+  SoftDotBwdArgs a;
+  a.target = target; a.context = context; a.ld_batch = ld_batch; a.ld_row = ld_row; a.mask = mask;
+  a.d_weighted = d_weighted; a.d_attn = d_attn; a.d_target = d_target; a.d_context = d_context;
+  a.B = B; a.L = L; a.D = D; a.output_prob = output_prob;
+  return vt_softdot_bwd_dispatch(a, (hipStream_t)stream);
 }
 
 int vt_softdot_attention_f32(const float* target, const float* context, int64_t ld_batch, int64_t ld_row,

@@ -73,8 +73,16 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     gate[g] = s;
   }
   if (active) {
-    const float cn = sigmoidf_(gate[1]) * a.c[e] + sigmoidf_(gate[0]) * tanhf_(gate[2]);
-    const float hn = sigmoidf_(gate[3]) * tanhf_(cn);
+    const float ig = sigmoidf_(gate[0]), fg = sigmoidf_(gate[1]), gg = tanhf_(gate[2]), og = sigmoidf_(gate[3]);
+    const float cp = a.c[e];
+    const float cn = fg * cp + ig * gg;
+    const float hn = og * tanhf_(cn);
+    if (a.sv_gates) {   // training: what the backward step needs (lstm_step_bwd_kernel)
+      float* sg = a.sv_gates + (long)brow * a.ld_svg + hid;
+      sg[0] = ig; sg[hs] = fg; sg[2 * hs] = gg; sg[3 * hs] = og;
+    }
+    if (a.sv_c) a.sv_c[(long)brow * a.ld_svc + hid] = cp;
+    if (a.sv_h) a.sv_h[(long)brow * a.ld_svh + hid] = f32_to_bf16(a.h_prev[e]);
     a.c[e] = cn;
     a.h_out[e] = hn;
     if (a.seq_out) a.seq_out[(long)brow * a.ld_seq + hid] = hn;
@@ -90,6 +98,84 @@ int vt_lstm_step_dispatch(const LstmStepArgs& a, hipStream_t stream) {
   if (a.h_prev == a.h_out) return VT_ERR_UNSUPPORTED;
   if ((((uintptr_t)a.h_prev) | ((uintptr_t)a.w_hh)) & 15) return VT_ERR_BAD_ALIGN;
   hipLaunchKernelGGL(lstm_step_kernel, dim3(a.hs / 16, (a.B + 15) / 16), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One step of back-propagation through time for that recurrence (the reference gets it from autograd through nn.LSTM /
+// nn.LSTMCell: agent.py:493-518 back-propagates the rollout loss through OscarEncoder and AttnDecoderLSTM).
+// Position t, with the gradient flowing in from the step that consumed h_t (position t_next):
+//   dh  = d_out[t] + (row active at t_next ? dgates[t_next] . W_hh : dh_final)
+//   dc += dh * o * (1 - tanh(c')^2);  do = dh * tanh(c');  di = dc * g;  dg = dc * i;  df = dc * c_prev;  dc <- dc * f
+//   dgates[t] = (di i(1-i), df f(1-f), dg (1-g^2), do o(1-o))     (pre-activation; bf16: it is the MFMA operand of the
+//   next step here and of the weight-gradient / input-gradient GEMMs afterwards)
+// A row with t >= lengths[b] passed its state through: its dgates are zero and dc stays.
+// Same decomposition as the forward step: workgroup = 16 hidden units x 16 batch rows, the 4 waves split K = 4*hs,
+// W_hh^T rows on the MFMA A port, the bf16 gate gradients of t_next on the B port.
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs a) {
+  __shared__ f32x4 part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+  const int hs = a.hs;
+  const int kl = (lane >> 4) * 8;
+  const int brow = b0 + (lane & 15);
+  const bool bvalid = brow < a.B;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (a.dg_next) {
+    const bf16_t* gp = a.dg_next + (long)(bvalid ? brow : 0) * a.ld_dgn + wave * hs + kl;
+    const bf16_t* wp = a.w_hh_t + (long)(h0 + (lane & 15)) * (4L * hs) + wave * hs + kl;
+    for (int k = 0; k < hs; k += 32) {
+      u32x4 gv = *(const u32x4*)(gp + k);
+      if (!bvalid) gv = (u32x4){0u, 0u, 0u, 0u};
+      const u32x4 wv = *(const u32x4*)(wp + k);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, gv), acc, 0, 0, 0);
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  const int r = wave;
+  const int hid = h0 + 4 * (lane >> 4) + r;
+  if (!bvalid) return;
+  const long e = (long)brow * hs + hid;
+  const int len = a.lengths ? a.lengths[brow] : 0x7fffffff;
+  bf16_t* dg = a.dg_out + (long)brow * a.ld_dg + hid;
+  float* dgf = a.dg_out_f32 ? a.dg_out_f32 + (long)brow * a.ld_dgf + hid : nullptr;
+  float d[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.t < len) {
+    float dh;
+    if (a.dg_next && a.t_next >= 0 && a.t_next < len) {
+      dh = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) dh += ((const float*)&part[w][lane])[r];
+    } else {
+      dh = a.dh_final ? a.dh_final[e] : 0.f;
+    }
+    if (a.d_out) dh += a.d_out[(long)brow * a.ld_dout + hid];
+    const float* sg = a.sv_gates + (long)brow * a.ld_svg + hid;
+    const float ig = sg[0], fg = sg[hs], gg = sg[2 * hs], og = sg[3 * hs];
+    const float cp = a.sv_c[(long)brow * a.ld_svc + hid];
+    const float tc = tanhf_(fg * cp + ig * gg);
+    const float dc = a.dc[e] + dh * og * (1.0f - tc * tc);
+    d[0] = dc * gg * ig * (1.0f - ig);
+    d[1] = dc * cp * fg * (1.0f - fg);
+    d[2] = dc * ig * (1.0f - gg * gg);
+    d[3] = dh * tc * og * (1.0f - og);
+    a.dc[e] = dc * fg;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    dg[(long)g * hs] = f32_to_bf16(d[g]);
+    if (dgf) dgf[(long)g * hs] = d[g];
+  }
+}
+
+int vt_lstm_step_bwd_dispatch(const LstmBwdArgs& a, hipStream_t stream) {
+  if (!a.w_hh_t || !a.dc || !a.sv_gates || !a.sv_c || !a.dg_out) return VT_ERR_NULL;
+  if (a.B <= 0 || a.hs <= 0 || (a.hs % 128) != 0 || a.t < 0) return VT_ERR_BAD_SHAPE;
+  if ((const void*)a.dg_next == (const void*)a.dg_out) return VT_ERR_UNSUPPORTED;   // other workgroups still read it
+  if (a.dg_next && ((a.ld_dgn & 7) || (((uintptr_t)a.dg_next) & 15))) return VT_ERR_BAD_ALIGN;
+  if (((uintptr_t)a.w_hh_t) & 15) return VT_ERR_BAD_ALIGN;
+  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(a.hs / 16, (a.B + 15) / 16), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
@@ -214,6 +300,125 @@ int vt_softdot_dispatch(const SoftDotArgs& a, hipStream_t stream) {
       hipFuncSetAttribute((const void*)softdot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return VT_ERR_HIP;
   hipLaunchKernelGGL(softdot_kernel, dim3(a.B), dim3(64 * SD_WAVES), lds, stream, a, parts);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient of the same block (autograd through agent_models.py:336-352 in the reference): with p = softmax(masked logits),
+//   dp[l]   = context[l] . d_weighted  (+ d_attn[l] when the probabilities were returned)
+//   dlog[l] = p[l] (dp[l] - sum_j p[j] dp[j])  (+ d_attn[l] when the masked logits were returned; a masked key gets 0:
+//             masked_fill_ cut it out of the graph)
+//   d_target = sum_l dlog[l] context[l];   d_context[l] = p[l] d_weighted + dlog[l] target
+// One workgroup per batch row; logits and dp in LDS from one pass over the context, d_target / d_context from a second.
+__global__ __launch_bounds__(64 * SD_WAVES) void softdot_bwd_kernel(SoftDotBwdArgs a, int parts) {
+  extern __shared__ float sl[];          // [L] logits -> p | [L] dp -> dlog | [2 * SD_WAVES] scratch | [parts][D] partial sums
+  float* ql = sl + a.L;
+  float* red = ql + a.L;
+  float* psum = red + 2 * SD_WAVES;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* ctx = a.context + (long)b * a.ld_batch;
+  const float* tg = a.target + (long)b * a.D;
+  const float* dw = a.d_weighted ? a.d_weighted + (long)b * a.D : nullptr;
+  const float* da = a.d_attn ? a.d_attn + (long)b * a.L : nullptr;
+  const unsigned char* mk = a.mask ? a.mask + (long)b * a.L : nullptr;
+  for (int l = wave; l < a.L; l += SD_WAVES) {
+    const float* row = ctx + (long)l * a.ld_row;
+    float s = 0.f, q = 0.f;
+    for (int d = lane; d < a.D; d += 64) {
+      const float c = row[d];
+      s += c * tg[d];
+      if (dw) q += c * dw[d];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (lane == 0) {
+      if (mk && mk[l]) s = -INFINITY;
+      sl[l] = s;
+      ql[l] = q + ((da && a.output_prob) ? da[l] : 0.f);
+    }
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int l = tid; l < a.L; l += 64 * SD_WAVES) m = fmaxf(m, sl[l]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < SD_WAVES; ++w) m = fmaxf(m, red[w]);
+  float z = 0.f;
+  for (int l = tid; l < a.L; l += 64 * SD_WAVES) {
+    const float e = expf(sl[l] - m);
+    sl[l] = e;
+    z += e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+  if (lane == 0) red[SD_WAVES + wave] = z;
+  __syncthreads();
+  z = 0.f;
+#pragma unroll
+  for (int w = 0; w < SD_WAVES; ++w) z += red[SD_WAVES + w];
+  const float inv = 1.0f / z;
+  __syncthreads();                       // red is reused below
+  float pd = 0.f;
+  for (int l = tid; l < a.L; l += 64 * SD_WAVES) {
+    const float p = sl[l] * inv;
+    sl[l] = p;
+    pd += p * ql[l];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pd += __shfl_xor(pd, o, 64);
+  if (lane == 0) red[wave] = pd;
+  __syncthreads();
+  pd = 0.f;
+#pragma unroll
+  for (int w = 0; w < SD_WAVES; ++w) pd += red[w];
+  for (int l = tid; l < a.L; l += 64 * SD_WAVES) {
+    float g = sl[l] * (ql[l] - pd);
+    if (da && !a.output_prob && !(mk && mk[l])) g += da[l];
+    ql[l] = g;
+  }
+  __syncthreads();
+  // thread = (key part, column): d_target partial sums over every parts-th key, d_context written on the way
+  const int cols = (64 * SD_WAVES) / parts;
+  const int part = tid / cols;
+  if (part < parts) {
+    for (int d = tid % cols; d < a.D; d += cols) {
+      float acc = 0.f;
+      const float t = tg[d], w = dw ? dw[d] : 0.f;
+      float* dcx = a.d_context ? a.d_context + ((long)b * a.L) * a.D + d : nullptr;
+      for (int l = part; l < a.L; l += parts) {
+        const float g = ql[l];
+        if (g != 0.f) acc += g * ctx[(long)l * a.ld_row + d];    // a masked key has g == 0 exactly (and may hold anything)
+        if (dcx) dcx[(long)l * a.D] = sl[l] * w + g * t;
+      }
+      psum[(long)part * a.D + d] = acc;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < a.D; c += 64 * SD_WAVES) {
+    float acc = 0.f;
+    for (int q = 0; q < parts; ++q) acc += psum[(long)q * a.D + c];
+    a.d_target[(long)b * a.D + c] = acc;
+  }
+}
+
+int vt_softdot_bwd_dispatch(const SoftDotBwdArgs& a, hipStream_t stream) {
+  if (!a.target || !a.context || !a.d_target) return VT_ERR_NULL;
+  if (!a.d_weighted && !a.d_attn) return VT_ERR_NULL;
+  if (a.B <= 0 || a.L <= 0 || a.D <= 0 || a.L > 8192) return VT_ERR_BAD_SHAPE;
+  int parts = (64 * SD_WAVES) / a.D;                 // key parts when a row has fewer columns than the workgroup threads
+  if (parts > 8) parts = 8;
+  if (parts > a.L) parts = a.L;
+  if (parts < 1) parts = 1;
+  const size_t lds = (2 * (size_t)a.L + 2 * SD_WAVES + (size_t)parts * a.D) * sizeof(float);
+  if (lds > 160 * 1024) return VT_ERR_BAD_SHAPE;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)softdot_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VT_ERR_HIP;
+  hipLaunchKernelGGL(softdot_bwd_kernel, dim3(a.B), dim3(64 * SD_WAVES), lds, stream, a, parts);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 

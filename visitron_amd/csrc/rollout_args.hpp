@@ -13,6 +13,37 @@ struct LstmStepArgs {
   int B, hs, t;
   const int* xrow_start;             // optional (compacted xproj rows): row of (b, t) = xrow_start[b] + t, xproj then
   long ldx_row;                      // points at row 0 and ldx_row is the row stride (ldx unused)
+  // training (all optional, rows of an inactive position are left as the caller initialised them):
+  float* sv_gates; long ld_svg;      // activated gates i, f, g, o of this step: row b at sv_gates + b * ld_svg, 4*hs wide
+  float* sv_c; long ld_svc;          // the cell state BEFORE this step, hs wide
+  bf16_t* sv_h; long ld_svh;         // the hidden state BEFORE this step as bf16 (the weight gradient's operand), hs wide
+};
+
+// One step of back-propagation through time for the same recurrence (lstm_step_bwd_kernel).
+struct LstmBwdArgs {
+  const bf16_t* dg_next; long ld_dgn;   // gate gradients of the step that consumed this step's h (row b at + b * ld), or null
+  const bf16_t* w_hh_t;                 // W_hh transposed: [hs, 4*hs] bf16
+  const float* dh_final;                // [B, hs] or null (zeros): gradient of the final hidden state
+  const float* d_out; long ld_dout;     // gradient of the padded output at this position (row b at + b * ld) or null
+  float* dc;                            // [B, hs] running cell-state gradient (initialised to the final state's), in place
+  const float* sv_gates; long ld_svg;   // what the forward step saved
+  const float* sv_c; long ld_svc;
+  bf16_t* dg_out; long ld_dg;           // this step's gate gradients (pre-activation), 4*hs wide, zeros for inactive rows
+  float* dg_out_f32; long ld_dgf;       // optional fp32 copy (the cell's dense backward reads it)
+  const int* lengths;                   // [B] or null
+  int B, hs, t, t_next;                 // t_next: position of dg_next (a row inactive there takes dh_final instead)
+};
+
+struct SoftDotBwdArgs {
+  const float* target;          // [B, D]
+  const float* context;         // [B, L, D] (strides as the forward)
+  long ld_batch, ld_row;
+  const unsigned char* mask;    // [B, L] or null
+  const float* d_weighted;      // [B, D] or null
+  const float* d_attn;          // [B, L] or null: gradient of the returned probabilities (output_prob) / masked logits
+  float* d_target;              // [B, D]
+  float* d_context;             // [B, L, D] contiguous, or null
+  int B, L, D, output_prob;
 };
 
 struct SoftDotArgs {

@@ -297,6 +297,16 @@ def _dense_residual_ln(mod, hidden_states, input_tensor):
     return y.view(shp).to(input_tensor.dtype)
 
 
+def _centered_mask(mask_f32):
+    """A per-key mask [B, S] shifted so that each sequence's largest value is 1: (1 - m) * -10000 then changes by one
+    constant per sequence, which a softmax over the keys does not see (encoder.py:238-241; oscar/modeling_bert.py:55-58).
+    A 0/1 mask with a kept key is unchanged bit for bit.  What it is for: the rollout caller's `~mask` of a uint8 tensor
+    (254 / 255, agent_models.py:267) turns into biases of +2.53e6 / +2.54e6, where fp32 resolves 0.25 -- the reference's
+    own softmax is then computed on scores rounded to that grid, and a log-sum-exp of that size cannot carry the backward's
+    recomputation.  Shifted, the same mask is 0 / 1 and every kernel sees well-scaled numbers."""
+    return (mask_f32 - mask_f32.amax(dim=1, keepdim=True) + 1.0).contiguous()
+
+
 def _additive_mask_2d(attention_mask, B, S):
     """The additive extended mask CaptionBertEncoder.forward receives: [B,1,1,S] (or [B,S]) -> contiguous fp32 [B,S];
     [B,1,S,S] (the reference's 3-D attention_mask, encoder.py:226-229) -> contiguous fp32 [B,S,S]."""
@@ -802,7 +812,7 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                     raise RuntimeError(
                         "attention_mask shape %s does not match [batch, history+text+region] = [%d, %d]"
                         % (tuple(attention_mask.shape), B, Sh + S))
-                mask_f32 = attention_mask.to(device=dev, dtype=torch.float32).contiguous()
+                mask_f32 = _centered_mask(attention_mask.to(device=dev, dtype=torch.float32))
             elif attention_mask.dim() == 3:   # encoder.py:228-229 + :238-241: per-query mask -> additive bias [B,S,S]
                 if attention_mask.shape != (B, S, S):
                     raise RuntimeError("3-D attention_mask shape %s does not match [%d, %d, %d]"
@@ -884,6 +894,25 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, head_mask=None,
                 img_feats=None, img_location_embeddings=None, encoder_history_states=None):
+        if self.training and torch.is_grad_enabled() and not _is_fp32(self) \
+                and any(p.requires_grad for p in self.parameters()):
+            # a caller that trains THROUGH the trunk (the rollout's OscarEncoder, agent.py:493-518): one autograd node
+            # backed by the engine's forward / backward kernels
+            if encoder_history_states or self.encoder.output_attentions or self.encoder.output_hidden_states:
+                raise NotImplementedError("trunk-level training serves the plain forward (no encoder_history_states, "
+                                          "output_attentions or output_hidden_states)")
+            ops._require_hip(input_ids)
+            from .training import autograd_trunk_forward
+
+            batch = dict(input_ids=input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask,
+                         position_ids=position_ids)
+            if attention_mask is not None and attention_mask.dim() not in (2, 3):
+                raise NotImplementedError
+            if img_feats is not None:
+                batch.update(img_feats=img_feats, img_location_embeddings=img_location_embeddings)
+            dt = next(self.parameters()).dtype
+            seq, pooled = autograd_trunk_forward(self, batch, head_mask)
+            return (seq.to(dt), pooled.to(dt))
         outs, pooled, x, B, S = self.run_trunk(input_ids, token_type_ids, attention_mask, position_ids, head_mask,
                                                img_feats, img_location_embeddings, encoder_history_states)
         dt = next(self.parameters()).dtype

@@ -797,6 +797,116 @@ def lstm_sequence_rows(xproj, row_start, h2, c, w_hh, T, lengths, seq_out=None, 
     return h2[0]
 
 
+# ---- rollout training (agent.py:493-518 back-propagates through OscarEncoder / AttnDecoderLSTM) ------------------------
+def lstm_step_train(xproj, h_prev, c_prev, w_hh):
+    """nn.LSTMCell step that keeps what its backward needs -> (h_1, c_1, saved) with saved = (gates fp32 [B,4hs] activated
+    i f g o, c_prev fp32, h_prev bf16)."""
+    _require_hip(xproj, h_prev, c_prev, w_hh)
+    B, hs = h_prev.shape
+    assert xproj.dtype == torch.float32 and xproj.shape == (B, 4 * hs) and xproj.stride(1) == 1
+    assert w_hh.dtype == BF16 and w_hh.shape == (4 * hs, hs) and w_hh.is_contiguous()
+    assert h_prev.dtype == torch.float32 and h_prev.is_contiguous() and c_prev.shape == (B, hs)
+    dev = xproj.device
+    h1 = torch.empty((B, hs), dtype=torch.float32, device=dev)
+    c1 = c_prev.detach().to(torch.float32).clone()
+    sv_g = torch.empty((B, 4 * hs), dtype=torch.float32, device=dev)
+    sv_c = torch.empty((B, hs), dtype=torch.float32, device=dev)
+    sv_h = torch.empty((B, hs), dtype=BF16, device=dev)
+    rc = _lib.load().vt_lstm_step_train_f32(_ptr(xproj), xproj.stride(0), _ptr(h_prev), _ptr(h1), _ptr(c1), _ptr(w_hh), None,
+                                            None, 0, B, hs, 0, _ptr(sv_g), _ptr(sv_c), _ptr(sv_h), _stream())
+    _lib.check(rc, "vt_lstm_step_train_f32")
+    return h1, c1, (sv_g, sv_c, sv_h)
+
+
+def lstm_step_bwd(dh, dc, saved, w_hh_t):
+    """Gradient of one nn.LSTMCell step: dh / dc fp32 [B,hs] (either may be None) -> (dgates fp32 [B,4hs], dgates bf16,
+    dc_prev fp32 [B,hs]).  The caller turns dgates into dx / dh_prev (dense products) and dW (vt_wgrad_bf16)."""
+    sv_g, sv_c, _ = saved
+    B, hs = sv_c.shape
+    dev = sv_c.device
+    _require_hip(dh, dc, sv_g, w_hh_t)
+    assert w_hh_t.dtype == BF16 and w_hh_t.shape == (hs, 4 * hs) and w_hh_t.is_contiguous()
+    dcb = torch.zeros((B, hs), dtype=torch.float32, device=dev) if dc is None else dc.detach().float().contiguous().clone()
+    dhf = None if dh is None else dh.detach().float().contiguous()
+    dg16 = torch.empty((B, 4 * hs), dtype=BF16, device=dev)
+    dg32 = torch.empty((B, 4 * hs), dtype=torch.float32, device=dev)
+    rc = _lib.load().vt_lstm_step_bwd_f32(None, 0, _ptr(w_hh_t), _ptr(dhf), None, 0, _ptr(dcb), _ptr(sv_g), sv_g.stride(0),
+                                          _ptr(sv_c), sv_c.stride(0), _ptr(dg16), dg16.stride(0), _ptr(dg32),
+                                          dg32.stride(0), None, B, hs, 0, -1, _stream())
+    _lib.check(rc, "vt_lstm_step_bwd_f32")
+    return dg32, dg16, dcb
+
+
+def lstm_sequence_train(xproj, w_hh, T, lengths=None, reverse=False):
+    """One nn.LSTM direction from a zero initial state (agent_models.py:238-254) over xproj fp32 [B,S,4hs], keeping what the
+    backward needs -> (seq_out fp32 [B,T,hs], h_T, c_T, saved)."""
+    _require_hip(xproj, w_hh, lengths)
+    B, S, G = xproj.shape
+    hs = G // 4
+    assert xproj.dtype == torch.float32 and xproj.stride(2) == 1 and 0 < T <= S
+    assert w_hh.dtype == BF16 and w_hh.shape == (4 * hs, hs) and w_hh.is_contiguous()
+    dev = xproj.device
+    h2 = (torch.zeros((B, hs), dtype=torch.float32, device=dev), torch.empty((B, hs), dtype=torch.float32, device=dev))
+    c = torch.zeros((B, hs), dtype=torch.float32, device=dev)
+    seq_out = torch.empty((B, T, hs), dtype=torch.float32, device=dev)
+    sv_g = torch.empty((B, S, 4 * hs), dtype=torch.float32, device=dev)
+    sv_c = torch.empty((B, S, hs), dtype=torch.float32, device=dev)
+    sv_h = torch.zeros((B, S, hs), dtype=BF16, device=dev)     # zeros: rows the recurrence never ran multiply zero dgates
+    with _timed("lstm_step", 2.0 * T * B * 4 * hs * hs, T * (2.0 * 4 * hs * hs + 4.0 * B * hs * 8)):
+        rc = _lib.load().vt_lstm_sequence_train_f32(
+            _ptr(xproj), xproj.stride(0), xproj.stride(1), _ptr(h2[0]), _ptr(h2[1]), _ptr(c), _ptr(w_hh), _ptr(lengths),
+            _ptr(seq_out), seq_out.stride(0), seq_out.stride(1), B, hs, int(T), 1 if reverse else 0, _ptr(sv_g), _ptr(sv_c),
+            _ptr(sv_h), S, _stream())
+    _lib.check(rc, "vt_lstm_sequence_train_f32")
+    return seq_out, h2[0], c, (sv_g, sv_c, sv_h)
+
+
+def lstm_sequence_bwd(d_seq_out, dh_final, dc_final, saved, w_hh_t, T, lengths=None, reverse=False):
+    """Back-propagation through the T steps of lstm_sequence_train -> dgates bf16 [B,S,4hs] (pre-activation gate gradients
+    = the gradient of xproj; zero where a row was inactive)."""
+    sv_g, sv_c, _ = saved
+    B, S, hs = sv_c.shape
+    dev = sv_c.device
+    _require_hip(d_seq_out, dh_final, dc_final, w_hh_t, lengths)
+    assert w_hh_t.dtype == BF16 and w_hh_t.shape == (hs, 4 * hs) and w_hh_t.is_contiguous()
+    if d_seq_out is not None:
+        d_seq_out = d_seq_out.detach().float()
+        if d_seq_out.stride(2) != 1:
+            d_seq_out = d_seq_out.contiguous()
+        assert d_seq_out.shape == (B, T, hs)
+    dhf = None if dh_final is None else dh_final.detach().float().contiguous()
+    dc = torch.zeros((B, hs), dtype=torch.float32, device=dev) if dc_final is None else dc_final.detach().float().contiguous().clone()
+    dg = torch.zeros((B, S, 4 * hs), dtype=BF16, device=dev)
+    with _timed("lstm_step_bwd", 2.0 * T * B * 4 * hs * hs, T * (2.0 * 4 * hs * hs + 4.0 * B * hs * 8)):
+        rc = _lib.load().vt_lstm_sequence_bwd_f32(
+            _ptr(d_seq_out), 0 if d_seq_out is None else d_seq_out.stride(0), 0 if d_seq_out is None else d_seq_out.stride(1),
+            _ptr(dhf), _ptr(dc), _ptr(w_hh_t), _ptr(lengths), _ptr(sv_g), _ptr(sv_c), _ptr(dg), S, B, hs, int(T),
+            1 if reverse else 0, _stream())
+    _lib.check(rc, "vt_lstm_sequence_bwd_f32")
+    return dg
+
+
+def softdot_attention_bwd(target, context, mask, d_weighted, d_attn, output_prob, want_d_context):
+    """Gradient of softdot_attention -> (d_target fp32 [B,D], d_context fp32 [B,L,D] | None)."""
+    _require_hip(target, context, mask, d_weighted, d_attn)
+    B, L, D = context.shape
+    assert target.dtype == torch.float32 and target.shape == (B, D) and target.is_contiguous()
+    assert context.dtype == torch.float32 and context.stride(2) == 1
+    m8 = None
+    if mask is not None:
+        m8 = (mask if mask.dtype == torch.uint8 else mask.to(torch.bool).view(torch.uint8)).contiguous()
+    dw = None if d_weighted is None else d_weighted.detach().float().contiguous()
+    da = None if d_attn is None else d_attn.detach().float().contiguous()
+    d_target = torch.empty((B, D), dtype=torch.float32, device=target.device)
+    d_ctx = torch.empty((B, L, D), dtype=torch.float32, device=target.device) if want_d_context else None
+    with _timed("softdot_attention_bwd", 6.0 * B * L * D, 12.0 * B * L * D):
+        rc = _lib.load().vt_softdot_attention_bwd_f32(
+            _ptr(target), _ptr(context), context.stride(0), context.stride(1), _ptr(m8), _ptr(dw), _ptr(da), _ptr(d_target),
+            _ptr(d_ctx), B, L, D, 1 if output_prob else 0, _stream())
+    _lib.check(rc, "vt_softdot_attention_bwd_f32")
+    return d_target, d_ctx
+
+
 # ---- fp32 parity path (csrc/fp32_path.hip): every operand, activation and accumulation in fp32 -----------------------
 def _f32ok(*ts):
     for t in ts:

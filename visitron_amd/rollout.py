@@ -1,11 +1,13 @@
-"""The rollout caller around the trunk, served by the HIP library -- inference only.
+"""The rollout caller around the trunk, served by the HIP library -- inference, and since round 2
+training: with grad enabled every block below is an autograd node whose backward is HIP kernels too
+(visitron_amd/rollout_autograd.py; the trunk node is the pretrain engine's forward / backward).
 
 Drop-ins for tasks/viewpoint_select/agent_models.py: `OscarEncoder` (:192-310), `SoftDotAttention` (:313-357) and
 `AttnDecoderLSTM` (:360-428): same constructor arguments, parameter names (so the reference's state dicts load:
 `lstm.weight_ih_l0`, `feat_att_layer.linear_in.weight`, ...), argument meaning and return values.  `nn.LSTM` /
 `nn.LSTMCell` are kept as parameter containers only; their arithmetic runs in vt_lstm_sequence_f32 / vt_lstm_step_f32,
-the dot attentions in vt_softdot_attention_f32, every dense projection in the NT GEMM.  No CPU fallback; training-mode
-dropout and autograd through these modules are not served (NotImplementedError / detached outputs).
+the dot attentions in vt_softdot_attention_f32, every dense projection in the NT GEMM.  No CPU fallback.  nn.Dropout
+(the modules' `drop`) is a torch elementwise op on the device in training mode.
 """
 import torch
 import torch.nn as nn
@@ -17,10 +19,11 @@ from .ops import ACT_NONE, ACT_TANH, BF16, round_up
 SKINNY_ROWS = 256   # up to this many rows the dense layers take vt_skinny_linear_f32 instead of the tiled GEMM
 
 
-def _no_train_dropout(module, p):
-    if module.training and p > 0.0:
-        raise NotImplementedError("the rollout modules are served for inference (model.eval()); dropout p=%g in "
-                                  "training mode is not implemented in the HIP path" % p)
+def _grad_mode(module, *tensors):
+    """True when the call must build an autograd graph: grad enabled and a parameter or an input requires grad."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(p.requires_grad for p in module.parameters()) or any(t is not None and t.requires_grad for t in tensors)
 
 
 class _Packed(object):
@@ -75,6 +78,7 @@ class SoftDotAttention(nn.Module):
         self.linear_out = nn.Linear(query_dim + ctx_dim, query_dim, bias=False)
         self.tanh = nn.Tanh()
         self._pk = _Packed()
+        self._pk_t = _Packed()
 
     def _weights(self):
         return self._pk.get((self.linear_in.weight, self.linear_out.weight),
@@ -85,8 +89,28 @@ class SoftDotAttention(nn.Module):
         target = _dense((h,), w_in).contiguous()
         return ops.softdot_attention(target, _ctx_f32(context), mask, want_weighted, want_attn, output_prob)
 
+    def _train_packs(self):
+        from .rollout_autograd import packed_linear
+
+        return self._pk_t.get((self.linear_in.weight, self.linear_out.weight),
+                              lambda: (packed_linear(self.linear_in.weight), packed_linear(self.linear_out.weight)))
+
+    def _forward_autograd(self, h, context, mask, output_tilde, output_prob):
+        """The same block as autograd nodes (training): dense -> softdot -> cat -> dense(tanh)."""
+        from . import rollout_autograd as ra
+
+        p_in, p_out = self._train_packs()
+        target = ra.dense(h, self.linear_in.weight, None, ACT_NONE, p_in)
+        weighted, attn = ra.softdot(target, context, mask, output_prob)
+        if output_tilde:
+            h_tilde = ra.dense(torch.cat((weighted, h.float()), 1), self.linear_out.weight, None, ACT_TANH, p_out)
+            return h_tilde, attn
+        return weighted, attn
+
     def forward(self, h, context, mask=None, output_tilde=True, output_prob=True):
         ops._require_hip(h, context)
+        if _grad_mode(self, h, context):
+            return self._forward_autograd(h, context, mask, output_tilde, output_prob)
         weighted, attn = self.attend(h, context, mask, True, True, output_prob)
         if output_tilde:
             h_tilde = _dense((weighted, h), self._weights()[1], act=ACT_TANH)
@@ -116,6 +140,7 @@ class AttnDecoderLSTM(nn.Module):
         self.attention_layer = SoftDotAttention(hidden_size, hidden_size)
         self.candidate_att_layer = SoftDotAttention(hidden_size, feature_size)
         self._pk = _Packed()
+        self._pk_t = _Packed()
 
     def _weights(self):
         emb, cell = self.embedding[0], self.lstm
@@ -127,9 +152,30 @@ class AttnDecoderLSTM(nn.Module):
 
         return self._pk.get((emb.weight, emb.bias, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh), build)
 
+    def _forward_autograd(self, action, feature, cand_feat, prev_h1, c_0, ctx, ctx_mask):
+        """agent_models.py:406-425 as autograd nodes (training; `drop` follows the module's training flag)."""
+        from . import rollout_autograd as ra
+
+        emb, cell = self.embedding[0], self.lstm
+        packs = self._pk_t.get((emb.weight, cell.weight_ih, cell.weight_hh),
+                               lambda: (ra.packed_linear(emb.weight), ra.packed_lstm(cell.weight_ih, cell.weight_hh)))
+        action_embeds = self.drop(ra.dense(action, emb.weight, emb.bias, ACT_TANH, packs[0]))          # :406-409
+        prev_h1_drop = self.drop(prev_h1)
+        attn_feat, _ = self.feat_att_layer(prev_h1_drop, feature, output_tilde=False)                   # :411-412
+        concat_input = torch.cat((action_embeds, attn_feat), 1)                                         # :414-416
+        h_1, c_1 = ra.lstm_cell(concat_input, prev_h1, c_0, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh,
+                                packs[1])                                                               # :417
+        h_tilde, _ = self.attention_layer(self.drop(h_1), ctx, ctx_mask)                                # :419-420
+        _, logit = self.candidate_att_layer(self.drop(h_tilde), cand_feat, output_prob=False)           # :423-425
+        return h_1, c_1, logit, h_tilde
+
     def forward(self, action, feature, cand_feat, h_0, prev_h1, c_0, ctx, ctx_mask=None):
         ops._require_hip(action, feature, cand_feat, prev_h1, c_0, ctx)
-        _no_train_dropout(self, self.drop.p)
+        if _grad_mode(self, action, feature, cand_feat, prev_h1, c_0, ctx):
+            return self._forward_autograd(action, feature, cand_feat, prev_h1, c_0, ctx, ctx_mask)
+        if self.training and self.drop.p > 0.0:
+            raise NotImplementedError("training-mode dropout without an autograd graph (torch.no_grad() in train()) is not "
+                                      "served; call eval() for inference")
         w = self._weights()
         action_embeds = _dense((action,), w["w_emb"], w["b_emb"], act=ACT_TANH)                 # :406
         attn_feat, _ = self.feat_att_layer.attend(prev_h1, feature, None, True, False, True)      # :411-412
@@ -164,6 +210,7 @@ class OscarEncoder(nn.Module):
         self.encoder_lstm2decoder_ht = nn.Linear(hidden_size * self.num_directions, decoder_hidden_size)
         self.encoder_lstm2decoder_ct = nn.Linear(hidden_size * self.num_directions, decoder_hidden_size)
         self._pk = _Packed()
+        self._pk_t = _Packed()
         self.compact_rows = True    # run the trunk on the positions below `lengths` only (when the mask agrees)
 
     def _weights(self):
@@ -184,9 +231,39 @@ class OscarEncoder(nn.Module):
 
         return self._pk.get(ps, build)
 
+    def _forward_autograd(self, inputs, lens, lens_dev, T, att_mask, position_ids, token_type_ids):
+        """agent_models.py:256-310 as autograd nodes (training): the trunk node (the pretrain engine's forward / backward),
+        one lstm_sequence node per direction, two dense nodes for the decoder's initial state."""
+        from . import rollout_autograd as ra
+
+        L, D, hs = self.lstm, self.num_directions, self.hidden_size
+        outputs = self.bert(inputs, token_type_ids=token_type_ids, attention_mask=att_mask, position_ids=position_ids)
+        output = outputs[0].float()
+        names = [""] + (["_reverse"] if D == 2 else [])
+        ps = [getattr(L, n + sfx) for sfx in names for n in ("weight_ih_l0", "weight_hh_l0")]
+        packs = self._pk_t.get(ps + [self.encoder_lstm2decoder_ht.weight, self.encoder_lstm2decoder_ct.weight], lambda: dict(
+            dirs=[ra.packed_lstm(getattr(L, "weight_ih_l0" + sfx), getattr(L, "weight_hh_l0" + sfx)) for sfx in names],
+            ht=ra.packed_linear(self.encoder_lstm2decoder_ht.weight), ct=ra.packed_linear(self.encoder_lstm2decoder_ct.weight)))
+        outs = []
+        for d, sfx in enumerate(names):
+            outs.append(ra.lstm_sequence(output, getattr(L, "weight_ih_l0" + sfx), getattr(L, "weight_hh_l0" + sfx),
+                                         getattr(L, "bias_ih_l0" + sfx), getattr(L, "bias_hh_l0" + sfx), lens_dev, T,
+                                         d == 1, packs["dirs"][d]))
+        if D == 2:                                                     # :289-297: (reverse, forward) order for the states
+            ctx = torch.cat((outs[0][0], outs[1][0]), 2)
+            h_t = torch.cat((outs[1][1], outs[0][1]), 1)
+            c_t = torch.cat((outs[1][2], outs[0][2]), 1)
+        else:
+            ctx, h_t, c_t = outs[0]
+        decoder_init = ra.dense(h_t, self.encoder_lstm2decoder_ht.weight, self.encoder_lstm2decoder_ht.bias, ACT_TANH,
+                                packs["ht"])                                                            # :299
+        if hs * D != self.dec_hidden_size:
+            c_t = ra.dense(c_t, self.encoder_lstm2decoder_ct.weight, self.encoder_lstm2decoder_ct.bias, ACT_NONE,
+                           packs["ct"])                                                                 # :300-301
+        return self.drop(ctx), decoder_init, c_t                                                        # :303-307
+
     def forward(self, inputs, lengths, mask, position_ids=None, token_type_ids=None):
         ops._require_hip(inputs)
-        _no_train_dropout(self, self.drop.p)
         if self.num_layers != 1:
             raise NotImplementedError("stacked encoder LSTMs (num_layers > 1) are not served")
         if self.reverse_input:
@@ -202,6 +279,11 @@ class OscarEncoder(nn.Module):
         T = int(lens.max())
         dev = inputs.device
         lens_dev = lens.to(dev, torch.int32)
+        if _grad_mode(self):
+            return self._forward_autograd(inputs, lens, lens_dev, T, att_mask, position_ids, token_type_ids)
+        if self.training and self.drop.p > 0.0:
+            raise NotImplementedError("training-mode dropout without an autograd graph (torch.no_grad() in train()) is not "
+                                      "served; call eval() for inference")
         # Only the first lengths[b] positions of a sequence are read below (pack_padded_sequence, :286).  When those are
         # exactly the unmasked ones (mask = 1 on padding, agent.py:181) the trunk runs on them alone: compacted rows,
         # no masked keys -- the same values at the positions that are read.

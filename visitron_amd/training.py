@@ -25,7 +25,7 @@ import os
 import torch.nn.functional as F
 
 from . import _lib, ops
-from .modeling import PreTrainOscar, _i64, invalidate_packed_weights
+from .modeling import BertImgModelwithLocationEmbeds, PreTrainOscar, _i64, invalidate_packed_weights
 from .ops import ACT_MUL, ACT_GELU, ACT_NONE, ACT_TANH, BF16, round_up
 
 ALIGN = 64  # elements; keeps every parameter view 256-byte aligned inside the slabs
@@ -73,6 +73,12 @@ class FlatParams(object):
                 p.grad = self.g[o:o + cnt].view(p.shape)
             self.off[n] = (o, cnt, tuple(p.shape))
         self.refresh_mirror()
+
+    def owns_params(self):
+        """False once something re-pointed a parameter's storage (another engine built over the same parameters -- the
+        full model's and the bare trunk's -- or model.to / load with assign): this slab is then stale."""
+        base = self.p.data_ptr()
+        return all(p.data_ptr() == base + 4 * o for _, p, o, _, _ in self.entries)
 
     def refresh_mirror(self):
         self.mirror.copy_(self.p)
@@ -151,11 +157,31 @@ def _ctx_raw(self, layer):
 _TrainBuffers.ctx_raw = _ctx_raw
 
 
+class _TrunkOnly(torch.nn.Module):
+    """A bare BertImgModelwithLocationEmbeds presented to the engine under the parameter names it has inside a
+    PreTrainOscar ("bert." + name): train.py:47 hands `model.bert` to the rollout agent, which trains through it."""
+
+    def __init__(self, trunk):
+        super().__init__()
+        self.bert = trunk
+        self.config = trunk.config
+
+
+class _State(object):
+    """The locals of a trunk forward that its backward reads (PretrainEngine._trunk_fwd / _trunk_bwd)."""
+
+    def __init__(self, d):
+        self.__dict__.update({k: v for k, v in d.items() if k != "self"})
+
+
 class PretrainEngine(object):
     def __init__(self, model, lr=5e-5, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999), correct_bias=True,
                  schedule="linear", warmup_steps=0, t_total=20000, process_group=None, bucket_mb=64,
                  loss_scale_by_world=True, attach_grads=True, grad_comm_dtype=None):
-        assert isinstance(model, PreTrainOscar)
+        if isinstance(model, BertImgModelwithLocationEmbeds):
+            model = _TrunkOnly(model)    # trunk-level training (the rollout's OscarEncoder owns just the trunk)
+        assert isinstance(model, (PreTrainOscar, _TrunkOnly))
+        self.has_heads = isinstance(model, PreTrainOscar)
         cfg = model.config
         if cfg.hidden_size != 64 * cfg.num_attention_heads:
             raise NotImplementedError("the HIP training path serves head size 64")
@@ -212,6 +238,7 @@ class PretrainEngine(object):
         # (B=36: 3 036 against 3 352 samples/s; B=64 x 656 and B=256 x 228: +6 %)
         self.compact_min_rows = 16384
         self._side_stream = None
+        self._fwd_serial = 0      # forwards issued: a backward must belong to the latest one (the buffers are shared)
         self._build_tables()
 
     # ------------------------------------------------------------------------------ tables
@@ -256,15 +283,16 @@ class PretrainEngine(object):
             for k, v in wt.items():
                 setattr(self.wt_tab[i], k, v.data_ptr())
         # non-encoder weights: bf16 mirror views and transposed copies
-        V = m.mlmhead.predictions.decoder.weight.shape[0]
-        C = m.token_head[0].weight.shape[0]
-        A = m.next_action.linear.weight.shape[0]
-        self.Vp, self.Cp, self.Ap = round_up(V, 64), round_up(C, 64), round_up(A, 64)
         dev = f.p.device
-        self.head_t = dict(
-            dec=torch.zeros((H, self.Vp), dtype=BF16, device=dev), tr=torch.empty((H, H), dtype=BF16, device=dev),
-            tok=torch.zeros((H, self.Cp), dtype=BF16, device=dev), act=torch.zeros((H, self.Ap), dtype=BF16, device=dev),
-            pool=torch.empty((H, H), dtype=BF16, device=dev))
+        self.head_t = dict(pool=torch.empty((H, H), dtype=BF16, device=dev))
+        if self.has_heads:
+            V = m.mlmhead.predictions.decoder.weight.shape[0]
+            C = m.token_head[0].weight.shape[0]
+            A = m.next_action.linear.weight.shape[0]
+            self.Vp, self.Cp, self.Ap = round_up(V, 64), round_up(C, 64), round_up(A, 64)
+            self.head_t.update(
+                dec=torch.zeros((H, self.Vp), dtype=BF16, device=dev), tr=torch.empty((H, H), dtype=BF16, device=dev),
+                tok=torch.zeros((H, self.Cp), dtype=BF16, device=dev), act=torch.zeros((H, self.Ap), dtype=BF16, device=dev))
         D = m.bert.img_dim
         self.kpad = round_up(D + 128, 64)
         self.w_img = torch.zeros((H, self.kpad), dtype=BF16, device=dev)
@@ -297,16 +325,14 @@ class PretrainEngine(object):
             for t, wt in self.wt:
                 pairs += [(t["w_qkv"], wt["wt_qkv"]), (t["w_ao"], wt["wt_ao"]), (t["w_in"], wt["wt_in"]),
                           (t["w_out"], wt["wt_out"])]
-            pairs += [(self._mirror(m.mlmhead.predictions.transform.dense.weight), self.head_t["tr"]),
-                      (self._mirror(m.bert.pooler.dense.weight), self.head_t["pool"]),
-                      (self._mirror(m.mlmhead.predictions.decoder.weight), self.head_t["dec"]),
-                      (self._mirror(m.token_head[0].weight), self.head_t["tok"]),
-                      (self._mirror(m.next_action.linear.weight), self.head_t["act"])]
+            pairs += [(self._mirror(m.bert.pooler.dense.weight), self.head_t["pool"])]
+            if self.has_heads:
+                pairs += [(self._mirror(m.mlmhead.predictions.transform.dense.weight), self.head_t["tr"]),
+                          (self._mirror(m.mlmhead.predictions.decoder.weight), self.head_t["dec"]),
+                          (self._mirror(m.token_head[0].weight), self.head_t["tok"]),
+                          (self._mirror(m.next_action.linear.weight), self.head_t["act"])]
             self._wt_batch = ops.TransposeBatch(pairs)
         self._wt_batch.run()
-        V = m.mlmhead.predictions.decoder.weight.shape[0]
-        C = m.token_head[0].weight.shape[0]
-        A = m.next_action.linear.weight.shape[0]
         self.w_img[:, :D].copy_(self._mirror(m.bert.img_embedding.weight))
         self.w_img[:, D:D + 128].copy_(self._mirror(m.bert.location_embeds.weight))
         torch.add(m.bert.img_embedding.bias.detach(), m.bert.location_embeds.bias.detach(), out=self.b_img)
@@ -338,12 +364,10 @@ class PretrainEngine(object):
         return max(0.0, float(self.t_total - s) / float(max(1.0, self.t_total - self.warmup_steps)))
 
     # ------------------------------------------------------------------------------ forward + backward
-    def forward_backward(self, batch, grad_scale=1.0, accumulate=False, comm=None, head_mask=None):
-        """One forward + backward; gradients of `grad_scale * loss` land in the flat slab (p.grad).
-        Returns the reference's 7-tuple (0-d fp32 tensors).  attention_mask: [B, S] (any numeric values, the reference's
-        (1 - m) * -10000 arithmetic) or the reference's 3-D form [B, S, S] (encoder.py:228-229); head_mask as the
-        reference takes it (encoder.py:248-265; the layer loop then runs op by op: the head scaling sits between the
-        attention kernel and the output projection in both directions)."""
+    def _trunk_fwd(self, batch, head_mask, labels, token_labels, training, allow_compact, comm=None):
+        """The trunk's forward (embeddings, region projection, encoder layers, pooler) with every activation the backward
+        needs kept in the (B, S) buffer set; returns the step's state (a namespace of the locals below).  labels /
+        token_labels (optional): the supervised rows are located here, where the host synchronises anyway."""
         m, cfg, f = self.model, self.cfg, self.flat
         self.refresh_derived_weights()
         f.reattach_grads()
@@ -354,7 +378,6 @@ class PretrainEngine(object):
         R = 0 if img is None else img.shape[1]
         S, H, I, nh, L = T + R, cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
         M = B * S
-        labels, token_labels, next_action = batch["labels"], batch["token_labels"], batch.get("next_action")
         am = batch.get("attention_mask")
         mask = None if am is None else am.to(torch.float32).contiguous()
         mask_additive = False
@@ -365,7 +388,9 @@ class PretrainEngine(object):
             mask_additive = True
         elif mask is not None and mask.shape != (B, S):
             raise RuntimeError("attention_mask must be [batch, text+region]")
-        from .modeling import _head_scale
+        from .modeling import _centered_mask, _head_scale
+        if mask is not None and not mask_additive:
+            mask = _centered_mask(mask)   # one constant per sequence off the additive bias: same softmax, well-scaled numbers
         hs = _head_scale(head_mask, cfg.num_hidden_layers, cfg.num_attention_heads, ids.device)
         if hs is not None and comm is not None:
             raise NotImplementedError("head_mask together with the chunked data-parallel backward")
@@ -374,8 +399,8 @@ class PretrainEngine(object):
         emb = m.bert.embeddings
         eps = emb.LayerNorm.variance_epsilon
         # dropout (nn.Dropout follows the module's training flag): same (p, seed) in forward and backward
-        p_h = float(cfg.hidden_dropout_prob) if m.training else 0.0
-        p_a = float(cfg.attention_probs_dropout_prob) if m.training else 0.0
+        p_h = float(cfg.hidden_dropout_prob) if training else 0.0
+        p_a = float(cfg.attention_probs_dropout_prob) if training else 0.0
         seed = (self.drop_seed_base + self.fb_count) & 0xFFFFFFFFFFFFFFFF
         self.fb_count += 1
         self.last_drop_seed = seed
@@ -387,11 +412,14 @@ class PretrainEngine(object):
                             emb.LayerNorm.bias.detach(), eps, bufs.x0, S, err_flag=err, drop=(p_h, seed, ops.SITE_EMB))
         # supervised-row compaction: torch.nonzero synchronises with the host, and here the GPU is all but idle
         # (start of the step) instead of between the encoder and the heads
-        lab = labels.reshape(-1)
-        idx_w = torch.nonzero(lab != -1).flatten()
-        tl = token_labels.reshape(-1)
-        idx_t = torch.nonzero(tl != -1).flatten()
-        Ml, Mt = int(idx_w.numel()), int(idx_t.numel())
+        lab = tl = idx_w = idx_t = None
+        Ml = Mt = 0
+        if labels is not None:
+            lab = labels.reshape(-1)
+            idx_w = torch.nonzero(lab != -1).flatten()
+            tl = token_labels.reshape(-1)
+            idx_t = torch.nonzero(tl != -1).flatten()
+            Ml, Mt = int(idx_w.numel()), int(idx_t.numel())
         # out-of-range input_ids / position_ids / token_type_ids: the reference's embedding lookup raises IndexError.
         # Checked before anything indexes the gradient tables with those ids (no extra wait: the nonzero calls above
         # have already drained the stream).
@@ -407,7 +435,8 @@ class PretrainEngine(object):
         # hidden states reach no loss and their gradient is exactly 0 -- drop them from every row-wise kernel.  Needs a
         # 0/1 mask, the [CLS] position and every supervised position kept; otherwise the padded path below.
         lay = None
-        if self.compact_rows and mask is not None and mask.dim() == 2 and hs is None and M >= self.compact_min_rows:
+        if allow_compact and self.compact_rows and mask is not None and mask.dim() == 2 and hs is None \
+                and M >= self.compact_min_rows:
             keep = mask != 0
             cand = ops.SeqLayout(keep)
             bad = ((mask != 0) & (mask != 1)).any() | (~keep[:, 0]).any()
@@ -435,8 +464,10 @@ class PretrainEngine(object):
                 ops.autotune_linear(hb, self.Vp, H, device=dev, out_f32=True)
                 ops.autotune_linear(hb, H, self.Vp, device=dev)
                 self._tuned_rows.add(("head", hb))
-        rows_w = idx_w if lay is None else lay.inverse.index_select(0, idx_w)   # supervised rows in the layout in use
-        rows_t = idx_t if lay is None else lay.inverse.index_select(0, idx_t)
+        rows_w = rows_t = None
+        if labels is not None:   # supervised rows in the layout in use
+            rows_w = idx_w if lay is None else lay.inverse.index_select(0, idx_w)
+            rows_t = idx_t if lay is None else lay.inverse.index_select(0, idx_t)
         cls_rows = (torch.arange(B, device=dev) * S) if lay is None else lay.start.to(torch.int64)
 
         # ---------------- forward ----------------
@@ -477,6 +508,24 @@ class PretrainEngine(object):
             pooled = ops.linear(cls_seq, self._mirror(m.bert.pooler.dense.weight), m.bert.pooler.dense.bias.detach(),
                                 act=ACT_TANH, out_f32=True)
         pooled_bf = pooled.to(BF16)
+
+        self._fwd_serial += 1
+        st = _State(locals())
+        st.serial = self._fwd_serial
+        return st
+
+    def forward_backward(self, batch, grad_scale=1.0, accumulate=False, comm=None, head_mask=None):
+        """One forward + backward; gradients of `grad_scale * loss` land in the flat slab (p.grad).
+        Returns the reference's 7-tuple (0-d fp32 tensors).  attention_mask: [B, S] (any numeric values, the reference's
+        (1 - m) * -10000 arithmetic) or the reference's 3-D form [B, S, S] (encoder.py:228-229); head_mask as the
+        reference takes it (encoder.py:248-265; the layer loop then runs op by op: the head scaling sits between the
+        attention kernel and the output projection in both directions)."""
+        st = self._trunk_fwd(batch, head_mask, batch["labels"], batch["token_labels"], self.model.training, True, comm)
+        m, cfg, f, dev, emb, bufs = self.model, self.cfg, self.flat, st.dev, st.emb, st.bufs
+        B, S, H, Mr, lay = st.B, st.S, st.H, st.Mr, st.lay
+        seq, pooled, pooled_bf, cls_seq, cls_rows = st.seq, st.pooled, st.pooled_bf, st.cls_seq, st.cls_rows
+        lab, tl, idx_w, idx_t, rows_w, rows_t, Ml, Mt = st.lab, st.tl, st.idx_w, st.idx_t, st.rows_w, st.rows_t, st.Ml, st.Mt
+        next_action = batch.get("next_action")
 
         # heads on supervised rows only
         V, C, A = cfg.vocab_size, cfg.detector_classes, cfg.action_space
@@ -585,6 +634,23 @@ class PretrainEngine(object):
             for prm in (m.next_action.linear.weight, m.next_action.linear.bias, m.bert.pooler.dense.weight,
                         m.bert.pooler.dense.bias):
                 self._grad(prm).zero_()
+        self._trunk_bwd(st, g32, acc, comm, word_grad_ready=True)
+        return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
+
+    def _trunk_bwd(self, st, g32, acc, comm=None, word_grad_ready=False):
+        """Back through the trunk: g32 fp32 [rows, H] = dL/d(sequence output) in the layout of the forward (st); the
+        gradients of the encoder layers, the embeddings and the region projection land in the flat slab."""
+        if st.serial != self._fwd_serial:
+            raise RuntimeError("the activations of this forward were overwritten by a later forward of the same engine; "
+                               "run backward before the next forward")
+        m, cfg, f, emb, bufs = self.model, self.cfg, self.flat, st.emb, st.bufs
+        B, T, R, S, H, I, nh, L, Mr, lay = st.B, st.T, st.R, st.S, st.H, st.I, st.nh, st.L, st.Mr, st.lay
+        hs, x_enc, enc_mask, mask_additive, dp_kw = st.hs, st.x_enc, st.enc_mask, st.mask_additive, st.dp_kw
+        p_h, p_a, seed, ids, tt, pos_ids, eps = st.p_h, st.p_a, st.seed, st.ids, st.tt, st.pos_ids, st.eps
+        img, img_pre, a_img, batch = st.img, st.img_pre if st.img is not None else None, st.a_img, st.batch
+        word_grad = self._grad(emb.word_embeddings.weight)
+        if not acc and not word_grad_ready:
+            word_grad.zero_()
         g = bufs.g[:Mr]
         g.copy_(g32)
         if ops.profiling() or hs is not None:
@@ -657,7 +723,44 @@ class PretrainEngine(object):
                 gi.add_(self.dw_img[:, :D]); gl.add_(self.dw_img[:, D:D + 128]); gbi.add_(self.db_img); gbl.add_(self.db_img)
             else:
                 gi.copy_(self.dw_img[:, :D]); gl.copy_(self.dw_img[:, D:D + 128]); gbi.copy_(self.db_img); gbl.copy_(self.db_img)
-        return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
+
+    # ------------------------------------------------------------------------------ trunk-level training
+    def trunk_forward(self, batch, head_mask=None, training=None):
+        """BertImgModelwithLocationEmbeds.forward for a caller that back-propagates through it (the rollout's
+        OscarEncoder, agent.py:493-518): -> (sequence_output fp32 [B,S,H], pooled_output fp32 [B,H], state).  Every
+        position is computed (the caller may read any of them)."""
+        if training is None:
+            training = self.model.bert.training
+        st = self._trunk_fwd(batch, head_mask, None, None, bool(training), False)
+        return st.seq.float().view(st.B, st.S, st.H), st.pooled.clone(), st
+
+    def trunk_backward(self, st, d_seq, d_pooled=None, accumulate=False):
+        """Gradients of the trunk's parameters into the flat slab, given dL/d(sequence_output) [B,S,H] and / or
+        dL/d(pooled_output) [B,H] (either may be None).  The pooler's gradients are zeroed when d_pooled is None, the
+        region projection's when the forward had no regions."""
+        m, bufs, acc = self.model, st.bufs, bool(accumulate)
+        B, S, H, M = st.B, st.S, st.H, st.M
+        g32 = bufs.g_seq32[:M]
+        if d_seq is None:
+            g32.zero_()
+        else:
+            g32.copy_(d_seq.detach().reshape(M, H))
+        pw, pb = m.bert.pooler.dense.weight, m.bert.pooler.dense.bias
+        if d_pooled is not None:
+            g_z = (d_pooled.detach().float() * (1.0 - st.pooled * st.pooled)).to(BF16)
+            ops.wgrad([dict(dy=g_z, x=st.seq.view(B, S * H)[:, :H], dw=self._grad(pw), db=self._grad(pb), accumulate=acc)], B)
+            g32.index_add_(0, st.cls_rows, ops.linear(g_z, self.head_t["pool"]).float())
+        elif not acc:
+            self._grad(pw).zero_()
+            self._grad(pb).zero_()
+        self._trunk_bwd(st, g32, acc)
+        if st.img is None and not acc:
+            for prm in (m.bert.img_embedding.weight, m.bert.img_embedding.bias, m.bert.location_embeds.weight,
+                        m.bert.location_embeds.bias):
+                self._grad(prm).zero_()
+            if getattr(m.bert, "use_img_layernorm", None):
+                self._grad(m.bert.LayerNorm.weight).zero_()
+                self._grad(m.bert.LayerNorm.bias).zero_()
 
     # ---- the launch sequences of vt_encoder_forward/backward_bf16 issued op by op (bench.py's per-kernel timing)
     def _encoder_forward_unrolled(self, bufs, x0, mask, B, S, p_h=0.0, p_a=0.0, seed=0, lay=None, mask_additive=False,
@@ -851,6 +954,41 @@ class _LossLazyGrads(torch.autograd.Function):
         return (None, None, None) + tuple(f.view(f.g, eng._name_of(p)) * grad_out for p in ctx.params)
 
 
+class _TrunkWithGrads(torch.autograd.Function):
+    """The trunk as ONE autograd node for callers that train through it (OscarEncoder in the rollout, agent.py:493-518):
+    forward = the engine's trunk forward (activations kept in its buffers), backward = its trunk backward, handing the
+    parameter gradients to autograd."""
+
+    @staticmethod
+    def forward(ctx, engine, batch, head_mask, *params):
+        seq, pooled, st = engine.trunk_forward(batch, head_mask)
+        ctx.engine, ctx.st = engine, st
+        ctx.names = [engine._name_of(p) for p in params]
+        ctx.set_materialize_grads(False)
+        return seq, pooled
+
+    @staticmethod
+    def backward(ctx, d_seq, d_pooled):
+        eng, st = ctx.engine, ctx.st
+        eng.trunk_backward(st, d_seq, d_pooled)
+        f = eng.flat
+        unused = set()
+        if st.img is None:
+            unused.update(("bert.img_embedding.", "bert.location_embeds.", "bert.LayerNorm."))
+        if d_pooled is None:
+            unused.add("bert.pooler.")
+        grads = [None if n.startswith(tuple(unused)) else f.view(f.g, n).clone() for n in ctx.names]
+        return (None, None, None) + tuple(grads)
+
+
+def autograd_trunk_forward(trunk, batch, head_mask=None):
+    """BertImgModelwithLocationEmbeds.forward with grad enabled: (sequence_output, pooled_output) that back-propagate into
+    the trunk's parameters through the HIP backward."""
+    eng = _bridge_engine(trunk)
+    params = [p for p in trunk.parameters() if p.requires_grad]
+    return _TrunkWithGrads.apply(eng, batch, head_mask, *params)
+
+
 def _bridge_engine(model):
     """The engine behind the autograd bridge (parameters stay the model's own: attach_grads=False).  An external torch
     optimizer owns the update there, and optimizers that write through `p.data` (the reference's pytorch-transformers
@@ -858,7 +996,7 @@ def _bridge_engine(model):
     changed since the last call.  The bf16 mirror (one fused cast of the slab) and the transposed copies are therefore
     rebuilt on EVERY bridged forward, and the inference-side packed copies are invalidated."""
     eng = getattr(model, "_vt_engine", None)
-    if eng is None or eng.flat.p.device != next(model.parameters()).device:
+    if eng is None or eng.flat.p.device != next(model.parameters()).device or not eng.flat.owns_params():
         eng = PretrainEngine(model, attach_grads=False)
         object.__setattr__(model, "_vt_engine", eng)
     else:
