@@ -126,12 +126,14 @@ def test_decoder_step_matches_oracle(dev):
         assert maxabs(got[2], want[2]) < 2e-2 * max(1.0, float(want[2].abs().max()))
         want_state, got_state = (want[3], want[1]), (got[3], got[1])      # agent.py:383: h1 <- h_tilde, c_t <- c_1
     assert float(c0.to(dev).sub(got_state[1]).abs().max()) > 0        # the caller's c_0 was not updated in place
-    # train() with dropout 0.5: with grad enabled the step is an autograd graph (tests/test_gpu_rollout_train.py); under
-    # no_grad there is no HIP dropout path for these modules -- refused, never a silent identity
+    # train() with dropout 0.5: the step runs as autograd nodes (tests/test_gpu_rollout_train.py) and nn.Dropout does its
+    # work -- with a graph when grad is enabled, forward only under no_grad (agent.py:476-489, test(use_dropout=True))
     prod.train()
-    with torch.no_grad(), pytest.raises(NotImplementedError):
-        prod(action.to(dev), feature.to(dev), cand.to(dev), None, h1.to(dev), c0.to(dev), ctx.to(dev))
-    out = prod(action.to(dev), feature.to(dev), cand.to(dev), None, h1.to(dev), c0.to(dev), ctx.to(dev))
+    args = (action.to(dev), feature.to(dev), cand.to(dev), None, h1.to(dev), c0.to(dev), ctx.to(dev))
+    with torch.no_grad():
+        o1, o2 = prod(*args), prod(*args)
+    assert not o1[2].requires_grad and float((o1[2] - o2[2]).abs().max()) > 0     # two dropout draws
+    out = prod(*args)
     assert out[2].requires_grad and out[0].requires_grad
 
 

@@ -212,14 +212,18 @@ def _rollout_pair(dev, bidirectional, dropout=0.0):
     return cfg, r_enc, p_enc.to(dev), r_dec, p_dec.to(dev)
 
 
-@pytest.mark.parametrize("bidirectional", [False, True])
-def test_rollout_training_matches_oracle(dev, bidirectional):
+@pytest.mark.parametrize("bidirectional,compact", [(False, False), (True, False), (False, True)])
+def test_rollout_training_matches_oracle(dev, bidirectional, compact):
     """Encoder + two teacher-forced decoder steps + cross-entropy over the candidate logits, as agent.py:373-412 builds the
     rollout loss; `loss.backward()` must give every parameter of the trunk, the encoder LSTM, the projections and the decoder
     the oracle's gradient."""
+    from visitron_amd.training import _bridge_engine
+
     cfg, r_enc, p_enc, r_dec, p_dec = _rollout_pair(dev, bidirectional)
     for m in (r_enc, p_enc, r_dec, p_dec):
         m.train()
+    eng = _bridge_engine(p_enc.bert)
+    eng.compact_min_rows = 0 if compact else 1 << 30     # the trunk node on the rows below the lengths only / on all rows
     B, S, C = 5, 24, 6
     g = torch.Generator().manual_seed(9)
     lens = [24, 20, 13, 13, 6]
@@ -245,7 +249,8 @@ def test_rollout_training_matches_oracle(dev, bidirectional):
     wl, wctx, wlogit = run(r_enc, r_dec, lambda t: t)
     wl.backward()
     gl, gctx, glogit = run(p_enc, p_dec, lambda t: t.to(dev))
-    tag = "rollout train%s" % (" bidirectional" if bidirectional else "")
+    assert (eng.last_layout is not None) == compact and (not compact or eng.last_rows == sum(lens))
+    tag = "rollout train%s%s" % (" bidirectional" if bidirectional else "", " compacted" if compact else "")
     check_close(tag + " ctx", gctx, wctx, 5e-2)
     check_close(tag + " logit", glogit, wlogit, 5e-2)
     check_close(tag + " loss", float(gl), float(wl), 5e-2)

@@ -894,10 +894,12 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, head_mask=None,
                 img_feats=None, img_location_embeddings=None, encoder_history_states=None):
-        if self.training and torch.is_grad_enabled() and not _is_fp32(self) \
-                and any(p.requires_grad for p in self.parameters()):
+        if self.training and not _is_fp32(self) and (
+                (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+                or self.config.hidden_dropout_prob > 0.0 or self.config.attention_probs_dropout_prob > 0.0):
             # a caller that trains THROUGH the trunk (the rollout's OscarEncoder, agent.py:493-518): one autograd node
-            # backed by the engine's forward / backward kernels
+            # backed by the engine's forward / backward kernels.  Also train() under torch.no_grad() with dropout on
+            # (agent.py:476-489, test(use_dropout=True)): the same forward with its dropout, no graph.
             if encoder_history_states or self.encoder.output_attentions or self.encoder.output_hidden_states:
                 raise NotImplementedError("trunk-level training serves the plain forward (no encoder_history_states, "
                                           "output_attentions or output_hidden_states)")

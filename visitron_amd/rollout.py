@@ -20,7 +20,12 @@ SKINNY_ROWS = 256   # up to this many rows the dense layers take vt_skinny_linea
 
 
 def _grad_mode(module, *tensors):
-    """True when the call must build an autograd graph: grad enabled and a parameter or an input requires grad."""
+    """True when the call takes the autograd-node form of the module: grad enabled and a parameter or an input requires
+    grad (a graph must be built), or train() with dropout on -- also under torch.no_grad() (agent.py:476-489,
+    test(use_dropout=True)), where the same nodes run forward only and nn.Dropout does its work."""
+    drop = getattr(module, "drop", None)
+    if module.training and drop is not None and drop.p > 0.0:
+        return True
     if not torch.is_grad_enabled():
         return False
     return any(p.requires_grad for p in module.parameters()) or any(t is not None and t.requires_grad for t in tensors)
@@ -173,9 +178,6 @@ class AttnDecoderLSTM(nn.Module):
         ops._require_hip(action, feature, cand_feat, prev_h1, c_0, ctx)
         if _grad_mode(self, action, feature, cand_feat, prev_h1, c_0, ctx):
             return self._forward_autograd(action, feature, cand_feat, prev_h1, c_0, ctx, ctx_mask)
-        if self.training and self.drop.p > 0.0:
-            raise NotImplementedError("training-mode dropout without an autograd graph (torch.no_grad() in train()) is not "
-                                      "served; call eval() for inference")
         w = self._weights()
         action_embeds = _dense((action,), w["w_emb"], w["b_emb"], act=ACT_TANH)                 # :406
         attn_feat, _ = self.feat_att_layer.attend(prev_h1, feature, None, True, False, True)      # :411-412
@@ -231,14 +233,27 @@ class OscarEncoder(nn.Module):
 
         return self._pk.get(ps, build)
 
-    def _forward_autograd(self, inputs, lens, lens_dev, T, att_mask, position_ids, token_type_ids):
+    def _forward_autograd(self, inputs, lens, lens_dev, T, mask, att_mask, position_ids, token_type_ids):
         """agent_models.py:256-310 as autograd nodes (training): the trunk node (the pretrain engine's forward / backward),
         one lstm_sequence node per direction, two dense nodes for the decoder's initial state."""
         from . import rollout_autograd as ra
 
         L, D, hs = self.lstm, self.num_directions, self.hidden_size
-        outputs = self.bert(inputs, token_type_ids=token_type_ids, attention_mask=att_mask, position_ids=position_ids)
-        output = outputs[0].float()
+        B, S = inputs.shape
+        output = None
+        if self.compact_rows and hasattr(self.bert, "run_trunk") and self.bert.training and mask.shape == (B, S):
+            # only the positions below `lengths` are read (pack_padded_sequence, :286): when those are exactly the unmasked
+            # ones the trunk node may run on them alone (the engine's row compaction), forward and backward
+            keep = torch.arange(S, device=inputs.device)[None, :] < lens_dev[:, None]
+            if bool(((mask != 0) == ~keep).all()):
+                from .training import autograd_trunk_forward
+
+                batch = dict(input_ids=inputs, token_type_ids=token_type_ids, attention_mask=att_mask,
+                             position_ids=position_ids)
+                output = autograd_trunk_forward(self.bert, batch, None, unmasked_only=True)[0]
+        if output is None:
+            output = self.bert(inputs, token_type_ids=token_type_ids, attention_mask=att_mask,
+                               position_ids=position_ids)[0].float()
         names = [""] + (["_reverse"] if D == 2 else [])
         ps = [getattr(L, n + sfx) for sfx in names for n in ("weight_ih_l0", "weight_hh_l0")]
         packs = self._pk_t.get(ps + [self.encoder_lstm2decoder_ht.weight, self.encoder_lstm2decoder_ct.weight], lambda: dict(
@@ -280,10 +295,7 @@ class OscarEncoder(nn.Module):
         dev = inputs.device
         lens_dev = lens.to(dev, torch.int32)
         if _grad_mode(self):
-            return self._forward_autograd(inputs, lens, lens_dev, T, att_mask, position_ids, token_type_ids)
-        if self.training and self.drop.p > 0.0:
-            raise NotImplementedError("training-mode dropout without an autograd graph (torch.no_grad() in train()) is not "
-                                      "served; call eval() for inference")
+            return self._forward_autograd(inputs, lens, lens_dev, T, mask, att_mask, position_ids, token_type_ids)
         # Only the first lengths[b] positions of a sequence are read below (pack_padded_sequence, :286).  When those are
         # exactly the unmasked ones (mask = 1 on padding, agent.py:181) the trunk runs on them alone: compacted rows,
         # no masked keys -- the same values at the positions that are read.

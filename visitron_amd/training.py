@@ -725,30 +725,41 @@ class PretrainEngine(object):
                 gi.copy_(self.dw_img[:, :D]); gl.copy_(self.dw_img[:, D:D + 128]); gbi.copy_(self.db_img); gbl.copy_(self.db_img)
 
     # ------------------------------------------------------------------------------ trunk-level training
-    def trunk_forward(self, batch, head_mask=None, training=None):
+    def trunk_forward(self, batch, head_mask=None, training=None, unmasked_only=False):
         """BertImgModelwithLocationEmbeds.forward for a caller that back-propagates through it (the rollout's
-        OscarEncoder, agent.py:493-518): -> (sequence_output fp32 [B,S,H], pooled_output fp32 [B,H], state).  Every
-        position is computed (the caller may read any of them)."""
+        OscarEncoder, agent.py:493-518): -> (sequence_output fp32 [B,S,H], pooled_output fp32 [B,H], state).
+        unmasked_only: the caller vouches that it reads sequence_output only at positions whose attention mask is not
+        zero (OscarEncoder: pack_padded_sequence drops the rest); the step may then run on those rows alone (the row
+        compaction of forward_backward) and the other positions of sequence_output are zero."""
         if training is None:
             training = self.model.bert.training
-        st = self._trunk_fwd(batch, head_mask, None, None, bool(training), False)
-        return st.seq.float().view(st.B, st.S, st.H), st.pooled.clone(), st
+        st = self._trunk_fwd(batch, head_mask, None, None, bool(training), bool(unmasked_only))
+        if st.lay is None:
+            seq = st.seq.float().view(st.B, st.S, st.H)
+        else:
+            seq = torch.zeros((st.M, st.H), dtype=torch.float32, device=st.dev)
+            seq.index_copy_(0, st.lay.index, st.seq.float())
+            seq = seq.view(st.B, st.S, st.H)
+        return seq, st.pooled.clone(), st
 
     def trunk_backward(self, st, d_seq, d_pooled=None, accumulate=False):
         """Gradients of the trunk's parameters into the flat slab, given dL/d(sequence_output) [B,S,H] and / or
         dL/d(pooled_output) [B,H] (either may be None).  The pooler's gradients are zeroed when d_pooled is None, the
         region projection's when the forward had no regions."""
         m, bufs, acc = self.model, st.bufs, bool(accumulate)
-        B, S, H, M = st.B, st.S, st.H, st.M
-        g32 = bufs.g_seq32[:M]
+        B, S, H, M, Mr, lay = st.B, st.S, st.H, st.M, st.Mr, st.lay
+        g32 = bufs.g_seq32[:Mr]
         if d_seq is None:
             g32.zero_()
-        else:
+        elif lay is None:
             g32.copy_(d_seq.detach().reshape(M, H))
+        else:
+            torch.index_select(d_seq.detach().reshape(M, H).float(), 0, lay.index, out=g32)
         pw, pb = m.bert.pooler.dense.weight, m.bert.pooler.dense.bias
         if d_pooled is not None:
             g_z = (d_pooled.detach().float() * (1.0 - st.pooled * st.pooled)).to(BF16)
-            ops.wgrad([dict(dy=g_z, x=st.seq.view(B, S * H)[:, :H], dw=self._grad(pw), db=self._grad(pb), accumulate=acc)], B)
+            x_cls = st.seq.view(B, S * H)[:, :H] if lay is None else st.cls_seq
+            ops.wgrad([dict(dy=g_z, x=x_cls, dw=self._grad(pw), db=self._grad(pb), accumulate=acc)], B)
             g32.index_add_(0, st.cls_rows, ops.linear(g_z, self.head_t["pool"]).float())
         elif not acc:
             self._grad(pw).zero_()
@@ -960,8 +971,8 @@ class _TrunkWithGrads(torch.autograd.Function):
     parameter gradients to autograd."""
 
     @staticmethod
-    def forward(ctx, engine, batch, head_mask, *params):
-        seq, pooled, st = engine.trunk_forward(batch, head_mask)
+    def forward(ctx, engine, batch, head_mask, unmasked_only, *params):
+        seq, pooled, st = engine.trunk_forward(batch, head_mask, unmasked_only=unmasked_only)
         ctx.engine, ctx.st = engine, st
         ctx.names = [engine._name_of(p) for p in params]
         ctx.set_materialize_grads(False)
@@ -978,15 +989,19 @@ class _TrunkWithGrads(torch.autograd.Function):
         if d_pooled is None:
             unused.add("bert.pooler.")
         grads = [None if n.startswith(tuple(unused)) else f.view(f.g, n).clone() for n in ctx.names]
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
-def autograd_trunk_forward(trunk, batch, head_mask=None):
-    """BertImgModelwithLocationEmbeds.forward with grad enabled: (sequence_output, pooled_output) that back-propagate into
-    the trunk's parameters through the HIP backward."""
+def autograd_trunk_forward(trunk, batch, head_mask=None, unmasked_only=False):
+    """BertImgModelwithLocationEmbeds.forward in training mode: (sequence_output, pooled_output) that back-propagate into the
+    trunk's parameters through the HIP backward; under torch.no_grad() the same forward (dropout included) without a graph.
+    unmasked_only: see PretrainEngine.trunk_forward."""
     eng = _bridge_engine(trunk)
+    if not torch.is_grad_enabled():
+        seq, pooled, _ = eng.trunk_forward(batch, head_mask, unmasked_only=unmasked_only)
+        return seq, pooled
     params = [p for p in trunk.parameters() if p.requires_grad]
-    return _TrunkWithGrads.apply(eng, batch, head_mask, *params)
+    return _TrunkWithGrads.apply(eng, batch, head_mask, bool(unmasked_only), *params)
 
 
 def _bridge_engine(model):
