@@ -46,7 +46,11 @@ _REC = None
 
 
 def effective_bound(name, bound):
-    rec = _recorded().get(name)
+    import os
+
+    # VT_PARITY_RECORD=1: a re-measurement run after a kernel change -- stated bounds only, every check recorded
+    # (gpurun_out/parity_measured.txt), then tools/merge_parity.py folds the run into the committed record
+    rec = None if os.environ.get("VT_PARITY_RECORD") == "1" else _recorded().get(name)
     if rec is None:
         return bound
     return min(bound, max(2.0 * rec, 0.1 * bound))

@@ -119,3 +119,48 @@ def test_data_parallel_gradient_ranges_are_aligned_and_tile_the_slab():
         assert int(cover.min()) == 1 and int(cover.max()) == 1
     with pytest.raises(ValueError):
         PretrainEngine(PreTrainOscar(mini_config()), grad_comm_dtype="fp8")
+
+
+def test_centered_mask_is_the_same_softmax_and_a_noop_for_plain_masks():
+    """modeling._centered_mask (the per-key mask shifted by one constant per sequence): bit-identical for 0/1 masks with a
+    kept key, 254/255 (the rollout's ~uint8 mask, agent_models.py:267) becomes 0/1, and the oracle trunk evaluated in float64
+    gives the same output for the raw and the centred mask."""
+    import copy
+
+    from oracle.modeling import BertImgModelwithLocationEmbeds as OTrunk
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import _centered_mask
+
+    m = torch.tensor([[1, 1, 1, 0, 0], [1, 0, 1, 1, 1]], dtype=torch.float32)
+    assert torch.equal(_centered_mask(m), m)
+    q = torch.tensor([[255, 255, 254, 254], [255, 255, 255, 255]], dtype=torch.float32)
+    assert torch.equal(_centered_mask(q), torch.tensor([[1, 1, 0, 0], [1, 1, 1, 1]], dtype=torch.float32))
+    assert torch.equal(_centered_mask(torch.zeros(2, 3)), torch.ones(2, 3))          # a fully masked sequence: uniform softmax
+    fr = torch.tensor([[0.25, 0.75, 0.5]])
+    assert torch.allclose(_centered_mask(fr), torch.tensor([[0.5, 1.0, 0.75]]))
+    torch.manual_seed(0)
+    trunk = OTrunk(mini_config()).double().eval()
+    ids = torch.randint(1, 500, (2, 4))
+    with torch.no_grad():
+        a = trunk(ids, attention_mask=q.to(torch.uint8))[0]
+        b = trunk(ids, attention_mask=_centered_mask(q))[0]
+    assert float((a - b).abs().max()) < 1e-6
+
+
+def test_flat_params_notice_when_another_engine_took_the_parameters():
+    """FlatParams.owns_params: the full model's engine and the bare trunk's engine (train.py:47 hands model.bert to the
+    rollout agent) cannot both back the same parameters; the one that lost them says so and is rebuilt by the bridge."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.training import FlatParams, _TrunkOnly
+
+    model = PreTrainOscar(mini_config())
+    full = FlatParams(model, attach_grads=False)
+    assert full.owns_params()
+    w = model.bert.pooler.dense.weight
+    before = w.detach().clone()
+    trunk = FlatParams(_TrunkOnly(model.bert), attach_grads=False)
+    assert trunk.owns_params() and not full.owns_params()
+    assert torch.equal(w.detach(), before)                        # values moved with the parameters
+    assert all(n.startswith("bert.") for n, *_ in trunk.entries)  # the names they have inside a PreTrainOscar
+    assert trunk.total < full.total

@@ -107,7 +107,7 @@ const char* vt_error_string(int code) {
   }
 }
 
-int vt_abi_version(void) { return 3; }
+int vt_abi_version(void) { return 4; }
 
 void vt_debug_set_gemm_variant(int variant) { vt_gemm_set_variant(variant); }
 void vt_debug_set_gemm_trace(void* buf) { vt_gemm_set_trace(buf); }

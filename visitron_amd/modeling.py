@@ -303,7 +303,8 @@ def _centered_mask(mask_f32):
     A 0/1 mask with a kept key is unchanged bit for bit.  What it is for: the rollout caller's `~mask` of a uint8 tensor
     (254 / 255, agent_models.py:267) turns into biases of +2.53e6 / +2.54e6, where fp32 resolves 0.25 -- the reference's
     own softmax is then computed on scores rounded to that grid, and a log-sum-exp of that size cannot carry the backward's
-    recomputation.  Shifted, the same mask is 0 / 1 and every kernel sees well-scaled numbers."""
+    recomputation.  Shifted, the same mask is 0 / 1 and every kernel sees well-scaled numbers.  bf16 paths only: the fp32
+    parity path keeps the literal arithmetic and reproduces the reference's rounded scores (tests/test_gpu_fp32.py)."""
     return (mask_f32 - mask_f32.amax(dim=1, keepdim=True) + 1.0).contiguous()
 
 
@@ -812,7 +813,9 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                     raise RuntimeError(
                         "attention_mask shape %s does not match [batch, history+text+region] = [%d, %d]"
                         % (tuple(attention_mask.shape), B, Sh + S))
-                mask_f32 = _centered_mask(attention_mask.to(device=dev, dtype=torch.float32))
+                mask_f32 = attention_mask.to(device=dev, dtype=torch.float32).contiguous()
+                if not _is_fp32(self):   # (the fp32 path adds the literal bias in fp32 like the reference, rounding and all)
+                    mask_f32 = _centered_mask(mask_f32)
             elif attention_mask.dim() == 3:   # encoder.py:228-229 + :238-241: per-query mask -> additive bias [B,S,S]
                 if attention_mask.shape != (B, S, S):
                     raise RuntimeError("3-D attention_mask shape %s does not match [%d, %d, %d]"
