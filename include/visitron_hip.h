@@ -304,6 +304,15 @@ int vt_softdot_attention_bwd_f32(const float* target, const float* context, int6
                                  const uint8_t* mask, const float* d_weighted, const float* d_attn, float* d_target,
                                  float* d_context, int B, int L, int D, int output_prob, vt_stream_t stream);
 
+/* The same gradient for a long context (the decoder's attention over the instruction, L = 511) spread over keys in two
+ * launches.  ws: vt_softdot_attention_bwd_split_ws_floats(B, L, D) floats of device scratch; afterwards its tail
+ * [B, chunks, D] (chunks = ceil(L / 32), starting 2*B*L floats in) holds partial d_target sums that the caller adds up over
+ * the chunk axis (no atomics).  d_context as above (optional). */
+int64_t vt_softdot_attention_bwd_split_ws_floats(int B, int L, int D);
+int vt_softdot_attention_bwd_split_f32(const float* target, const float* context, int64_t ld_batch, int64_t ld_row,
+                                       const uint8_t* mask, const float* d_weighted, const float* d_attn, float* d_context,
+                                       float* ws, int B, int L, int D, int output_prob, vt_stream_t stream);
+
 /* out[c, r] = in[r, c] (bf16; R, C multiples of 8): refreshes the transposed weight copies (W^T of every nn.Linear on the
  * path, oscar/modeling_bert.py:43-45,94,119,120) that the
  * dgrad GEMMs consume (vt_layer_weights_t). */

@@ -40,7 +40,7 @@ def _grads_close(tag, prod, ref, tol):
     return errs
 
 
-@pytest.mark.parametrize("D,L,prob", [(512, 80, True), (2052, 36, False), (128, 7, True), (132, 300, False)])
+@pytest.mark.parametrize("D,L,prob", [(512, 80, True), (2052, 36, False), (128, 7, True), (132, 300, False), (512, 511, True)])
 def test_softdot_backward_matches_autograd(dev, D, L, prob):
     from visitron_amd import ops
 

@@ -120,6 +120,10 @@ def main():
           "encoder forward %.1f, decoder steps forward %.1f, backward %.1f, clip + Adam %.1f ms; loss %.3f"
           % (B, S, steps, ms, wall, B / ms * 1e3, parts[0], parts[1], parts[2], parts[3], float(marks["loss"].detach())))
     print("   peak device memory %.1f GB" % (torch.cuda.max_memory_allocated() / 2 ** 30))
+    ops.profile_begin()
+    train_iter()
+    for k, v in sorted(ops.profile_end().items(), key=lambda kv: -kv[1]["ms"]):
+        print("   %-24s %8.3f ms  n=%d" % (k, v["ms"], v["n"]))
 
 
 if __name__ == "__main__":

@@ -107,6 +107,9 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_softdot_attention_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "vt_softdot_attention_bwd_split_ws_floats": (c_int64, [c_int, c_int, c_int]),
+    "vt_softdot_attention_bwd_split_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_softdot_attention_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          c_int, c_int, c_void_p]),
     "vt_transpose_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),

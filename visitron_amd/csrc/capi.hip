@@ -90,6 +90,8 @@ int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream);
 int vt_lstm_step_dispatch(const LstmStepArgs& a, hipStream_t stream);
 int vt_lstm_step_bwd_dispatch(const LstmBwdArgs& a, hipStream_t stream);
 int vt_softdot_bwd_dispatch(const SoftDotBwdArgs& a, hipStream_t stream);
+int vt_softdot_bwd_split_dispatch(const SoftDotBwdArgs& a, float* ws, hipStream_t stream);
+long vt_softdot_bwd_split_ws_floats(int B, int L, int D);
 int vt_softdot_dispatch(const SoftDotArgs& a, hipStream_t stream);
 int vt_skinny_linear_dispatch(const SkinnyArgs& a, hipStream_t stream);
 
@@ -371,6 +373,18 @@ int vt_softdot_attention_bwd_f32(const float* target, const float* context, int6
   a.d_weighted = d_weighted; a.d_attn = d_attn; a.d_target = d_target; a.d_context = d_context;
   a.B = B; a.L = L; a.D = D; a.output_prob = output_prob;
   return vt_softdot_bwd_dispatch(a, (hipStream_t)stream);
+}
+
+int64_t vt_softdot_attention_bwd_split_ws_floats(int B, int L, int D) { return vt_softdot_bwd_split_ws_floats(B, L, D); }
+
+int vt_softdot_attention_bwd_split_f32(const float* target, const float* context, int64_t ld_batch, int64_t ld_row,
+                                       const uint8_t* mask, const float* d_weighted, const float* d_attn, float* d_context,
+                                       float* ws, int B, int L, int D, int output_prob, vt_stream_t stream) {
+  SoftDotBwdArgs a;
+  a.target = target; a.context = context; a.ld_batch = ld_batch; a.ld_row = ld_row; a.mask = mask;
+  a.d_weighted = d_weighted; a.d_attn = d_attn; a.d_target = nullptr; a.d_context = d_context;
+  a.B = B; a.L = L; a.D = D; a.output_prob = output_prob;
+  return vt_softdot_bwd_split_dispatch(a, ws, (hipStream_t)stream);
 }
 
 int vt_softdot_attention_f32(const float* target, const float* context, int64_t ld_batch, int64_t ld_row,

@@ -405,6 +405,110 @@ __global__ __launch_bounds__(64 * SD_WAVES) void softdot_bwd_kernel(SoftDotBwdAr
   }
 }
 
+// The same gradient for a long context (the decoder's attention over the 511 instruction positions: one workgroup per
+// batch row leaves 3/4 of the chip idle and walks 1 MB three times) as two launches spread over keys:
+//   softdot_bwd_dots  : one wave per key -> logit[b,l] (masked: -inf) and dp[b,l]            grid (L / 4 keys, B)
+//   softdot_bwd_apply : every workgroup redoes the row's softmax statistics from those two [L] vectors (cheap), then its
+//                       SDB_KEYS keys: d_context rows and a partial d_target                    grid (L / SDB_KEYS, B)
+// the partial d_target sums [B, chunks, D] are added up by the caller (no atomics: the result is reproducible).
+#define SDB_KEYS 32
+__global__ __launch_bounds__(256) void softdot_bwd_dots(SoftDotBwdArgs a, float* sl_g, float* ql_g) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l = blockIdx.x * 4 + wave;
+  if (l >= a.L) return;
+  const float* row = a.context + (long)b * a.ld_batch + (long)l * a.ld_row;
+  const float* tg = a.target + (long)b * a.D;
+  const float* dw = a.d_weighted ? a.d_weighted + (long)b * a.D : nullptr;
+  float s = 0.f, q = 0.f;
+  for (int d = lane; d < a.D; d += 64) {
+    const float c = row[d];
+    s += c * tg[d];
+    if (dw) q += c * dw[d];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if (lane == 0) {
+    if (a.mask && a.mask[(long)b * a.L + l]) s = -INFINITY;
+    if (a.d_attn && a.output_prob) q += a.d_attn[(long)b * a.L + l];
+    sl_g[(long)b * a.L + l] = s;
+    ql_g[(long)b * a.L + l] = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void softdot_bwd_apply(SoftDotBwdArgs a, const float* sl_g, const float* ql_g,
+                                                         float* dt_part, int chunks) {
+  __shared__ float red[8];
+  __shared__ float gk[SDB_KEYS], pk[SDB_KEYS];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* sl = sl_g + (long)b * a.L;
+  const float* ql = ql_g + (long)b * a.L;
+  float m = -INFINITY;
+  for (int l = tid; l < a.L; l += 256) m = fmaxf(m, sl[l]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float z = 0.f, pd = 0.f;
+  for (int l = tid; l < a.L; l += 256) {
+    const float e = expf(sl[l] - m);
+    z += e;
+    pd += e * ql[l];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { z += __shfl_xor(z, o, 64); pd += __shfl_xor(pd, o, 64); }
+  __syncthreads();
+  if (lane == 0) { red[wave] = z; red[4 + wave] = pd; }
+  __syncthreads();
+  z = red[0] + red[1] + red[2] + red[3];
+  pd = (red[4] + red[5] + red[6] + red[7]) / z;
+  const float inv = 1.0f / z;
+  const int l0 = chunk * SDB_KEYS;
+  const int nk = min(SDB_KEYS, a.L - l0);
+  if (tid < nk) {
+    const int l = l0 + tid;
+    const float p = expf(sl[l] - m) * inv;
+    float g = p * (ql[l] - pd);
+    if (a.d_attn && !a.output_prob && !(a.mask && a.mask[(long)b * a.L + l])) g += a.d_attn[(long)b * a.L + l];
+    pk[tid] = p;
+    gk[tid] = g;
+  }
+  __syncthreads();
+  const float* ctx = a.context + (long)b * a.ld_batch + (long)l0 * a.ld_row;
+  const float* tg = a.target + (long)b * a.D;
+  const float* dw = a.d_weighted ? a.d_weighted + (long)b * a.D : nullptr;
+  float* dcx = a.d_context ? a.d_context + ((long)b * a.L + l0) * a.D : nullptr;
+  for (int d = tid; d < a.D; d += 256) {
+    const float t = tg[d], w = dw ? dw[d] : 0.f;
+    float acc = 0.f;
+    for (int k = 0; k < nk; ++k) {
+      const float g = gk[k];
+      if (g != 0.f) acc += g * ctx[(long)k * a.ld_row + d];
+      if (dcx) dcx[(long)k * a.D + d] = pk[k] * w + g * t;
+    }
+    dt_part[((long)b * chunks + chunk) * a.D + d] = acc;
+  }
+}
+
+// split form: scratch = 2 * B * L floats (logits, dp) + B * chunks * D floats (partial d_target), chunks = ceil(L / SDB_KEYS)
+long vt_softdot_bwd_split_ws_floats(int B, int L, int D) {
+  return 2L * B * L + (long)B * ((L + SDB_KEYS - 1) / SDB_KEYS) * D;
+}
+
+int vt_softdot_bwd_split_dispatch(const SoftDotBwdArgs& a, float* ws, hipStream_t stream) {
+  if (!a.target || !a.context || !ws) return VT_ERR_NULL;
+  if (!a.d_weighted && !a.d_attn) return VT_ERR_NULL;
+  if (a.B <= 0 || a.L <= 0 || a.D <= 0 || a.B > 65535) return VT_ERR_BAD_SHAPE;
+  const int chunks = (a.L + SDB_KEYS - 1) / SDB_KEYS;
+  float* sl = ws;
+  float* ql = ws + (long)a.B * a.L;
+  float* part = ql + (long)a.B * a.L;
+  hipLaunchKernelGGL(softdot_bwd_dots, dim3((a.L + 3) / 4, a.B), dim3(256), 0, stream, a, sl, ql);
+  hipLaunchKernelGGL(softdot_bwd_apply, dim3(chunks, a.B), dim3(256), 0, stream, a, (const float*)sl, (const float*)ql, part,
+                     chunks);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
 int vt_softdot_bwd_dispatch(const SoftDotBwdArgs& a, hipStream_t stream) {
   if (!a.target || !a.context || !a.d_target) return VT_ERR_NULL;
   if (!a.d_weighted && !a.d_attn) return VT_ERR_NULL;

@@ -886,6 +886,9 @@ def lstm_sequence_bwd(d_seq_out, dh_final, dc_final, saved, w_hh_t, T, lengths=N
     return dg
 
 
+SOFTDOT_SPLIT_KEYS = 128   # contexts at least this long take the two-launch form of the soft-dot backward (shorter: slower)
+
+
 def softdot_attention_bwd(target, context, mask, d_weighted, d_attn, output_prob, want_d_context):
     """Gradient of softdot_attention -> (d_target fp32 [B,D], d_context fp32 [B,L,D] | None)."""
     _require_hip(target, context, mask, d_weighted, d_attn)
@@ -897,8 +900,17 @@ def softdot_attention_bwd(target, context, mask, d_weighted, d_attn, output_prob
         m8 = (mask if mask.dtype == torch.uint8 else mask.to(torch.bool).view(torch.uint8)).contiguous()
     dw = None if d_weighted is None else d_weighted.detach().float().contiguous()
     da = None if d_attn is None else d_attn.detach().float().contiguous()
-    d_target = torch.empty((B, D), dtype=torch.float32, device=target.device)
     d_ctx = torch.empty((B, L, D), dtype=torch.float32, device=target.device) if want_d_context else None
+    if L >= SOFTDOT_SPLIT_KEYS:   # a long context: two launches spread over keys instead of one workgroup per batch row
+        lib = _lib.load()
+        ws = torch.empty(int(lib.vt_softdot_attention_bwd_split_ws_floats(B, L, D)), dtype=torch.float32, device=target.device)
+        with _timed("softdot_attention_bwd", 6.0 * B * L * D, 12.0 * B * L * D):
+            rc = lib.vt_softdot_attention_bwd_split_f32(
+                _ptr(target), _ptr(context), context.stride(0), context.stride(1), _ptr(m8), _ptr(dw), _ptr(da), _ptr(d_ctx),
+                _ptr(ws), B, L, D, 1 if output_prob else 0, _stream())
+        _lib.check(rc, "vt_softdot_attention_bwd_split_f32")
+        return ws[2 * B * L:].view(B, -1, D).sum(1), d_ctx
+    d_target = torch.empty((B, D), dtype=torch.float32, device=target.device)
     with _timed("softdot_attention_bwd", 6.0 * B * L * D, 12.0 * B * L * D):
         rc = _lib.load().vt_softdot_attention_bwd_f32(
             _ptr(target), _ptr(context), context.stride(0), context.stride(1), _ptr(m8), _ptr(dw), _ptr(da), _ptr(d_target),
