@@ -188,6 +188,18 @@ def test_trunk_level_training_matches_oracle(dev):
     (got2 * w2.to(dev)).sum().backward()
     errs = _grads_close("trunk-level train (text only, inverted uint8 mask)", pt, rt64, 2e-2)
     assert not any(n.startswith(("pooler.", "img_embedding.", "location_embeds.")) for n in errs)
+    # eval() with grad enabled: the inference path's values, differentiable on demand (the engine recomputes on backward)
+    rt.eval()
+    pt.eval()
+    rt.zero_grad()
+    pt.zero_grad()
+    want = rt(**b)
+    ((want[0] * ws).sum() + (want[1] * wp).sum()).backward()
+    got = pt(**{k: v.to(dev) for k, v in b.items()})
+    assert got[0].requires_grad
+    check_close("trunk-level eval+grad sequence_output", got[0], want[0], 5e-2)
+    ((got[0] * ws.to(dev)).sum() + (got[1] * wp.to(dev)).sum()).backward()
+    _grads_close("trunk-level eval mode with grad enabled", pt, rt, 2e-2)
 
 
 def _rollout_pair(dev, bidirectional, dropout=0.0):

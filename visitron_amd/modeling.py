@@ -925,7 +925,19 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
         f32 = None if _is_fp32(self) else self.encoder._final_f32
         # (the fp32 copy lives in the encoder's workspace and is rewritten by the next call: hand out a copy)
         sequence_output = outs[-1].view(B, S, H).to(dt) if f32 is None else f32.view(B, S, H).to(dt, copy=True)
-        outputs = (sequence_output, pooled.to(dt))
+        pooled = pooled.to(dt)
+        if torch.is_grad_enabled() and not self.training and not _is_fp32(self) and not encoder_history_states \
+                and any(p.requires_grad for p in self.parameters()):
+            # eval() with grad enabled: the values above stand; a backward through them, if it ever comes, recomputes the
+            # forward in the engine (no dropout in eval mode: the same function) and runs its trunk backward
+            from .training import lazy_autograd_trunk
+
+            batch = dict(input_ids=input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask,
+                         position_ids=position_ids)
+            if img_feats is not None:
+                batch.update(img_feats=img_feats, img_location_embeddings=img_location_embeddings)
+            sequence_output, pooled = lazy_autograd_trunk(self, batch, head_mask, sequence_output, pooled)
+        outputs = (sequence_output, pooled)
         if self.encoder.output_hidden_states:
             hidden = (x.view(B, S, H).to(dt),) + tuple(o.view(B, S, H).to(dt) for o in outs[:-1]) + (sequence_output,)
             outputs = outputs + (hidden,)

@@ -992,6 +992,39 @@ class _TrunkWithGrads(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+class _TrunkLazyGrads(torch.autograd.Function):
+    """eval() with grad enabled at trunk level (the values come from the inference path, nothing is saved): the engine's
+    trunk forward + backward run only if `.backward()` is actually called -- dropout is the identity in eval mode, so the
+    recomputation sees the same function (the trunk-level twin of _LossLazyGrads)."""
+
+    @staticmethod
+    def forward(ctx, trunk, batch, head_mask, seq, pooled, *params):
+        ctx.trunk, ctx.batch, ctx.head_mask, ctx.params = trunk, dict(batch), head_mask, params
+        ctx.set_materialize_grads(False)
+        return seq.detach().clone(), pooled.detach().clone()
+
+    @staticmethod
+    def backward(ctx, d_seq, d_pooled):
+        eng = _bridge_engine(ctx.trunk)
+        _, _, st = eng.trunk_forward(ctx.batch, ctx.head_mask, training=False)
+        eng.trunk_backward(st, d_seq, d_pooled)
+        f = eng.flat
+        unused = []
+        if st.img is None:
+            unused += ["bert.img_embedding.", "bert.location_embeds.", "bert.LayerNorm."]
+        if d_pooled is None:
+            unused.append("bert.pooler.")
+        names = [eng._name_of(p) for p in ctx.params]
+        grads = [None if n.startswith(tuple(unused)) else f.view(f.g, n).clone() for n in names]
+        return (None, None, None, None, None) + tuple(grads)
+
+
+def lazy_autograd_trunk(trunk, batch, head_mask, seq, pooled):
+    """The inference path's (sequence_output, pooled_output) made differentiable on demand (eval mode, grad enabled)."""
+    params = [p for p in trunk.parameters() if p.requires_grad]
+    return _TrunkLazyGrads.apply(trunk, batch, head_mask, seq, pooled, *params)
+
+
 def autograd_trunk_forward(trunk, batch, head_mask=None, unmasked_only=False):
     """BertImgModelwithLocationEmbeds.forward in training mode: (sequence_output, pooled_output) that back-propagate into the
     trunk's parameters through the HIP backward; under torch.no_grad() the same forward (dropout included) without a graph.
