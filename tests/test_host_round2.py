@@ -164,3 +164,16 @@ def test_flat_params_notice_when_another_engine_took_the_parameters():
     assert torch.equal(w.detach(), before)                        # values moved with the parameters
     assert all(n.startswith("bert.") for n, *_ in trunk.entries)  # the names they have inside a PreTrainOscar
     assert trunk.total < full.total
+
+
+def test_data_parallel_replicas_are_refused_with_the_way_out():
+    """multi-gpu-dp (pretrain.py:93-94) is not served: a DataParallel replica says so (and names the DDP route) instead of
+    failing on a missing parameter somewhere inside."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+
+    model = PreTrainOscar(mini_config())
+    replica = model._replicate_for_data_parallel()
+    replica._former_parameters = {}
+    with pytest.raises(NotImplementedError, match="one process per GPU"):
+        replica(torch.zeros(1, 4, dtype=torch.int64))

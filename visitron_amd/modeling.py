@@ -297,6 +297,16 @@ def _dense_residual_ln(mod, hidden_states, input_tensor):
     return y.view(shp).to(input_tensor.dtype)
 
 
+def _refuse_data_parallel_replica(module):
+    """torch.nn.DataParallel (the reference's `multi-gpu-dp` mode, pretrain.py:93-94) re-creates the module per forward as
+    replicas whose weights are plain broadcast tensors (no Parameters): the flat slabs, the packed bf16 copies and the saved
+    activations here belong to ONE device and one module object.  Refused with the way out instead of failing somewhere
+    inside: one process per GPU (the reference's `multi-gpu-ddp` mode, pretrain.py:96-102; PretrainEngine / bench.py --gpus N)."""
+    if hasattr(module, "_former_parameters"):
+        raise NotImplementedError("torch.nn.DataParallel replicas are not served by the HIP path; run one process per GPU "
+                                  "(DistributedDataParallel, or PretrainEngine with torch.distributed)")
+
+
 def _centered_mask(mask_f32):
     """A per-key mask [B, S] shifted so that each sequence's largest value is 1: (1 - m) * -10000 then changes by one
     constant per sequence, which a softmax over the keys does not see (encoder.py:238-241; oscar/modeling_bert.py:55-58).
@@ -897,6 +907,7 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, position_ids=None, head_mask=None,
                 img_feats=None, img_location_embeddings=None, encoder_history_states=None):
+        _refuse_data_parallel_replica(self)
         if self.training and not _is_fp32(self) and (
                 (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
                 or self.config.hidden_dropout_prob > 0.0 or self.config.attention_probs_dropout_prob > 0.0):
@@ -1052,6 +1063,7 @@ class PreTrainOscar(BertPreTrainedModel):
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, labels=None, token_labels=None,
                 position_ids=None, head_mask=None, img_feats=None, img_location_embeddings=None, next_action=None,
                 text_only=False):
+        _refuse_data_parallel_replica(self)
         if text_only:
             return self.bert(input_ids, position_ids=position_ids, token_type_ids=token_type_ids,
                              attention_mask=attention_mask, head_mask=head_mask, img_feats=img_feats,
