@@ -1,0 +1,93 @@
+"""GPU: seeded random shapes through the whole path -- batch, text length, region count, mask pattern, label density --
+against the oracle: trunk outputs and the inference 7-tuple, then one training step with every gradient.  The fixed cases
+elsewhere pin the configurations BASELINE names; this sweeps the tile tails in between (rows not a multiple of any tile,
+sequence lengths around the attention kernels' 32 / 64 / 256 boundaries, a single region, no supervised position ...)."""
+import pytest
+import torch
+
+from helpers import check_bf16_tensor, check_close, model_pair
+
+pytestmark = pytest.mark.gpu
+TRUNK_KEYS = ("input_ids", "attention_mask", "img_feats", "img_location_embeddings")
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 2e-3 * (b.numel() ** 0.5)))
+
+
+def _case(cfg, seed):
+    from visitron_amd.synth import make_batch
+
+    g = torch.Generator().manual_seed(1000 + seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    B = r(1, 9)
+    T = [2, 3, 7, 31, 32, 33, 63, 64][r(0, 7)] if seed % 3 else r(2, cfg.max_position_embeddings)
+    R = [0, 1, 5, 20, 36][r(0, 4)]
+    b = make_batch(cfg, B, text_len=T, region_len=R, seed=seed)
+    S = T + R
+    kind = seed % 4
+    m = b["attention_mask"].clone()
+    if kind == 1:                                   # holes anywhere but position 0
+        holes = torch.rand(B, S, generator=g) < 0.2
+        holes[:, 0] = False
+        m = m * (~holes)
+    elif kind == 2:                                 # everything attended
+        m = torch.ones_like(m)
+    elif kind == 3 and B > 1:                       # one sequence fully masked
+        m[r(0, B - 1)] = 0
+    b["attention_mask"] = m
+    if seed % 5 == 0:
+        b["labels"].fill_(-1)                       # no MLM target: NaN like the criterion
+    if seed % 7 == 0:
+        b["next_action"][r(0, B - 1)] = -1
+    return b, (B, T, R, kind)
+
+
+def _close_or_both_nan(a, b, tol):
+    a, b = float(torch.as_tensor(a).detach()), float(torch.as_tensor(b).detach())
+    return (a != a and b != b) or abs(a - b) < tol
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_shapes_inference_and_training_step(dev, seed):
+    from oracle.modeling import PreTrainOscar as OModel
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.training import PretrainEngine
+
+    cfg = mini_config(num_hidden_layers=2 + seed % 2, use_img_layernorm=bool(seed % 2), img_layer_norm_eps=1e-12)
+    # (weights N(0, 0.03): between the reference's init, 0.02, and the 0.05 the fixed cases stress the bf16 path with)
+    ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=50 + seed, device=dev, weight_std=0.03)
+    b, shape = _case(cfg, seed)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    tag = "fuzz %02d B%d T%d R%d mask%d" % ((seed,) + shape)
+    trunk = {k: b[k] for k in TRUNK_KEYS if k in b}
+    with torch.no_grad():
+        want = ref.bert(**trunk)
+        got = prod.bert(**{k: bd[k] for k in trunk})
+    # the large tensor: maximum, rms and the share of elements beyond 5e-2, as at the base config (helpers.check_bf16_tensor)
+    check_bf16_tensor(tag + " sequence_output", got[0], want[0], 8e-2, 1.3e-2, beyond_frac=1e-3)
+    check_close(tag + " pooled_output", got[1], want[1], 5e-2)
+    if "img_feats" not in b:
+        return                                      # PreTrainOscar's callers always pass regions
+    with torch.no_grad():
+        want7, got7 = ref(**b), prod(**bd)
+    for i in range(7):
+        assert _close_or_both_nan(got7[i], want7[i], 5e-2 if i < 4 else 1e-6), (tag, i, float(got7[i]), float(want7[i]))
+    prod.train()
+    eng = PretrainEngine(prod)
+    eng.compact_min_rows = 0 if seed % 2 else 1 << 30
+    ref.zero_grad()
+    w = ref(**b)
+    o = eng.forward_backward(bd)
+    torch.cuda.synchronize()
+    for i in range(7):
+        assert _close_or_both_nan(o[i], w[i], 5e-2 if i < 4 else 1e-6), (tag, "train", i, float(o[i]), float(w[i]))
+    if float(w[0]) != float(w[0]):
+        return                                      # NaN loss (no supervised row): nothing to differentiate
+    w[0].backward()
+    wg = dict(ref.named_parameters())
+    errs = {n: _rel(p.grad, wg[n].grad) for n, p in prod.named_parameters() if wg[n].grad is not None}
+    worst = max(errs, key=errs.get)
+    check_close(tag + " grads worst rel-L2", errs[worst], 0.0, 0.03)
