@@ -164,15 +164,15 @@ class AttnDecoderLSTM(nn.Module):
         emb, cell = self.embedding[0], self.lstm
         packs = self._pk_t.get((emb.weight, cell.weight_ih, cell.weight_hh),
                                lambda: (ra.packed_linear(emb.weight), ra.packed_lstm(cell.weight_ih, cell.weight_hh)))
-        action_embeds = self.drop(ra.dense(action, emb.weight, emb.bias, ACT_TANH, packs[0]))          # :406-409
-        prev_h1_drop = self.drop(prev_h1)
-        attn_feat, _ = self.feat_att_layer(prev_h1_drop, feature, output_tilde=False)                   # :411-412
-        concat_input = torch.cat((action_embeds, attn_feat), 1)                                         # :414-416
-        h_1, c_1 = ra.lstm_cell(concat_input, prev_h1, c_0, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh,
-                                packs[1])                                                               # :417
-        h_tilde, _ = self.attention_layer(self.drop(h_1), ctx, ctx_mask)                                # :419-420
-        _, logit = self.candidate_att_layer(self.drop(h_tilde), cand_feat, output_prob=False)           # :423-425
-        return h_1, c_1, logit, h_tilde
+        # the step as a chain of nodes; `drop` sits where the reference applies it (:406-425): on the action embedding, on
+        # the query of each of the three attentions, never on the state the cell carries forward
+        emb_a = self.drop(ra.dense(action, emb.weight, emb.bias, ACT_TANH, packs[0]))
+        seen, _ = self.feat_att_layer(self.drop(prev_h1), feature, output_tilde=False)
+        h_1, c_1 = ra.lstm_cell(torch.cat((emb_a, seen), 1), prev_h1, c_0, cell.weight_ih, cell.weight_hh, cell.bias_ih,
+                                cell.bias_hh, packs[1])
+        h_att, _ = self.attention_layer(self.drop(h_1), ctx, ctx_mask)
+        _, scores = self.candidate_att_layer(self.drop(h_att), cand_feat, output_prob=False)
+        return h_1, c_1, scores, h_att
 
     def forward(self, action, feature, cand_feat, h_0, prev_h1, c_0, ctx, ctx_mask=None):
         ops._require_hip(action, feature, cand_feat, prev_h1, c_0, ctx)
