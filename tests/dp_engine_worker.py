@@ -38,21 +38,30 @@ def main():
     eng.compact_min_rows = 0
     assert eng.world == world == 2
     shard = {k: v.to(dev) for k, v in make_batch(cfg, 3, text_len=20, region_len=10, seed=100 + rank).items()}
-    # the step, with the gradients captured between the all-reduce and AdamW
-    captured = {}
-    step = eng.optimizer_step
+    # the step, with the gradients captured between the all-reduce and AdamW -- which runs per arrived range (the layer
+    # chunks in launch order, then the embeddings / heads tail): every element exactly once
+    total = eng.flat.total
+    captured = {"g": torch.zeros(total), "cover": torch.zeros(total, dtype=torch.bool), "calls": 0, "scale": None}
+    adam_ranges = eng._adam_ranges
 
-    def spy(grad_scale=1.0, grads=None):
+    def spy(consts, ranges, grad_scale, grads=None):
         torch.cuda.synchronize()
         assert (grads is not None) == (comm_dtype == "bf16")      # AdamW is handed the reduced bf16 copy
-        captured["g"] = (eng.flat.g if grads is None else grads).detach().float().cpu().clone()
+        src = eng.flat.g if grads is None else grads
+        for s_, e_ in ranges:
+            assert not bool(captured["cover"][s_:e_].any())
+            captured["g"][s_:e_] = src[s_:e_].detach().float().cpu()
+            captured["cover"][s_:e_] = True
         captured["scale"] = grad_scale
-        return step(grad_scale=grad_scale, grads=grads)
+        captured["calls"] += 1
+        return adam_ranges(consts, ranges, grad_scale, grads)
 
-    eng.optimizer_step = spy
+    eng._adam_ranges = spy
     out = eng.train_step(shard, overlap=True, layers_per_chunk=2)
     torch.cuda.synchronize()
     assert abs(captured["scale"] - 1.0 / world) < 1e-12
+    assert bool(captured["cover"].all()) and captured["calls"] == 3      # two chunks of two layers + the tail
+    assert eng.step_count == 1 and eng.sched_step == 1
     metrics = all_reduce_metrics([v if torch.is_tensor(v) else torch.tensor(float(v), device=dev) for v in out])
     torch.save({"g": captured["g"], "p": eng.flat.p.detach().cpu(), "out": [float(v) for v in out],
                 "metrics": [float(v) for v in metrics]}, os.path.join(out_dir, "rank%d.pt" % rank))

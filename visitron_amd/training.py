@@ -844,9 +844,8 @@ class PretrainEngine(object):
                        dict(dy=g_pre2_dn, x=a["ctx"], dw=gr["d_w_ao"], db=gr["d_b_ao"], accumulate=acc)], M)
 
     # ------------------------------------------------------------------------------ optimizer
-    def optimizer_step(self, grad_scale=1.0, grads=None):
-        """AdamW.step() + scheduler.step() (pretrain.py:192-193) as two fused launches (decay / no-decay)."""
-        f = self.flat
+    def _adam_begin(self):
+        """Advance Adam's step counter and return this step's constants (lr after the schedule, bias-corrected step size)."""
         self.step_count += 1
         t = self.step_count
         lr = self.lr * self.lr_factor()
@@ -854,20 +853,32 @@ class PretrainEngine(object):
         step_size = lr
         if self.correct_bias:
             step_size = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
-        nd = f.n_decay
+        return lr, step_size, b1, b2
+
+    def _adam_ranges(self, consts, ranges, grad_scale, grads=None):
+        """The fused AdamW on [start, end) ranges of the flat slabs (weight decay by region: pretrain.py:109-127)."""
+        f = self.flat
+        lr, step_size, b1, b2 = consts
         g = f.g if grads is None else grads   # fp32 slab, or the all-reduced bf16 communication copy
-        if nd > 0:
-            ops.adamw_flat(f.p[:nd], g[:nd], f.m[:nd], f.v[:nd], f.mirror[:nd], lr, step_size, b1, b2, self.eps, self.wd,
-                           grad_scale)
-        if f.total > nd:
-            ops.adamw_flat(f.p[nd:], g[nd:], f.m[nd:], f.v[nd:], f.mirror[nd:], lr, step_size, b1, b2, self.eps, 0.0,
-                           grad_scale)
+        nd = f.n_decay
+        for s_, e_ in ranges:
+            for lo, hi, wd in ((s_, min(e_, nd), self.wd), (max(s_, nd), e_, 0.0)):
+                if hi > lo:
+                    ops.adamw_flat(f.p[lo:hi], g[lo:hi], f.m[lo:hi], f.v[lo:hi], f.mirror[lo:hi], lr, step_size, b1, b2,
+                                   self.eps, wd, grad_scale)
+
+    def _adam_end(self):
         self.sched_step += 1
-        f.mark_fresh()
+        self.flat.mark_fresh()
         self._wt_dirty = True
         # the fused kernel wrote the slab through raw pointers: no parameter's _version moved, so the packed bf16
         # copies the inference path caches (encoder layers, region projection, rollout modules) are told explicitly
         invalidate_packed_weights()
+
+    def optimizer_step(self, grad_scale=1.0, grads=None):
+        """AdamW.step() + scheduler.step() (pretrain.py:192-193) as two fused launches (decay / no-decay)."""
+        self._adam_ranges(self._adam_begin(), [(0, self.flat.total)], grad_scale, grads)
+        self._adam_end()
 
     def all_reduce_grads(self):
         """Sum the flat gradient slab over the data-parallel group in fixed-size buckets (no overlap)."""
@@ -894,21 +905,34 @@ class PretrainEngine(object):
         else:
             from .distributed import all_reduce_ranges, complement_ranges
 
-            handles = []
+            handles, launched = [], []   # launched: (ranges, first handle, one past the last handle) per launch call
 
             def reduce_ranges(rng):
+                n0 = len(handles)
                 if self.g16 is None:
                     all_reduce_ranges(self.flat.g, rng, self.bucket_elems, self.pg, handles)
-                    return
-                for s_, e_ in rng:   # bf16 communication copy of the range, then its all-reduce (same byte size per bucket)
-                    if e_ > s_:
-                        ops.cast_to_bf16(self.flat.g[s_:e_], self.g16[s_:e_])
-                all_reduce_ranges(self.g16, rng, 2 * self.bucket_elems, self.pg, handles)
+                else:
+                    for s_, e_ in rng:   # bf16 communication copy of the range, then its all-reduce (same bytes per bucket)
+                        if e_ > s_:
+                            ops.cast_to_bf16(self.flat.g[s_:e_], self.g16[s_:e_])
+                    all_reduce_ranges(self.g16, rng, 2 * self.bucket_elems, self.pg, handles)
+                launched.append((list(rng), n0, len(handles)))
 
             launch = _force_comm or reduce_ranges
             comm = dict(layers_per_chunk=layers_per_chunk, launch=launch, done=[])
             out = self.forward_backward(batch, grad_scale=scale, comm=comm)
             launch(complement_ranges(self.flat.total, comm["done"]))  # embeddings, region projection, heads
+            if _force_comm is None:
+                # AdamW per arrived range, in launch order (last layers first, the embeddings / heads tail last): the update
+                # of the encoder's 85 M parameters runs while the tail's all-reduce is still in flight.  (wait() makes this
+                # stream wait for the communicator's, not the host.)
+                consts = self._adam_begin()
+                for rng, h0, h1 in launched:
+                    for h in handles[h0:h1]:
+                        h.wait()
+                    self._adam_ranges(consts, rng, 1.0 / ws, self.g16)   # 1 / ws: DDP's mean over ranks
+                self._adam_end()
+                return out
             for h in handles:
                 h.wait()
         use16 = self.g16 is not None and _force_comm is None
