@@ -555,3 +555,33 @@ def test_ragged_and_degenerate_inputs_training_step(dev):
             errs = {n: _rel(p_.grad, wg[n].grad) for n, p_ in prod.named_parameters()}
             worst = max(errs, key=errs.get)
             check_close(tag + " grads worst rel-L2", errs[worst], 0.0, 0.03)
+
+
+def test_train_mode_under_no_grad_runs_the_forward_with_dropout(dev):
+    """model.train() inside torch.no_grad() (dropout on, no graph): the engine's forward alone -- a 7-tuple that differs
+    from call to call (two dropout draws), no gradient anywhere; with dropout 0 it is the eval-mode result."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config(hidden_dropout_prob=0.2, attention_probs_dropout_prob=0.2)
+    torch.manual_seed(0)
+    m = PreTrainOscar(cfg).to(dev).train()
+    b = _to(make_batch(cfg, 4, text_len=20, region_len=8, seed=3), dev)
+    with torch.no_grad():
+        o1, o2 = m(**b), m(**b)
+        s1, s2 = m.bert(b["input_ids"], attention_mask=b["attention_mask"][:, :20])[0], \
+            m.bert(b["input_ids"], attention_mask=b["attention_mask"][:, :20])[0]
+    assert all(float(v) == float(v) for v in o1[:4]) and float(o1[0]) != float(o2[0])
+    assert not o1[0].requires_grad and all(p.grad is None for p in m.parameters())
+    assert not s1.requires_grad and float((s1 - s2).abs().max()) > 0
+    m.eval()
+    with torch.no_grad():
+        e = m(**b)
+    assert abs(float(e[0]) - float(o1[0])) < 1.0          # same model, dropout noise only
+    cfg0 = mini_config()
+    m0 = PreTrainOscar(cfg0).to(dev)
+    with torch.no_grad():
+        a = m0.train()(**b)
+        c = m0.eval()(**b)
+    check_close("train() under no_grad, dropout 0, equals eval()", float(a[0]), float(c[0]), 1e-5)

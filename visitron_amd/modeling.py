@@ -1083,6 +1083,14 @@ class PreTrainOscar(BertPreTrainedModel):
             from .training import autograd_forward
 
             return autograd_forward(self, batch, head_mask=head_mask)
+        if self.training and not _is_fp32(self) and (self.config.hidden_dropout_prob > 0.0
+                                                     or self.config.attention_probs_dropout_prob > 0.0):
+            # train() under torch.no_grad() (or with frozen parameters): the engine's forward with its dropout, no backward
+            if token_labels is None:
+                raise NameError("token_prediction")
+            from .training import _bridge_engine
+
+            return _bridge_engine(self).forward_backward(batch, head_mask=head_mask, backward=False)
         outs, pooled, _, B, S = self.bert.run_trunk(
             input_ids, token_type_ids, attention_mask, position_ids, head_mask, img_feats, img_location_embeddings)
         if token_labels is None:

@@ -514,12 +514,12 @@ class PretrainEngine(object):
         st.serial = self._fwd_serial
         return st
 
-    def forward_backward(self, batch, grad_scale=1.0, accumulate=False, comm=None, head_mask=None):
+    def forward_backward(self, batch, grad_scale=1.0, accumulate=False, comm=None, head_mask=None, backward=True):
         """One forward + backward; gradients of `grad_scale * loss` land in the flat slab (p.grad).
         Returns the reference's 7-tuple (0-d fp32 tensors).  attention_mask: [B, S] (any numeric values, the reference's
         (1 - m) * -10000 arithmetic) or the reference's 3-D form [B, S, S] (encoder.py:228-229); head_mask as the
         reference takes it (encoder.py:248-265; the layer loop then runs op by op: the head scaling sits between the
-        attention kernel and the output projection in both directions)."""
+        attention kernel and the output projection in both directions).  backward=False: the forward and its 7-tuple only."""
         st = self._trunk_fwd(batch, head_mask, batch["labels"], batch["token_labels"], self.model.training, True, comm)
         m, cfg, f, dev, emb, bufs = self.model, self.cfg, self.flat, st.dev, st.emb, st.bufs
         B, S, H, Mr, lay = st.B, st.S, st.H, st.Mr, st.lay
@@ -578,6 +578,8 @@ class PretrainEngine(object):
         else:
             next_loss, action_acc = 0, 0
         loss = mask_loss + next_loss + token_loss
+        if not backward:   # train() under torch.no_grad(): the forward with its dropout, nothing else
+            return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
 
         # ---------------- backward ----------------
         gs = float(grad_scale)
