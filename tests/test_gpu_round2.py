@@ -585,3 +585,39 @@ def test_train_mode_under_no_grad_runs_the_forward_with_dropout(dev):
         a = m0.train()(**b)
         c = m0.eval()(**b)
     check_close("train() under no_grad, dropout 0, equals eval()", float(a[0]), float(c[0]), 1e-5)
+
+
+def test_engine_state_dict_resumes_the_run(dev):
+    """PretrainEngine.state_dict / load_state_dict (AdamW moments by parameter name, step / scheduler / dropout counters):
+    two steps, checkpoint, two more steps == a fresh model + engine restored from the checkpoint taking the same two steps
+    (dropout on: the seeds continue too)."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import make_batch
+    from visitron_amd.training import PretrainEngine
+
+    cfg = mini_config(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    torch.manual_seed(11)
+    a = PreTrainOscar(cfg).to(dev).train()
+    ea = PretrainEngine(a, lr=2e-3, warmup_steps=3, t_total=10)
+    batches = [_to(make_batch(cfg, 4, text_len=16, region_len=6, seed=40 + i), dev) for i in range(4)]
+    for i in range(2):
+        ea.train_step(batches[i])
+    ck_model = {k: v.detach().clone() for k, v in a.state_dict().items()}
+    ck_opt = ea.state_dict()
+    la = [float(ea.train_step(batches[i])[0]) for i in (2, 3)]
+    torch.manual_seed(99)                                   # a different process: different initial seed, fresh init
+    b = PreTrainOscar(cfg).to(dev).train()
+    b.load_state_dict(ck_model)
+    b.tie_weights()
+    eb = PretrainEngine(b, lr=1.0)                          # hyper-parameters come from the checkpoint
+    eb.load_state_dict(ck_opt)
+    assert eb.step_count == 2 and eb.lr == 2e-3 and eb.warmup_steps == 3
+    lb = [float(eb.train_step(batches[i])[0]) for i in (2, 3)]
+    for x, y in zip(la, lb):
+        check_close("resumed engine: loss", x, y, 1e-5)
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    worst = max(float((pa[n].detach() - pb[n].detach()).abs().max()) for n in pa)
+    check_close("resumed engine: weights after two more steps", worst, 0.0, 1e-6)
+    with pytest.raises(KeyError):
+        eb.load_state_dict(dict(ck_opt, state={}))

@@ -882,6 +882,36 @@ class PretrainEngine(object):
         self._adam_ranges(self._adam_begin(), [(0, self.flat.total)], grad_scale, grads)
         self._adam_end()
 
+    # ------------------------------------------------------------------------------ optimizer state (resume)
+    def state_dict(self):
+        """What a resumed run needs beside the model's own state_dict: AdamW's moments per parameter NAME (layout-
+        independent), the step / scheduler / dropout counters and the hyper-parameters.  (The reference checkpoints weights
+        only, pretrain.py:247-270; this is the fused optimizer's counterpart of torch.optim's state_dict.)"""
+        f = self.flat
+        state = {n: dict(exp_avg=f.view(f.m, n).detach().clone(), exp_avg_sq=f.view(f.v, n).detach().clone())
+                 for n, _, _, _, _ in f.entries}
+        return dict(state=state, step_count=self.step_count, sched_step=self.sched_step, fb_count=self.fb_count,
+                    drop_seed_base=self.drop_seed_base,
+                    hyper=dict(lr=self.lr, weight_decay=self.wd, eps=self.eps, betas=tuple(self.betas),
+                               correct_bias=self.correct_bias, schedule=self.schedule, warmup_steps=self.warmup_steps,
+                               t_total=self.t_total))
+
+    def load_state_dict(self, sd, load_hyper=True):
+        f = self.flat
+        missing = [n for n, _, _, _, _ in f.entries if n not in sd["state"]]
+        if missing:
+            raise KeyError("optimizer state has no entry for %s" % ", ".join(missing[:5]))
+        for n, _, _, _, _ in f.entries:
+            f.view(f.m, n).copy_(sd["state"][n]["exp_avg"])
+            f.view(f.v, n).copy_(sd["state"][n]["exp_avg_sq"])
+        self.step_count, self.sched_step = int(sd["step_count"]), int(sd["sched_step"])
+        self.fb_count, self.drop_seed_base = int(sd["fb_count"]), int(sd["drop_seed_base"])
+        if load_hyper:
+            h = sd["hyper"]
+            self.lr, self.wd, self.eps, self.betas = h["lr"], h["weight_decay"], h["eps"], tuple(h["betas"])
+            self.correct_bias, self.schedule = h["correct_bias"], h["schedule"]
+            self.warmup_steps, self.t_total = h["warmup_steps"], h["t_total"]
+
     def all_reduce_grads(self):
         """Sum the flat gradient slab over the data-parallel group in fixed-size buckets (no overlap)."""
         if self.world == 1:
