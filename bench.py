@@ -255,7 +255,8 @@ def main():
             # committed PMC passes of this command (profiles/README.md), null when that file is absent
             traffic, traffic_src = None, None
             here = os.path.dirname(os.path.abspath(__file__))
-            for rel in ("profiles/r02/train_b256_pmc_hbm_traffic_v2.json", "profiles/r02/train_b256_pmc_hbm_traffic_v1.json",
+            for rel in ("profiles/r02/train_b256_pmc_hbm_traffic_v3.json", "profiles/r02/train_b256_pmc_hbm_traffic_v2.json",
+                        "profiles/r02/train_b256_pmc_hbm_traffic_v1.json",
                         "profiles/r01/train_b256_pmc_hbm_traffic_v6.json"):
                 tp = os.path.join(here, rel)
                 if train and a.batch == 256 and os.path.exists(tp):
