@@ -32,15 +32,22 @@ for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
     ops.autotune_linear(M, N, K, device=dev)
     t_blas = timeit(lambda: torch.matmul(x, w.t(), out=y))
     t_ours = timeit(lambda: ops.linear(x, w, out=y))
-    ops.set_gemm_variant(15)
-    t_v15 = timeit(lambda: ops.linear(x, w, out=y))
-    ops.set_gemm_variant(16)
-    t_v16 = timeit(lambda: ops.linear(x, w, out=y))
+    best = None
+    per = []
+    for v in ops.GEMM_CANDIDATES:   # every autotuner candidate, one by one (the tuned pick above is one noisy measurement)
+        ops.set_gemm_variant(v)
+        try:
+            t = timeit(lambda: ops.linear(x, w, out=y))
+        except RuntimeError:
+            continue
+        per.append((v, t))
+        if best is None or t < best[1]:
+            best = (v, t)
     ops.set_gemm_variant(-1)
     fl = 2.0 * M * N * K
-    print("  N=%5d K=%5d  blas %7.1f us %6.0f TF | ours(tuned) %7.1f us %6.0f TF | v15 %7.1f us %6.0f TF | v16 %7.1f us %6.0f TF" % (
-        N, K, t_blas * 1e6, fl / t_blas * 1e-12, t_ours * 1e6, fl / t_ours * 1e-12, t_v15 * 1e6, fl / t_v15 * 1e-12,
-        t_v16 * 1e6, fl / t_v16 * 1e-12))
+    print("  N=%5d K=%5d  blas %7.1f us %6.0f TF | ours(tuned) %7.1f us %6.0f TF | best variant %2d %7.1f us %6.0f TF  (%s)" % (
+        N, K, t_blas * 1e6, fl / t_blas * 1e-12, t_ours * 1e6, fl / t_ours * 1e-12, best[0], best[1] * 1e6,
+        fl / best[1] * 1e-12, " ".join("%d:%.0f" % (v, t * 1e6) for v, t in per)))
 print("TN  dw[N,K] = dy[M,N]^T x[M,K]")
 for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
     x = torch.randn(M, K, device=dev).to(BF16)
