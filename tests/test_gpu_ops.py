@@ -761,7 +761,7 @@ def test_linear_tail_rows_launch(dev, act, res, pre, drop_p):
     r = _rand((M, N), g).to(dev, BF16) if (res or act == 3) else None
     drop = (drop_p, 4242, ops.site_out(1)) if drop_p else ops.NO_DROP
     lib = _lib.load()
-    lib.vt_gemm_tune(M, N, K, act, 16)
+    lib.vt_gemm_tune(M, N, K, ops.tune_kind(act, residual=res, pre_act=pre), 16)
     outs = []
     for mode in (-1, -2):          # single launch, then with the tail launch
         lib.vt_debug_set_gemm_variant(mode)

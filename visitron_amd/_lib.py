@@ -26,6 +26,11 @@ class LayerActs(ctypes.Structure):  # vt_layer_acts
         "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd")]
 
 
+class LayerWeightsLn(ctypes.Structure):  # vt_layer_weights_ln
+    _fields_ = [(n, c_void_p) for n in (
+        "w_qkv", "g_qkv", "h_qkv", "w_ao", "cb_ao", "gamma_in", "w_in", "g_in", "h_in", "w_out", "cb_out", "ln1_g")]
+
+
 class LayerWeightsT(ctypes.Structure):  # vt_layer_weights_t
     _fields_ = [(n, c_void_p) for n in ("wt_qkv", "wt_ao", "wt_in", "wt_out")]
 
@@ -158,6 +163,15 @@ SIGNATURES = {
     "vt_embed_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                        c_void_p, c_void_p]),
+    "vt_linear_ln_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float,
+                                  c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_void_p]),
+    "vt_ln_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64,
+                            c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "vt_ln_stream_init": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_float,
+                                  c_void_p]),
+    "vt_encoder_forward_ln_bf16": (c_int, [ctypes.POINTER(LayerWeightsLn), c_int] + [c_void_p] * 10 + [
+        c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int64, c_void_p]),
     "vt_encoder_forward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerActs), c_int, c_void_p,
                                         c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                         c_float, c_float, c_uint64, c_void_p]),

@@ -707,45 +707,63 @@ void vt_gemm_set_variant(int v) {
 }
 
 // Shape -> variant table filled by the host-side autotuner (visitron_amd.ops.autotune_linear) before
-// the shapes are used; read-only afterwards.  Exact-match lookup; misses fall back to the heuristic.
-// One table PER DEVICE (the calling thread's current device), guarded by a mutex: threads driving different GPUs of one
-// process (torch.nn.DataParallel) tune and look up independently.
-struct TuneEntry { int M, N, K, act, variant; };
-struct TuneTable { TuneEntry e[256]; int n; };
+// the shapes are used; read-only afterwards.  One table PER DEVICE (the calling thread's current device), guarded by a
+// mutex: threads driving different GPUs of one process (torch.nn.DataParallel) tune and look up independently.
+// The key is (M, N, K, what the epilogue does): kind = act | residual << 4 | second output << 5 | fp32 output << 6 |
+// deferred-LayerNorm mode << 8 -- a plain dgrad and the out-proj with its residual are the same (M, N, K, act) and not
+// the same kernel time (VT_TUNE_KIND below is what vt_gemm_dispatch looks up; vt_gemm_tune takes the same number).
+#define VT_TUNE_KIND(act, has_r, has_c2, out_f32, ln_mode) \
+  ((act) | ((has_r) ? 16 : 0) | ((has_c2) ? 32 : 0) | ((out_f32) ? 64 : 0) | ((ln_mode) << 8))
+struct TuneEntry { int M, N, K, kind, variant; };
+struct TuneTable { TuneEntry e[512]; int n; };
 static TuneTable g_tune_dev[VT_MAX_DEVICES];
 static std::mutex g_tune_mu;
-void vt_gemm_tune_set(int M, int N, int K, int act, int variant) {
+void vt_gemm_tune_set(int M, int N, int K, int kind, int variant) {
   const int dev = vt_current_device();
   if (dev < 0) return;
   std::lock_guard<std::mutex> lock(g_tune_mu);
   TuneEntry* g_tune = g_tune_dev[dev].e;
   int& g_ntune = g_tune_dev[dev].n;
   for (int i = 0; i < g_ntune; ++i)
-    if (g_tune[i].M == M && g_tune[i].N == N && g_tune[i].K == K && g_tune[i].act == act) { g_tune[i].variant = variant; return; }
-  if (g_ntune < 256) g_tune[g_ntune++] = TuneEntry{M, N, K, act, variant};
+    if (g_tune[i].M == M && g_tune[i].N == N && g_tune[i].K == K && g_tune[i].kind == kind) { g_tune[i].variant = variant; return; }
+  if (g_ntune < 512) g_tune[g_ntune++] = TuneEntry{M, N, K, kind, variant};
 }
-static int gemm_pick_variant(int M, int N, int K, int act) {
+// ln_only: the caller can only run the 256x256-tile kernels (deferred-LayerNorm epilogues)
+int vt_gemm_pick_variant(int M, int N, int K, int kind) {
   const int dev = vt_current_device();
-  std::lock_guard<std::mutex> lock(g_tune_mu);
-  const TuneEntry* g_tune = g_tune_dev[dev < 0 ? 0 : dev].e;
-  const int g_ntune = dev < 0 ? 0 : g_tune_dev[dev].n;
-  for (int i = 0; i < g_ntune; ++i)
-    if (g_tune[i].M == M && g_tune[i].N == N && g_tune[i].K == K && g_tune[i].act == act) return g_tune[i].variant;
-  // a row count the tuner has not seen (compacted batches change it every step): the entry of the same (N, K, act)
-  // whose M is nearest, within 25 %
-  int best = -1;
-  long best_d = 0;
-  for (int i = 0; i < g_ntune; ++i)
-    if (g_tune[i].N == N && g_tune[i].K == K && g_tune[i].act == act) {
-      const long d = g_tune[i].M > M ? g_tune[i].M - M : M - g_tune[i].M;
-      if (4 * d <= g_tune[i].M && (best < 0 || d < best_d)) { best = i; best_d = d; }
+  const bool ln_only = (kind >> 8) != 0;
+  {
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    const TuneEntry* g_tune = g_tune_dev[dev < 0 ? 0 : dev].e;
+    const int g_ntune = dev < 0 ? 0 : g_tune_dev[dev].n;
+    for (int i = 0; i < g_ntune; ++i)
+      if (g_tune[i].M == M && g_tune[i].N == N && g_tune[i].K == K && g_tune[i].kind == kind) return g_tune[i].variant;
+    // a row count the tuner has not seen (compacted batches change it every step): the entry of the same (N, K, kind)
+    // whose M is nearest, within 25 %; failing that the same shape under another epilogue of the same activation
+    for (int pass = 0; pass < 2; ++pass) {
+      int best = -1;
+      long best_d = 0;
+      for (int i = 0; i < g_ntune; ++i) {
+        const bool same = pass == 0 ? g_tune[i].kind == kind
+                                    : ((g_tune[i].kind & 15) == (kind & 15) && (g_tune[i].kind >> 8) == (kind >> 8));
+        if (g_tune[i].N == N && g_tune[i].K == K && same) {
+          const long d = g_tune[i].M > M ? g_tune[i].M - M : M - g_tune[i].M;
+          if (4 * d <= g_tune[i].M && (best < 0 || d < best_d)) { best = i; best_d = d; }
+        }
+      }
+      if (best >= 0) return g_tune[best].variant;
     }
-  if (best >= 0) return g_tune[best].variant;
+  }
+  if (ln_only) {   // untuned: persistent 256-row tiles when they fill the chip, else one tile per workgroup
+    const int cus = vt_device_cus();
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    return t256 >= 2L * (cus > 0 ? cus : 256) ? 16 : 23;
+  }
   // heuristic: wave-quantisation efficiency x measured relative rate of each tile
   auto eff = [](long tiles, int slots) { const double w = (double)tiles / slots; return w / (double)((long)(w + 0.999)); };
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   const long t192 = (long)((M + 255) / 256) * ((N + 191) / 192);
-  const double gelu_pen = (act == ACT_GELU) ? 0.84 : 1.0;
+  const double gelu_pen = ((kind & 15) == ACT_GELU) ? 0.84 : 1.0;
   const double s1 = eff(t128, 512) * 1.0;
   const double s9 = (N >= 192 && M >= 256) ? eff(t192, 256) * 1.12 * gelu_pen : 0.0;
   return s9 > s1 ? 9 : GEMM_DEFAULT_VARIANT;
@@ -821,10 +839,13 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   g.grp_rows = grp_rows; g.grp_stride = grp_stride;
   if (drop) g.drop = *drop; else { g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f; }
   g.trace = (unsigned long long*)g_gemm_trace;
+  g.ln_mode = 0; g.ln_np = 0; g.ln_rows = 0; g.ln_inv_n = 0.f; g.ln_eps = 0.f; g.ln_stats = nullptr; g.colv = nullptr;
+  g.R32 = nullptr; g.C32 = nullptr; g.stats_out = nullptr; g.ldr32 = 0; g.ldc32 = 0;
   if (g.drop.thresh && (long)M * N >= (1L << 32)) return VT_ERR_UNSUPPORTED;
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-  const int variant = g_gemm_variant >= 0 ? g_gemm_variant : gemm_pick_variant(M, N, K, act);
+  const int variant = g_gemm_variant >= 0 ? g_gemm_variant
+                                          : vt_gemm_pick_variant(M, N, K, VT_TUNE_KIND(act, R != nullptr, C2 != nullptr, out_f32 != 0, 0));
   auto launch = [&](const GemmArgs& ga, int v) {
     switch (act * 2 + (out_f32 ? 1 : 0)) {
       case 0: return launch_gemm<ACT_NONE, false>(ga, v, stream);
@@ -867,4 +888,35 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
     }
   }
   return launch(g, variant);
+}
+
+// ---- deferred-LayerNorm GEMMs (GemmArgs::ln_mode; gemm_v7_ln.hip) --------------------------------------------------
+int vt_gemm_ln_launch(const GemmArgs& g, int act, int variant, hipStream_t stream);
+// mode 1: C = act(rstd_r (A W^T - mean_r colv) + bias), statistics of A's rows (row length K) from stats_in;
+// mode 2: v = A W^T + bias + colv * ((R32 - mean_r) rstd_r) (row length N) -> C32 (fp32), C (bf16), stats_out.
+int vt_gemm_ln_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const float* colv,
+                        const float* stats_in, int np, long stat_rows, float eps, int ln_mode, const float* R32, long ldr32,
+                        void* C, long ldc, float* C32, long ldc32, float* stats_out, int M, int N, int K, int act,
+                        hipStream_t stream) {
+  if (!A || !W || !C || !bias || !colv || !stats_in) return VT_ERR_NULL;
+  if (ln_mode != 1 && ln_mode != 2) return VT_ERR_UNSUPPORTED;
+  if (ln_mode == 2 && (!R32 || !C32 || !stats_out)) return VT_ERR_NULL;
+  if (M <= 0 || N <= 0 || K < 128 || (K % GEMM_BK) != 0 || (N & 127)) return VT_ERR_BAD_SHAPE;
+  const int row_len = ln_mode == 1 ? K : N;   // the LayerNorm runs over the rows of A (mode 1) / of the stream (mode 2)
+  if ((row_len & 127) || np != row_len / 128 || np > 8 || stat_rows < M || (stat_rows & 1)) return VT_ERR_BAD_SHAPE;
+  if ((lda % 8) || (ldw % 8) || (ldc % 8) || (ln_mode == 2 && ((ldr32 % 4) || (ldc32 % 4)))) return VT_ERR_BAD_ALIGN;
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)colv | (uintptr_t)stats_in | (uintptr_t)R32 |
+       (uintptr_t)C32 | (uintptr_t)stats_out) & 15)
+    return VT_ERR_BAD_ALIGN;
+  GemmArgs g;
+  g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.R = nullptr; g.C = C; g.C2 = nullptr;
+  g.lda = lda; g.ldw = ldw; g.ldr = 0; g.ldc = ldc; g.ldc2 = 0;
+  g.M = M; g.N = N; g.K = K; g.grp_rows = 0; g.grp_stride = 0; g.tiles_m = 0; g.tiles_n = 0;
+  g.trace = nullptr;
+  g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f;
+  g.ln_mode = ln_mode; g.ln_np = np; g.ln_rows = (int)stat_rows; g.ln_inv_n = 1.0f / (float)row_len; g.ln_eps = eps;
+  g.ln_stats = stats_in; g.colv = colv; g.R32 = R32; g.C32 = C32; g.stats_out = stats_out; g.ldr32 = ldr32; g.ldc32 = ldc32;
+  int variant = g_gemm_variant >= 0 ? g_gemm_variant : vt_gemm_pick_variant(M, N, K, VT_TUNE_KIND(act, 0, 0, 0, ln_mode));
+  if (variant != 15 && variant != 16 && (variant < 18 || variant > 23)) variant = 16;   // only the 256x256-tile kernels
+  return vt_gemm_ln_launch(g, act, variant, stream);
 }

@@ -486,6 +486,46 @@ class _PackedEncoder(object):
         self.tensors, self.table = keep, table
 
 
+class _PackedEncoderLn(object):
+    """Weights of the deferred-LayerNorm layer loop (vt_encoder_forward_ln_bf16; include/visitron_hip.h has the
+    arithmetic).  The LayerNorm that closes sub-layer i is applied where its output is consumed, so its gamma / beta are
+    folded into the CONSUMING projections: W' = W * gamma over the input columns (bf16), g = row sums of W' (as the kernel
+    will see it, after rounding), h = W beta + b; the dense + residual GEMMs take bias + beta and gamma as vectors.
+    Layer 0's input (the embedding output) is not normalised again: gamma 1, beta 0."""
+
+    def __init__(self, encoder):
+        H = encoder._hidden
+        dev = next(encoder.parameters()).device
+        keep, table = [], (_lib.LayerWeightsLn * len(encoder.layer))()
+        gamma_in = torch.ones(H, dtype=torch.float32, device=dev)
+        beta_in = torch.zeros(H, dtype=torch.float32, device=dev)
+
+        def fold(W, b, gamma, beta):
+            W = W.detach().float()
+            wf = (W * gamma[None, :]).to(BF16).contiguous()
+            return wf, wf.float().sum(1).contiguous(), (W @ beta + b.detach().float()).contiguous()
+
+        for i, layer in enumerate(encoder.layer):
+            att, so = layer.attention.self, layer.attention.output
+            Wqkv = torch.cat([att.query.weight, att.key.weight, att.value.weight], 0)
+            bqkv = torch.cat([att.query.bias, att.key.bias, att.value.bias], 0)
+            w_qkv, g_qkv, h_qkv = fold(Wqkv, bqkv, gamma_in, beta_in)
+            g1, b1 = _f32(so.LayerNorm.weight), _f32(so.LayerNorm.bias)
+            w_in, g_in, h_in = fold(layer.intermediate.dense.weight, layer.intermediate.dense.bias, g1, b1)
+            t = dict(
+                w_qkv=w_qkv, g_qkv=g_qkv, h_qkv=h_qkv,
+                w_ao=_bf16(so.dense.weight), cb_ao=(_f32(so.dense.bias) + beta_in).contiguous(), gamma_in=gamma_in.contiguous(),
+                w_in=w_in, g_in=g_in, h_in=h_in,
+                w_out=_bf16(layer.output.dense.weight), cb_out=(_f32(layer.output.dense.bias) + b1).contiguous(), ln1_g=g1,
+            )
+            keep.append(t)
+            for k, v in t.items():
+                setattr(table[i], k, v.data_ptr())
+            gamma_in, beta_in = _f32(layer.output.LayerNorm.weight), _f32(layer.output.LayerNorm.bias)
+        self.tensors, self.table = keep, table
+        self.final_gamma, self.final_beta = gamma_in, beta_in
+
+
 # Packed bf16 weight copies (encoder layers, region projection, rollout modules) are cached and keyed on each
 # parameter's (storage address, version) PLUS this process-wide generation.  Writers that change parameter values
 # without bumping ``_version`` -- the fused AdamW kernel (raw pointers into the flat slab) and torch optimizers that
@@ -545,6 +585,11 @@ class CaptionBertEncoder(nn.Module):
         # 4.9e-2 on the base config (rms 1.06e-2 -> 1.02e-2: the bf16 weights of the twelve layers set that, not the last
         # roundings) and costs 6 % of a B = 64 forward (op-by-op last layer, two fp32-output GEMM epilogues): off by default.
         self.precise_final = os.environ.get("VT_PRECISE_FINAL", "0") == "1"
+        # inference, default: the layer loop with its LayerNorms deferred (run_ln): no LayerNorm pass, fp32 residual stream.
+        # VT_DEFERRED_LN=0 (or the attribute) keeps the seven-launch layer with bf16 activations between all kernels.
+        self.deferred_ln = os.environ.get("VT_DEFERRED_LN", "1") != "0"
+        self._packed_ln = None
+        self._packed_ln_key = None
 
     # ---- cached state -----------------------------------------------------------------
     def packed(self):
@@ -553,6 +598,75 @@ class CaptionBertEncoder(nn.Module):
             self._packed = _PackedEncoder(self)
             self._packed_key = key
         return self._packed
+
+    def packed_ln(self):
+        key = _param_key(self)
+        if self._packed_ln is None or key != self._packed_ln_key:
+            self._packed_ln = _PackedEncoderLn(self)
+            self._packed_ln_key = key
+        return self._packed_ln
+
+    def serves_deferred_ln(self, history=None, seq=None):
+        """The deferred-LayerNorm loop serves the plain eval forward: hidden size a multiple of 128 (<= 1024: eight
+        statistics slices), no per-layer outputs asked for, every row present."""
+        return (self.deferred_ln and history is None and seq is None and not self.output_attentions
+                and not self.output_hidden_states and self._hidden == self._heads * 64 and self._hidden % 128 == 0
+                and self._hidden <= 1024 and self._inter % 128 == 0)
+
+    def _workspace_ln(self, M, device):
+        key = ("ln", M, str(device))
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        H, I = self._hidden, self._inter
+        rows, np_ = round_up(M, 16), H // 128
+        bf = lambda n: torch.empty((M, n), dtype=BF16, device=device)
+        f32 = lambda n: torch.empty((M, n), dtype=torch.float32, device=device)
+        st = lambda: torch.zeros((np_, rows, 2), dtype=torch.float32, device=device)
+        ws = dict(a=(bf(H), f32(H), st()), b=(bf(H), f32(H), st()), qkv=bf(3 * H), ctx=bf(H), mid=bf(I), out16=bf(H), out32=f32(H))
+        ops.autotune_encoder_shapes_ln(M, H, I, device=device)   # once per token count
+        if len(self._ws) > 4:
+            self._ws.clear()
+        self._ws[key] = ws
+        return ws
+
+    def run_ln(self, x32, B, S, mask_f32, mask_additive, head_scale=None):
+        """The deferred-LayerNorm layer loop: x32 fp32 [B*S, H] (the embedding output; a workspace buffer from
+        `ln_input_buffer` saves a copy) -> (sequence output bf16 [B*S, H], the same in fp32).  Both live in the workspace and
+        are rewritten by the next call."""
+        for layer in self.layer:
+            _no_train_dropout(layer, layer.attention.self.dropout.p)
+            _no_train_dropout(layer, layer.output.dropout.p)
+        pk = self.packed_ln()
+        M = B * S
+        ws = self._workspace_ln(M, x32.device)
+        sa, sb = ws["a"], ws["b"]
+        H, nh, I, eps = self._hidden, self._heads, self._inter, self._eps
+        if x32.data_ptr() != sa[1].data_ptr():
+            sa[1].copy_(x32)
+        ops.ln_stream_init(sa[1], sa[0], sa[2], eps)
+        self._last_attentions = None
+        if ops.profiling():   # bench.py's per-kernel timing: the same launches, issued one by one
+            for i, t in enumerate(pk.tensors):
+                hs_i = None if head_scale is None else head_scale[i].contiguous()
+                ops.linear_ln(sa[0], t["w_qkv"], t["h_qkv"], t["g_qkv"], sa[2], eps, 1, out=ws["qkv"])
+                ops.attention_fwd(ws["qkv"], B, S, nh, mask=mask_f32, mask_additive=mask_additive, head_scale=hs_i, out=ws["ctx"])
+                ops.linear_ln(ws["ctx"], t["w_ao"], t["cb_ao"], t["gamma_in"], sa[2], eps, 2, out=sb[0], r32=sa[1], out32=sb[1],
+                              stats_out=sb[2])
+                ops.linear_ln(sb[0], t["w_in"], t["h_in"], t["g_in"], sb[2], eps, 1, act=ACT_GELU, out=ws["mid"])
+                ops.linear_ln(ws["mid"], t["w_out"], t["cb_out"], t["ln1_g"], sb[2], eps, 2, out=sa[0], r32=sb[1], out32=sa[1],
+                              stats_out=sa[2])
+        else:
+            ops.encoder_forward_ln(pk.table, sa, sb, ws["qkv"], ws["ctx"], ws["mid"], mask_f32, mask_additive, head_scale,
+                                   B, S, H, nh, I, eps)
+        ops.ln_apply(sa[1], sa[2], pk.final_gamma, pk.final_beta, eps, out16=ws["out16"], out32=ws["out32"])
+        self._final_f32 = ws["out32"]
+        return ws["out16"], ws["out32"]
+
+    def ln_input_buffer(self, M, device):
+        """The workspace's fp32 stream buffer [M, H]: a caller that writes the embedding output straight into it spares
+        run_ln a copy."""
+        return self._workspace_ln(M, device)["a"][1]
 
     def _workspace(self, M, B, device, keep_all):
         """Activation buffers + ctypes table.  keep_all: one `out` buffer per layer
@@ -717,6 +831,10 @@ class CaptionBertEncoder(nn.Module):
                                 history=encoder_history_states)
             if not self.output_hidden_states:
                 outs = outs[-1:]
+        elif self.serves_deferred_ln(history=encoder_history_states):
+            ops._require_hip(hidden_states)
+            out16, _ = self.run_ln(hidden_states.detach().reshape(B * S, H).float().contiguous(), B, S, mask, True, hs)
+            outs = [out16]
         else:
             outs = self.run(_as_bf16_2d(hidden_states), B, S, mask, True, hs, history=encoder_history_states)
         dt = hidden_states.dtype
@@ -841,6 +959,32 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                 raise NotImplementedError("compacted rows are served by the bf16 path")
             return self._run_trunk_f32(input_ids, token_type_ids, position_ids, img_feats, img_location_embeddings,
                                        encoder_history_states, mask_f32, mask_is_additive, hs, B, T, R, S, H)
+        if keep is None and self.encoder.serves_deferred_ln(history=encoder_history_states):
+            # default inference path: the embedding output in fp32, straight into the encoder's fp32 residual stream
+            emb = self.embeddings
+            _no_train_dropout(emb, emb.dropout.p)
+            x32 = self.encoder.ln_input_buffer(B * S, dev)
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            ops.embed_layernorm_f32(_i64(input_ids), _i64(token_type_ids), _i64(position_ids), _f32(emb.word_embeddings.weight),
+                                    _f32(emb.position_embeddings.weight), _f32(emb.token_type_embeddings.weight),
+                                    _f32(emb.LayerNorm.weight), _f32(emb.LayerNorm.bias), emb.LayerNorm.variance_epsilon, x32, S,
+                                    err_flag=err)
+            emb._last_err = err
+            if img_feats is not None:
+                _no_train_dropout(self, self.dropout.p)
+                w, b, kpad = self._packed_img()
+                a = ops.pack_concat(
+                    img_feats.reshape(B * R, -1).float().contiguous(),
+                    img_location_embeddings.reshape(B * R, -1).float().contiguous(), kpad)
+                ops.linear(a, w, b, out=x32[T:], ldc=H, grp_rows=R, grp_stride=S, out_f32=True)
+                if self.use_img_layernorm:
+                    ops.layernorm_rows(x32[T:], _f32(self.LayerNorm.weight), _f32(self.LayerNorm.bias),
+                                       self.LayerNorm.variance_epsilon, out=x32[T:], M=B * R, grp_rows=R, grp_stride=S)
+            self._last_layout = None
+            out16, _ = self.encoder.run_ln(x32, B, S, mask_f32, mask_is_additive, hs)
+            pooled = self.pooler.pooled(out16, B, S)
+            _check_index_error(emb)
+            return [out16], pooled, x32, B, S
         x = torch.empty((B * S, H), dtype=BF16, device=dev)
         self.embeddings.write_rows(x, S, input_ids, token_type_ids, position_ids)  # rows b*S + [0,T)
         if img_feats is not None:

@@ -123,6 +123,72 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
     return out
 
 
+def linear_ln(a, w, bias, colv, stats, eps, ln_mode, act=ACT_NONE, out=None, r32=None, out32=None, stats_out=None, M=None):
+    """A GEMM of the deferred-LayerNorm inference path (vt_linear_ln_bf16; include/visitron_hip.h has the arithmetic).
+    a [M,K] bf16 = the bf16 copy of the stream (mode 1) or a plain activation (mode 2); stats fp32 [np, rows, 2] = the
+    partial row statistics of the stream being normalised; mode 2 also takes the fp32 stream r32 [M,N] and returns the new
+    stream (out bf16, out32 fp32, stats_out)."""
+    _require_hip(a, w, bias, colv, stats, out, r32, out32, stats_out)
+    assert a.dtype == BF16 and w.dtype == BF16 and stats.dtype == torch.float32 and stats.is_contiguous()
+    N, K = w.shape
+    if M is None:
+        M = a.shape[0]
+    np_, rows = stats.shape[0], stats.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    if ln_mode == 2:
+        assert r32 is not None and r32.dtype == torch.float32
+        if out32 is None:
+            out32 = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        if stats_out is None:
+            stats_out = torch.empty((N // 128, rows, 2), dtype=torch.float32, device=a.device)
+        assert stats_out.shape[1] == rows and stats_out.is_contiguous()
+    with _timed("gemm_nt_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N) + (8.0 * M * N if ln_mode == 2 else 0.0)):
+        rc = _lib.load().vt_linear_ln_bf16(
+            _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(colv), _ptr(stats), np_, rows, float(eps), int(ln_mode),
+            _ptr(r32), 0 if r32 is None else r32.stride(0), _ptr(out), out.stride(0), _ptr(out32),
+            0 if out32 is None else out32.stride(0), _ptr(stats_out), M, N, K, int(act), _stream())
+    _lib.check(rc, "vt_linear_ln_bf16")
+    return (out, out32, stats_out) if ln_mode == 2 else out
+
+
+def ln_apply(v32, stats, gamma, beta, eps, out16=None, out32=None, M=None):
+    """LayerNorm of a stream (fp32 rows + partial statistics) written as bf16 and / or fp32."""
+    _require_hip(v32, stats, gamma, beta, out16, out32)
+    assert v32.dtype == torch.float32 and stats.dtype == torch.float32 and stats.is_contiguous()
+    if M is None:
+        M = v32.shape[0]
+    H = gamma.numel()
+    with _timed("ln_apply_rows", 0.0, M * H * (4.0 + (2.0 if out16 is not None else 0.0) + (4.0 if out32 is not None else 0.0))):
+        rc = _lib.load().vt_ln_apply(_ptr(v32), v32.stride(0), _ptr(stats), stats.shape[0], stats.shape[1], _ptr(gamma), _ptr(beta),
+                                     float(eps), _ptr(out16), 0 if out16 is None else out16.stride(0), _ptr(out32),
+                                     0 if out32 is None else out32.stride(0), M, H, _stream())
+    _lib.check(rc, "vt_ln_apply")
+
+
+def ln_stream_init(x32, x16, stats, eps, M=None):
+    """x32 fp32 [M,H] enters the deferred-LayerNorm stack as it is: bf16 copy + identity statistics."""
+    _require_hip(x32, x16, stats)
+    assert x32.dtype == torch.float32 and x16.dtype == BF16 and stats.dtype == torch.float32 and stats.is_contiguous()
+    if M is None:
+        M = x32.shape[0]
+    with _timed("ln_stream_init", 0.0, M * x32.shape[1] * 6.0):
+        rc = _lib.load().vt_ln_stream_init(_ptr(x32), x32.stride(0), _ptr(x16), x16.stride(0), _ptr(stats), stats.shape[0],
+                                           stats.shape[1], M, x32.shape[1], float(eps), _stream())
+    _lib.check(rc, "vt_ln_stream_init")
+
+
+def encoder_forward_ln(layer_weights, stream_a, stream_b, qkv, ctx, mid, mask, mask_additive, head_scale, B, S, H, nh, I, eps):
+    """The deferred-LayerNorm layer loop in C.  stream_x = (bf16 copy, fp32 rows, statistics)."""
+    _require_hip(stream_a[0], mask, head_scale)
+    rows = stream_a[2].shape[1]
+    rc = _lib.load().vt_encoder_forward_ln_bf16(
+        layer_weights, len(layer_weights), _ptr(stream_a[0]), _ptr(stream_a[1]), _ptr(stream_a[2]), _ptr(stream_b[0]),
+        _ptr(stream_b[1]), _ptr(stream_b[2]), _ptr(qkv), _ptr(ctx), _ptr(mid), _ptr(mask), _mask_mode(mask, mask_additive, B, S),
+        _ptr(head_scale), B, S, H, nh, I, float(eps), rows, _stream())
+    _lib.check(rc, "vt_encoder_forward_ln_bf16")
+
+
 # 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring), 256x256 with 128x128 wave tiles
 # and AGPR accumulators (15: one tile per workgroup, 16: persistent; 18 .. 21: the persistent kernel on 224- / 192- / 160- / 128-row tiles; 22 / 23: the one-tile-per-workgroup kernel on 224- / 192-row tiles,
 # which balance the rounds over the 256 CUs when the 256-row tiling leaves the last round mostly empty).
@@ -154,51 +220,124 @@ def force_gemm_variant(v):
     _lib.load().vt_debug_set_gemm_variant(AUTO_VARIANT if v is None else int(v))
 
 
-def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device="cuda", reps=8, out_f32=False):
-    """Time the GEMM kernel variants on one shape (random data, HIP events) and register the fastest in the
-    library's shape table.  Synchronises; call it before the timed region / graph capture."""
-    key = (M, N, K, act)
+def tune_kind(act, residual=False, pre_act=False, out_f32=False, ln_mode=0):
+    """The epilogue part of the autotuner's key, as the library derives it from a call's arguments (VT_TUNE_KIND in
+    csrc/gemm_bf16.hip): act | 16 residual / factor operand | 32 second output | 64 fp32 output | ln_mode << 8."""
+    return int(act) | (16 if (residual or act == ACT_MUL) else 0) | (32 if pre_act else 0) | (64 if out_f32 else 0) | (int(ln_mode) << 8)
+
+
+LN_GEMM_CANDIDATES = (15, 16, 18, 19, 20, 21, 22, 23)   # the deferred-LayerNorm epilogues exist on the 256x256-tile kernels
+TUNE_ROUNDS = 3          # interleaved timing rounds per candidate; a candidate's time is the MEDIAN of its rounds
+TUNE_KEEP_DEFAULT = 0.03   # the committed default stays unless a candidate beats it by more than this fraction
+_defaults = None
+
+
+def _default_table():
+    """visitron_amd/gemm_defaults.json: kernel choices measured on an MI355X for the path's own shapes ("M,N,K,kind" ->
+    variant), committed with the package.  A box whose timings are noisy keeps them (TUNE_KEEP_DEFAULT); VT_AUTOTUNE=0
+    takes them without timing anything (nearest M of the same (N, K, kind) within 25 %)."""
+    global _defaults
+    if _defaults is None:
+        import json
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_defaults.json")
+        _defaults = {}
+        if os.path.exists(path):
+            with open(path) as fh:
+                for k, v in json.load(fh).items():
+                    if not k.startswith("_"):
+                        _defaults[tuple(int(x) for x in k.split(","))] = int(v)
+    return _defaults
+
+
+def _default_variant(key):
+    tab = _default_table()
+    if key in tab:
+        return tab[key]
+    M, N, K, kind = key
+    best, best_d = None, None
+    for (m, n, k, kd), v in tab.items():
+        if (n, k, kd) == (N, K, kind) and 4 * abs(m - M) <= m and (best_d is None or abs(m - M) < best_d):
+            best, best_d = v, abs(m - M)
+    return best
+
+
+def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device="cuda", reps=6, out_f32=False, ln_mode=0):
+    """Time the GEMM kernel variants on one shape AND epilogue (random data, HIP events) and register the fastest in the
+    library's table.  Every candidate is timed in TUNE_ROUNDS interleaved rounds (candidate order inside a round, rounds
+    outside: drift of the clock or of a neighbour's load hits all candidates alike) and judged by its median; the committed
+    default (gemm_defaults.json) is kept unless beaten by more than TUNE_KEEP_DEFAULT.  Synchronises; call it before the
+    timed region / graph capture."""
+    kind = tune_kind(act, residual, pre_act, out_f32, ln_mode)
+    key = (M, N, K, kind)
     if _forced_variant is not None:
         return _forced_variant
     if key in _tuned:
         return _tuned[key]
     lib = _lib.load()
+    usable = lambda v: v is not None and (v not in PERSISTENT_VARIANTS or PERSISTENT_GEMM_OK)
     saved = _tune_file_table().get("%d,%d,%d,%d" % key)
-    if saved is not None and (saved not in PERSISTENT_VARIANTS or PERSISTENT_GEMM_OK):   # VT_TUNE_FILE: a previous run's choices
-        lib.vt_gemm_tune(M, N, K, act, int(saved))
+    if usable(saved):   # VT_TUNE_FILE: a previous run's choices
+        lib.vt_gemm_tune(M, N, K, kind, int(saved))
         _tuned[key] = int(saved)
+        return _tuned[key]
+    default = _default_variant(key)
+    if os.environ.get("VT_AUTOTUNE", "1") == "0" and usable(default):
+        lib.vt_gemm_tune(M, N, K, kind, int(default))
+        _tuned[key] = int(default)
         return _tuned[key]
     g = torch.Generator(device=device).manual_seed(M + N + K)   # on the device: a CPU draw of M x 3072 values costs seconds
     a = torch.randn(M, K, generator=g, device=device).to(BF16)
     w = (torch.randn(N, K, generator=g, device=device) * 0.03).to(BF16)
     b = torch.zeros(N, device=device)
-    r = torch.randn(M, N, generator=g, device=device).to(BF16) if (residual or act == ACT_MUL) else None
-    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=device)
-    pre = torch.empty((M, N), dtype=BF16, device=device) if pre_act else None
-    best, best_t = GEMM_CANDIDATES[0], float("inf")
-    for v in GEMM_CANDIDATES:
-        if v in PERSISTENT_VARIANTS and not PERSISTENT_GEMM_OK:
-            continue
-        lib.vt_debug_set_gemm_variant(v)
-        try:
-            for _ in range(2):
-                linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre, out_f32=out_f32)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre, out_f32=out_f32)
-            e1.record()
-            torch.cuda.synchronize()
-            t = e0.elapsed_time(e1)
-        except RuntimeError:
-            t = float("inf")
-        if os.environ.get("VT_TUNE_VERBOSE"):
-            print("  tune M=%d N=%d K=%d act=%d res=%d pre=%d variant %2d: %8.1f us %6.0f TF" % (
-                M, N, K, act, int(r is not None), int(pre_act), v, t / reps * 1e3, 2.0 * M * N * K / (t / reps * 1e-3) * 1e-12))
-        if t < best_t:
-            best, best_t = v, t
+    if ln_mode:
+        H = K if ln_mode == 1 else N
+        np_, rows = H // 128, round_up(M, 16)
+        stats = torch.zeros((np_, rows, 2), device=device)
+        stats[0, :, 1] = float(H)
+        colv = torch.ones(N, device=device)
+        r32 = torch.randn(M, N, generator=g, device=device) if ln_mode == 2 else None
+        out = torch.empty((M, N), dtype=BF16, device=device)
+        o32 = torch.empty((M, N), device=device) if ln_mode == 2 else None
+        so = torch.empty((N // 128, rows, 2), device=device) if ln_mode == 2 else None
+
+        def run():
+            linear_ln(a, w, b, colv, stats, 1e-12, ln_mode, act=act, out=out, r32=r32, out32=o32, stats_out=so)
+    else:
+        r = torch.randn(M, N, generator=g, device=device).to(BF16) if (residual or act == ACT_MUL) else None
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=device)
+        pre = torch.empty((M, N), dtype=BF16, device=device) if pre_act else None
+
+        def run():
+            linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre, out_f32=out_f32)
+    cands = [v for v in (LN_GEMM_CANDIDATES if ln_mode else GEMM_CANDIDATES) if usable(v)]
+    times = {v: [] for v in cands}
+    for rnd in range(TUNE_ROUNDS):
+        for v in list(cands):
+            lib.vt_debug_set_gemm_variant(v)
+            try:
+                for _ in range(2 if rnd == 0 else 1):
+                    run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) / reps)
+            except RuntimeError:
+                cands.remove(v)
+                times.pop(v, None)
     lib.vt_debug_set_gemm_variant(AUTO_VARIANT)
-    lib.vt_gemm_tune(M, N, K, act, best)
+    med = {v: sorted(t)[len(t) // 2] for v, t in times.items() if t}
+    best = min(med, key=med.get)
+    if usable(default) and default in med and med[default] <= med[best] * (1.0 + TUNE_KEEP_DEFAULT):
+        best = default
+    if os.environ.get("VT_TUNE_VERBOSE"):
+        for v in sorted(med):
+            print("  tune M=%d N=%d K=%d kind=%d variant %2d: %8.1f us %6.0f TF  (rounds %s)%s" % (
+                M, N, K, kind, v, med[v] * 1e3, 2.0 * M * N * K / (med[v] * 1e-3) * 1e-12,
+                " ".join("%.1f" % (t * 1e3) for t in times[v]), "  <- chosen" if v == best else ""))
+    lib.vt_gemm_tune(M, N, K, kind, best)
     _tuned[key] = best
     _tune_file_store(key, best)
     return best
@@ -232,6 +371,14 @@ def _tune_file_store(key, best):
         json.dump(tab, fh, indent=0, sort_keys=True)
 
 
+def autotune_encoder_shapes_ln(M, H, I, device="cuda"):
+    """The five GEMM launches of one deferred-LayerNorm encoder layer at M token rows (four distinct shape / epilogue pairs)."""
+    return dict(qkv=autotune_linear(M, 3 * H, H, ln_mode=1, device=device),
+                attn_out=autotune_linear(M, H, H, ln_mode=2, device=device),
+                ffn_up=autotune_linear(M, I, H, act=ACT_GELU, ln_mode=1, device=device),
+                ffn_down=autotune_linear(M, H, I, ln_mode=2, device=device))
+
+
 def autotune_encoder_shapes(M, H, I, training=False, device="cuda"):
     """Tune every GEMM shape of one encoder layer at M token rows (forward; plus the dgrads when training)."""
     res = {}
@@ -242,6 +389,8 @@ def autotune_encoder_shapes(M, H, I, training=False, device="cuda"):
     if training:
         res["d_ffn_down"] = autotune_linear(M, I, H, act=ACT_MUL, device=device)
         res["d_qkv"] = autotune_linear(M, H, 3 * H, residual=True, device=device)
+        res["d_ffn_up"] = autotune_linear(M, H, I, residual=True, device=device)    # same kernel entry as ffn_down: listed for the record
+        res["d_attn_out"] = autotune_linear(M, H, H, device=device)                  # the plain dgrad: not the out-proj's entry
     return res
 
 

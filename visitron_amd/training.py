@@ -369,6 +369,7 @@ class PretrainEngine(object):
         needs kept in the (B, S) buffer set; returns the step's state (a namespace of the locals below).  labels /
         token_labels (optional): the supervised rows are located here, where the host synchronises anyway."""
         m, cfg, f = self.model, self.cfg, self.flat
+        self._require_ownership()
         self.refresh_derived_weights()
         f.reattach_grads()
         ids = _i64(batch["input_ids"])
@@ -846,8 +847,20 @@ class PretrainEngine(object):
                        dict(dy=g_pre2_dn, x=a["ctx"], dw=gr["d_w_ao"], db=gr["d_b_ao"], accumulate=acc)], M)
 
     # ------------------------------------------------------------------------------ optimizer
+    def _require_ownership(self):
+        """The model's parameters must still live in THIS engine's flat slab.  Building another engine over the same
+        parameters (the trunk-level engine behind a training-mode `model.bert(...)` call, `model.to(...)`, a load with
+        assign) re-points `p.data` elsewhere without touching `_version`: this engine would then read and update a stale
+        slab and mirror while the model's real parameters never change.  Refused loudly instead."""
+        if not self.flat.owns_params():
+            raise RuntimeError(
+                "this PretrainEngine no longer owns the model's parameters (their storage was re-pointed: another engine was "
+                "built over them -- e.g. by a training-mode call through model.bert -- or the model was moved); build a new "
+                "PretrainEngine(model) and carry the optimizer state over with state_dict() / load_state_dict()")
+
     def _adam_begin(self):
         """Advance Adam's step counter and return this step's constants (lr after the schedule, bias-corrected step size)."""
+        self._require_ownership()
         self.step_count += 1
         t = self.step_count
         lr = self.lr * self.lr_factor()
