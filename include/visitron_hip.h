@@ -439,31 +439,33 @@ int vt_encoder_forward_bf16(const vt_layer_weights* layers, const vt_layer_acts*
 
 /* ---- the encoder stack in eval mode with its LayerNorms DEFERRED (the inference path) -----------------------------
  * Same arithmetic as vt_encoder_forward_bf16 (CaptionBertEncoder.forward, oscar/modeling_bert.py:140-169; BertSelfOutput /
- * BertOutput: LayerNorm(dense(h) + input), :94,120) with no LayerNorm pass and an fp32 residual stream:
- * between two sub-layers the stream is the PRE-LayerNorm sum v, held as fp32 [M,H] + a bf16 copy (the next GEMM's A
- * operand) + partial row statistics stats[p][row] = (sum, sum of squares) over columns 128 p .. 128 p + 127 (p < H / 128,
- * rows per slice = stat_rows >= M, even).  LayerNorm(v) is applied where v is consumed:
+ * BertOutput: LayerNorm(dense(h) + input), :94,120) with no LayerNorm pass and a residual stream that is not rounded to
+ * bf16 twice per sub-layer: between two sub-layers the stream is the PRE-LayerNorm sum v, held as fp16 [M,H] (11
+ * significant bits; saturating at +-65504) + a bf16 copy (the next GEMM's A operand) + partial row statistics of the
+ * unrounded fp32 sums, stats[p][row] = (sum, sum of squares) over columns 128 p .. 128 p + 127 (p < H / 128, rows per slice =
+ * stat_rows >= M, even).  LayerNorm(v) is applied where v is consumed:
  *   ln_mode 1 (projection of LN(v): query|key|value :43-45, BertIntermediate.dense :119)
  *       C = act(rstd_r * (A W'^T - mean_r * colv) + bias),  A = bf16 copy of v, W' = W * gamma (per input column),
  *       colv[n] = sum_k W'[n,k], bias[n] = sum_k W[n,k] beta[k] + b[n]   -- LN(v) W^T + b, normalisation on the accumulator;
  *   ln_mode 2 (dense + residual whose residual is LN(v): BertSelfOutput.dense :94, BertOutput.dense :120)
- *       v' = A W^T + bias + colv * (R32 - mean_r) * rstd_r,  colv = gamma, bias = b + beta, R32 = v (fp32);
- *       v' -> C32 (fp32), C (bf16) and stats_out (the slices of this call's columns).
+ *       v' = A W^T + bias + colv * (R_f16 - mean_r) * rstd_r,  colv = gamma, bias = b + beta, R_f16 = v (the fp16 stream);
+ *       v' -> C_f16 (the new stream), C (its bf16 copy) and stats_out (the slices of this call's columns).
  * mean_r / rstd_r come from stats_in (row length K in mode 1, N in mode 2; np = that / 128 <= 8).  bf16 output only,
  * N % 128 == 0, K % 64 == 0, K >= 128; no dropout (eval mode).  vt_ln_apply materialises LN(v) where a caller needs the
  * normalised tensor itself (the encoder's output); vt_ln_stream_init turns a plain fp32 tensor into a stream whose
  * statistics say "already normalised" (the embedding output entering layer 0). */
 int vt_linear_ln_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* colv,
-                      const float* stats_in, int np, int64_t stat_rows, float ln_eps, int ln_mode, const float* R32,
-                      int64_t ldr32, void* C, int64_t ldc, float* C32, int64_t ldc32, float* stats_out, int M, int N, int K,
+                      const float* stats_in, int np, int64_t stat_rows, float ln_eps, int ln_mode, const void* R_f16,
+                      int64_t ldrs, void* C, int64_t ldc, void* C_f16, int64_t ldcs, float* stats_out, int M, int N, int K,
                       int act, vt_stream_t stream);
-/* y = (v - mean) * rstd * gamma + beta per row of v [M,H] fp32; y_bf16 and / or y_f32 (either may be NULL). */
-int vt_ln_apply(const float* v, int64_t ldv, const float* stats, int np, int64_t stat_rows, const float* gamma,
+/* y = (v - mean) * rstd * gamma + beta per row of the fp16 stream v [M,H]; y_bf16 and / or y_f32 (either may be NULL). */
+int vt_ln_apply(const void* v, int64_t ldv, const float* stats, int np, int64_t stat_rows, const float* gamma,
                 const float* beta, float ln_eps, void* y_bf16, int64_t ldy16, float* y_f32, int64_t ldy32, int64_t M, int H,
                 vt_stream_t stream);
-/* x fp32 [M,H] -> its bf16 copy and identity statistics (mean 0, rstd 1): x enters the deferred-LayerNorm stack as is. */
-int vt_ln_stream_init(const float* x, int64_t ldx, void* x_bf16, int64_t ldy, float* stats, int np, int64_t stat_rows,
-                      int64_t M, int H, float ln_eps, vt_stream_t stream);
+/* x fp32 [M,H] -> the stream (x_f16), its bf16 copy and identity statistics (mean 0, rstd 1): x enters the
+ * deferred-LayerNorm stack as it is. */
+int vt_ln_stream_init(const float* x, int64_t ldx, void* x_f16, int64_t lds, void* x_bf16, int64_t ldy, float* stats, int np,
+                      int64_t stat_rows, int64_t M, int H, float ln_eps, vt_stream_t stream);
 
 typedef struct vt_layer_weights_ln {
   const void* w_qkv;  const float* g_qkv; const float* h_qkv; /* [3H,H] bf16 (q|k|v weights) * gamma_in; its row sums; W beta_in + b */
@@ -473,11 +475,11 @@ typedef struct vt_layer_weights_ln {
   const void* w_out;  const float* cb_out;                    /* output.dense [H,I]; its bias + ln1 beta */
   const float* ln1_g;                                         /* attention.output.LayerNorm gamma */
 } vt_layer_weights_ln;
-/* Stream A (s16_a, s32_a, stats_a) holds the layer-0 input on entry (vt_ln_stream_init) and the LAST layer's pre-LayerNorm
- * sum on return (vt_ln_apply with that layer's output.LayerNorm gives the encoder output); stream B and qkv [M,3H],
- * ctx [M,H], mid [M,I] (bf16) are scratch.  Five launches per layer. */
-int vt_encoder_forward_ln_bf16(const vt_layer_weights_ln* layers, int num_layers, void* s16_a, float* s32_a, float* stats_a,
-                               void* s16_b, float* s32_b, float* stats_b, void* qkv, void* ctx, void* mid, const float* mask,
+/* Stream A (s16_a bf16 copy, sf_a fp16, stats_a) holds the layer-0 input on entry (vt_ln_stream_init) and the LAST layer's
+ * pre-LayerNorm sum on return (vt_ln_apply with that layer's output.LayerNorm gives the encoder output); stream B and
+ * qkv [M,3H], ctx [M,H], mid [M,I] (bf16) are scratch.  Five launches per layer. */
+int vt_encoder_forward_ln_bf16(const vt_layer_weights_ln* layers, int num_layers, void* s16_a, void* sf_a, float* stats_a,
+                               void* s16_b, void* sf_b, float* stats_b, void* qkv, void* ctx, void* mid, const float* mask,
                                int mask_additive, const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps,
                                int64_t stat_rows, vt_stream_t stream);
 

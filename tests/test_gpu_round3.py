@@ -350,13 +350,16 @@ def test_linear_ln_epilogues_match_their_arithmetic(dev, variant, M):
         a = (torch.randn(M, I, generator=g) * 0.7).to(torch.bfloat16)
         W = (torch.randn(H, I, generator=g) * 0.03).to(torch.bfloat16)
         cb = 0.05 * torch.randn(H, generator=g) + beta
-        out16, out32, so = ops.linear_ln(a.to(dev), W.to(dev), cb.to(dev), gamma.to(dev), st.to(dev), eps, 2, r32=v.to(dev))
+        vs = v.to(torch.float16)                              # the stream as it is stored; its statistics are those of the fp32 sums
+        out16, out_s, so = ops.linear_ln(a.to(dev), W.to(dev), cb.to(dev), gamma.to(dev), st.to(dev), eps, 2, rs=vs.to(dev))
         torch.cuda.synchronize()
-        want = a.float() @ W.float().t() + cb + gamma * ((v - mean) * rstd)
-        check_close("linear_ln mode 2 fp32 stream (variant %d, M %d)" % (variant, M), out32, want, 2e-3)
-        assert torch.equal(out16.float().cpu(), out32.cpu().to(torch.bfloat16).float())          # the bf16 copy IS the rounded stream
-        want_st = _row_stats(out32.cpu(), rows)
-        check_close("linear_ln mode 2 statistics (variant %d, M %d)" % (variant, M), so[:, :M], want_st[:, :M], 2e-2)
+        want = a.float() @ W.float().t() + cb + gamma * ((vs.float() - mean) * rstd)
+        # fp16 stream: half an ulp of an 11-bit mantissa; its bf16 copy: of an 8-bit one
+        check_close("linear_ln mode 2 fp16 stream (variant %d, M %d)" % (variant, M), out_s, want, 2.0 ** -11 * float(want.abs().max()) + 1e-3)
+        check_close("linear_ln mode 2 bf16 copy (variant %d, M %d)" % (variant, M), out16, want, 2.0 ** -8 * float(want.abs().max()) + 1e-3)
+        want_st = _row_stats(want, rows)
+        check_close("linear_ln mode 2 statistics (variant %d, M %d)" % (variant, M), so[:, :M], want_st[:, :M],
+                    1e-4 * float(want_st.abs().max()))
         # ---- mode 1: act(rstd * (x W'^T - mean * g) + h), x = bf16 copy of v
         for act in (ops.ACT_NONE, ops.ACT_GELU):
             Wp = (torch.randn(I, H, generator=g) * 0.03)
@@ -385,23 +388,26 @@ def test_ln_apply_and_stream_init(dev):
     gamma, beta = 1.0 + 0.1 * torch.randn(H, generator=g), 0.1 * torch.randn(H, generator=g)
     o16 = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
     o32 = torch.empty(M, H, device=dev)
-    ops.ln_apply(v.to(dev), st.to(dev), gamma.to(dev), beta.to(dev), eps, out16=o16, out32=o32)
-    want = torch.nn.functional.layer_norm(v, (H,), gamma, beta, eps)
+    vs = v.to(torch.float16)
+    ops.ln_apply(vs.to(dev), st.to(dev), gamma.to(dev), beta.to(dev), eps, out16=o16, out32=o32)
+    mean, var = v.mean(-1, keepdim=True), v.var(-1, unbiased=False, keepdim=True)
+    want = (vs.float() - mean) * torch.rsqrt(var + eps) * gamma + beta           # statistics of the fp32 sums, values of the stored stream
     check_close("ln_apply fp32", o32, want, 1e-4)
     assert torch.equal(o16.float().cpu(), o32.cpu().to(torch.bfloat16).float())
     x16 = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
+    xs = torch.empty(M, H, dtype=torch.float16, device=dev)
     st2 = torch.full((H // 128, rows, 2), 7.0, device=dev)
-    ops.ln_stream_init(v.to(dev), x16, st2, eps)
-    assert torch.equal(x16.float().cpu(), v.to(torch.bfloat16).float())
+    ops.ln_stream_init(v.to(dev), xs, x16, st2, eps)
+    assert torch.equal(x16.float().cpu(), v.to(torch.bfloat16).float()) and torch.equal(xs.cpu(), vs)
     s = st2.cpu()
     assert float(s[:, :M, 0].abs().max()) == 0.0 and float(s[1:, :M, 1].abs().max()) == 0.0
     assert torch.allclose(s[0, :M, 1], torch.full((M,), float(H)))
 
 
 def test_deferred_layernorm_path_equals_the_seven_launch_layer(dev):
-    """The default inference path (LayerNorms deferred, fp32 residual stream) against the seven-launch layer with its
-    LayerNorm passes (VT_DEFERRED_LN=0) on the same weights: the two differ by bf16 roundings only, and the deferred path is
-    the closer one to the fp32 oracle."""
+    """The default inference path (LayerNorms deferred, fp32 residual stream) and the seven-launch layer with its LayerNorm
+    passes (VT_DEFERRED_LN=0), both against the fp32 oracle on the same weights: both inside 5e-2, the deferred path the
+    closer one."""
     from oracle.modeling import BertImgModelwithLocationEmbeds as OTrunk
     from visitron_amd.config import mini_config
     from visitron_amd.modeling import BertImgModelwithLocationEmbeds
@@ -417,10 +423,11 @@ def test_deferred_layernorm_path_equals_the_seven_launch_layer(dev):
         prod.encoder.deferred_ln = False
         o_seq, o_pool = prod(**_to(b, dev))[:2]
         prod.encoder.deferred_ln = True
-    e_new, e_old = check_close("deferred-LN trunk sequence_output (mini)", g_seq, w_seq, TOL), float((o_seq.cpu() - w_seq).abs().max())
+    e_new = check_close("deferred-LN trunk sequence_output (mini)", g_seq, w_seq, TOL)
+    e_old = check_close("seven-launch layer trunk sequence_output (mini)", o_seq, w_seq, TOL)
     check_close("deferred-LN trunk pooled_output (mini)", g_pool, w_pool, TOL)
-    check_close("deferred-LN vs seven-launch layer (mini)", g_seq, o_seq, TOL)
     print("deferred-LN max error %.3e, seven-launch layer %.3e" % (e_new, e_old))
+    assert e_new <= e_old + 5e-3, "the fp32 residual stream should not be the less accurate of the two"
     # a head_mask and a per-query (3-D) mask go through the same loop
     hm = torch.ones(cfg.num_hidden_layers, cfg.num_attention_heads)
     hm[1, 0] = 0.0

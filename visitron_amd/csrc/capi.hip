@@ -83,14 +83,14 @@ int vt_embed_layernorm_f32_dispatch(const int64_t* ids, const int64_t* type_ids,
 
 void vt_gemm_tune_set(int M, int N, int K, int kind, int variant);
 int vt_gemm_ln_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const float* colv,
-                        const float* stats_in, int np, long stat_rows, float eps, int ln_mode, const float* R32, long ldr32,
-                        void* C, long ldc, float* C32, long ldc32, float* stats_out, int M, int N, int K, int act,
+                        const float* stats_in, int np, long stat_rows, float eps, int ln_mode, const void* Rs, long ldrs,
+                        void* C, long ldc, void* Cs, long ldcs, float* stats_out, int M, int N, int K, int act,
                         hipStream_t stream);
-int vt_ln_apply_dispatch(const float* v, long ldv, const float* stats, int np, long stat_rows, const float* gamma,
+int vt_ln_apply_dispatch(const void* v, long ldv, const float* stats, int np, long stat_rows, const float* gamma,
                          const float* beta, float eps, void* y16, long ldy16, float* y32, long ldy32, long M, int H,
                          hipStream_t stream);
-int vt_ln_stream_init_dispatch(const float* x, long ldx, void* y16, long ldy, float* stats, int np, long stat_rows, long M,
-                               int H, float eps, hipStream_t stream);
+int vt_ln_stream_init_dispatch(const float* x, long ldx, void* s16, long lds, void* y16, long ldy, float* stats, int np,
+                               long stat_rows, long M, int H, float eps, hipStream_t stream);
 void vt_attn_bwd_set_waves(int w);
 
 #include "wgrad_common.hpp"
@@ -521,35 +521,35 @@ int vt_wgrad_bf16(const vt_wgrad_problem* problems, int nprob, int M, vt_stream_
 
 // ---- deferred-LayerNorm inference path ------------------------------------------------------------------------------
 int vt_linear_ln_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* colv,
-                      const float* stats_in, int np, int64_t stat_rows, float ln_eps, int ln_mode, const float* R32,
-                      int64_t ldr32, void* C, int64_t ldc, float* C32, int64_t ldc32, float* stats_out, int M, int N, int K,
+                      const float* stats_in, int np, int64_t stat_rows, float ln_eps, int ln_mode, const void* R_f16,
+                      int64_t ldrs, void* C, int64_t ldc, void* C_f16, int64_t ldcs, float* stats_out, int M, int N, int K,
                       int act, vt_stream_t stream) {
-  return vt_gemm_ln_dispatch(A, lda, W, ldw, bias, colv, stats_in, np, stat_rows, ln_eps, ln_mode, R32, ldr32, C, ldc, C32,
-                             ldc32, stats_out, M, N, K, act, (hipStream_t)stream);
+  return vt_gemm_ln_dispatch(A, lda, W, ldw, bias, colv, stats_in, np, stat_rows, ln_eps, ln_mode, R_f16, ldrs, C, ldc, C_f16,
+                             ldcs, stats_out, M, N, K, act, (hipStream_t)stream);
 }
 
-int vt_ln_apply(const float* v, int64_t ldv, const float* stats, int np, int64_t stat_rows, const float* gamma,
+int vt_ln_apply(const void* v, int64_t ldv, const float* stats, int np, int64_t stat_rows, const float* gamma,
                 const float* beta, float ln_eps, void* y_bf16, int64_t ldy16, float* y_f32, int64_t ldy32, int64_t M, int H,
                 vt_stream_t stream) {
   return vt_ln_apply_dispatch(v, ldv, stats, np, stat_rows, gamma, beta, ln_eps, y_bf16, ldy16, y_f32, ldy32, M, H,
                               (hipStream_t)stream);
 }
 
-int vt_ln_stream_init(const float* x, int64_t ldx, void* x_bf16, int64_t ldy, float* stats, int np, int64_t stat_rows,
-                      int64_t M, int H, float ln_eps, vt_stream_t stream) {
-  return vt_ln_stream_init_dispatch(x, ldx, x_bf16, ldy, stats, np, stat_rows, M, H, ln_eps, (hipStream_t)stream);
+int vt_ln_stream_init(const float* x, int64_t ldx, void* x_f16, int64_t lds, void* x_bf16, int64_t ldy, float* stats, int np,
+                      int64_t stat_rows, int64_t M, int H, float ln_eps, vt_stream_t stream) {
+  return vt_ln_stream_init_dispatch(x, ldx, x_f16, lds, x_bf16, ldy, stats, np, stat_rows, M, H, ln_eps, (hipStream_t)stream);
 }
 
 // CaptionBertEncoder.forward (oscar/modeling_bert.py:140-169) in eval mode with the LayerNorms deferred: five launches per
 // layer (no LayerNorm pass; the residual stream stays fp32):
 //   qkv GEMM (LN of the incoming stream folded in) -> fused attention -> out-proj GEMM (+ LN(stream) as residual; new
 //   stream + statistics) -> FFN-up GEMM (LN folded in, GELU) -> FFN-down GEMM (+ LN(stream); new stream + statistics)
-int vt_encoder_forward_ln_bf16(const vt_layer_weights_ln* layers, int num_layers, void* s16_a, float* s32_a, float* stats_a,
-                               void* s16_b, float* s32_b, float* stats_b, void* qkv, void* ctx, void* mid, const float* mask,
+int vt_encoder_forward_ln_bf16(const vt_layer_weights_ln* layers, int num_layers, void* s16_a, void* sf_a, float* stats_a,
+                               void* s16_b, void* sf_b, float* stats_b, void* qkv, void* ctx, void* mid, const float* mask,
                                int mask_additive, const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps,
                                int64_t stat_rows, vt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!layers || !s16_a || !s32_a || !stats_a || !s16_b || !s32_b || !stats_b || !qkv || !ctx || !mid) return VT_ERR_NULL;
+  if (!layers || !s16_a || !sf_a || !stats_a || !s16_b || !sf_b || !stats_b || !qkv || !ctx || !mid) return VT_ERR_NULL;
   if (num_layers <= 0 || B <= 0 || S <= 0 || nh <= 0 || H != nh * 64 || (H % 128) || (I % 128) || H > 1024) return VT_ERR_BAD_SHAPE;
   const int M = B * S, np = H / 128;
   for (int l = 0; l < num_layers; ++l) {
@@ -562,13 +562,13 @@ int vt_encoder_forward_ln_bf16(const vt_layer_weights_ln* layers, int num_layers
     rc = vt_attention_fwd_dispatch(qkv, 3L * H, mask, mask_additive, head_scale ? head_scale + (long)l * nh : nullptr, ctx, H,
                                    nullptr, B, S, nh, 64, stream, &nodrop);
     if (rc) return rc;
-    rc = vt_gemm_ln_dispatch(ctx, H, w.w_ao, H, w.cb_ao, w.gamma_in, stats_a, np, stat_rows, ln_eps, 2, s32_a, H, s16_b, H, s32_b,
+    rc = vt_gemm_ln_dispatch(ctx, H, w.w_ao, H, w.cb_ao, w.gamma_in, stats_a, np, stat_rows, ln_eps, 2, sf_a, H, s16_b, H, sf_b,
                              H, stats_b, M, H, H, VT_ACT_NONE, stream);
     if (rc) return rc;
     rc = vt_gemm_ln_dispatch(s16_b, H, w.w_in, H, w.h_in, w.g_in, stats_b, np, stat_rows, ln_eps, 1, nullptr, 0, mid, I, nullptr, 0,
                              nullptr, M, I, H, VT_ACT_GELU, stream);
     if (rc) return rc;
-    rc = vt_gemm_ln_dispatch(mid, I, w.w_out, I, w.cb_out, w.ln1_g, stats_b, np, stat_rows, ln_eps, 2, s32_b, H, s16_a, H, s32_a, H,
+    rc = vt_gemm_ln_dispatch(mid, I, w.w_out, I, w.cb_out, w.ln1_g, stats_b, np, stat_rows, ln_eps, 2, sf_b, H, s16_a, H, sf_a, H,
                              stats_a, M, H, I, VT_ACT_NONE, stream);
     if (rc) return rc;
   }

@@ -840,7 +840,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   if (drop) g.drop = *drop; else { g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f; }
   g.trace = (unsigned long long*)g_gemm_trace;
   g.ln_mode = 0; g.ln_np = 0; g.ln_rows = 0; g.ln_inv_n = 0.f; g.ln_eps = 0.f; g.ln_stats = nullptr; g.colv = nullptr;
-  g.R32 = nullptr; g.C32 = nullptr; g.stats_out = nullptr; g.ldr32 = 0; g.ldc32 = 0;
+  g.Rs = nullptr; g.Cs = nullptr; g.stats_out = nullptr; g.ldrs = 0; g.ldcs = 0;
   if (g.drop.thresh && (long)M * N >= (1L << 32)) return VT_ERR_UNSUPPORTED;
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
@@ -893,20 +893,20 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
 // ---- deferred-LayerNorm GEMMs (GemmArgs::ln_mode; gemm_v7_ln.hip) --------------------------------------------------
 int vt_gemm_ln_launch(const GemmArgs& g, int act, int variant, hipStream_t stream);
 // mode 1: C = act(rstd_r (A W^T - mean_r colv) + bias), statistics of A's rows (row length K) from stats_in;
-// mode 2: v = A W^T + bias + colv * ((R32 - mean_r) rstd_r) (row length N) -> C32 (fp32), C (bf16), stats_out.
+// mode 2: v = A W^T + bias + colv * ((Rs - mean_r) rstd_r) (row length N) -> Cs (fp16), C (bf16), stats_out.
 int vt_gemm_ln_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const float* colv,
-                        const float* stats_in, int np, long stat_rows, float eps, int ln_mode, const float* R32, long ldr32,
-                        void* C, long ldc, float* C32, long ldc32, float* stats_out, int M, int N, int K, int act,
+                        const float* stats_in, int np, long stat_rows, float eps, int ln_mode, const void* Rs, long ldrs,
+                        void* C, long ldc, void* Cs, long ldcs, float* stats_out, int M, int N, int K, int act,
                         hipStream_t stream) {
   if (!A || !W || !C || !bias || !colv || !stats_in) return VT_ERR_NULL;
   if (ln_mode != 1 && ln_mode != 2) return VT_ERR_UNSUPPORTED;
-  if (ln_mode == 2 && (!R32 || !C32 || !stats_out)) return VT_ERR_NULL;
+  if (ln_mode == 2 && (!Rs || !Cs || !stats_out)) return VT_ERR_NULL;
   if (M <= 0 || N <= 0 || K < 128 || (K % GEMM_BK) != 0 || (N & 127)) return VT_ERR_BAD_SHAPE;
   const int row_len = ln_mode == 1 ? K : N;   // the LayerNorm runs over the rows of A (mode 1) / of the stream (mode 2)
   if ((row_len & 127) || np != row_len / 128 || np > 8 || stat_rows < M || (stat_rows & 1)) return VT_ERR_BAD_SHAPE;
-  if ((lda % 8) || (ldw % 8) || (ldc % 8) || (ln_mode == 2 && ((ldr32 % 4) || (ldc32 % 4)))) return VT_ERR_BAD_ALIGN;
-  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)colv | (uintptr_t)stats_in | (uintptr_t)R32 |
-       (uintptr_t)C32 | (uintptr_t)stats_out) & 15)
+  if ((lda % 8) || (ldw % 8) || (ldc % 8) || (ln_mode == 2 && ((ldrs % 8) || (ldcs % 8)))) return VT_ERR_BAD_ALIGN;
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)colv | (uintptr_t)stats_in | (uintptr_t)Rs |
+       (uintptr_t)Cs | (uintptr_t)stats_out) & 15)
     return VT_ERR_BAD_ALIGN;
   GemmArgs g;
   g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = bias; g.R = nullptr; g.C = C; g.C2 = nullptr;
@@ -915,7 +915,7 @@ int vt_gemm_ln_dispatch(const void* A, long lda, const void* W, long ldw, const 
   g.trace = nullptr;
   g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f;
   g.ln_mode = ln_mode; g.ln_np = np; g.ln_rows = (int)stat_rows; g.ln_inv_n = 1.0f / (float)row_len; g.ln_eps = eps;
-  g.ln_stats = stats_in; g.colv = colv; g.R32 = R32; g.C32 = C32; g.stats_out = stats_out; g.ldr32 = ldr32; g.ldc32 = ldc32;
+  g.ln_stats = stats_in; g.colv = colv; g.Rs = (const uint16_t*)Rs; g.Cs = (uint16_t*)Cs; g.stats_out = stats_out; g.ldrs = ldrs; g.ldcs = ldcs;
   int variant = g_gemm_variant >= 0 ? g_gemm_variant : vt_gemm_pick_variant(M, N, K, VT_TUNE_KIND(act, 0, 0, 0, ln_mode));
   if (variant != 15 && variant != 16 && (variant < 18 || variant > 23)) variant = 16;   // only the 256x256-tile kernels
   return vt_gemm_ln_launch(g, act, variant, stream);

@@ -17,14 +17,15 @@ struct GemmArgs {
   DropCfg drop;              // dropout on act(acc + bias) BEFORE the residual add (BertSelfOutput / BertOutput /
                              // image embedding); element index = m * N + n
   // ---- deferred LayerNorm (the inference path's fused residual + LayerNorm, gemm_v7_ln.hip) ---------------------
-  // The residual stream between two sub-layers is the PRE-LayerNorm sum v, kept as fp32 [M, H] (the stream itself) plus a
-  // bf16 copy (the next GEMM's A operand) plus per-row partial statistics stats[p][row] = (sum, sum of squares) over the
-  // 128-column slice p (p < H / 128).  LayerNorm itself is never run as a pass of its own:
+  // The residual stream between two sub-layers is the PRE-LayerNorm sum v, kept as fp16 [M, H] (the stream itself: 11
+  // significant bits against bf16's 8; values beyond +-65504 saturate) plus a bf16 copy (the next GEMM's A operand) plus
+  // per-row partial statistics stats[p][row] = (sum, sum of squares) of the UNROUNDED fp32 sums over the 128-column slice p
+  // (p < H / 128).  LayerNorm itself is never run as a pass of its own:
   //   ln_mode 1 (consumer: QKV, FFN-up)    C = act(rstd_r * (A W'^T - mean_r * g) + h)     A = bf16 copy of v, W' = W * gamma,
   //                                        g = rowsum(W') (colv), h = W beta + b (bias): LN(v) W^T + b with the
   //                                        normalisation applied to the accumulator;
-  //   ln_mode 2 (producer: out-proj, FFN-down)  v' = A W^T + cb + LN(v)                    LN(v) = (R32 - mean_r) rstd_r gamma
-  //                                        (colv) + beta, cb = b + beta (bias); writes v' as fp32 (C32), bf16 (C) and its
+  //   ln_mode 2 (producer: out-proj, FFN-down)  v' = A W^T + cb + LN(v)                    LN(v) = (Rs - mean_r) rstd_r gamma
+  //                                        (colv) + beta, cb = b + beta (bias); writes v' as fp16 (Cs), bf16 (C) and its
   //                                        partial statistics (stats_out, slices of this tile's columns).
   int ln_mode;
   int ln_np;                 // partials per row of ln_stats (H / 128, <= 8)
@@ -32,10 +33,10 @@ struct GemmArgs {
   float ln_inv_n, ln_eps;    // 1 / H, LayerNorm epsilon
   const float* ln_stats;     // [ln_np][ln_rows][2]
   const float* colv;         // per-column vector, see above
-  const float* R32;          // mode 2: the fp32 stream in (row stride ldr32)
-  float* C32;                // mode 2: the fp32 stream out (row stride ldc32)
+  const uint16_t* Rs;        // mode 2: the fp16 stream in (row stride ldrs)
+  uint16_t* Cs;              // mode 2: the fp16 stream out (row stride ldcs)
   float* stats_out;          // mode 2: [N / 128][ln_rows][2]
-  long ldr32, ldc32;
+  long ldrs, ldcs;
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_MUL = 3 };  // MUL: out = acc * R (R = saved gelu'(pre-activation))

@@ -580,16 +580,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     V8_TRACE_RT();
     V7_EPILOGUE()
-    if (LNM == 2) {
-      // the epilogue's ring wants the registers: the next tile's first fragments (read by the last K-step) are simply read
-      // again from the stage they still sit in, so they are not live across it
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (i < MTN) V7_LDSR(xf[0][i], xa0, i * 2048);
-        V7_LDSR(wf[0][i], wa0, i * 2048);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
     V8_TRACE_RT();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

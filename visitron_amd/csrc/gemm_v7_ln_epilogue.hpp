@@ -12,8 +12,9 @@
 // Slab s = 0 .. 2 MTN - 1 is row block s % MTN of column half s / MTN (16 rows x 64 columns of the 16 MTN x 128 wave tile);
 // a lane (j = lane & 15, gq = lane >> 4) owns row j of the block and 16 consecutive columns 16 gq .. 16 gq + 15.
 //   mode 1   v = act(ra_r * acc + (rb_r * g_c + h_c))            ra = rstd_r, rb = -mean_r * rstd_r of the A operand's row r
-//   mode 2   v = acc + cb_c + gamma_c * (R32_rc * ra_r + rb_r)   v -> C32 (fp32), C (bf16), and its row sums / sums of
-//            squares over the wave's 128 columns -> one statistics slice (stats_out[2 * column tile + column wave]).
+//   mode 2   v = acc + cb_c + gamma_c * (Rs_rc * ra_r + rb_r)    v -> Cs (fp16: the stream), C (bf16: the next GEMM's operand),
+//            and its row sums / sums of squares over the wave's 128 columns -> one statistics slice
+//            (stats_out[2 * column tile + column wave]).
 #pragma once
 
 // A register pin (the value is final / stays where it is from here on).  NOT an empty asm statement: hipcc's hazard
@@ -23,15 +24,29 @@
 // s_nop inside, what the recognizer assumes is true.
 #define V7_LN_PIN(...) asm volatile("s_nop 0" : __VA_ARGS__)
 
-// The fp32 stream of mode 2 comes through a ring of V7_LN_RING slabs (4 x 16 B per lane and slab = 16 registers): eight
-// slabs as in v7_epilogue_fast would take 128 registers; six cover the ~3.5 us the stream takes to arrive under load at
-// ~0.6 us of arithmetic and stores per slab.
-#define V7_LN_RING 6
+// The fp16 stream of mode 2 comes through a ring of V7_LN_RING slabs (2 x 16 B per lane and slab = 8 registers), as the
+// bf16 residual does in v7_epilogue_fast: eight slabs cover the ~3.5 us the stream takes to arrive under load.
+// (The stream was fp32 at first: 10 bytes per element through this epilogue against 6 now, and these GEMMs are
+// memory-bound in it -- out-proj at M = 14 592: 38.5 us against 23.6 us for the plain bf16 residual epilogue.  An
+// emulation of the forward with an fp16 stream gives the same error against the fp32 reference as an fp32 stream:
+// 2.2e-2 against 2.1e-2 on the base config, where the bf16 stream of the seven-launch layer gives 7.4e-2.)
+#define V7_LN_RING 8
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float f16lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+__device__ __forceinline__ float f16hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+// two fp32 -> one dword of fp16, round to nearest even, saturating at the largest finite fp16 (a pre-LayerNorm sum of that
+// size does not occur in a BERT-class model; it must not become an infinity that the next LayerNorm turns into NaN)
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  lo = __builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f);
+  hi = __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f);
+  const f16x2_t v = __builtin_convertvector((f32x2){lo, hi}, f16x2_t);
+  return __builtin_bit_cast(uint32_t, v);
+}
 // VMEM operations younger than slab s's ring loads at the moment slab s waits for them (T slabs; LD loads and ST stores
 // per slab; issue order per slab: wait, arithmetic, loads of slab s + RING, stores of slab s; prologue: slabs 0 .. RING-1)
 constexpr int v7_ln_vmcnt(int s, int T) {
-  const int D = V7_LN_RING, LD = 4, ST = 6;   // every second slab issues a seventh store (the row block's statistics):
-                                                // counting 6 makes the wait ask for a little more than needed, never less
+  const int D = V7_LN_RING, LD = 2, ST = 4;   // every second slab issues a fifth store (the row block's statistics):
+                                                // counting 4 makes the wait ask for a little more than needed, never less
   int n = 0;
   if (s < D) {
     n += LD * ((T < D ? T : D) - 1 - s);
@@ -40,10 +55,9 @@ constexpr int v7_ln_vmcnt(int s, int T) {
     n += ST;
     for (int k = s - D + 1; k < s; ++k) n += (k + D < T ? LD : 0) + ST;
   }
-  // The counter has six bits and must never be asked to hold more than 63 operations: after its wait a slab issues up to
-  // LD + ST + 1 = 11 more, so the wait leaves at most 52 in flight (a smaller count only waits for more of the OLDER operations:
-  // stores issued six slabs ago).  Measured: with 56 + 10 in flight (14- and 16-slab tiles) the waits stop meaning what they
-  // say and slabs read their ring registers before the data has landed; 12-slab tiles (at most 62) were right.
+  // The counter has six bits: a wave must never have more than 63 operations in flight.  After its wait a slab issues up to
+  // LD + ST + 1 = 7 more, so the wait leaves at most 52 (a smaller count only waits for more of the OLDER operations: stores
+  // issued a ring ago).
   return n > 52 ? 52 : n;
 }
 
@@ -81,11 +95,10 @@ __device__ __forceinline__ void v7_ln_colvec(unsigned slot, int ecr, int gq, flo
 // Mode 2: row block outside, column half inside: a row block's sums are finished (and stored) after its second slab, so two
 // running sums are alive instead of 2 MTN, and the two 256-byte halves of a stream row are written back to back; the
 // per-column vectors are read again for every slab (eight ds_read_b128, issued in front of the slab's VMEM wait).
-// Register budget of mode 2 (the reason for all of this): 96 ring + 32 column vectors + 16 values + ~30 addresses and row
-// factors, under a 256-register ceiling shared with what the kernel keeps across the epilogue.  The ring registers are
-// written by loads hipcc does not see: anything the allocator moves out of the way (a copy to an AGPR, a v_mov) BEFORE the
-// data has landed carries the old bits -- which is what 16 row factors + 16 running sums on top of the above caused on the
-// 224- and 256-row tiles (wrong rows that came and went).  tests/test_build_isa.py checks that no such copy exists.
+// Register budget of mode 2 (the reason for this): the ring registers are written by loads hipcc does not see, so anything
+// the allocator moves out of the way (a copy to an AGPR, a v_mov) BEFORE the data has landed carries the old bits -- which is
+// what 16 row factors + 16 running sums in registers beside a 96-register fp32 ring caused on the 224- and 256-row tiles
+// (wrong rows that came and went).  tests/test_build_isa.py checks that the epilogue makes no such copy.
 template <int LNM, int MTN>
 struct V7LnOrder {
   static constexpr int mt(int s) { return LNM == 2 ? s / 2 : s % MTN; }
@@ -140,14 +153,14 @@ __device__ __forceinline__ void v7_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[8
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS operations complete in order: its own writes are visible to it
   }
 
-  // mode 2 state: descriptors of the fp32 stream in / out, the ring
-  const int ldr_b = (int)g.ldr32 * 4, ldo_b = (int)g.ldc32 * 4;
-  const u32x4 rs_r = v7_rsrc(LNM == 2 ? g.R32 + (long)m0 * g.ldr32 : nullptr, LNM == 2 ? (unsigned)rows * ldr_b : 0u);
-  const u32x4 rs_o = v7_rsrc(LNM == 2 ? g.C32 + (long)m0 * g.ldc32 : nullptr, LNM == 2 ? (unsigned)rows * ldo_b : 0u);
-  const int vo_r = j * ldr_b + gq * 64, vo_o = j * ldo_b + gq * 64;
+  // mode 2 state: descriptors of the fp16 stream in / out, the ring
+  const int ldr_b = (int)g.ldrs * 2, ldo_b = (int)g.ldcs * 2;
+  const u32x4 rs_r = v7_rsrc(LNM == 2 ? g.Rs + (long)m0 * g.ldrs : nullptr, LNM == 2 ? (unsigned)rows * ldr_b : 0u);
+  const u32x4 rs_o = v7_rsrc(LNM == 2 ? g.Cs + (long)m0 * g.ldcs : nullptr, LNM == 2 ? (unsigned)rows * ldo_b : 0u);
+  const int vo_r = j * ldr_b + gq * 32, vo_o = j * ldo_b + gq * 32;
   const int part = (n0 >> 7) + wn;   // mode 2: the statistics slice this wave's 128 columns make
   const u32x4 rs_s = v7_rsrc(LNM == 2 ? g.stats_out + (long)part * g.ln_rows * 2 : nullptr, LNM == 2 ? (unsigned)g.M * 8u : 0u);
-  u32x4 ring[V7_LN_RING][4];
+  u32x4 ring[V7_LN_RING][2];
   float s1 = 0.f, s2 = 0.f;
   float c0[16], c1[16];   // mode 1: h, g; mode 2: cb, gamma -- of the slab's column half
   typedef V7LnOrder<LNM, MTN> Ord;
@@ -155,11 +168,9 @@ __device__ __forceinline__ void v7_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[8
 #define V7_LN_RING_LOAD(S)                                                                                  \
   {                                                                                                         \
     constexpr int mt_ = Ord::mt(S), nh_ = Ord::nh(S), sl_ = (S) % V7_LN_RING;                               \
-    const int so_ = (16 * MTN * wm + 16 * mt_) * ldr_b + (n0 + 128 * wn + 64 * nh_) * 4;                    \
+    const int so_ = (16 * MTN * wm + 16 * mt_) * ldr_b + (n0 + 128 * wn + 64 * nh_) * 2;                    \
     v7_buf_load16_at<0>(ring[sl_][0], rs_r, vo_r, so_);                                                     \
     v7_buf_load16_at<16>(ring[sl_][1], rs_r, vo_r, so_);                                                    \
-    v7_buf_load16_at<32>(ring[sl_][2], rs_r, vo_r, so_);                                                    \
-    v7_buf_load16_at<48>(ring[sl_][3], rs_r, vo_r, so_);                                                    \
   }
 #define V7_LN_SLAB(S)                                                                                       \
   if ((S) < 2 * MTN) {                                                                                      \
@@ -185,22 +196,27 @@ __device__ __forceinline__ void v7_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[8
           v[4 * t + e] = apply_act<ACT>(fmaf(ra, acc[MT][4 * NH + t][e], fmaf(rb, c1[4 * t + e], c0[4 * t + e]))); \
     } else {                                                                                                \
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(v7_ln_vmcnt((S), 2 * MTN)) : "memory");                      \
-      V7_LN_PIN("+v"(ring[SL][0]), "+v"(ring[SL][1]), "+v"(ring[SL][2]), "+v"(ring[SL][3]));                \
+      V7_LN_PIN("+v"(ring[SL][0]), "+v"(ring[SL][1]));                                                      \
       if (NH == 0) { s1 = 0.f; s2 = 0.f; }                                                                  \
       _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                     \
-          const float xh = fmaf(__uint_as_float(ring[SL][t][e]), ra, rb);                                   \
+          /* column 4 t + e of the lane's 16: dword (4 t + e) / 2 of the slab's 8, its low or high half */     \
+          const uint32_t rw_ = ring[SL][t >> 1][2 * (t & 1) + (e >> 1)];                                    \
+          const float xh = fmaf((e & 1) ? f16hi(rw_) : f16lo(rw_), ra, rb);                                 \
           const float w = fmaf(xh, c1[4 * t + e], acc[MT][4 * NH + t][e] + c0[4 * t + e]);                  \
           v[4 * t + e] = w;                                                                                 \
           s1 += w;                                                                                          \
           s2 = fmaf(w, w, s2);                                                                              \
         }                                                                                                   \
       if ((S) + V7_LN_RING < 2 * MTN) V7_LN_RING_LOAD((S) + V7_LN_RING)                                     \
-      const int so_o = so_row * ldo_b + ec * 4;                                                             \
-      v7_buf_store16_at<0>((u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rs_o, vo_o, so_o);      \
-      v7_buf_store16_at<16>((u32x4){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rs_o, vo_o, so_o);     \
-      v7_buf_store16_at<32>((u32x4){__float_as_uint(v[8]), __float_as_uint(v[9]), __float_as_uint(v[10]), __float_as_uint(v[11])}, rs_o, vo_o, so_o);   \
-      v7_buf_store16_at<48>((u32x4){__float_as_uint(v[12]), __float_as_uint(v[13]), __float_as_uint(v[14]), __float_as_uint(v[15])}, rs_o, vo_o, so_o); \
+      const int so_o = so_row * ldo_b + ec * 2;                                                             \
+      u32x4 h0, h1;                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+        h0[i] = pack_f16x2(v[2 * i], v[2 * i + 1]);                                                         \
+        h1[i] = pack_f16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);                                                 \
+      }                                                                                                     \
+      v7_buf_store16_at<0>(h0, rs_o, vo_o, so_o);                                                           \
+      v7_buf_store16_at<16>(h1, rs_o, vo_o, so_o);                                                          \
     }                                                                                                       \
     u32x4 o0, o1;                                                                                           \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
@@ -223,8 +239,9 @@ __device__ __forceinline__ void v7_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[8
     }                                                                                                       \
   }
 
-  if (LNM == 2) {   // ring prologue: the first V7_LN_RING slabs
-    V7_LN_RING_LOAD(0) V7_LN_RING_LOAD(1) V7_LN_RING_LOAD(2) V7_LN_RING_LOAD(3) V7_LN_RING_LOAD(4) V7_LN_RING_LOAD(5)
+  if (LNM == 2) {   // ring prologue: the first V7_LN_RING slabs (every tile has at least eight: MTN >= 4)
+    V7_LN_RING_LOAD(0) V7_LN_RING_LOAD(1) V7_LN_RING_LOAD(2) V7_LN_RING_LOAD(3)
+    V7_LN_RING_LOAD(4) V7_LN_RING_LOAD(5) V7_LN_RING_LOAD(6) V7_LN_RING_LOAD(7)
   }
   V7_LN_SLAB(0) V7_LN_SLAB(1) V7_LN_SLAB(2) V7_LN_SLAB(3) V7_LN_SLAB(4) V7_LN_SLAB(5) V7_LN_SLAB(6) V7_LN_SLAB(7)
   V7_LN_SLAB(8) V7_LN_SLAB(9) V7_LN_SLAB(10) V7_LN_SLAB(11) V7_LN_SLAB(12) V7_LN_SLAB(13) V7_LN_SLAB(14) V7_LN_SLAB(15)

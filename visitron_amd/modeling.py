@@ -585,7 +585,7 @@ class CaptionBertEncoder(nn.Module):
         # 4.9e-2 on the base config (rms 1.06e-2 -> 1.02e-2: the bf16 weights of the twelve layers set that, not the last
         # roundings) and costs 6 % of a B = 64 forward (op-by-op last layer, two fp32-output GEMM epilogues): off by default.
         self.precise_final = os.environ.get("VT_PRECISE_FINAL", "0") == "1"
-        # inference, default: the layer loop with its LayerNorms deferred (run_ln): no LayerNorm pass, fp32 residual stream.
+        # inference, default: the layer loop with its LayerNorms deferred (run_ln): no LayerNorm pass, fp16 residual stream.
         # VT_DEFERRED_LN=0 (or the attribute) keeps the seven-launch layer with bf16 activations between all kernels.
         self.deferred_ln = os.environ.get("VT_DEFERRED_LN", "1") != "0"
         self._packed_ln = None
@@ -621,9 +621,12 @@ class CaptionBertEncoder(nn.Module):
         H, I = self._hidden, self._inter
         rows, np_ = round_up(M, 16), H // 128
         bf = lambda n: torch.empty((M, n), dtype=BF16, device=device)
+        f16 = lambda n: torch.empty((M, n), dtype=torch.float16, device=device)
         f32 = lambda n: torch.empty((M, n), dtype=torch.float32, device=device)
         st = lambda: torch.zeros((np_, rows, 2), dtype=torch.float32, device=device)
-        ws = dict(a=(bf(H), f32(H), st()), b=(bf(H), f32(H), st()), qkv=bf(3 * H), ctx=bf(H), mid=bf(I), out16=bf(H), out32=f32(H))
+        # a / b: the two residual streams (bf16 copy, fp16 rows, statistics); x32: the embedding output entering layer 0
+        ws = dict(a=(bf(H), f16(H), st()), b=(bf(H), f16(H), st()), x32=f32(H), qkv=bf(3 * H), ctx=bf(H), mid=bf(I), out16=bf(H),
+                  out32=f32(H))
         ops.autotune_encoder_shapes_ln(M, H, I, device=device)   # once per token count
         if len(self._ws) > 4:
             self._ws.clear()
@@ -631,9 +634,8 @@ class CaptionBertEncoder(nn.Module):
         return ws
 
     def run_ln(self, x32, B, S, mask_f32, mask_additive, head_scale=None):
-        """The deferred-LayerNorm layer loop: x32 fp32 [B*S, H] (the embedding output; a workspace buffer from
-        `ln_input_buffer` saves a copy) -> (sequence output bf16 [B*S, H], the same in fp32).  Both live in the workspace and
-        are rewritten by the next call."""
+        """The deferred-LayerNorm layer loop: x32 fp32 [B*S, H] (the embedding output) -> (sequence output bf16 [B*S, H], the
+        same in fp32).  Both live in the workspace and are rewritten by the next call."""
         for layer in self.layer:
             _no_train_dropout(layer, layer.attention.self.dropout.p)
             _no_train_dropout(layer, layer.output.dropout.p)
@@ -642,19 +644,17 @@ class CaptionBertEncoder(nn.Module):
         ws = self._workspace_ln(M, x32.device)
         sa, sb = ws["a"], ws["b"]
         H, nh, I, eps = self._hidden, self._heads, self._inter, self._eps
-        if x32.data_ptr() != sa[1].data_ptr():
-            sa[1].copy_(x32)
-        ops.ln_stream_init(sa[1], sa[0], sa[2], eps)
+        ops.ln_stream_init(x32, sa[1], sa[0], sa[2], eps)
         self._last_attentions = None
         if ops.profiling():   # bench.py's per-kernel timing: the same launches, issued one by one
             for i, t in enumerate(pk.tensors):
                 hs_i = None if head_scale is None else head_scale[i].contiguous()
                 ops.linear_ln(sa[0], t["w_qkv"], t["h_qkv"], t["g_qkv"], sa[2], eps, 1, out=ws["qkv"])
                 ops.attention_fwd(ws["qkv"], B, S, nh, mask=mask_f32, mask_additive=mask_additive, head_scale=hs_i, out=ws["ctx"])
-                ops.linear_ln(ws["ctx"], t["w_ao"], t["cb_ao"], t["gamma_in"], sa[2], eps, 2, out=sb[0], r32=sa[1], out32=sb[1],
+                ops.linear_ln(ws["ctx"], t["w_ao"], t["cb_ao"], t["gamma_in"], sa[2], eps, 2, out=sb[0], rs=sa[1], out_s=sb[1],
                               stats_out=sb[2])
                 ops.linear_ln(sb[0], t["w_in"], t["h_in"], t["g_in"], sb[2], eps, 1, act=ACT_GELU, out=ws["mid"])
-                ops.linear_ln(ws["mid"], t["w_out"], t["cb_out"], t["ln1_g"], sb[2], eps, 2, out=sa[0], r32=sb[1], out32=sa[1],
+                ops.linear_ln(ws["mid"], t["w_out"], t["cb_out"], t["ln1_g"], sb[2], eps, 2, out=sa[0], rs=sb[1], out_s=sa[1],
                               stats_out=sa[2])
         else:
             ops.encoder_forward_ln(pk.table, sa, sb, ws["qkv"], ws["ctx"], ws["mid"], mask_f32, mask_additive, head_scale,
@@ -664,9 +664,8 @@ class CaptionBertEncoder(nn.Module):
         return ws["out16"], ws["out32"]
 
     def ln_input_buffer(self, M, device):
-        """The workspace's fp32 stream buffer [M, H]: a caller that writes the embedding output straight into it spares
-        run_ln a copy."""
-        return self._workspace_ln(M, device)["a"][1]
+        """The workspace's fp32 buffer [M, H] for the embedding output (what run_ln takes as x32)."""
+        return self._workspace_ln(M, device)["x32"]
 
     def _workspace(self, M, B, device, keep_all):
         """Activation buffers + ctypes table.  keep_all: one `out` buffer per layer
@@ -960,7 +959,7 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
             return self._run_trunk_f32(input_ids, token_type_ids, position_ids, img_feats, img_location_embeddings,
                                        encoder_history_states, mask_f32, mask_is_additive, hs, B, T, R, S, H)
         if keep is None and self.encoder.serves_deferred_ln(history=encoder_history_states):
-            # default inference path: the embedding output in fp32, straight into the encoder's fp32 residual stream
+            # default inference path: the embedding output in fp32, the encoder's residual stream in fp16 (not bf16)
             emb = self.embeddings
             _no_train_dropout(emb, emb.dropout.p)
             x32 = self.encoder.ln_input_buffer(B * S, dev)

@@ -123,12 +123,15 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
     return out
 
 
-def linear_ln(a, w, bias, colv, stats, eps, ln_mode, act=ACT_NONE, out=None, r32=None, out32=None, stats_out=None, M=None):
+F16 = torch.float16
+
+
+def linear_ln(a, w, bias, colv, stats, eps, ln_mode, act=ACT_NONE, out=None, rs=None, out_s=None, stats_out=None, M=None):
     """A GEMM of the deferred-LayerNorm inference path (vt_linear_ln_bf16; include/visitron_hip.h has the arithmetic).
     a [M,K] bf16 = the bf16 copy of the stream (mode 1) or a plain activation (mode 2); stats fp32 [np, rows, 2] = the
-    partial row statistics of the stream being normalised; mode 2 also takes the fp32 stream r32 [M,N] and returns the new
-    stream (out bf16, out32 fp32, stats_out)."""
-    _require_hip(a, w, bias, colv, stats, out, r32, out32, stats_out)
+    partial row statistics of the stream being normalised; mode 2 also takes the fp16 stream rs [M,N] and returns the new
+    stream (out: its bf16 copy, out_s: fp16, stats_out)."""
+    _require_hip(a, w, bias, colv, stats, out, rs, out_s, stats_out)
     assert a.dtype == BF16 and w.dtype == BF16 and stats.dtype == torch.float32 and stats.is_contiguous()
     N, K = w.shape
     if M is None:
@@ -137,49 +140,51 @@ def linear_ln(a, w, bias, colv, stats, eps, ln_mode, act=ACT_NONE, out=None, r32
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=a.device)
     if ln_mode == 2:
-        assert r32 is not None and r32.dtype == torch.float32
-        if out32 is None:
-            out32 = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        assert rs is not None and rs.dtype == F16
+        if out_s is None:
+            out_s = torch.empty((M, N), dtype=F16, device=a.device)
         if stats_out is None:
             stats_out = torch.empty((N // 128, rows, 2), dtype=torch.float32, device=a.device)
         assert stats_out.shape[1] == rows and stats_out.is_contiguous()
-    with _timed("gemm_nt_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N) + (8.0 * M * N if ln_mode == 2 else 0.0)):
+    with _timed("gemm_nt_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N) + (4.0 * M * N if ln_mode == 2 else 0.0)):
         rc = _lib.load().vt_linear_ln_bf16(
             _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(colv), _ptr(stats), np_, rows, float(eps), int(ln_mode),
-            _ptr(r32), 0 if r32 is None else r32.stride(0), _ptr(out), out.stride(0), _ptr(out32),
-            0 if out32 is None else out32.stride(0), _ptr(stats_out), M, N, K, int(act), _stream())
+            _ptr(rs), 0 if rs is None else rs.stride(0), _ptr(out), out.stride(0), _ptr(out_s),
+            0 if out_s is None else out_s.stride(0), _ptr(stats_out), M, N, K, int(act), _stream())
     _lib.check(rc, "vt_linear_ln_bf16")
-    return (out, out32, stats_out) if ln_mode == 2 else out
+    return (out, out_s, stats_out) if ln_mode == 2 else out
 
 
-def ln_apply(v32, stats, gamma, beta, eps, out16=None, out32=None, M=None):
-    """LayerNorm of a stream (fp32 rows + partial statistics) written as bf16 and / or fp32."""
-    _require_hip(v32, stats, gamma, beta, out16, out32)
-    assert v32.dtype == torch.float32 and stats.dtype == torch.float32 and stats.is_contiguous()
+def ln_apply(vs, stats, gamma, beta, eps, out16=None, out32=None, M=None):
+    """LayerNorm of a stream (fp16 rows + partial statistics) written as bf16 and / or fp32."""
+    _require_hip(vs, stats, gamma, beta, out16, out32)
+    assert vs.dtype == F16 and stats.dtype == torch.float32 and stats.is_contiguous()
     if M is None:
-        M = v32.shape[0]
+        M = vs.shape[0]
     H = gamma.numel()
-    with _timed("ln_apply_rows", 0.0, M * H * (4.0 + (2.0 if out16 is not None else 0.0) + (4.0 if out32 is not None else 0.0))):
-        rc = _lib.load().vt_ln_apply(_ptr(v32), v32.stride(0), _ptr(stats), stats.shape[0], stats.shape[1], _ptr(gamma), _ptr(beta),
+    with _timed("ln_apply_rows", 0.0, M * H * (2.0 + (2.0 if out16 is not None else 0.0) + (4.0 if out32 is not None else 0.0))):
+        rc = _lib.load().vt_ln_apply(_ptr(vs), vs.stride(0), _ptr(stats), stats.shape[0], stats.shape[1], _ptr(gamma), _ptr(beta),
                                      float(eps), _ptr(out16), 0 if out16 is None else out16.stride(0), _ptr(out32),
                                      0 if out32 is None else out32.stride(0), M, H, _stream())
     _lib.check(rc, "vt_ln_apply")
 
 
-def ln_stream_init(x32, x16, stats, eps, M=None):
-    """x32 fp32 [M,H] enters the deferred-LayerNorm stack as it is: bf16 copy + identity statistics."""
-    _require_hip(x32, x16, stats)
-    assert x32.dtype == torch.float32 and x16.dtype == BF16 and stats.dtype == torch.float32 and stats.is_contiguous()
+def ln_stream_init(x32, xs, x16, stats, eps, M=None):
+    """x32 fp32 [M,H] enters the deferred-LayerNorm stack as it is: the stream xs (fp16), its bf16 copy x16, identity
+    statistics."""
+    _require_hip(x32, xs, x16, stats)
+    assert x32.dtype == torch.float32 and xs.dtype == F16 and x16.dtype == BF16 and stats.dtype == torch.float32
+    assert stats.is_contiguous()
     if M is None:
         M = x32.shape[0]
-    with _timed("ln_stream_init", 0.0, M * x32.shape[1] * 6.0):
-        rc = _lib.load().vt_ln_stream_init(_ptr(x32), x32.stride(0), _ptr(x16), x16.stride(0), _ptr(stats), stats.shape[0],
-                                           stats.shape[1], M, x32.shape[1], float(eps), _stream())
+    with _timed("ln_stream_init", 0.0, M * x32.shape[1] * 8.0):
+        rc = _lib.load().vt_ln_stream_init(_ptr(x32), x32.stride(0), _ptr(xs), xs.stride(0), _ptr(x16), x16.stride(0), _ptr(stats),
+                                           stats.shape[0], stats.shape[1], M, x32.shape[1], float(eps), _stream())
     _lib.check(rc, "vt_ln_stream_init")
 
 
 def encoder_forward_ln(layer_weights, stream_a, stream_b, qkv, ctx, mid, mask, mask_additive, head_scale, B, S, H, nh, I, eps):
-    """The deferred-LayerNorm layer loop in C.  stream_x = (bf16 copy, fp32 rows, statistics)."""
+    """The deferred-LayerNorm layer loop in C.  stream_x = (bf16 copy, fp16 rows, statistics)."""
     _require_hip(stream_a[0], mask, head_scale)
     rows = stream_a[2].shape[1]
     rc = _lib.load().vt_encoder_forward_ln_bf16(
@@ -295,13 +300,13 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
         stats = torch.zeros((np_, rows, 2), device=device)
         stats[0, :, 1] = float(H)
         colv = torch.ones(N, device=device)
-        r32 = torch.randn(M, N, generator=g, device=device) if ln_mode == 2 else None
+        r16 = torch.randn(M, N, generator=g, device=device).to(F16) if ln_mode == 2 else None
         out = torch.empty((M, N), dtype=BF16, device=device)
-        o32 = torch.empty((M, N), device=device) if ln_mode == 2 else None
+        o16 = torch.empty((M, N), dtype=F16, device=device) if ln_mode == 2 else None
         so = torch.empty((N // 128, rows, 2), device=device) if ln_mode == 2 else None
 
         def run():
-            linear_ln(a, w, b, colv, stats, 1e-12, ln_mode, act=act, out=out, r32=r32, out32=o32, stats_out=so)
+            linear_ln(a, w, b, colv, stats, 1e-12, ln_mode, act=act, out=out, rs=r16, out_s=o16, stats_out=so)
     else:
         r = torch.randn(M, N, generator=g, device=device).to(BF16) if (residual or act == ACT_MUL) else None
         out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=device)
