@@ -112,6 +112,11 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
       }                                                                                                   \
       v7_buf_store16(p0, rs_c2, vo_c2, so_row * ldc2_b + ec * 2);                                         \
       v7_buf_store16_o16(p1, rs_c2, vo_c2, so_row * ldc2_b + ec * 2);                                     \
+    } else if (ACT == ACT_GELU) {   /* inference (nothing saved for a backward): the transcendental-free form */ \
+      _Pragma("unroll") for (int i = 0; i < 16; i += 4) {                                                 \
+        const f32x4 gg = gelu_poly4((f32x4){v[i], v[i + 1], v[i + 2], v[i + 3]});                         \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) v[i + e] = gg[e];                                   \
+      }                                                                                                   \
     } else {                                                                                              \
       _Pragma("unroll") for (int i = 0; i < 16; ++i) v[i] = apply_act<ACT>(v[i]);                         \
     }                                                                                                     \

@@ -191,9 +191,13 @@ __device__ __forceinline__ void v7_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[8
     _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                           \
       V7_LN_PIN("+a"(acc[MT][4 * NH + t]));   /* stays in AGPRs until its slab's turn */                     \
     if (LNM == 1) {                                                                                         \
-      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                       \
+        f32x4 z;                                                                                            \
         _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                       \
-          v[4 * t + e] = apply_act<ACT>(fmaf(ra, acc[MT][4 * NH + t][e], fmaf(rb, c1[4 * t + e], c0[4 * t + e]))); \
+          z[e] = fmaf(ra, acc[MT][4 * NH + t][e], fmaf(rb, c1[4 * t + e], c0[4 * t + e]));                  \
+        if (ACT == ACT_GELU) z = gelu_poly4(z);                                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) v[4 * t + e] = (ACT == ACT_GELU) ? z[e] : apply_act<ACT>(z[e]); \
+      }                                                                                                     \
     } else {                                                                                                \
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(v7_ln_vmcnt((S), 2 * MTN)) : "memory");                      \
       V7_LN_PIN("+v"(ring[SL][0]), "+v"(ring[SL][1]));                                                      \
