@@ -70,28 +70,11 @@ def check_close(name, got, want, bound, kind="maxabs"):
         raise ValueError(kind)
     stated, bound = float(bound), effective_bound(name, float(bound))
     _MEASURED.append((name, kind, err, bound))
-    print("PARITY %-58s %-7s measured %.3e  bound %.3e (stated %.1e)" % (name, kind, err, bound, stated))
+    print("PARITY %-58s %-7s measured %.3e  bound %.3e (stated %.1e: margin x%.1f)" % (
+        name, kind, err, bound, stated, stated / err if err > 0 else float("inf")))
     assert err <= bound, "%s: %s error %.4e exceeds the bound %.4e (stated %.1e, tightened by the recorded value)" % (
         name, kind, err, bound, stated)
     return err
-
-
-def check_bf16_tensor(name, got, want, max_bound, rms_bound, target=5e-2, beyond_frac=1e-4):
-    """A large bf16-path tensor against the fp32 oracle.  north_star's bf16 tolerance is 5e-2 absolute; with bf16
-    operands (8-bit mantissas on every weight and activation of 12 layers) the error of the base config is ~1e-2 RMS, so
-    the MAXIMUM over 10^5 .. 10^7 elements lands at 5 .. 6 sigma = 4.5e-2 .. 6e-2: recorded as it is.  Asserted: the
-    maximum (bound <= 2x measured), the RMS, and that at most `beyond_frac` of the elements lie beyond the 5e-2 target."""
-    g, w = torch.as_tensor(got).detach().float().cpu(), torch.as_tensor(want).detach().float().cpu()
-    d = (g.reshape(w.shape) - w).abs()
-    check_close(name + " [max-abs]", g, w, max_bound)
-    rms = float(d.pow(2).mean().sqrt())
-    frac = float((d > target).float().mean())
-    _MEASURED.append((name + " [rms]", "rms", rms, rms_bound))
-    _MEASURED.append((name + " [fraction beyond %.0e]" % target, "frac", frac, beyond_frac))
-    print("PARITY %-58s rms %.3e (bound %.3e)  fraction beyond %.0e: %.2e of %d (bound %.0e)" % (
-        name, rms, rms_bound, target, frac, d.numel(), beyond_frac))
-    assert rms <= rms_bound, "%s: rms %.3e > %.3e" % (name, rms, rms_bound)
-    assert frac <= beyond_frac, "%s: %.2e of the elements beyond %.0e" % (name, frac, target)
 
 
 def measured():

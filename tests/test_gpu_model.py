@@ -3,7 +3,7 @@ and weights.  Tolerance from BASELINE.json north_star: 5e-2 for the bf16 path.""
 import pytest
 import torch
 
-from helpers import check_bf16_tensor, check_close, maxabs, model_pair
+from helpers import check_close, maxabs, model_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -156,17 +156,23 @@ def test_base_config_cfg1_matches_oracle(dev):
         w_scores, _, w_act = ref.heads(w_seq, w_pool)
         g_scores = prod.mlmhead(g_seq)
         g_act = prod.next_action(g_pool)
-    # north_star: 5e-2 ABSOLUTE for the bf16 path.  Met by the action logits, the pooled output and the losses with
-    # margin; the two big tensors sit AT it (measured max-abs 4.9e-2 over 3.5e5 hidden states, 5.9e-2 over 1.4e7 MLM
-    # logits at ~1e-2 rms -- see helpers.check_bf16_tensor); the fp32 path (tests/test_gpu_fp32.py) meets 1e-3.
-    check_bf16_tensor("base cfg1 sequence_output", g_seq, w_seq, max_bound=8e-2, rms_bound=1.3e-2)
-    # opt-in: the last layer with fp32 pre-LayerNorm sums and an fp32 result (CaptionBertEncoder.precise_final)
-    prod.bert.encoder.precise_final = True
+    # north_star: 5e-2 ABSOLUTE for the bf16 path -- asserted as it stands on every output, these harsher-than-init weights
+    # included (hash weights of std 0.03, LayerNorm gains 1 +- 0.1, non-zero biases; the reference's own init is the case of
+    # tests/test_gpu_round3.py).  Round 2 missed it on the two large tensors (5.9e-2 / 6.6e-2 with the bf16 residual stream
+    # of the seven-launch layer); the deferred-LayerNorm path with its fp16 stream is what closed it.
+    check_close("base cfg1 sequence_output", g_seq, w_seq, TOL_BF16)
+    check_close("base cfg1 prediction_scores", g_scores, w_scores, TOL_BF16)
+    # the seven-launch layer (VT_DEFERRED_LN=0: what training-mode forwards and compacted rows still run), recorded with its
+    # round-2 bound; and its opt-in fp32 last layer
+    prod.bert.encoder.deferred_ln = False
     with torch.no_grad():
+        g_seq7 = prod.bert(**{k: b[k].to(dev) for k in trunk_keys})[0]
+        prod.bert.encoder.precise_final = True
         g_seq2 = prod.bert(**{k: b[k].to(dev) for k in trunk_keys})[0]
     prod.bert.encoder.precise_final = False
-    check_bf16_tensor("base cfg1 sequence_output (precise_final)", g_seq2, w_seq, max_bound=7e-2, rms_bound=1.3e-2)
-    check_bf16_tensor("base cfg1 prediction_scores", g_scores, w_scores, max_bound=8e-2, rms_bound=1.3e-2)
+    prod.bert.encoder.deferred_ln = True
+    check_close("base cfg1 sequence_output (seven-launch layer, bf16 residual stream)", g_seq7, w_seq, 8e-2)
+    check_close("base cfg1 sequence_output (seven-launch layer, precise_final)", g_seq2, w_seq, 7e-2)
     check_close("base cfg1 pooled_output", g_pool, w_pool, TOL_BF16)
     check_close("base cfg1 action_scores", g_act, w_act, TOL_BF16)
     for i, n in enumerate(("loss", "mask_loss", "next_loss", "token_loss")):

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check_bf16_tensor, check_close, model_pair
+from helpers import check_close, model_pair
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,8 +48,8 @@ def test_base_config_long_dialog_cfg4_forward_backward(dev):
         g_seq, g_pool = prod.bert(**{k: b[k].to(dev) for k in TRUNK_KEYS})[:2]
         g_scores = prod.mlmhead(g_seq)
         g_act = prod.next_action(g_pool)
-    check_bf16_tensor("base S=656 sequence_output", g_seq, w_seq, max_bound=8e-2, rms_bound=1.3e-2)
-    check_bf16_tensor("base S=656 prediction_scores", g_scores, w_scores, max_bound=8e-2, rms_bound=1.3e-2)
+    check_close("base S=656 sequence_output", g_seq, w_seq, 5e-2)
+    check_close("base S=656 prediction_scores", g_scores, w_scores, 5e-2)
     check_close("base S=656 pooled_output", g_pool, w_pool, 5e-2)
     check_close("base S=656 action_scores", g_act, w_act, 5e-2)
     # golden slice of the same case (no oracle call needed to check it)

@@ -301,6 +301,7 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
   }
 
 #define V7_TR nullptr
+#define V7_RING_PRE (LNM == 2)
 template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R, int MTN = 8, int LNM = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   constexpr int TH = 32 * MTN;   // tile height (see gemm_nt_bf16_v8): 256, or 224 / 192 to fill one round better
@@ -375,6 +376,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
 #define V7_DMA_W(rs, d, i) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(smem + (d) + V7_WOFF + (i) * 1024), 16, vw[(i) & 1], sw[i], 0, 0)
 
+  // deferred-LayerNorm mode 2: the first ring of residual-stream slabs goes out before anything else (see
+  // v7_ln_ring_prefetch); the prologue's operand wait below covers them
+  u32x4 ln_ring[V7_LN_RING][2];
+  if constexpr (LNM == 2) v7_ln_ring_prefetch<LNM, MTN>(g, ln_ring, wave, m0, n0);
+
   // prologue: tiles 0 and 1 in flight, substep-0 fragments of tile 0 in set 0
   {
     __amdgpu_buffer_rsrc_t rx0 = rsrc_x(0), rw0 = rsrc_w(0), rx1 = rsrc_x(1), rw1 = rsrc_w(1);
@@ -389,6 +395,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
     for (int i = 0; i < 8; ++i) V7_DMA_W(rw1, dst + V7_STAGE, i);
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (LNM == 2) {   // the ring has landed (older than the 16 pieces still in flight): its registers are final from here
+#pragma unroll
+      for (int i = 0; i < V7_LN_RING; ++i) V7_LN_PIN("+v"(ln_ring[i][0]), "+v"(ln_ring[i][1]));
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (i < MTN) V7_LDSR(xf[0][i], xa0, i * 2048);
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   // plain register epilogue, slab by slab
 #define V7_EPILOGUE()                                                                                     \
   if constexpr (LNM != 0) {                                                                               \
-    v7_epilogue_ln<ACT, LNM, MTN>(g, acc, lane, wave, m0, n0, lds0);                                      \
+    v7_epilogue_ln<ACT, LNM, MTN, V7_RING_PRE>(g, acc, lane, wave, m0, n0, lds0, ln_ring);                \
   } else if (EPI_LDS) {                                                                                   \
     v7_epilogue_fast<ACT, HAS_R, MTN>(g, acc, lane, wave, m0, n0, lds0);                                  \
   } else {                                                                                                \
@@ -450,6 +460,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
 // on one L2 are neighbours.
 #undef V7_TR
 #define V7_TR tr
+#undef V7_RING_PRE
+#define V7_RING_PRE false
 // MTN (row blocks of 16 per wave, 8 .. 4 = tile height TH 256 .. 128): with ~200 row tiles of 256 the
 // three column tiles of the N = 768 shapes make 600 tiles = 2.34 rounds on 256 CUs, paid as 3; 224-row tiles make 681 =
 // 2.66 rounds of tiles that are 7/8 the work -- the same 3 rounds, 12.5 % fewer MFMAs.  The host picks per shape.
@@ -530,6 +542,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
 
   f32x4 acc[8][8];
   u32x4 xf[2][8], wf[2][8];
+  u32x4 ln_ring[V7_LN_RING][2];   // deferred-LayerNorm mode 2: filled inside the epilogue (tiles of a persistent workgroup drift apart)
 
   if (first >= c1) return;   // uniform: more workgroups than tiles on this XCD
   // debug trace: slot 0 = realtime (100 MHz) at entry, 1 = shader clock at entry, then per tile (realtime): K loop

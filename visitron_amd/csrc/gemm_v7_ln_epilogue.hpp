@@ -105,8 +105,31 @@ struct V7LnOrder {
   static constexpr int nh(int s) { return LNM == 2 ? s % 2 : s / MTN; }
 };
 
-template <int ACT, int LNM, int MTN>
-__device__ __forceinline__ void v7_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[8][8], int lane_in, int wave, int m0, int n0, unsigned lds0) {
+// The ring's first V7_LN_RING slabs, issued by the one-tile-per-workgroup kernel at its very start (PRE): with a single round
+// of tiles every workgroup reaches its epilogue at the same moment, and stream loads issued there arrive together with
+// everybody else's at the memory's pace; issued before the K loop they have long landed (the prologue's operand wait covers
+// them: they are older) and two thirds of a 192-row tile's stream never wait.
+template <int LNM, int MTN>
+__device__ __forceinline__ void v7_ln_ring_prefetch(const GemmArgs& g, u32x4 (&ring)[V7_LN_RING][2], int wave, int m0, int n0) {
+  typedef V7LnOrder<LNM, MTN> Ord;
+  const int lane = v7_lane_now();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int gq = lane >> 4, j = lane & 15;
+  const int rows = g.M - m0 < 32 * MTN ? g.M - m0 : 32 * MTN;
+  const int ldr_b = (int)g.ldrs * 2;
+  const u32x4 rs_r = v7_rsrc(g.Rs + (long)m0 * g.ldrs, (unsigned)rows * ldr_b);
+  const int vo_r = j * ldr_b + gq * 32;
+#pragma unroll
+  for (int s_ = 0; s_ < V7_LN_RING; ++s_) {
+    const int so_ = (16 * MTN * wm + 16 * Ord::mt(s_)) * ldr_b + (n0 + 128 * wn + 64 * Ord::nh(s_)) * 2;
+    v7_buf_load16_at<0>(ring[s_][0], rs_r, vo_r, so_);
+    v7_buf_load16_at<16>(ring[s_][1], rs_r, vo_r, so_);
+  }
+}
+
+template <int ACT, int LNM, int MTN, bool PRE = false>
+__device__ __forceinline__ void v7_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[8][8], int lane_in, int wave, int m0, int n0, unsigned lds0,
+                                               u32x4 (&ring)[V7_LN_RING][2]) {
   static_assert(LNM == 1 || LNM == 2, "deferred-LayerNorm mode");
   // every per-lane address below derives from a lane index computed here: as loop invariants of the tile loop the allocator
   // would compute them once at kernel entry and park them in scratch across the K loop
@@ -160,7 +183,6 @@ __device__ __forceinline__ void v7_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[8
   const int vo_r = j * ldr_b + gq * 32, vo_o = j * ldo_b + gq * 32;
   const int part = (n0 >> 7) + wn;   // mode 2: the statistics slice this wave's 128 columns make
   const u32x4 rs_s = v7_rsrc(LNM == 2 ? g.stats_out + (long)part * g.ln_rows * 2 : nullptr, LNM == 2 ? (unsigned)g.M * 8u : 0u);
-  u32x4 ring[V7_LN_RING][2];
   float s1 = 0.f, s2 = 0.f;
   float c0[16], c1[16];   // mode 1: h, g; mode 2: cb, gamma -- of the slab's column half
   typedef V7LnOrder<LNM, MTN> Ord;
@@ -199,7 +221,8 @@ __device__ __forceinline__ void v7_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[8
         _Pragma("unroll") for (int e = 0; e < 4; ++e) v[4 * t + e] = (ACT == ACT_GELU) ? z[e] : apply_act<ACT>(z[e]); \
       }                                                                                                     \
     } else {                                                                                                \
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(v7_ln_vmcnt((S), 2 * MTN)) : "memory");                      \
+      if (!PRE || (S) >= V7_LN_RING)   /* PRE: the first ring of slabs landed before the K loop */              \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(v7_ln_vmcnt((S), 2 * MTN)) : "memory");                    \
       V7_LN_PIN("+v"(ring[SL][0]), "+v"(ring[SL][1]));                                                      \
       if (NH == 0) { s1 = 0.f; s2 = 0.f; }                                                                  \
       _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
@@ -243,7 +266,7 @@ __device__ __forceinline__ void v7_epilogue_ln(const GemmArgs& g, f32x4 (&acc)[8
     }                                                                                                       \
   }
 
-  if (LNM == 2) {   // ring prologue: the first V7_LN_RING slabs (every tile has at least eight: MTN >= 4)
+  if (LNM == 2 && !PRE) {   // ring prologue: the first V7_LN_RING slabs (every tile has at least eight: MTN >= 4)
     V7_LN_RING_LOAD(0) V7_LN_RING_LOAD(1) V7_LN_RING_LOAD(2) V7_LN_RING_LOAD(3)
     V7_LN_RING_LOAD(4) V7_LN_RING_LOAD(5) V7_LN_RING_LOAD(6) V7_LN_RING_LOAD(7)
   }
