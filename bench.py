@@ -255,11 +255,14 @@ def main():
             # committed PMC passes of this command (profiles/README.md), null when that file is absent
             traffic, traffic_src = None, None
             here = os.path.dirname(os.path.abspath(__file__))
-            for rel in ("profiles/r02/train_b256_pmc_hbm_traffic_v3.json", "profiles/r02/train_b256_pmc_hbm_traffic_v2.json",
-                        "profiles/r02/train_b256_pmc_hbm_traffic_v1.json",
-                        "profiles/r01/train_b256_pmc_hbm_traffic_v6.json"):
+            # (the PMC passes of THIS configuration: train B=256 or forward B=64, default shapes; newest round first)
+            default_shape = a.text == 128 and a.regions == 100 and a.batch == (256 if train else 64)
+            rels = (("profiles/r03/train_b256_pmc_hbm_traffic.json", "profiles/r02/train_b256_pmc_hbm_traffic_v3.json",
+                     "profiles/r01/train_b256_pmc_hbm_traffic_v6.json") if train else
+                    ("profiles/r03/fwd_b64_pmc_hbm_traffic.json",))
+            for rel in rels:
                 tp = os.path.join(here, rel)
-                if train and a.batch == 256 and os.path.exists(tp):
+                if default_shape and os.path.exists(tp):
                     traffic, traffic_src = json.load(open(tp))["hbm_bytes_per_launch"], rel
                     break
             roofline = {
@@ -288,10 +291,11 @@ def main():
                     sub["input_ids"], attention_mask=sub["attention_mask"], img_feats=sub["img_feats"],
                     img_location_embeddings=sub["img_location_embeddings"])
                 sc, _, act = full.head_outputs(outs[-1], pooled)
+                seq_sub = trunk(**sub)[0]                    # what a caller of the trunk is handed (fp32)
                 # the same two sequences inside the full timed batch must give the same rows
                 seq_full = trunk(**batch)[0][:2]
             gpu_out = dict(batch={k: v.cpu() for k, v in sub.items()}, state={k: v.cpu() for k, v in full.state_dict().items()},
-                           sequence_output=outs[-1].float().cpu().view(B2, S2, -1), prediction_scores=sc.float().cpu().view(B2, S2, -1),
+                           sequence_output=seq_sub.float().cpu().view(B2, S2, -1), prediction_scores=sc.float().cpu().view(B2, S2, -1),
                            action_scores=act.float().cpu(), sequence_output_in_full_batch=seq_full.float().cpu())
         cpu_baseline = run_cpu_baseline(cfg, a.text, a.regions, train, gpu_out)
 
@@ -318,6 +322,12 @@ def main():
                 "parallelism": ("dp%d (flat-slab gradient all-reduce over RCCL)" if train else "dp%d (replicas, no collective)") % world,
                 "weights": "random init N(0,0.02), seed 0",
                 "dropout": a.dropout if train else 0.0,
+                # bf16 operands on the matrix cores, fp32 accumulation everywhere.  Inference keeps the residual stream
+                # between sub-layers in fp16 (+ a bf16 copy for the next GEMM) and defers every LayerNorm into the GEMM
+                # epilogues that consume it; training keeps bf16 activations and LayerNorm passes (its backward reads them)
+                "residual_stream": ("bf16 (seven-launch layer, LayerNorm passes)" if train else
+                                    ("fp16, LayerNorms deferred into the GEMM epilogues" if trunk.encoder.serves_deferred_ln()
+                                     else "bf16 (seven-launch layer, LayerNorm passes)")),
                 # training computes the real rows only: positions with attention mask 0 (text tails, missing regions;
                 # 12.5 % of this synthetic batch, as in the reference's data) are read by nothing in the step -- same
                 # losses and gradients as the padded run (tests/test_gpu_train.py); VT_COMPACT_ROWS=0 computes them all
@@ -336,7 +346,8 @@ def main():
             "mfma_frac_whole_forward": (None if (train and fwd_value is None) else
                                         round(f_enc * (fwd_value if train else value) / world / (PEAK_BF16_TFLOPS * 1e12), 4)),
             "roofline": roofline,
-            # the autotuner's pick per (M, N, K, act) -- kernel variant numbers as in csrc/gemm_bf16.hip
+            # the autotuner's pick per (M, N, K, kind) -- kind = act | 16 residual | 32 second output | 64 fp32 out |
+            # deferred-LayerNorm mode << 8; kernel variant numbers as in csrc/gemm_bf16.hip
             "gemm_variants": {"%d,%d,%d,%d" % k: v for k, v in sorted(ops._tuned.items())},
             "device": device_info(dev),
             "cpu_baseline": cpu_baseline,

@@ -240,3 +240,76 @@ def test_persistent_lstm_recurrence_equals_step_launches(dev, B, hs, S):
         seqp = outs[("persistent", "padded")][0]
         for b in range(B):
             assert float(seqp[b, int(lens[b]):].abs().max() if int(lens[b]) < S else 0.0) == 0.0
+
+
+def test_decoder_step_replayed_from_a_graph_equals_the_direct_step(dev):
+    """AttnDecoderLSTM.use_graph: the inference step captured as a HIP graph per input geometry and replayed -- same four
+    results as the direct launches, bit for bit, over steps that feed each other (agent.py:383), a changed geometry (a new
+    capture) and a weight update (captures are keyed on the parameters' versions)."""
+    from visitron_amd.rollout import AttnDecoderLSTM
+
+    ang, emb, hs, feat = 4, 64, 512, 2048 + 4
+    torch.manual_seed(4)
+    dec = AttnDecoderLSTM(ang, emb, hs, 0.5, feature_size=feat).eval().to(dev)
+    g = torch.Generator().manual_seed(8)
+
+    def inputs(B, L, C):
+        action = torch.randn(B, ang, generator=g).to(dev)
+        feature = (torch.randn(B, 36, feat, generator=g).abs() * 0.3).to(dev)
+        cand = (torch.randn(B, C, feat, generator=g).abs() * 0.3).to(dev)
+        h1, c0 = (torch.randn(B, hs, generator=g) * 0.3).to(dev), (torch.randn(B, hs, generator=g) * 0.3).to(dev)
+        ctx = (torch.randn(B, L, hs, generator=g) * 0.5).to(dev)
+        mask = torch.zeros(B, L, dtype=torch.bool)
+        mask[:, L - 5:] = True
+        return action, feature, cand, h1, c0, ctx, mask.to(dev)
+
+    for B, L, C in ((7, 45, 11), (3, 20, 5), (7, 45, 11)):
+        action, feature, cand, h1, c0, ctx, mask = inputs(B, L, C)
+        hd, cd, hg, cg = h1, c0, h1, c0
+        for _ in range(3):
+            with torch.no_grad():
+                dec.use_graph = False
+                want = dec(action, feature, cand, None, hd, cd, ctx, mask)
+                dec.use_graph = True
+                got = dec(action, feature, cand, None, hg, cg, ctx, mask)
+            for gi, wi in zip(got, want):
+                assert gi.shape == wi.shape and torch.equal(gi, wi)
+            hd, cd, hg, cg = want[3], want[1], got[3], got[1]
+    assert len(dec._graphs) == 2
+    with torch.no_grad():
+        dec.embedding[0].weight.mul_(1.5)          # a real update bumps the parameter's version: a fresh capture
+        dec.use_graph = False
+        want = dec(action, feature, cand, None, h1, c0, ctx, mask)
+        dec.use_graph = True
+        got = dec(action, feature, cand, None, h1, c0, ctx, mask)
+    assert all(torch.equal(gi, wi) for gi, wi in zip(got, want)) and len(dec._graphs) == 3
+
+
+def test_persistent_lstm_timeout_restores_the_state_and_falls_back(dev):
+    """The persistent recurrence's bounded waits: on a time-out some workgroups may already have written their final
+    state.  The wrapper restores the caller's h / c from its own copies and lets the step launches run -- forced here by
+    the test hook, the result must equal the step-launch path bit for bit."""
+    from visitron_amd import ops
+
+    B, hs, S = 16, 256, 12
+    g = torch.Generator().manual_seed(3)
+    xp = (torch.randn(B, S, 4 * hs, generator=g) * 0.5).to(dev)
+    w_hh = (torch.randn(4 * hs, hs, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    lens = torch.tensor([12] * 6 + [9] * 5 + [3] * 5, dtype=torch.int32, device=dev)
+
+    def run(force, persistent):
+        ops.LSTM_PERSISTENT, ops._LSTM_FORCE_TIMEOUT[0] = persistent, force
+        try:
+            h2 = (torch.full((B, hs), 0.25, device=dev), torch.empty(B, hs, device=dev))
+            c = torch.full((B, hs), -0.5, device=dev)
+            seq = torch.zeros(B, S, hs, device=dev)
+            ops.lstm_sequence(xp, h2, c, w_hh, S, lens, seq)
+            torch.cuda.synchronize()
+            return h2[0].clone(), c.clone(), seq
+        finally:
+            ops.LSTM_PERSISTENT, ops._LSTM_FORCE_TIMEOUT[0] = True, False
+
+    want = run(False, False)       # the step launches
+    got = run(True, True)          # the persistent launch "times out": restore, then the step launches
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)

@@ -10,6 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvisitron_hip.so")
 LIB_PATH = os.environ.get("VT_HIP_LIB", LIB_PATH)   # A/B builds of the kernels (tools/): same ABI, other path
 
+# error codes of include/visitron_hip.h
+VT_OK, VT_ERR_BAD_SHAPE, VT_ERR_BAD_ALIGN, VT_ERR_NULL, VT_ERR_UNSUPPORTED, VT_ERR_HIP = 0, -1, -2, -3, -4, -5
+
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 c_uint64, c_uint32 = ctypes.c_uint64, ctypes.c_uint32
 DROP = [c_float, c_uint64, c_uint32]  # (p, step seed, site)

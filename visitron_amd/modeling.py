@@ -1142,20 +1142,32 @@ class PreTrainOscar(BertPreTrainedModel):
 
     LOSS_ROWS_PER_CHUNK = 8192   # labelled rows per decoder GEMM + fused CE launch (1 GB of fp32 logits at a time)
 
-    def _mlm_loss_on_labelled_rows(self, seq_bf16, labels):
+    def _labelled_rows(self, labels, token_labels):
+        """The rows that carry an MLM label / a region-token label, located with ONE host synchronisation for both heads
+        (the counts and the out-of-range checks travel together; the row indices come from a stable argsort cut at the
+        count, which needs no size from the device): -> ((y_all, idx, n) for the MLM head, the same for the token head)."""
+        V, C = self.mlmhead.predictions.decoder.weight.shape[0], self.token_head[0].weight.shape[0]
+        yw, yt = labels.reshape(-1), token_labels.reshape(-1)
+        have_w, have_t = yw != -1, yt != -1
+        info = torch.stack([have_w.sum(), have_t.sum(), ((yw >= V) | (yw < -1)).any().to(torch.int64),
+                            ((yt >= C) | (yt < -1)).any().to(torch.int64)]).tolist()
+        for bad, ncls in ((info[2], V), (info[3], C)):
+            if bad:   # CrossEntropyLoss raises on a target outside [0, classes) other than ignore_index
+                raise IndexError("Target out of bounds for a criterion with %d classes (ignore_index = -1)" % ncls)
+        rows = lambda have, n: torch.argsort((~have).to(torch.int8), stable=True)[:n]
+        return (yw, rows(have_w, info[0]), int(info[0])), (yt, rows(have_t, info[1]), int(info[1]))
+
+    def _mlm_loss_on_labelled_rows(self, seq_bf16, located):
         """(mean CE over the positions with a label, their argmax accuracy) of the MLM head -- encoder.py:377, 387-389,
         402-413 -- from the labelled rows only, chunked: transform GEMM (+GELU), LayerNorm, decoder GEMM, fused
         log-sum-exp / argmax (vt_ce_softmax_rows without its gradient output).  No labelled row: NaN, as the criterion."""
-        y_all = labels.reshape(-1)
-        idx = torch.nonzero(y_all != -1).flatten()
-        n = int(idx.numel())
+        y_all, idx, n = located
         dev = seq_bf16.device
         if n == 0:
             nan = torch.full((), float("nan"), dtype=torch.float32, device=dev)
             return nan, nan.clone()
         p = self.mlmhead.predictions
         V = p.decoder.weight.shape[0]
-        _check_targets(y_all, V)
         w_tr, w_dec = _bf16(p.transform.dense.weight), _bf16(p.decoder.weight)
         loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
         hits = torch.zeros((), dtype=torch.int64, device=dev)
@@ -1172,19 +1184,16 @@ class PreTrainOscar(BertPreTrainedModel):
             hits += (amax == y).sum()
         return loss_sum / n, hits.float() / n
 
-    def _token_loss_on_labelled_rows(self, seq_bf16, token_labels):
+    def _token_loss_on_labelled_rows(self, seq_bf16, located):
         """The masked-region-token head (encoder.py:323-326, 380-385, 423-431): Linear + Softmax, then CrossEntropy on
         the probabilities -- loss and argmax of the labelled rows from vt_ce_double_softmax_rows."""
-        y_all = token_labels.reshape(-1)
-        idx = torch.nonzero(y_all != -1).flatten()
-        n = int(idx.numel())
+        y_all, idx, n = located
         dev = seq_bf16.device
         if n == 0:
             nan = torch.full((), float("nan"), dtype=torch.float32, device=dev)
             return nan, nan.clone()
         lin = self.token_head[0]
         C = lin.weight.shape[0]
-        _check_targets(y_all, C)
         y = y_all.index_select(0, idx)
         z = torch.empty((n, round_up(C, 4)), dtype=torch.float32, device=dev)
         ops.linear(seq_bf16.index_select(0, idx), _bf16(lin.weight), _f32(lin.bias), out=z, out_f32=True)
@@ -1250,8 +1259,9 @@ class PreTrainOscar(BertPreTrainedModel):
             # that carry a label: every criterion ignores -1 (encoder.py:321) and the accuracies drop those positions
             # (:402-431).  So the two wide heads run on the labelled rows alone and their logits go straight into the
             # fused loss + argmax kernels -- [B, S, 30522] fp32 (7 GB at B = 256) is never written.
-            mask_loss, words_accuracy = self._mlm_loss_on_labelled_rows(outs[-1], labels)
-            token_loss, token_accuracy = self._token_loss_on_labelled_rows(outs[-1], token_labels)
+            loc_w, loc_t = self._labelled_rows(labels, token_labels)      # the call's one host synchronisation
+            mask_loss, words_accuracy = self._mlm_loss_on_labelled_rows(outs[-1], loc_w)
+            token_loss, token_accuracy = self._token_loss_on_labelled_rows(outs[-1], loc_t)
             action_scores = self.next_action(pooled)
         next_loss = self.criterion(action_scores, next_action) if next_action is not None else 0
         loss = mask_loss + next_loss + token_loss
@@ -1265,12 +1275,6 @@ class PreTrainOscar(BertPreTrainedModel):
 
             loss = lazy_autograd_loss(self, batch, loss, head_mask=head_mask)
         return (loss, mask_loss, next_loss, token_loss, words_accuracy, action_accuracy, token_accuracy)
-
-
-def _check_targets(y, n_classes):
-    """CrossEntropyLoss raises on a target outside [0, classes) other than ignore_index; the fused kernels index with it."""
-    if bool(((y >= n_classes) | (y < -1)).any()):
-        raise IndexError("Target out of bounds for a criterion with %d classes (ignore_index = -1)" % n_classes)
 
 
 def _supervised_accuracy(scores, labels):

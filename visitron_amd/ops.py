@@ -856,6 +856,7 @@ def softdot_attention(target, context, mask=None, want_weighted=True, want_attn=
 # VT_LSTM_PERSISTENT=0 keeps the one-launch-per-position form.  Scratch (exchange buffers + sync words) per (B, hs, device).
 LSTM_PERSISTENT = os.environ.get("VT_LSTM_PERSISTENT", "1") != "0"
 _lstm_ws = {}
+_LSTM_FORCE_TIMEOUT = [False]   # test hook: treat every persistent launch as timed out (exercises the restore + fallback)
 
 
 def _lstm_persistent(xproj, ldx_b, ldx_t, row_start, h, c, w_hh, lengths, seq_out, T, reverse):
@@ -864,22 +865,33 @@ def _lstm_persistent(xproj, ldx_b, ldx_t, row_start, h, c, w_hh, lengths, seq_ou
     B, hs = c.shape
     if not LSTM_PERSISTENT or B > 64 or hs not in (128, 256, 512, 1024):
         return False
+    if torch.cuda.is_current_stream_capturing():
+        return False   # the time-out word is read back by the host: not inside a graph capture (the step launches are)
     lib = _lib.load()
-    key = (B, hs, str(c.device))
+    # scratch (exchange buffers, arrival counter, time-out word) per shape, device AND stream: two streams running the
+    # recurrence side by side must not share a counter
+    key = (B, hs, str(c.device), int(torch.cuda.current_stream().cuda_stream))
     ws = _lstm_ws.get(key)
     if ws is None:
         ws = torch.empty(int(lib.vt_lstm_sequence_persistent_ws_bytes(B, hs)), dtype=torch.uint8, device=c.device)
         _lstm_ws[key] = ws
+    # a workgroup that runs out of its bounded wait leaves the state partly advanced (the others may have finished the
+    # last step): the caller's h / c are restored from these copies before the step launches take over
+    h_keep, c_keep = h.clone(), c.clone()
     with _timed("lstm_persistent", 2.0 * T * B * 4 * hs * hs, T * 4.0 * B * hs * 8):
         rc = lib.vt_lstm_sequence_persistent_f32(
             _ptr(xproj), ldx_b, ldx_t, _ptr(row_start), _ptr(h), _ptr(c), _ptr(w_hh), _ptr(lengths), _ptr(seq_out),
             0 if seq_out is None else seq_out.stride(0), 0 if seq_out is None else seq_out.stride(1), B, hs, int(T),
             1 if reverse else 0, _ptr(ws), ws.numel(), _stream())
-    if rc == -4:   # VT_ERR_UNSUPPORTED
+    if rc == _lib.VT_ERR_UNSUPPORTED:
         return False
     _lib.check(rc, "vt_lstm_sequence_persistent_f32")
     # the timeout word (one 4-byte read-back; the recurrence's result is consumed right after anyway)
-    return int(ws[4:8].view(torch.int32).item()) == 0
+    if int(ws[4:8].view(torch.int32).item()) != 0 or _LSTM_FORCE_TIMEOUT[0]:
+        h.copy_(h_keep)
+        c.copy_(c_keep)
+        return False
+    return True
 
 
 def lstm_sequence(xproj, h2, c, w_hh, T, lengths=None, seq_out=None, reverse=False):
