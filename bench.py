@@ -320,6 +320,8 @@ def main():
                                "trunk forward (embeddings + region projection + encoder + pooler) [BASELINE configs[1]]"),
                 "global_batch": world * a.batch, "seq_len": S,
                 "parallelism": ("dp%d (flat-slab gradient all-reduce over RCCL)" if train else "dp%d (replicas, no collective)") % world,
+                # the data-parallel exchange moves a bf16 copy of the gradient slab by default (VT_GRAD_COMM=fp32: the fp32 slab)
+                "grad_comm_dtype": (engine.grad_comm_dtype if (train and world > 1) else None),
                 "weights": "random init N(0,0.02), seed 0",
                 "dropout": a.dropout if train else 0.0,
                 # bf16 operands on the matrix cores, fp32 accumulation everywhere.  Inference keeps the residual stream

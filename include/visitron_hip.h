@@ -55,6 +55,9 @@ void vt_debug_set_wgrad_kernel(int mode);
  * kind = act | 16 (a residual / factor operand R) | 32 (the second output C2) | 64 (fp32 output) | ln_mode << 8
  * (vt_linear_ln_bf16): the out-proj with its residual and a plain dgrad of the same (M, N, K) are different entries. */
 void vt_gemm_tune(int M, int N, int K, int kind, int variant);
+/* The persistent GEMM kernels launch one workgroup per compute unit; with k > 0 they leave k compute units free (for the
+ * collective kernels of a data-parallel step that run beside the backward).  Process-global, 0 by default. */
+void vt_gemm_reserve_cus(int k);
 /* Tuning hook: 4 or 8 waves per workgroup in the attention backward (default 8). Process-global. */
 void vt_debug_set_attn_bwd_waves(int waves);
 

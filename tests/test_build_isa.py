@@ -40,6 +40,25 @@ def test_agpr_gemm_kernels_have_no_scratch(tmp_path):
         assert "scratch_" not in text, name
 
 
+def test_deferred_layernorm_gemm_kernels_keep_their_ring_in_place(tmp_path):
+    """gemm_v7_ln.hip: the deferred-LayerNorm epilogues.  No scratch; no register parked in an AGPR (v_accvgpr_write) --
+    the residual-stream ring is written by loads hipcc does not see, and a copy made before the data has landed carries
+    the old bits (that is what broke the 224- and 256-row tiles while 16 row factors and 16 running sums sat in registers
+    beside the ring); and no EMPTY inline-asm statement: hipcc's hazard recognizer counts one as an instruction and drops
+    the wait state a packed fp32 op needs before a dependent one (the pins carry an s_nop)."""
+    ks = _kernels(_device_asm(os.path.join(CSRC, "gemm_v7_ln.hip"), tmp_path))
+    assert len(ks) == 24                       # 8 tile heights x (2 activations of mode 1 + mode 2)
+    for name, text in ks.items():
+        m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", text)
+        assert m and int(m.group(1)) == 0, name
+        assert "scratch_" not in text, name
+        assert "v_accvgpr_write" not in text, name
+        lines = [l.strip() for l in text.splitlines()]
+        last_mfma = max(i for i, l in enumerate(lines) if l.startswith("v_mfma"))   # the epilogue follows the K loop's last MFMA
+        for i in range(last_mfma, len(lines) - 1):
+            assert not (lines[i].startswith(";;#ASMSTART") and lines[i + 1].startswith(";;#ASMEND")), (name, i)
+
+
 def test_wgrad_v8_fragment_registers_are_left_alone(tmp_path):
     """gemm_wgrad_tn_v8 names v[96:227] in its instruction text (transposing-read fragments, the bias ones operand);
     nothing the compiler emits may touch them, and the code object's register count must cover them."""

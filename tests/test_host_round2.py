@@ -177,3 +177,67 @@ def test_data_parallel_replicas_are_refused_with_the_way_out():
     replica._former_parameters = {}
     with pytest.raises(NotImplementedError, match="one process per GPU"):
         replica(torch.zeros(1, 4, dtype=torch.int64))
+
+
+# ---- round 3: host logic of the deferred-LayerNorm path and the autotuner's keys ---------------------------------
+def test_tune_kind_matches_the_library_key():
+    """ops.tune_kind must produce what VT_TUNE_KIND (csrc/gemm_bf16.hip) derives from a call's arguments."""
+    from visitron_amd import ops
+
+    assert ops.tune_kind(ops.ACT_NONE) == 0
+    assert ops.tune_kind(ops.ACT_NONE, residual=True) == 16
+    assert ops.tune_kind(ops.ACT_GELU, pre_act=True) == 1 + 32
+    assert ops.tune_kind(ops.ACT_MUL) == 3 + 16                       # the factor operand counts as a residual
+    assert ops.tune_kind(ops.ACT_NONE, out_f32=True) == 64
+    assert ops.tune_kind(ops.ACT_GELU, ln_mode=1) == 1 + 256 and ops.tune_kind(ops.ACT_NONE, ln_mode=2) == 512
+    src = open(os.path.join(ROOT, "visitron_amd", "csrc", "gemm_bf16.hip")).read()
+    assert "((act) | ((has_r) ? 16 : 0) | ((has_c2) ? 32 : 0) | ((out_f32) ? 64 : 0) | ((ln_mode) << 8))" in src
+
+
+def test_default_variant_table_lookup(tmp_path, monkeypatch):
+    from visitron_amd import ops
+
+    monkeypatch.setattr(ops, "_defaults", {(14592, 768, 768, 512): 23, (58368, 768, 768, 512): 16, (14592, 2304, 768, 256): 19})
+    assert ops._default_variant((14592, 768, 768, 512)) == 23
+    assert ops._default_variant((15000, 768, 768, 512)) == 23          # nearest M of the same (N, K, kind), within 25 %
+    assert ops._default_variant((30000, 768, 768, 512)) is None        # too far from both
+    assert ops._default_variant((14592, 768, 768, 16)) is None         # another epilogue is another entry
+
+
+def test_deferred_layernorm_weight_folding_is_the_same_function():
+    """_PackedEncoderLn: LN(v) W^T + b == rstd (v W'^T - mean g) + h and dense + LN(v) == acc + cb + gamma x^ for the folded
+    operands, checked in fp64-ish torch arithmetic on the CPU (no kernel involved: the algebra the kernels implement)."""
+    import torch
+
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import CaptionBertEncoder, _PackedEncoderLn
+
+    cfg = mini_config()
+    torch.manual_seed(3)
+    enc = CaptionBertEncoder(cfg)
+    for p in enc.parameters():
+        torch.nn.init.normal_(p, 0.0, 0.2) if p.dim() > 1 else torch.nn.init.uniform_(p, 0.5, 1.5)
+    pk = _PackedEncoderLn(enc)
+    H, eps = cfg.hidden_size, cfg.layer_norm_eps
+    v = torch.randn(9, H) * 2.0 + 0.7
+    mean, var = v.mean(-1, keepdim=True), v.var(-1, unbiased=False, keepdim=True)
+    rstd = torch.rsqrt(var + eps)
+    l0, l1 = enc.layer[0], enc.layer[1]
+    # layer 1's query|key|value projection consumes LN2 of layer 0
+    ln = l0.output.LayerNorm
+    x = torch.nn.functional.layer_norm(v, (H,), ln.weight, ln.bias, eps)
+    att = l1.attention.self
+    want = torch.cat([att.query(x), att.key(x), att.value(x)], -1)
+    t = pk.tensors[1]
+    got = rstd * (v @ t["w_qkv"].float().t() - mean * t["g_qkv"]) + t["h_qkv"]
+    assert float((got - want).abs().max()) < 3e-2 * float(want.abs().max())          # W' is rounded to bf16
+    # layer 1's attention.output: dense(ctx) + LN2_0(v): bias + beta and gamma as vectors
+    ctx = torch.randn(9, H)
+    so = l1.attention.output
+    want2 = so.dense(ctx) + x
+    got2 = ctx @ so.dense.weight.t() + t["cb_ao"] + t["gamma_in"] * ((v - mean) * rstd)
+    assert float((got2 - want2).abs().max()) < 1e-4
+    # layer 0's input is not normalised again
+    t0 = pk.tensors[0]
+    assert torch.equal(t0["gamma_in"], torch.ones(H)) and float(t0["cb_ao"].sub(l0.attention.output.dense.bias).abs().max()) == 0.0
+    assert pk.final_gamma is not None and torch.equal(pk.final_gamma, enc.layer[-1].output.LayerNorm.weight.detach())

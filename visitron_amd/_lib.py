@@ -63,6 +63,7 @@ SIGNATURES = {
     "vt_debug_set_wgrad_kernel": (None, [c_int]),
     "vt_gemm_tune": (None, [c_int, c_int, c_int, c_int, c_int]),
     "vt_debug_set_attn_bwd_waves": (None, [c_int]),
+    "vt_gemm_reserve_cus": (None, [c_int]),
     "vt_linear_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_linear_bf16_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,

@@ -82,6 +82,7 @@ int vt_embed_layernorm_f32_dispatch(const int64_t* ids, const int64_t* type_ids,
                                     int* err_flag, hipStream_t stream);
 
 void vt_gemm_tune_set(int M, int N, int K, int kind, int variant);
+void vt_gemm_set_reserved_cus(int k);
 int vt_gemm_ln_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const float* colv,
                         const float* stats_in, int np, long stat_rows, float eps, int ln_mode, const void* Rs, long ldrs,
                         void* C, long ldc, void* Cs, long ldcs, float* stats_out, int M, int N, int K, int act,
@@ -129,6 +130,7 @@ void vt_debug_set_wgrad_kernel(int mode) {
 }
 void vt_gemm_tune(int M, int N, int K, int kind, int variant) { vt_gemm_tune_set(M, N, K, kind, variant); }
 void vt_debug_set_attn_bwd_waves(int waves) { vt_attn_bwd_set_waves(waves); }
+void vt_gemm_reserve_cus(int k) { vt_gemm_set_reserved_cus(k); }
 
 int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* R,
                    int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int act, int out_f32, int grp_rows,

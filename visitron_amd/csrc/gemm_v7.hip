@@ -2,8 +2,19 @@
 // launchers of the kernels in gemm_v7_kernels.hpp with the plain epilogues.
 #include "gemm_v7_kernels.hpp"
 
-static int v8_grid(int tiles) {
+// Compute units the persistent grid leaves free (vt_gemm_reserve_cus): with a collective running beside the backward (one
+// process per GPU, RCCL kernels on a few CUs) a persistent workgroup mapped onto a busy CU would stall its share of the
+// tiles for a kernel time; launched with cus - k workgroups the grid fits beside it.  0 by default.
+static std::atomic<int> g_reserved_cus{0};
+void vt_gemm_set_reserved_cus(int k) { g_reserved_cus.store(k < 0 ? 0 : k, std::memory_order_relaxed); }
+int vt_gemm_persistent_cus() {
   const int cus = vt_device_cus();   // of the calling thread's current device
+  if (cus <= 0) return -1;
+  const int k = g_reserved_cus.load(std::memory_order_relaxed);
+  return cus - k >= 8 ? cus - k : cus;
+}
+static int v8_grid(int tiles) {
+  const int cus = vt_gemm_persistent_cus();
   if (cus <= 0) return -1;
   return tiles < cus ? tiles : cus;
 }

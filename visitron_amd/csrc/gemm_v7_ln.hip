@@ -3,6 +3,8 @@
 // its own so that it compiles beside gemm_v7.hip.
 #include "gemm_v7_kernels.hpp"
 
+int vt_gemm_persistent_cus();   // gemm_v7.hip: the device's CU count less the reserved ones
+
 template <int ACT, int LNM>
 static int launch_ln(const GemmArgs& g, int persistent, int mtn, hipStream_t stream) {
   GemmArgs ga = g;
@@ -12,7 +14,7 @@ static int launch_ln(const GemmArgs& g, int persistent, int mtn, hipStream_t str
   void (*kern)(GemmArgs) = nullptr;
   int grid = tiles;
   if (persistent) {
-    const int cus = vt_device_cus();
+    const int cus = vt_gemm_persistent_cus();
     if (cus <= 0) return VT_ERR_HIP;
     grid = tiles < cus ? tiles : cus;
     switch (mtn) {

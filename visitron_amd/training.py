@@ -348,7 +348,14 @@ class PretrainEngine(object):
             b = _TrainBuffers(cfg.num_hidden_layers, B * S, B, S, cfg.hidden_size, cfg.intermediate_size,
                               cfg.num_attention_heads, self.flat.p.device)
             if self.world > 1:
-                ops.PERSISTENT_GEMM_OK = False   # collectives share the CUs with the backward (see ops.py)
+                # collectives share the CUs with the backward (see ops.py): by default the persistent GEMM stands down;
+                # VT_GEMM_RESERVE_CUS=k keeps it and launches it on (CUs - k) workgroups instead, leaving k compute units to
+                # the RCCL kernels (not measured on a multi-GPU node yet: opt-in)
+                k = int(os.environ.get("VT_GEMM_RESERVE_CUS", "0"))
+                if k > 0:
+                    _lib.load().vt_gemm_reserve_cus(k)
+                else:
+                    ops.PERSISTENT_GEMM_OK = False
             ops.autotune_encoder_shapes(B * S, cfg.hidden_size, cfg.intermediate_size, training=True,
                                         device=self.flat.p.device)
             self._bufs[key] = b
@@ -907,7 +914,10 @@ class PretrainEngine(object):
                     drop_seed_base=self.drop_seed_base,
                     hyper=dict(lr=self.lr, weight_decay=self.wd, eps=self.eps, betas=tuple(self.betas),
                                correct_bias=self.correct_bias, schedule=self.schedule, warmup_steps=self.warmup_steps,
-                               t_total=self.t_total))
+                               t_total=self.t_total,
+                               # what travelled in the gradient all-reduce of the run that wrote this state (recorded, not
+                               # restored: it is a property of the launch, and it changes the result at rounding level)
+                               grad_comm_dtype=self.grad_comm_dtype, world_size=self.world))
 
     def load_state_dict(self, sd, load_hyper=True):
         f = self.flat
