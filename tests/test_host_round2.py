@@ -241,3 +241,34 @@ def test_deferred_layernorm_weight_folding_is_the_same_function():
     t0 = pk.tensors[0]
     assert torch.equal(t0["gamma_in"], torch.ones(H)) and float(t0["cb_ao"].sub(l0.attention.output.dense.bias).abs().max()) == 0.0
     assert pk.final_gamma is not None and torch.equal(pk.final_gamma, enc.layer[-1].output.LayerNorm.weight.detach())
+
+
+def test_gelu_polynomial_of_the_epilogues_meets_its_stated_error():
+    """csrc/common.hpp gelu_poly4: the degree-8 fit of (Phi(x) - 0.5) / x used by the bf16 GEMM epilogues
+    (hidden_act "gelu", oscar/modeling_bert.py:104-109 through pytorch-transformers' erf form).  The coefficients are read
+    from the source and evaluated here in fp32 as the kernel does: |Phi - exact| <= 2.6e-5, |GELU - exact| <= 1.2e-4 on a
+    dense grid."""
+    import re
+
+    import numpy as np
+    from scipy.special import erf
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "visitron_amd", "csrc", "common.hpp")).read()
+    for fn in ("gelu_poly4",):
+        body = src[src.index("%s(f32x4 x" % fn):]
+        body = body[:body.index("\n}\n")]
+        first = re.search(r"p = t \* ([0-9.e+-]+)f ([+-]) ([0-9.e+-]+)f;", body)
+        coef = [float(first.group(1)), float(first.group(2) + first.group(3))]
+        coef += [float(m.group(1) + m.group(2)) for m in re.finditer(r"p = p \* t ([+-]) ([0-9.e+-]+)f;", body)]
+        assert len(coef) == 9, fn
+        x = np.linspace(-9, 9, 400001).astype(np.float32)
+        xc = np.clip(x, np.float32(-4.5), np.float32(4.5))
+        t = xc * xc
+        p = np.full_like(t, np.float32(coef[0]))
+        for c in coef[1:]:
+            p = p * t + np.float32(c)
+        phi = np.maximum(xc * p + np.float32(0.5), np.float32(0))
+        x64 = x.astype(np.float64)
+        exact_phi = 0.5 * (1 + erf(x64 / np.sqrt(2)))
+        assert np.abs(phi - exact_phi).max() <= 2.6e-5, fn
+        assert np.abs(x * phi - x64 * exact_phi).max() <= 1.2e-4, fn
