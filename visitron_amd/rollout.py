@@ -337,9 +337,11 @@ class OscarEncoder(nn.Module):
     def forward(self, inputs, lengths, mask, position_ids=None, token_type_ids=None):
         ops._require_hip(inputs)
         if self.num_layers != 1:
-            raise NotImplementedError("stacked encoder LSTMs (num_layers > 1) are not served")
+            raise NotImplementedError("stacked encoder LSTMs (num_layers > 1, agent_models.py:204,221) are not served: the "
+                                      "reference's only caller, agent.py:110-117, leaves the default 1")
         if self.reverse_input:
-            raise NotImplementedError("reverse_input is not served (every reference caller leaves it False)")
+            raise NotImplementedError("reverse_input (agent_models.py:205,210) is not served: the reference's only caller, "
+                                      "agent.py:110-117, leaves it False")
         att_mask = ~mask                                               # :267 (uint8 masks: 254/255, the trunk keeps that)
         B, S = inputs.shape
         H = self.transformer_hidden_size
