@@ -105,11 +105,16 @@ int vt_debug_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_s
  * already-additive [B,S] bias when mask_additive == 1 (what CaptionBertEncoder.forward receives), or an additive
  * per-query bias [B,S,S] when mask_additive == 2 (the reference's 3-D attention_mask, encoder.py:226-229; forward and
  * vt_attention_probs_f32 only, the backward returns VT_ERR_UNSUPPORTED).  lse (optional, [B,nh,S]) gets
- * the natural-log log-sum-exp of the masked scores for the backward pass. */
+ * the natural-log log-sum-exp of the masked scores for the backward pass.
+ * keep_bits (optional; training with drop_p > 0): the kernel also writes its keep decisions, one word per (32-query block,
+ * key): keep_bits[((b*nh + h) * nqb + qb) * kpitch + key], bit j = keep(query 32 qb + j, key), nqb = ceil(S/32),
+ * kpitch = 32 nqb (VT_KEEP_WORDS(B, nh, S) words).  The backward kernels read them back instead of re-deriving the mask
+ * from the hash (a third of their vector instructions). */
+#define VT_KEEP_WORDS(B, nh, S) ((int64_t)(B) * (nh) * (((S) + 31) / 32) * (((S) + 31) / 32 * 32))
 int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive,
                           const float* head_scale, void* ctx, int64_t ld_ctx, float* lse, int B, int S,
                           int nh, int head_size, float drop_p, uint64_t drop_seed, uint32_t drop_site,
-                          vt_stream_t stream);
+                          uint32_t* keep_bits, vt_stream_t stream);
 
 /* The attention probabilities the reference returns under config.output_attentions (oscar/modeling_bert.py:58-66,
  * 74-79; eval mode): probs[b,h,q,k] = exp(q.k/8 + bias[k] - lse[b,h,q]) [* head_scale[h]], fp32 [B,nh,S,S], from qkv
@@ -123,11 +128,13 @@ int vt_attention_probs_f32(const void* qkv, int64_t ld_qkv, const float* mask, i
  * Autograd of oscar/modeling_bert.py:47-72 inside loss.backward() (tasks/viewpoint_select/
  * pretrain.py:191).  S <= 256: no atomics, bitwise reproducible, dq32_ws may be NULL.  S > 256: the
  * keys are processed in blocks of 256 and dq is accumulated with fp32 atomics in dq32_ws, an fp32
- * [B*S, nh*64] scratch slab (zeroed here), then rounded to bf16. */
+ * [B*S, nh*64] scratch slab (zeroed here), then rounded to bf16.  keep_bits: the words the forward wrote (same
+ * drop_p / seed / site), or NULL = recompute the mask from the hash. */
 int vt_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
                           int64_t ld_ctx, const float* mask, int mask_additive, const float* lse,
                           float* delta_ws, void* dqkv, int64_t ld_dqkv, float* dq32_ws, int B, int S, int nh,
-                          int head_size, float drop_p, uint64_t drop_seed, uint32_t drop_site, vt_stream_t stream);
+                          int head_size, float drop_p, uint64_t drop_seed, uint32_t drop_site, const uint32_t* keep_bits,
+                          vt_stream_t stream);
 
 /* y = BertLayerNorm(x) over rows of H (biased variance, eps inside the sqrt); x already holds
  * dense(h) + bias + residual.  BertSelfOutput / BertOutput LayerNorm (called at
@@ -431,6 +438,7 @@ typedef struct vt_layer_acts {
   void* out;       /* [M,H]  bf16 layer output */
   float* lse;      /* [B,nh,S] or null */
   float* ln1_mean; float* ln1_rstd; float* ln2_mean; float* ln2_rstd; /* [M] or null */
+  uint32_t* keep_bits; /* VT_KEEP_WORDS(B, nh, S) words or null: the attention dropout's keep decisions (see vt_attention_fwd_bf16) */
 } vt_layer_acts;
 
 /* x: [B*S, H] bf16 embedding output (layer-0 input).  head_scale: [L, nh] fp32 or null.
@@ -545,12 +553,13 @@ int vt_encoder_backward_overlap_bf16(const vt_layer_weights* layers, const vt_la
  * do not exist, so inference keeps the padded entry points. */
 int vt_attention_fwd_seq_bf16(const void* qkv, int64_t ld_qkv, const float* head_scale, void* ctx, int64_t ld_ctx,
                               float* lse, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
-                              uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, vt_stream_t stream);
+                              uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, uint32_t* keep_bits,
+                              vt_stream_t stream);
 int vt_attention_bwd_seq_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
                               int64_t ld_ctx, const float* lse, float* delta_ws, void* dqkv, int64_t ld_dqkv,
                               float* dq32_ws, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
                               uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, int64_t rows,
-                              vt_stream_t stream);
+                              const uint32_t* keep_bits, vt_stream_t stream);
 int vt_encoder_forward_seq_bf16(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers, const void* x,
                                 const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps, float p_hidden,
                                 float p_attn, uint64_t drop_seed, int64_t rows, const int32_t* seq_start,

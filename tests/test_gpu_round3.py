@@ -440,3 +440,81 @@ def test_deferred_layernorm_path_equals_the_seven_launch_layer(dev):
         want = ref(**dict(b, attention_mask=m3), head_mask=hm)[0]
         got = prod(**_to(dict(b, attention_mask=m3), dev), head_mask=hm.to(dev))[0]
     check_close("deferred-LN trunk with head_mask and a 3-D mask (mini)", got, want, TOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# a1 (training): the attention dropout's keep decisions handed from the forward to the backward kernel
+# ------------------------------------------------------------------------------------------------
+BF16 = torch.bfloat16
+
+
+def _unpack_keep_words(words, B, nh, S):
+    """keep_bits [B*nh, nqb, kpitch] words -> bool [B*nh, nqb*32 (query), kpitch (key)]: bit j of word (qb, key) = query 32 qb + j."""
+    nqb = (S + 31) // 32
+    w = words.view(B * nh, nqb, nqb * 32).cpu().to(torch.int64) & 0xFFFFFFFF
+    bits = (w[:, :, None, :] >> torch.arange(32)[None, None, :, None]) & 1          # [bh, qb, j, key]
+    return bits.reshape(B * nh, nqb * 32, nqb * 32).bool()
+
+
+@pytest.mark.parametrize("B,S,nh", [(2, 228, 3), (1, 37, 2), (2, 300, 2), (1, 64, 1)])
+def test_attention_keep_words_are_the_hash_mask_and_drive_the_backward(dev, B, S, nh):
+    """Training with attention_probs dropout (oscar/modeling_bert.py:62): the forward kernel writes its keep decisions as
+    one word per (32-query block, key); they must BE the counter-hash mask (vt_debug_dropout_mask: what the oracle tests
+    feed to torch), the context must not change, and the backward reading them must return bit for bit what the backward
+    re-deriving the mask from the hash returns."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(7 * S + nh)
+    H = nh * 64
+    drop = (0.2, 1234, ops.site_attn(2))
+    qkv = (torch.randn(B * S, 3 * H, generator=g) * 0.9).to(dev, BF16)
+    dctx = (torch.randn(B * S, H, generator=g) * 0.6).to(dev, BF16)
+    mask = (torch.rand(B, S, generator=g) > 0.2).float()
+    mask[:, 0] = 1.0
+    mask = mask.to(dev)
+    lse0 = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
+    lse1 = torch.zeros_like(lse0)
+    words = torch.full((ops.keep_words(B, nh, S),), -1, dtype=torch.int32, device=dev)
+    ctx0 = ops.attention_fwd(qkv, B, S, nh, mask=mask, lse=lse0, drop=drop)
+    ctx1 = ops.attention_fwd(qkv, B, S, nh, mask=mask, lse=lse1, drop=drop, keep_bits=words)
+    torch.cuda.synchronize()
+    assert torch.equal(ctx0, ctx1) and torch.equal(lse0, lse1)
+    got = _unpack_keep_words(words, B, nh, S)[:, :S, :S]
+    want = torch.stack([ops.dropout_mask(S * S, drop, head_index=i, device=dev).view(S, S) for i in range(B * nh)]).bool().cpu()
+    assert torch.equal(got, want)
+    d0 = ops.attention_bwd(qkv, dctx, ctx0, lse0, B, S, nh, mask=mask, drop=drop)
+    d1 = ops.attention_bwd(qkv, dctx, ctx1, lse1, B, S, nh, mask=mask, drop=drop, keep_bits=words)
+    torch.cuda.synchronize()
+    if S <= 256:
+        assert torch.equal(d0, d1)                      # no atomics below 257 keys: bitwise
+    else:
+        assert float((d0.float() - d1.float()).abs().max()) <= 2.0 ** -7 * float(d0.float().abs().max())
+
+
+def test_attention_keep_words_on_compacted_rows(dev):
+    """The same on the training step's compacted layout (per-sequence start / length; the hash index runs over the sequence's
+    own length): words of sequence b against the mask of an n_b x n_b site, gradient bit for bit."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    B, S, nh = 3, 96, 2
+    H = nh * 64
+    lens = torch.tensor([96, 50, 33])
+    keep = torch.arange(S)[None, :] < lens[:, None]
+    seq = ops.SeqLayout(keep.to(dev))
+    drop = (0.1, 77, ops.site_attn(0))
+    qkv = (torch.randn(seq.rows, 3 * H, generator=g) * 0.8).to(dev, BF16)
+    dctx = torch.randn(seq.rows, H, generator=g).to(dev, BF16)
+    lse = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
+    words = torch.zeros(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev)
+    ctx = ops.attention_fwd(qkv, B, S, nh, lse=lse, drop=drop, seq=seq, keep_bits=words)
+    d1 = ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, seq=seq, keep_bits=words)
+    d0 = ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, seq=seq)
+    torch.cuda.synchronize()
+    assert torch.equal(d0, d1)
+    got = _unpack_keep_words(words, B, nh, S)
+    for b in range(B):
+        n = int(lens[b])
+        for h in range(nh):
+            want = ops.dropout_mask(n * n, drop, head_index=b * nh + h, device=dev).view(n, n).bool().cpu()
+            assert torch.equal(got[b * nh + h, :n, :n], want), (b, h)

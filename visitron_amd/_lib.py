@@ -26,7 +26,7 @@ class LayerWeights(ctypes.Structure):  # vt_layer_weights
 class LayerActs(ctypes.Structure):  # vt_layer_acts
     _fields_ = [(n, c_void_p) for n in (
         "qkv", "ctx", "attn_pre", "attn_out", "mid_pre", "mid", "out_pre", "out", "lse",
-        "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd")]
+        "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd", "keep_bits")]
 
 
 class LayerWeightsLn(ctypes.Structure):  # vt_layer_weights_ln
@@ -74,7 +74,7 @@ SIGNATURES = {
                                        c_int, c_void_p]),
     "vt_attention_bwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int]
-                              + DROP + [c_void_p]),
+                              + DROP + [c_void_p, c_void_p]),
     "vt_layernorm_bwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_int64] + DROP
                               + [c_void_p]),
@@ -134,10 +134,10 @@ SIGNATURES = {
                                                  ctypes.POINTER(BwdWorkspace), c_int, c_int, c_int, c_int, c_int, c_float,
                                                  c_int, c_float, c_float, c_uint64, c_int, c_void_p, c_void_p]),
     "vt_attention_fwd_seq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int]
-                                  + DROP + [c_void_p, c_void_p, c_void_p]),
+                                  + DROP + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "vt_attention_bwd_seq_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                           c_int64, c_void_p, c_int, c_int, c_int, c_int] + DROP
-                                  + [c_void_p, c_void_p, c_int64, c_void_p]),
+                                  + [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "vt_encoder_forward_seq_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerActs), c_int, c_void_p, c_void_p,
                                             c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_uint64, c_int64,
                                             c_void_p, c_void_p, c_void_p]),
@@ -147,7 +147,7 @@ SIGNATURES = {
                                              c_int, c_int, c_float, c_int, c_float, c_float, c_uint64, c_int, c_int64,
                                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "vt_attention_fwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p,
-                                      c_int, c_int, c_int, c_int] + DROP + [c_void_p]),
+                                      c_int, c_int, c_int, c_int] + DROP + [c_void_p, c_void_p]),
     "vt_layernorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "vt_embed_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

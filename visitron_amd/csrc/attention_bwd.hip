@@ -41,6 +41,9 @@ struct AttnBwdArgs {
   const int* seq_len;     // lse / delta keep their [B, nh, S] layout.  Null: sequence b = rows b*S .. b*S + S
   float scale;          // 1 / sqrt(head_size)
   DropCfg drop;         // the forward's attention-probability dropout (same seed / indexing)
+  // the forward's keep decisions (AttnArgs::keep_bits in attention_fwd.hip): word [((b*nh + h) * nqb + qb) * kpitch + key],
+  // bit j = keep(query 32 qb + j, key).  Null: the 8-wave kernel re-derives them from the hash like the 4-wave kernel does.
+  const uint32_t* keep_bits;
 };
 
 // LDS map (bytes)
@@ -413,6 +416,9 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
 }
 
 // 8-wave form: wave w owns keys 32w..32w+31 (one key tile), <= 256 VGPRs, two waves per SIMD.
+// BITS: the dropout keep flags come from the words the forward wrote (one 4-byte load per lane and slice, one bit-field
+// extract and two ands per element) instead of the hash (about ten vector instructions per element, a third of the loop)
+template <bool BITS>
 __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -470,6 +476,15 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
     if (wave < 4) glds16(base + (long)q * a.ld_qkv + (c << 3), smem + AB_Q + buf * 4096 + pw * 1024);
     else glds16(dobase + (long)q * a.ld_d + (c << 3), smem + AB_DO + buf * 4096 + pw * 1024);
   };
+  // the keep words of this lane's key: one per 32-query slice, fetched a slice ahead like the row constants
+  const uint32_t* keep_p = nullptr;
+  if (BITS) {
+    const long nqb = (Smax + 31) >> 5, kpitch = nqb << 5;
+    const long key = kb0 + 32 * wave + r;
+    keep_p = a.keep_bits + ((long)b * a.nh + head) * nqb * kpitch + (key < kpitch ? key : kpitch - 1);
+  }
+  const long keep_step = (long)((Smax + 31) >> 5) << 5;
+  uint32_t kw_next = BITS ? keep_p[0] : 0u;
   store_rows(load_rows(0), 0);
   load_slice(0, 0);
 
@@ -571,8 +586,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
     // those LDS reads would make hipcc wait for it first); buffer buf^1 was last read in slice sl-1,
     // which every wave left through the barrier below
     float next_rowv = 0.f;
+    const uint32_t kw_cur = kw_next >> (4 * h2);   // bit (i&3) + 8(i>>2) = element i's query
     if (sl + 1 < nslices) {
       next_rowv = load_rows(sl + 1);
+      if (BITS) kw_next = keep_p[(long)(sl + 1) * keep_step];
       load_slice(sl + 1, buf ^ 1);
     }
 
@@ -590,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       // P = exp(s/8 + mask - lse);  dS = P (dP - delta) / 8
       f32x16 pacc;
       bool keep[16];
-      if (dr.thresh) attn_bwd_keep16(dr, (uint32_t)(sl * 32 + 4 * h2), (uint32_t)(kb0 + 32 * wave + r), (uint32_t)S, keep);
+      if (!BITS && dr.thresh) attn_bwd_keep16(dr, (uint32_t)(sl * 32 + 4 * h2), (uint32_t)(kb0 + 32 * wave + r), (uint32_t)S, keep);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const f32x4 lse4_g = *(const f32x4*)(rowv + 8 * g4 + 4 * h2);
@@ -605,7 +622,11 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
           }
           const float p = __builtin_amdgcn_exp2f((s - lse4_g[e]) * LOG2E);
           float dpv = dpacc[i], pv = p;
-          if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
+          if (BITS) {   // (launched only with dropout on)
+            const int km = __builtin_amdgcn_sbfe((int)kw_cur, (i & 3) + 8 * (i >> 2), 1);   // 0 / -1
+            dpv = __int_as_float(__float_as_int(dpv) & km);
+            pv = __int_as_float(__float_as_int(p) & km);
+          } else if (dr.thresh) {  // O = (P * mask / (1-p)) V: dP and the P that feeds dV carry the mask, dS keeps P
             dpv = keep[i] ? dpv : 0.f;
             pv = keep[i] ? p : 0.f;
           }
@@ -771,7 +792,7 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
                               long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream,
                               const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr,
-                              long rows_total = 0) {
+                              long rows_total = 0, const uint32_t* keep_bits = nullptr) {
   if (mask_additive == 2 && (!mask || seq_start)) return VT_ERR_NULL;   // per-query bias [B, S, S]
   if (!qkv || !dctx || !ctx || !lse || !delta_ws || !dqkv) return VT_ERR_NULL;
   if (head_size != 64) return VT_ERR_UNSUPPORTED;
@@ -798,12 +819,15 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   a.seq_start = seq_start; a.seq_len = seq_len;
   a.scale = 1.0f / sqrtf((float)head_size);
   if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
+  a.keep_bits = a.drop.thresh ? keep_bits : nullptr;
   if (g_attn_bwd_waves == 4) {
     hipLaunchKernelGGL(attention_bwd_d64, dim3(nh, B, nkb), dim3(256), AB_LDS_BYTES, stream, a);
   } else {
-    static VtLdsAttrOnce attr8;
-    if (!attr8.set((const void*)attention_bwd_d64_w8, AB_LDS_BYTES)) return VT_ERR_HIP;
-    hipLaunchKernelGGL(attention_bwd_d64_w8, dim3(nh, B, nkb), dim3(512), AB_LDS_BYTES, stream, a);
+    static VtLdsAttrOnce attr8, attr8b;
+    if (!attr8.set((const void*)attention_bwd_d64_w8<false>, AB_LDS_BYTES)) return VT_ERR_HIP;
+    if (!attr8b.set((const void*)attention_bwd_d64_w8<true>, AB_LDS_BYTES)) return VT_ERR_HIP;
+    if (a.keep_bits) hipLaunchKernelGGL(attention_bwd_d64_w8<true>, dim3(nh, B, nkb), dim3(512), AB_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL(attention_bwd_d64_w8<false>, dim3(nh, B, nkb), dim3(512), AB_LDS_BYTES, stream, a);
   }
   if (nkb > 1) {
     const long n = rows * (nh * 8);

@@ -39,6 +39,10 @@ struct AttnArgs {
   // seq_start[b]; lse keeps its [B, nh, S] layout.  Null: every sequence has S rows, sequence b starts at row b * S.
   const int* seq_start;
   const int* seq_len;
+  // Training: the keep decisions of the probability dropout, written out for the backward kernel (which otherwise spends a
+  // third of its vector instructions re-deriving them from the hash).  keep_bits[((b*nh + h) * nqb + qb) * kpitch + key]:
+  // bit j = keep(query 32 qb + j, key), nqb = ceil(S / 32), kpitch = S rounded up to 32.  Null: nothing written.
+  uint32_t* keep_bits;
 };
 
 #define LOG2E 1.4426950408889634f
@@ -47,6 +51,15 @@ struct AttnArgs {
 #define ATT_SV (ATT_KCHUNK * 128)
 #define ATT_SBIAS (2 * ATT_KCHUNK * 128)
 #define ATT_LDS_BYTES (2 * ATT_KCHUNK * 128 + ATT_KCHUNK * 4)
+
+// lanes L0..L3 (constants) of the VGPR `dst` = the wave-uniform values v0..v3 (hipcc has no builtin for v_writelane_b32).
+// The values are lane masks a v_cmp has just written: a VALU write of an SGPR needs wait states before v_writelane reads
+// it (measured: without them the first write of a group carried the previous compare's mask), and hipcc's hazard
+// recognizer does not look inside an asm statement -- hence the s_nop.
+#define ATT_WRITELANE4(dst, v0, v1, v2, v3, L0, L1, L2, L3)                                                    \
+  asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %6\n\t"                      \
+               "v_writelane_b32 %0, %3, %7\n\tv_writelane_b32 %0, %4, %8"                                      \
+               : "+v"(dst) : "s"(v0), "s"(v1), "s"(v2), "s"(v3), "n"(L0), "n"(L1), "n"(L2), "n"(L3))
 
 __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
   // two transposed 4x16 block reads (keys k..k+3 and k+8..k+11), 8 bf16 per lane
@@ -57,7 +70,9 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
+// KEEP: also write the dropout keep words (AttnArgs::keep_bits; training with probability dropout)
+template <bool KEEP>
+__global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -133,6 +148,12 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
     __syncthreads();
 
     if (wave_active) {
+      // this wave's row of the keep words (uniform base; see AttnArgs::keep_bits)
+      uint32_t* keep_tile = KEEP ? a.keep_bits : nullptr;
+      if (KEEP) {
+        const long nqb = (Smax + 31) >> 5;
+        keep_tile += ((((long)b * a.nh + head) * nqb + (q0 >> 5)) * nqb << 5) + kc;
+      }
       for (int kt = 0; kt < ntiles; ++kt) {
         // ---- S^T tile = K[32 keys] . Q^T ----
         f32x16 sacc;
@@ -190,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
         for (int s2 = 0; s2 < 2; ++s2) {
           typedef __attribute__((ext_vector_type(8))) short short8v;
           u32x4 pbw;
+          int kw = 0;   // lane 16 s2 + l, l < 16: the keep word of key 32 kt + 16 s2 + l over this wave's 32 queries
           if (dr.thresh) {  // drop probabilities AFTER the row sum was taken (the normaliser uses all of them)
             // S even: the tile's eight key pairs sit at fixed offsets from one pair index -> one multiply per half tile
             const uint32_t xb = vt_hash_pre(dr.seed, (q_elem + (uint32_t)(kc + kt * 32 + 4 * h2)) >> 1);
@@ -202,8 +224,16 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
               else { k0 = vt_keep(dr, e); k1 = vt_keep(dr, e + 1); }
               sacc[i] = k0 ? sacc[i] : 0.f;          // the 1 / (1 - p) factor is uniform: applied once to O below
               sacc[i + 1] = k1 ? sacc[i + 1] : 0.f;
+              if (KEEP) {
+                // a compare's lane mask IS the word the backward wants: lanes 0..31 = this wave's queries against key
+                // (i&3) + 8(i>>2), lanes 32..63 the same queries against that key + 4; each goes to the lane of its key
+                const uint64_t m0 = __builtin_amdgcn_ballot_w64(k0), m1 = __builtin_amdgcn_ballot_w64(k1);
+                const int ki = (i & 3) + 8 * (i >> 2);
+                ATT_WRITELANE4(kw, (uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32), ki, ki + 4, ki + 1, ki + 5);
+              }
             }
           }
+          if (KEEP && dr.thresh && (lane >> 4) == s2) keep_tile[kt * 32 + lane] = (uint32_t)kw;
 #pragma unroll
           for (int j = 0; j < 4; ++j) pbw[j] = pack_bf16x2(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1]);
           const bf16x8 pb = __builtin_bit_cast(bf16x8, pbw);
@@ -242,14 +272,16 @@ __global__ __launch_bounds__(512, 2) void attention_fwd_d64(AttnArgs a) {
 
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                               long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream,
-                              const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr) {
+                              const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr,
+                              uint32_t* keep_bits = nullptr) {
   if (!qkv || !ctx) return VT_ERR_NULL;
   if (head_size != 64) return VT_ERR_UNSUPPORTED;
   if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
   if ((ld_qkv % 8) || (ld_ctx % 8) || ld_qkv < 3L * nh * 64 || ld_ctx < (long)nh * 64) return VT_ERR_BAD_ALIGN;
   if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return VT_ERR_BAD_ALIGN;
-  static VtLdsAttrOnce attr;
-  if (!attr.set((const void*)attention_fwd_d64, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  static VtLdsAttrOnce attr, attr_keep;
+  if (!attr.set((const void*)attention_fwd_d64<false>, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  if (!attr_keep.set((const void*)attention_fwd_d64<true>, ATT_LDS_BYTES)) return VT_ERR_HIP;
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = (bf16_t*)ctx; a.lse = lse;
   a.ld_qkv = ld_qkv; a.ld_ctx = ld_ctx; a.B = B; a.S = S; a.nh = nh;
@@ -258,8 +290,10 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   if ((seq_start == nullptr) != (seq_len == nullptr)) return VT_ERR_NULL;
   if (seq_start && mask) return VT_ERR_UNSUPPORTED;   // compacted rows carry no masked keys
   a.seq_start = seq_start; a.seq_len = seq_len;
+  a.keep_bits = keep_bits;
   dim3 grid((S + 255) / 256, nh, B);
-  hipLaunchKernelGGL(attention_fwd_d64, grid, dim3(512), ATT_LDS_BYTES, stream, a);
+  if (keep_bits && a.drop.thresh) hipLaunchKernelGGL(attention_fwd_d64<true>, grid, dim3(512), ATT_LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL(attention_fwd_d64<false>, grid, dim3(512), ATT_LDS_BYTES, stream, a);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
@@ -308,7 +342,7 @@ int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask,
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = nullptr;
   a.lse = const_cast<float*>(lse);
-  a.ld_qkv = ld_qkv; a.ld_ctx = 0; a.B = B; a.S = S; a.nh = nh; a.seq_start = nullptr; a.seq_len = nullptr;
+  a.ld_qkv = ld_qkv; a.ld_ctx = 0; a.B = B; a.S = S; a.nh = nh; a.seq_start = nullptr; a.seq_len = nullptr; a.keep_bits = nullptr;
   a.scale = 1.0f / sqrtf((float)head_size);
   a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f;
   hipLaunchKernelGGL(attention_probs_d64, dim3(S, nh, B), dim3(256), 0, stream, a, probs);

@@ -10,7 +10,7 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
                               long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream,
                               const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr,
-                              long rows_total = 0);
+                              long rows_total = 0, const uint32_t* keep_bits = nullptr);
 int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
                               hipStream_t stream, void* dx2 = nullptr, long lddx2 = 0, const DropCfg* drop = nullptr);
@@ -50,7 +50,8 @@ int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask,
                                 const float* lse, float* probs, int B, int S, int nh, int head_size, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                               long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream,
-                              const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr);
+                              const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr,
+                              uint32_t* keep_bits = nullptr);
 int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
                           float* mean, float* rstd, int M, int H, float eps, int grp_rows, int grp_stride,
                           hipStream_t stream);
@@ -119,7 +120,7 @@ const char* vt_error_string(int code) {
   }
 }
 
-int vt_abi_version(void) { return 5; }
+int vt_abi_version(void) { return 6; }
 
 void vt_debug_set_gemm_variant(int variant) { vt_gemm_set_variant(variant); }
 void vt_debug_set_gemm_trace(void* buf) { vt_gemm_set_trace(buf); }
@@ -163,21 +164,23 @@ int vt_debug_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_s
 int vt_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
                           int64_t ld_ctx, const float* mask, int mask_additive, const float* lse, float* delta_ws,
                           void* dqkv, int64_t ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size,
-                          float drop_p, uint64_t drop_seed, uint32_t drop_site, vt_stream_t stream) {
+                          float drop_p, uint64_t drop_seed, uint32_t drop_site, const uint32_t* keep_bits,
+                          vt_stream_t stream) {
   const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_attention_bwd_dispatch(qkv, ld_qkv, dctx, ld_d, ctx, ld_ctx, mask, mask_additive, lse, delta_ws, dqkv,
-                                   ld_dqkv, dq32_ws, B, S, nh, head_size, (hipStream_t)stream, &d);
+                                   ld_dqkv, dq32_ws, B, S, nh, head_size, (hipStream_t)stream, &d, nullptr, nullptr, 0,
+                                   keep_bits);
 }
 
 int vt_attention_bwd_seq_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int64_t ld_d, const void* ctx,
                               int64_t ld_ctx, const float* lse, float* delta_ws, void* dqkv, int64_t ld_dqkv,
                               float* dq32_ws, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
                               uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, int64_t rows,
-                              vt_stream_t stream) {
+                              const uint32_t* keep_bits, vt_stream_t stream) {
   if (!seq_start || !seq_len) return VT_ERR_NULL;
   const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_attention_bwd_dispatch(qkv, ld_qkv, dctx, ld_d, ctx, ld_ctx, nullptr, 0, lse, delta_ws, dqkv, ld_dqkv, dq32_ws,
-                                   B, S, nh, head_size, (hipStream_t)stream, &d, seq_start, seq_len, rows);
+                                   B, S, nh, head_size, (hipStream_t)stream, &d, seq_start, seq_len, rows, keep_bits);
 }
 
 int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ldy, const float* gamma, void* dx,
@@ -422,19 +425,20 @@ int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_str
 
 int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                           int64_t ld_ctx, float* lse, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
-                          uint32_t drop_site, vt_stream_t stream) {
+                          uint32_t drop_site, uint32_t* keep_bits, vt_stream_t stream) {
   const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_attention_fwd_dispatch(qkv, ld_qkv, mask, mask_additive, head_scale, ctx, ld_ctx, lse, B, S, nh, head_size,
-                                   (hipStream_t)stream, &d);
+                                   (hipStream_t)stream, &d, nullptr, nullptr, keep_bits);
 }
 
 int vt_attention_fwd_seq_bf16(const void* qkv, int64_t ld_qkv, const float* head_scale, void* ctx, int64_t ld_ctx,
                               float* lse, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
-                              uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, vt_stream_t stream) {
+                              uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, uint32_t* keep_bits,
+                              vt_stream_t stream) {
   if (!seq_start || !seq_len) return VT_ERR_NULL;
   const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_attention_fwd_dispatch(qkv, ld_qkv, nullptr, 0, head_scale, ctx, ld_ctx, lse, B, S, nh, head_size,
-                                   (hipStream_t)stream, &d, seq_start, seq_len);
+                                   (hipStream_t)stream, &d, seq_start, seq_len, keep_bits);
 }
 
 int vt_attention_probs_f32(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive, const float* head_scale,
@@ -605,7 +609,8 @@ static int encoder_forward_impl(const vt_layer_weights* layers, const vt_layer_a
     const DropCfg d_so = vt_make_drop(p_hidden, drop_seed, VT_SITE_SELFOUT(l));
     const DropCfg d_out = vt_make_drop(p_hidden, drop_seed, VT_SITE_OUT(l));
     rc = vt_attention_fwd_dispatch(a.qkv, 3L * H, mask, mask_additive, head_scale ? head_scale + (long)l * nh : nullptr, a.ctx, H,
-                                   a.lse, B, S, nh, 64, stream, &d_att, rows ? seq_start : nullptr, rows ? seq_len : nullptr);
+                                   a.lse, B, S, nh, 64, stream, &d_att, rows ? seq_start : nullptr, rows ? seq_len : nullptr,
+                                   a.keep_bits);
     if (rc) return rc;
     rc = vt_gemm_dispatch(a.ctx, H, w.w_ao, H, w.b_ao, cur, H, a.attn_pre, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream, nullptr, 0, &d_so);
     if (rc) return rc;
@@ -728,7 +733,7 @@ static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_
     if (rc) return rc;
     rc = vt_attention_bwd_dispatch(a.qkv, 3L * H, ws->g_ctx, H, a.ctx, H, mask, mask_additive, a.lse, ws->delta, ws->g_qkv,
                                    3L * H, ws->dq32, B, S, nh, 64, stream, &d_att, rows ? seq_start : nullptr,
-                                   rows ? seq_len : nullptr, rows);
+                                   rows ? seq_len : nullptr, rows, a.keep_bits);
     if (rc) return rc;
     // through the packed q|k|v projection, plus the residual branch: dL/d(layer input) -> g
     rc = vt_gemm_dispatch(ws->g_qkv, 3L * H, wt.wt_qkv, 3L * H, nullptr, ws->g_pre2, H, g, H, M, H, 3 * H, VT_ACT_NONE, 0, 0, 0, stream);

@@ -430,12 +430,20 @@ class SeqLayout(object):
         self.inverse = torch.where(flat, inv, torch.full_like(inv, -1))
 
 
+def keep_words(B, nh, S):
+    """Words of a dropout keep buffer (VT_KEEP_WORDS in include/visitron_hip.h): one per (batch, head, 32-query block, key)."""
+    nqb = (S + 31) // 32
+    return B * nh * nqb * nqb * 32
+
+
 def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None, out=None, lse=None, drop=NO_DROP,
-                  seq=None):
+                  seq=None, keep_bits=None):
     """qkv [B*S, 3*nh*64] bf16, mask fp32 [B,S] -> context [B*S, nh*64] bf16.  seq (SeqLayout): compacted rows, no
-    mask."""
-    _require_hip(qkv, mask, head_scale, out, lse)
+    mask.  keep_bits (int32 [keep_words(B, nh, S)], training with dropout): receives the keep decisions for attention_bwd."""
+    _require_hip(qkv, mask, head_scale, out, lse, keep_bits)
     assert qkv.dtype == BF16
+    if keep_bits is not None:
+        assert keep_bits.dtype == torch.int32 and keep_bits.is_contiguous() and keep_bits.numel() >= keep_words(B, nh, S)
     H = nh * 64
     if seq is not None:
         assert mask is None and seq.B == B and seq.S == S and qkv.shape[0] >= seq.rows
@@ -444,7 +452,7 @@ def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None
         with _timed("attention_fwd_d64", 4.0 * B * nh * S * S * 64, 2.0 * seq.rows * 4 * H):
             rc = _lib.load().vt_attention_fwd_seq_bf16(
                 _ptr(qkv), qkv.stride(0), _ptr(head_scale), _ptr(out), out.stride(0), _ptr(lse), B, S, nh, 64,
-                float(drop[0]), int(drop[1]), int(drop[2]), _ptr(seq.start), _ptr(seq.length), _stream())
+                float(drop[0]), int(drop[1]), int(drop[2]), _ptr(seq.start), _ptr(seq.length), _ptr(keep_bits), _stream())
         _lib.check(rc, "vt_attention_fwd_seq_bf16")
         return out
     if out is None:
@@ -453,7 +461,7 @@ def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None
     with _timed("attention_fwd_d64", 4.0 * B * nh * S * S * 64, 2.0 * B * S * 4 * H):
         rc = _lib.load().vt_attention_fwd_bf16(
             _ptr(qkv), qkv.stride(0), _ptr(mask), mode, _ptr(head_scale), _ptr(out),
-            out.stride(0), _ptr(lse), B, S, nh, 64, float(drop[0]), int(drop[1]), int(drop[2]), _stream())
+            out.stride(0), _ptr(lse), B, S, nh, 64, float(drop[0]), int(drop[1]), int(drop[2]), _ptr(keep_bits), _stream())
     _lib.check(rc, "vt_attention_fwd_bf16")
     return out
 
@@ -521,9 +529,12 @@ def pack_concat(s0, s1, kpad, out=None):
 
 
 def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False, out=None, delta_ws=None, dq32_ws=None,
-                  drop=NO_DROP, seq=None):
-    """Gradient of attention_fwd w.r.t. the packed qkv: returns dqkv [B*S, 3*nh*64] bf16 (seq: compacted rows)."""
-    _require_hip(qkv, dctx, ctx, lse, mask, out)
+                  drop=NO_DROP, seq=None, keep_bits=None):
+    """Gradient of attention_fwd w.r.t. the packed qkv: returns dqkv [B*S, 3*nh*64] bf16 (seq: compacted rows).
+    keep_bits: the buffer attention_fwd filled with the same drop (else the mask is recomputed from the hash)."""
+    _require_hip(qkv, dctx, ctx, lse, mask, out, keep_bits)
+    if keep_bits is not None:
+        assert keep_bits.dtype == torch.int32 and keep_bits.is_contiguous() and keep_bits.numel() >= keep_words(B, nh, S)
     H = nh * 64
     nrows = B * S if seq is None else seq.rows
     if out is None:
@@ -538,14 +549,14 @@ def attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=None, mask_additive=False,
             rc = _lib.load().vt_attention_bwd_seq_bf16(
                 _ptr(qkv), qkv.stride(0), _ptr(dctx), dctx.stride(0), _ptr(ctx), ctx.stride(0), _ptr(lse), _ptr(delta_ws),
                 _ptr(out), out.stride(0), _ptr(dq32_ws), B, S, nh, 64, float(drop[0]), int(drop[1]), int(drop[2]),
-                _ptr(seq.start), _ptr(seq.length), seq.rows, _stream())
+                _ptr(seq.start), _ptr(seq.length), seq.rows, _ptr(keep_bits), _stream())
         _lib.check(rc, "vt_attention_bwd_seq_bf16")
         return out
     with _timed("attention_bwd_d64", 10.0 * B * nh * S * S * 64, 2.0 * B * S * 9 * H):
         rc = _lib.load().vt_attention_bwd_bf16(
             _ptr(qkv), qkv.stride(0), _ptr(dctx), dctx.stride(0), _ptr(ctx), ctx.stride(0), _ptr(mask),
             _mask_mode(mask, mask_additive, B, S), _ptr(lse), _ptr(delta_ws), _ptr(out), out.stride(0), _ptr(dq32_ws), B, S, nh, 64,
-            float(drop[0]), int(drop[1]), int(drop[2]), _stream())
+            float(drop[0]), int(drop[1]), int(drop[2]), _ptr(keep_bits), _stream())
     _lib.check(rc, "vt_attention_bwd_bf16")
     return out
 

@@ -108,6 +108,11 @@ class FlatParams(object):
                 p.grad = self.g[o:o + cnt].view(p.shape)
 
 
+# VT_ATTN_KEEP_BITS=0: the attention backward re-derives the dropout mask from the hash instead of reading the words the
+# forward wrote (same mask either way; A/B switch)
+KEEP_BITS = os.environ.get("VT_ATTN_KEEP_BITS", "1") != "0"
+
+
 class _TrainBuffers(object):
     """Per-(B,S) activation store and gradient scratch, plus the ctypes tables for the C loops."""
 
@@ -118,6 +123,8 @@ class _TrainBuffers(object):
         for i in range(L):
             d = dict(qkv=mk(3 * H), ctx=mk(H), attn_pre=mk(H), attn_out=mk(H), mid_pre=mk(I), mid=mk(I),
                      out_pre=mk(H), out=mk(H), lse=torch.empty((B, nh, S), dtype=torch.float32, device=dev))
+            if KEEP_BITS:   # the attention dropout's keep decisions, forward -> backward (25 MB per layer at B = 256)
+                d["keep_bits"] = torch.empty(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev)
             self.layers.append(d)
             for k, v in d.items():
                 setattr(self.acts[i], k, v.data_ptr())
@@ -791,17 +798,18 @@ class PretrainEngine(object):
         cur = x0
         n = x0.shape[0]
         for l, ((t, _), a) in enumerate(zip(self._keep, bufs.layers)):
-            a = {k: (v if k == "lse" else v[:n]) for k, v in a.items()}   # the rows in use (all, or the compacted ones)
+            a = {k: (v if k in ("lse", "keep_bits") else v[:n]) for k, v in a.items()}   # the rows in use (all, or the compacted ones)
+            kb = a.get("keep_bits") if p_a > 0.0 else None
             ops.linear(cur, t["w_qkv"], t["b_qkv"], out=a["qkv"])
             if hs is None:
                 ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, mask_additive=mask_additive, out=a["ctx"], lse=a["lse"],
-                                  drop=(p_a, seed, ops.site_attn(l)), seq=lay)
+                                  drop=(p_a, seed, ops.site_attn(l)), seq=lay, keep_bits=kb)
             else:
                 # head_mask (oscar/modeling_bert.py:65-66): the attention kernel's own context is kept for the backward
                 # (ctx_raw), its per-head scaled copy is what the output projection sees
                 raw = bufs.ctx_raw(l)[:n]
                 ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, mask_additive=mask_additive, out=raw, lse=a["lse"],
-                                  drop=(p_a, seed, ops.site_attn(l)), seq=lay)
+                                  drop=(p_a, seed, ops.site_attn(l)), seq=lay, keep_bits=kb)
                 ops.scale_heads(raw, hs[l].contiguous(), out=a["ctx"])
             ops.linear(a["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=a["attn_pre"], drop=(p_h, seed, ops.site_selfout(l)))
             ops.layernorm(a["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=a["attn_out"])
@@ -827,7 +835,7 @@ class PretrainEngine(object):
         w = {k: (v[:M] if k in rowed else v) for k, v in bufs.ws_t.items()}
         for l in range(cfg.num_hidden_layers - 1, -1, -1):
             (t, gr), a, (_, wt) = self._keep[l], bufs.layers[l], self.wt[l]
-            a = {k: (v if k == "lse" else v[:M]) for k, v in a.items()}
+            a = {k: (v if k in ("lse", "keep_bits") else v[:M]) for k, v in a.items()}
             x_in = x0 if l == 0 else bufs.layers[l - 1]["out"][:M]
             hd = p_h > 0.0   # with hidden dropout the dense outputs' gradients are the masked copies
             g_pre_dn, g_pre2_dn = (w["g_pre_d"], w["g_pre2_d"]) if hd else (w["g_pre"], w["g_pre2"])
@@ -846,7 +854,7 @@ class PretrainEngine(object):
                 ctx_l = bufs.ctx_raw(l)[:M]
             ops.attention_bwd(a["qkv"], g_ctx, ctx_l, a["lse"], B, S, nh, mask=mask, mask_additive=mask_additive,
                               out=w["g_qkv"], delta_ws=w["delta"], dq32_ws=w.get("dq32"), drop=(p_a, seed, ops.site_attn(l)),
-                              seq=lay)
+                              seq=lay, keep_bits=a.get("keep_bits") if p_a > 0.0 else None)
             ops.linear(w["g_qkv"], wt["wt_qkv"], residual=w["g_pre2"], out=g)
             ops.wgrad([dict(dy=w["g_mid"], x=a["attn_out"], dw=gr["d_w_in"], db=gr["d_b_in"], accumulate=acc),
                        dict(dy=g_pre_dn, x=a["mid"], dw=gr["d_w_out"], db=gr["d_b_out"], accumulate=acc),
