@@ -36,4 +36,10 @@ def timeit(fn):
 tf = timeit(lambda: ops.attention_fwd(qkv, B, S, nh, mask=mask, lse=lse, drop=drop))
 tb = timeit(lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=mask, out=out, delta_ws=delta, drop=drop))
 fl = 4.0 * B * nh * S * S * 64
-print("B=%d S=%d p=%.2f: fwd %.1f us (%.0f TF/s)  bwd %.1f us (%.0f TF/s)" % (B, S, p, tf, fl / tf * 1e-6, tb, 2.5 * fl / tb * 1e-6))
+print("%s B=%d S=%d p=%.2f: fwd %.1f us (%.0f TF/s)  bwd %.1f us (%.0f TF/s)" % (
+    os.environ.get("VT_HIP_LIB", "default lib"), B, S, p, tf, fl / tf * 1e-6, tb, 2.5 * fl / tb * 1e-6))
+if p > 0 and hasattr(ops, "keep_words"):   # the forward writing its keep words, the backward reading them
+    kb = torch.zeros(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev)
+    tfk = timeit(lambda: ops.attention_fwd(qkv, B, S, nh, mask=mask, lse=lse, drop=drop, keep_bits=kb))
+    tbk = timeit(lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=mask, out=out, delta_ws=delta, drop=drop, keep_bits=kb))
+    print("    with keep words: fwd %.1f us  bwd %.1f us" % (tfk, tbk))

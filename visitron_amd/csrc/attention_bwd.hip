@@ -440,7 +440,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   const int nslices = (S + 31) >> 5;
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
-  const float ds_scale = a.scale * dr.scale;   // 1 / sqrt(d) times dropout's 1 / (1-p) (1 when off)
+  const float ds_scale = a.scale * dr.scale;   // 1 / sqrt(d) times dropout's 1 / (1-p) (1 when off): applied to dK once at the
+                                               // end and to each slice's four dQ values, not to every dS element
   const int kcount = (S - kb0) < 256 ? (S - kb0) : 256;
   const int nkt = (kcount + 31) >> 5;  // 32-key steps of this key block for dQ
 
@@ -632,9 +633,12 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
           }
           // dropout's uniform 1 / (1-p) is not applied per element: dV takes it once at the end, and in
           // dS = P (mask dP / (1-p) - delta) / 8 it moves outside the bracket: ds_scale = 1 / (8 (1-p)), the row constant arrives
-          // as delta (1-p) (attn_delta_rows)
+          // as delta (1-p) (attn_delta_rows); ds_scale itself multiplies the dK accumulators at the end and dQ per slice
+          // (348 -> 337 us per launch at B = 256; measured on the same box and NOT taken: log2(e) folded into scale / bias / lse
+          // -- 16 multiplies fewer, 364-374 us, as in round 2 --, dS as fma(P o M, dP, -P delta) 340-349 us, the previous
+          // slice's dQ product issued under this slice's element-wise work 384 us at 256 registers)
           pacc[i] = pv;
-          sacc[i] = p * (dpv - del4_g[e]) * ds_scale;  // dS' (scales folded in)
+          sacc[i] = p * (dpv - del4_g[e]);   // dS' up to ds_scale
         }
       }
       // dV^T += dO^T P ; dK^T += Q^T dS'   (k = q, 2 steps of 16)
@@ -693,6 +697,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       }
     }
     // store dQ: lane (q_local = lane&15, g): d = 16w + 4g .. +3
+    dq0 *= ds_scale;
     if (a.dq32 == nullptr) {
       const int q = sl * 32 + 16 * dqq + (lane & 15);
       if (q < S) {
@@ -731,8 +736,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       u32x4 k0, k1, v0, v1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        k0[i] = pack_bf16x2(dk[dt][kt][2 * i], dk[dt][kt][2 * i + 1]);
-        k1[i] = pack_bf16x2(dk[dt][kt][8 + 2 * i], dk[dt][kt][8 + 2 * i + 1]);
+        k0[i] = pack_bf16x2(dk[dt][kt][2 * i] * ds_scale, dk[dt][kt][2 * i + 1] * ds_scale);
+        k1[i] = pack_bf16x2(dk[dt][kt][8 + 2 * i] * ds_scale, dk[dt][kt][8 + 2 * i + 1] * ds_scale);
         v0[i] = pack_bf16x2(dv[dt][kt][2 * i] * dr.scale, dv[dt][kt][2 * i + 1] * dr.scale);
         v1[i] = pack_bf16x2(dv[dt][kt][8 + 2 * i] * dr.scale, dv[dt][kt][8 + 2 * i + 1] * dr.scale);
       }
