@@ -579,7 +579,7 @@ class CaptionBertEncoder(nn.Module):
         self._packed = None
         self._packed_key = None
         self._ws = {}
-        self._final_f32 = None
+        self._final_f32, self._final_f32_fresh = None, False
         # inference, opt-in (VT_PRECISE_FINAL=1 or the attribute): the last layer's pre-LayerNorm sums and its output also
         # in fp32 (see run()).  It takes the returned hidden states' max-abs error against the fp32 reference from 5.9e-2 to
         # 4.9e-2 on the base config (rms 1.06e-2 -> 1.02e-2: the bf16 weights of the twelve layers set that, not the last
@@ -625,8 +625,7 @@ class CaptionBertEncoder(nn.Module):
         f32 = lambda n: torch.empty((M, n), dtype=torch.float32, device=device)
         st = lambda: torch.zeros((np_, rows, 2), dtype=torch.float32, device=device)
         # a / b: the two residual streams (bf16 copy, fp16 rows, statistics); x32: the embedding output entering layer 0
-        ws = dict(a=(bf(H), f16(H), st()), b=(bf(H), f16(H), st()), x32=f32(H), qkv=bf(3 * H), ctx=bf(H), mid=bf(I), out16=bf(H),
-                  out32=f32(H))
+        ws = dict(a=(bf(H), f16(H), st()), b=(bf(H), f16(H), st()), x32=f32(H), qkv=bf(3 * H), ctx=bf(H), mid=bf(I), out16=bf(H))
         ops.autotune_encoder_shapes_ln(M, H, I, device=device)   # once per token count
         if len(self._ws) > 4:
             self._ws.clear()
@@ -659,9 +658,12 @@ class CaptionBertEncoder(nn.Module):
         else:
             ops.encoder_forward_ln(pk.table, sa, sb, ws["qkv"], ws["ctx"], ws["mid"], mask_f32, mask_additive, head_scale,
                                    B, S, H, nh, I, eps)
-        ops.ln_apply(sa[1], sa[2], pk.final_gamma, pk.final_beta, eps, out16=ws["out16"], out32=ws["out32"])
-        self._final_f32 = ws["out32"]
-        return ws["out16"], ws["out32"]
+        # the fp32 rows are what the caller is handed: a fresh tensor per call (written once by the kernel, no copy out of
+        # the workspace); the bf16 rows stay in the workspace for the pooler / heads
+        out32 = torch.empty((M, H), dtype=torch.float32, device=x32.device)
+        ops.ln_apply(sa[1], sa[2], pk.final_gamma, pk.final_beta, eps, out16=ws["out16"], out32=out32)
+        self._final_f32, self._final_f32_fresh = out32, True
+        return ws["out16"], out32
 
     def ln_input_buffer(self, M, device):
         """The workspace's fp32 buffer [M, H] for the embedding output (what run_ln takes as x32)."""
@@ -704,7 +706,7 @@ class CaptionBertEncoder(nn.Module):
         pk = self.packed()
         ws = self._workspace(B * S, B, x_bf16.device, self.output_hidden_states)
         self._last_attentions = None
-        self._final_f32 = None
+        self._final_f32, self._final_f32_fresh = None, False
         if history is not None:   # encoder_history_states: layer i attends over cat([history[i], hidden], 1) (:148-155)
             probs = [] if self.output_attentions else None
             outs = self._run_unrolled(pk, ws, x_bf16, B, S, mask_f32, mask_additive, head_scale, probs, history)
@@ -748,7 +750,7 @@ class CaptionBertEncoder(nn.Module):
         ops.linear(sh["mid"], t["w_out"], t["b_out"], residual=sh["attn_out"], out=ws["pre32"], out_f32=True)
         ops.layernorm_rows(ws["pre32"], t["ln2_g"], t["ln2_b"], eps, out=ws["outs"][L - 1])
         ops.layernorm_rows(ws["pre32"], t["ln2_g"], t["ln2_b"], eps, out=ws["final32"])
-        self._final_f32 = ws["final32"]
+        self._final_f32, self._final_f32_fresh = ws["final32"], False
         return ws["outs"]
 
     def _run_unrolled(self, pk, ws, x, B, S, mask, mask_additive, head_scale, probs=None, history=None):
@@ -837,8 +839,8 @@ class CaptionBertEncoder(nn.Module):
         else:
             outs = self.run(_as_bf16_2d(hidden_states), B, S, mask, True, hs, history=encoder_history_states)
         dt = hidden_states.dtype
-        if not _is_fp32(self) and self._final_f32 is not None:   # (a copy: the fp32 buffer is rewritten by the next call)
-            last = self._final_f32.view(B, S, H).to(dt, copy=True)
+        if not _is_fp32(self) and self._final_f32 is not None:   # (a copy when the fp32 rows live in the workspace)
+            last = self._final_f32.view(B, S, H).to(dt, copy=not self._final_f32_fresh)
         else:
             last = outs[-1].view(B, S, H).to(dt)
         outputs = (last,)
@@ -1077,8 +1079,9 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
         dt = next(self.parameters()).dtype
         H = self.config.hidden_size
         f32 = None if _is_fp32(self) else self.encoder._final_f32
-        # (the fp32 copy lives in the encoder's workspace and is rewritten by the next call: hand out a copy)
-        sequence_output = outs[-1].view(B, S, H).to(dt) if f32 is None else f32.view(B, S, H).to(dt, copy=True)
+        # (fp32 rows that live in the encoder's workspace are rewritten by the next call: hand out a copy of those)
+        sequence_output = (outs[-1].view(B, S, H).to(dt) if f32 is None
+                           else f32.view(B, S, H).to(dt, copy=not self.encoder._final_f32_fresh))
         pooled = pooled.to(dt)
         if torch.is_grad_enabled() and not self.training and not _is_fp32(self) and not encoder_history_states \
                 and any(p.requires_grad for p in self.parameters()):
