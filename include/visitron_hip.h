@@ -124,7 +124,8 @@ int vt_attention_probs_f32(const void* qkv, int64_t ld_qkv, const float* mask, i
                            int head_size, vt_stream_t stream);
 
 /* Backward of vt_attention_fwd_bf16: dqkv = dq | dk | dv packed like qkv.  ctx is the forward output,
- * lse its saved log-sum-exp, delta_ws a [B,nh,S] fp32 scratch (rowsum(dctx*ctx) is computed into it).
+ * lse its saved log-sum-exp, delta_ws a [B,nh,S] fp32 scratch (the 4-wave kernel and the debug form 10 compute
+ * rowsum(dctx*ctx) into it with a separate pass; the default 8-wave kernel forms that row constant itself from ctx).
  * Autograd of oscar/modeling_bert.py:47-72 inside loss.backward() (tasks/viewpoint_select/
  * pretrain.py:191).  S <= 256: no atomics, bitwise reproducible, dq32_ws may be NULL.  S > 256: the
  * keys are processed in blocks of 256 and dq is accumulated with fp32 atomics in dq32_ws, an fp32

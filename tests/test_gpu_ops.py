@@ -562,7 +562,7 @@ def _attn_keep(ops, B, nh, S, drop, dev):
 
 
 @pytest.mark.parametrize("B,S,nh,waves", [(2, 228, 3, 8), (1, 37, 2, 8), (2, 300, 2, 8), (1, 656, 1, 8), (2, 228, 2, 4),
-                                          (1, 300, 1, 4)])
+                                          (1, 300, 1, 4), (2, 228, 3, 10), (1, 37, 2, 10), (2, 300, 2, 10)])
 def test_attention_dropout_fwd_bwd_match_autograd(dev, B, S, nh, waves):
     """attention_probs dropout (oscar/modeling_bert.py:62) with the kernel's own keep-mask fed to torch."""
     from visitron_amd import ops
@@ -671,7 +671,7 @@ def test_transpose_batch(dev):
         ops.TransposeBatch([(pairs[0][0], pairs[1][1])])   # shape mismatch is refused on the host
 
 
-@pytest.mark.parametrize("B,S,nh,waves", [(5, 228, 3, 8), (3, 300, 2, 8), (4, 228, 2, 4), (2, 656, 1, 8)])
+@pytest.mark.parametrize("B,S,nh,waves", [(5, 228, 3, 8), (3, 300, 2, 8), (4, 228, 2, 4), (2, 656, 1, 8), (5, 228, 3, 10), (3, 300, 2, 10)])
 def test_attention_on_compacted_rows_equals_masked_padded_run(dev, B, S, nh, waves):
     """The *_seq_* attention entry points (rows of padded keys dropped, per-sequence start / length) against the padded
     kernels with the same keys masked: context rows, log-sum-exp and the packed q|k|v gradient of the real rows agree."""

@@ -44,6 +44,8 @@ struct AttnBwdArgs {
   // the forward's keep decisions (AttnArgs::keep_bits in attention_fwd.hip): word [((b*nh + h) * nqb + qb) * kpitch + key],
   // bit j = keep(query 32 qb + j, key).  Null: the 8-wave kernel re-derives them from the hash like the 4-wave kernel does.
   const uint32_t* keep_bits;
+  // the forward's context rows [B*S, ld_ctx] for the kernels that form delta = rowsum(dO o O) themselves (8-wave, DELTA)
+  const bf16_t* ctx; long ld_ctx; float delta_mul;
 };
 
 // LDS map (bytes)
@@ -418,7 +420,9 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
 // 8-wave form: wave w owns keys 32w..32w+31 (one key tile), <= 256 VGPRs, two waves per SIMD.
 // BITS: the dropout keep flags come from the words the forward wrote (one 4-byte load per lane and slice, one bit-field
 // extract and two ands per element) instead of the hash (about ten vector instructions per element, a third of the loop)
-template <bool BITS>
+// DELTA: the row constant delta = rowsum(dO o O) (x (1-p) under dropout) is formed here, a slice ahead, from 8 bytes of dO
+// and of O per thread (16 threads per query), instead of by a separate pass over both tensors (attn_delta_rows)
+template <bool BITS, bool DELTA>
 __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -461,12 +465,29 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
     if (tid < 64) {
       const int qq = sl * 32 + (tid & 31);
       if (tid < 32) v = qq < S ? lse_p[qq] : INFINITY;  // +inf => P = 0 for padded queries
-      else v = qq < S ? del_p[qq] : 0.f;
+      else if (!DELTA) v = qq < S ? del_p[qq] : 0.f;
     }
     return v;
   };
   auto store_rows = [&](float v, int buf) {
-    if (tid < 64) ((float*)(smem + AB_ROW + buf * 256))[tid] = v;
+    if (tid < (DELTA ? 32 : 64)) ((float*)(smem + AB_ROW + buf * 256))[tid] = v;
+  };
+  // DELTA: thread t = (query t >> 4 of the slice, 4 head columns 4 (t & 15)): its 8 bytes of dO and of O
+  const bf16_t* obase = DELTA ? a.ctx + row0 * a.ld_ctx + head * 64 + 4 * (tid & 15) : nullptr;
+  auto load_do_o = [&](int sl, u32x2& xd, u32x2& xo) {
+    int q = sl * 32 + (tid >> 4);
+    q = q < S ? q : S - 1;
+    xd = *(const u32x2*)(dobase + (long)q * a.ld_d + 4 * (tid & 15));
+    xo = *(const u32x2*)(obase + (long)q * a.ld_ctx);
+  };
+  auto store_delta = [&](u32x2 xd, u32x2 xo, int buf) {
+    float v = bf16lo(xd[0]) * bf16lo(xo[0]) + bf16hi(xd[0]) * bf16hi(xo[0]) + bf16lo(xd[1]) * bf16lo(xo[1]) + bf16hi(xd[1]) * bf16hi(xo[1]);
+    // sum over the 16 lanes of a query (one DPP row): xor 1, xor 2, mirror within 8, mirror within 16
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));
+    if ((tid & 15) == 0) ((float*)(smem + AB_ROW + buf * 256))[32 + (tid >> 4)] = v * a.delta_mul;
   };
   auto load_slice = [&](int sl, int buf) {
     const int pw = wave & 3;
@@ -486,6 +507,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   }
   const long keep_step = (long)((Smax + 31) >> 5) << 5;
   uint32_t kw_next = BITS ? keep_p[0] : 0u;
+  u32x2 nd = {0u, 0u}, no = {0u, 0u};
+  if (DELTA) { load_do_o(0, nd, no); store_delta(nd, no, 0); }
   store_rows(load_rows(0), 0);
   load_slice(0, 0);
 
@@ -590,6 +613,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
     const uint32_t kw_cur = kw_next >> (4 * h2);   // bit (i&3) + 8(i>>2) = element i's query
     if (sl + 1 < nslices) {
       next_rowv = load_rows(sl + 1);
+      if (DELTA) load_do_o(sl + 1, nd, no);
       if (BITS) kw_next = keep_p[(long)(sl + 1) * keep_step];
       load_slice(sl + 1, buf ^ 1);
     }
@@ -667,7 +691,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       }
     }
 
-    if (sl + 1 < nslices) store_rows(next_rowv, buf ^ 1);
+    if (sl + 1 < nslices) {
+      store_rows(next_rowv, buf ^ 1);
+      if (DELTA) store_delta(nd, no, buf ^ 1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next slice's DMA (issued above) has landed
     __syncthreads();                                   // ... and every wave's dS' is in the image
 
@@ -790,8 +817,10 @@ __global__ __launch_bounds__(256) void attn_dq_round(const float* __restrict__ d
   *(u32x4*)(dqkv + row * ld_dqkv + col) = o;
 }
 
+// 8 (default): the 8-wave kernel forming delta = rowsum(dO o O) itself; 10: the same kernel behind a separate
+// attn_delta_rows pass (the form before round 3's last change: 330-338 against 320 us per launch at B = 256); 4: the 4-wave kernel
 static int g_attn_bwd_waves = 8;
-void vt_attn_bwd_set_waves(int w) { g_attn_bwd_waves = (w == 4) ? 4 : 8; }
+void vt_attn_bwd_set_waves(int w) { g_attn_bwd_waves = (w == 4 || w == 10) ? w : 8; }
 
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
@@ -812,9 +841,10 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   if ((seq_start == nullptr) != (seq_len == nullptr)) return VT_ERR_NULL;
   if (seq_start && (mask || rows_total <= 0)) return VT_ERR_UNSUPPORTED;   // compacted rows carry no masked keys
   const long rows = seq_start ? rows_total : (long)B * S;
-  hipLaunchKernelGGL(attn_delta_rows, dim3((unsigned)((S + 3) / 4), B), dim3(256), 0, stream, (const bf16_t*)dctx, ld_d,
-                     (const bf16_t*)ctx, ld_ctx, delta_ws, B, S, nh, seq_start, seq_len,
-                     (drop && drop->thresh) ? 1.0f / drop->scale : 1.0f);
+  const float delta_mul = (drop && drop->thresh) ? 1.0f / drop->scale : 1.0f;
+  if (g_attn_bwd_waves != 8)
+    hipLaunchKernelGGL(attn_delta_rows, dim3((unsigned)((S + 3) / 4), B), dim3(256), 0, stream, (const bf16_t*)dctx, ld_d,
+                       (const bf16_t*)ctx, ld_ctx, delta_ws, B, S, nh, seq_start, seq_len, delta_mul);
   AttnBwdArgs a;
   a.qkv = (const bf16_t*)qkv; a.dctx = (const bf16_t*)dctx; a.mask = mask; a.mask_additive = mask_additive;
   a.lse = lse; a.delta = delta_ws; a.dqkv = (bf16_t*)dqkv;
@@ -825,14 +855,23 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   a.scale = 1.0f / sqrtf((float)head_size);
   if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
   a.keep_bits = a.drop.thresh ? keep_bits : nullptr;
+  a.ctx = (const bf16_t*)ctx; a.ld_ctx = ld_ctx; a.delta_mul = delta_mul;
   if (g_attn_bwd_waves == 4) {
     hipLaunchKernelGGL(attention_bwd_d64, dim3(nh, B, nkb), dim3(256), AB_LDS_BYTES, stream, a);
   } else {
-    static VtLdsAttrOnce attr8, attr8b;
-    if (!attr8.set((const void*)attention_bwd_d64_w8<false>, AB_LDS_BYTES)) return VT_ERR_HIP;
-    if (!attr8b.set((const void*)attention_bwd_d64_w8<true>, AB_LDS_BYTES)) return VT_ERR_HIP;
-    if (a.keep_bits) hipLaunchKernelGGL(attention_bwd_d64_w8<true>, dim3(nh, B, nkb), dim3(512), AB_LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL(attention_bwd_d64_w8<false>, dim3(nh, B, nkb), dim3(512), AB_LDS_BYTES, stream, a);
+    static VtLdsAttrOnce attr8, attr8b, attr8d, attr8bd;
+    if (!attr8.set((const void*)attention_bwd_d64_w8<false, false>, AB_LDS_BYTES)) return VT_ERR_HIP;
+    if (!attr8b.set((const void*)attention_bwd_d64_w8<true, false>, AB_LDS_BYTES)) return VT_ERR_HIP;
+    if (!attr8d.set((const void*)attention_bwd_d64_w8<false, true>, AB_LDS_BYTES)) return VT_ERR_HIP;
+    if (!attr8bd.set((const void*)attention_bwd_d64_w8<true, true>, AB_LDS_BYTES)) return VT_ERR_HIP;
+    const dim3 grid(nh, B, nkb);
+    if (g_attn_bwd_waves == 8) {
+      if (a.keep_bits) hipLaunchKernelGGL((attention_bwd_d64_w8<true, true>), grid, dim3(512), AB_LDS_BYTES, stream, a);
+      else hipLaunchKernelGGL((attention_bwd_d64_w8<false, true>), grid, dim3(512), AB_LDS_BYTES, stream, a);
+    } else {
+      if (a.keep_bits) hipLaunchKernelGGL((attention_bwd_d64_w8<true, false>), grid, dim3(512), AB_LDS_BYTES, stream, a);
+      else hipLaunchKernelGGL((attention_bwd_d64_w8<false, false>), grid, dim3(512), AB_LDS_BYTES, stream, a);
+    }
   }
   if (nkb > 1) {
     const long n = rows * (nh * 8);

@@ -666,7 +666,8 @@ def ce_double_softmax_rows(z, y, V, dz, scale):
 
 
 def set_attn_bwd_waves(waves):
-    """Tuning/test hook: 4- or 8-wave attention backward kernel (8 is the default)."""
+    """Tuning/test hook: 8 = the 8-wave attention backward kernel (default; forms delta = rowsum(dO o O) itself), 10 = the same
+    behind a separate delta pass, 4 = the 4-wave kernel."""
     _lib.load().vt_debug_set_attn_bwd_waves(int(waves))
 
 
