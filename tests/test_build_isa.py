@@ -90,3 +90,37 @@ def test_generated_wgrad_step_is_current():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_wgrad_step.py")], check=True,
                          stdout=subprocess.PIPE).stdout.decode()
     assert out == open(os.path.join(CSRC, "wgrad_v8_step.inc")).read()
+
+
+def test_attention_kernels_register_budgets_and_the_writelane_hazard(tmp_path):
+    """attention_fwd.hip / attention_bwd.hip: the forward must stay within 128 VGPRs (two 8-wave workgroups per CU, four
+    waves per SIMD: the kernel is bound by vector issue and lives on that occupancy), the inference instantiation without
+    scratch; the backward without scratch.  The training forward moves each compare's lane mask into the lane of its key
+    with v_writelane_b32 from inline asm: hipcc's hazard recognizer does not see into the statement, and without wait states
+    after the v_cmp that wrote the SGPR the first word of a group carried the PREVIOUS compare's mask (measured) -- every
+    group of v_writelane_b32 must follow an s_nop of at least 4."""
+    asm = _device_asm(os.path.join(CSRC, "attention_fwd.hip"), tmp_path)
+    ks = _kernels(asm)
+    fwd = {n: t for n, t in ks.items() if "attention_fwd_d64" in n}
+    assert len(fwd) == 2
+    for name, text in fwd.items():
+        assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", text).group(1)) <= 128, name
+        keep = "ILb1E" in name
+        if not keep:
+            assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", text).group(1)) == 0, name
+            assert "v_writelane_b32" not in text, name
+        else:
+            lines = [l.strip() for l in text.splitlines() if l.strip() and not l.strip().startswith(";")]
+            idx = [i for i, l in enumerate(lines) if l.startswith("v_writelane_b32")]
+            assert len(idx) == 32, (name, len(idx))            # 16 compares x 2 half-waves per 32-key tile
+            for i in idx:
+                j = i
+                while lines[j].startswith("v_writelane_b32"):
+                    j -= 1
+                m = re.match(r"s_nop (\d+)", lines[j])
+                assert m and int(m.group(1)) >= 4, (name, lines[j])
+    ks = _kernels(_device_asm(os.path.join(CSRC, "attention_bwd.hip"), tmp_path))
+    bwd = {n: t for n, t in ks.items() if "attention_bwd_d64" in n}
+    assert len(bwd) == 5                                        # 4 waves; 8 waves x (hash | keep words) x (delta pass | in-kernel)
+    for name, text in bwd.items():
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", text).group(1)) == 0, name
