@@ -180,6 +180,14 @@ int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const in
                            int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
                            int accumulate, float drop_p, uint64_t drop_seed, vt_stream_t stream);
 
+/* The table gradient of an embedding lookup (BertEmbeddings' three nn.Embedding backward passes inside loss.backward(),
+ * tasks/viewpoint_select/pretrain.py:191; torch: one float atomic per element and row): grad[id, :] += sum of the rows of
+ * `de` that looked `id` up.  The caller passes the ids stably sorted (sorted_ids) with the sort's permutation (perm: sorted
+ * position -> row of de); every run of equal ids is added by one workgroup in the rows' original order -- no atomics,
+ * bitwise reproducible.  Rows whose id equals skip_id (nn.Embedding's padding_idx; -1 = none) contribute nothing. */
+int vt_embed_table_grad(const int64_t* sorted_ids, const int64_t* perm, const float* de, int64_t ld_de, float* grad,
+                        int64_t ld_grad, int64_t n, int H, int64_t n_rows_table, int64_t skip_id, vt_stream_t stream);
+
 /* Fused AdamW over a flat fp32 slab of n parameters (n % 4 == 0), the pytorch-transformers rule of
  * tasks/viewpoint_select/pretrain.py:128-130: m,v moments; p -= step_size * m / (sqrt(v) + eps) with
  * step_size = lr * sqrt(1 - b2^t) / (1 - b1^t) supplied by the host; then p -= lr * wd * p.  g is

@@ -518,3 +518,36 @@ def test_attention_keep_words_on_compacted_rows(dev):
         for h in range(nh):
             want = ops.dropout_mask(n * n, drop, head_index=b * nh + h, device=dev).view(n, n).bool().cpu()
             assert torch.equal(got[b * nh + h, :n, :n], want), (b, h)
+
+
+def test_embed_table_grad_equals_index_add_and_is_reproducible(dev):
+    """BertEmbeddings' table gradients (nn.Embedding backward inside loss.backward(), pretrain.py:191): the atomics-free
+    run-wise sum against torch's index_add_ in float64, with repeated ids ([CLS]-like: one id in every row block), a
+    padding id whose rows must add nothing, accumulation into a non-zero table, and twice the same bits."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    n, H, V, pad = 4096, 768, 3000, 0
+    ids = torch.randint(1, V, (n,), generator=g)
+    ids[::64] = 101                      # a frequent id
+    ids[5::7] = pad                      # padding rows
+    ids[-1] = V - 1
+    de = torch.randn(n, H, generator=g)
+    base = torch.randn(V, H, generator=g)
+    want = base.double().clone()
+    keep = ids != pad
+    want.index_add_(0, ids[keep], de[keep].double())
+    outs = []
+    for _ in range(2):
+        grad = base.clone().to(dev)
+        ops.embed_table_grad(ids.to(dev), de.to(dev), grad, skip_id=pad)
+        torch.cuda.synchronize()
+        outs.append(grad.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0].double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert torch.equal(outs[0][pad], base[pad])                      # the padding row is left alone
+    # no skip id: every row counts (position / token-type tables)
+    grad = torch.zeros(V, H, device=dev)
+    ops.embed_table_grad(ids.to(dev), de.to(dev), grad)
+    want2 = torch.zeros(V, H, dtype=torch.float64).index_add_(0, ids, de.double())
+    assert float((grad.cpu().double() - want2).abs().max()) <= 1e-5 * float(want2.abs().max())

@@ -1104,3 +1104,48 @@ int vt_dropout_mask_dispatch(uint8_t* out, long n, const DropCfg& d, hipStream_t
   hipLaunchKernelGGL(dropout_mask_dump, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, n, d);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
+
+// ---- table gradients of an embedding lookup without atomics ------------------------------------------------------
+// grad[id[i], :] += sum of de[perm[j], :] over the rows j whose id equals id[i], for the sorted id list `sorted_ids`
+// (perm = the stable sort's permutation): the scatter-add of BertEmbeddings' backward (torch: index_add_ = 25 M float
+// atomics for the word table at B = 256, 179 us, and an order of additions that changes from run to run).  One workgroup
+// per sorted position; it works only if its position starts a run of equal ids (and the id is not `skip_id`, the padding
+// index whose rows torch.nn.Embedding leaves without gradient), and then owns that table row: plain loads and stores, the
+// rows of the run added in their original order (bitwise reproducible).  Runs are short (a token id seldom repeats in a
+// batch; [CLS] repeats B times: 4 waves x 64 rows).
+__global__ __launch_bounds__(256) void embed_table_grad_runs(const long* __restrict__ sorted_ids, const long* __restrict__ perm,
+                                                             const float* __restrict__ de, long ld_de, float* __restrict__ grad,
+                                                             long ld_grad, long n, int H, long n_rows_table, long skip_id) {
+  __shared__ int s_len;
+  const long i = blockIdx.x;
+  const long id = sorted_ids[i];
+  if (id == skip_id || id < 0 || id >= n_rows_table) return;          // uniform per workgroup
+  if (i > 0 && sorted_ids[i - 1] == id) return;                       // not the head of its run
+  if (threadIdx.x == 0) {
+    long j = i + 1;
+    while (j < n && sorted_ids[j] == id) ++j;
+    s_len = (int)(j - i);
+  }
+  __syncthreads();
+  const int len = s_len;
+  float* gr = grad + id * ld_grad;
+  for (int c = threadIdx.x * 4; c < H; c += 1024) {
+    f32x4 acc = *(const f32x4*)(gr + c);
+    for (int j = 0; j < len; ++j) {
+      const f32x4 v = *(const f32x4*)(de + perm[i + j] * ld_de + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    *(f32x4*)(gr + c) = acc;
+  }
+}
+
+int vt_embed_table_grad_dispatch(const long* sorted_ids, const long* perm, const float* de, long ld_de, float* grad, long ld_grad,
+                                 long n, int H, long n_rows_table, long skip_id, hipStream_t stream) {
+  if (!sorted_ids || !perm || !de || !grad) return VT_ERR_NULL;
+  if (n <= 0 || H <= 0 || (H & 3) || n_rows_table <= 0 || n > 0x7fffffffL) return VT_ERR_BAD_SHAPE;
+  if ((ld_de & 3) || (ld_grad & 3) || (((uintptr_t)de | (uintptr_t)grad) & 15)) return VT_ERR_BAD_ALIGN;
+  hipLaunchKernelGGL(embed_table_grad_runs, dim3((unsigned)n), dim3(256), 0, stream, sorted_ids, perm, de, ld_de, grad, ld_grad, n,
+                     H, n_rows_table, skip_id);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

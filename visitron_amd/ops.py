@@ -428,6 +428,14 @@ class SeqLayout(object):
         self.rows = int(self.index.numel())                     # host sync (the step has one for the labels anyway)
         inv = torch.cumsum(flat.to(torch.int64), 0) - 1
         self.inverse = torch.where(flat, inv, torch.full_like(inv, -1))
+        self._gather = None
+
+    def gather_index(self, zero_row):
+        """int64 [B*S]: for every padded position its compact row, or `zero_row` (a row the caller keeps at zero) where the
+        position was dropped -- un-compaction as ONE index_select instead of a fill + index_copy."""
+        if self._gather is None or self._gather[0] != zero_row:
+            self._gather = (zero_row, torch.where(self.inverse < 0, torch.full_like(self.inverse, zero_row), self.inverse))
+        return self._gather[1]
 
 
 def keep_words(B, nh, S):
@@ -597,6 +605,21 @@ def embed_layernorm_bwd(ids, type_ids, pos_ids, word, pos, typ, gamma, eps, g, S
         float(eps), 1 if accumulate else 0, float(drop[0]), int(drop[1]), _stream())
     _lib.check(rc, "vt_embed_layernorm_bwd")
     return de
+
+
+def embed_table_grad(ids, de, grad, skip_id=None):
+    """grad[ids[i], :] += de[i, :] for every row i (ids int64 [n], de fp32 [n, H], grad fp32 [rows, H]) without atomics: a
+    stable sort of the ids, then one workgroup per run of equal ids (bitwise reproducible; rows with id == skip_id add
+    nothing -- nn.Embedding's padding_idx)."""
+    _require_hip(ids, de, grad)
+    assert ids.dtype == torch.int64 and de.dtype == torch.float32 and grad.dtype == torch.float32
+    assert de.stride(1) == 1 and grad.stride(1) == 1 and ids.numel() == de.shape[0] and de.shape[1] == grad.shape[1]
+    sorted_ids, perm = torch.sort(ids.reshape(-1), stable=True)
+    rc = _lib.load().vt_embed_table_grad(_ptr(sorted_ids), _ptr(perm), _ptr(de), de.stride(0), _ptr(grad), grad.stride(0),
+                                         ids.numel(), de.shape[1], grad.shape[0], -1 if skip_id is None else int(skip_id),
+                                         _stream())
+    _lib.check(rc, "vt_embed_table_grad")
+    return grad
 
 
 def adamw_flat(p, g, m, v, p_bf16, lr, step_size, b1, b2, eps, wd, grad_scale=1.0):

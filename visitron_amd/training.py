@@ -599,8 +599,10 @@ class PretrainEngine(object):
         # ---------------- backward ----------------
         gs = float(grad_scale)
         acc = bool(accumulate)
-        g32 = bufs.g_seq32[:Mr]
-        g32.zero_()
+        # dL/d(sequence output): zero except at the supervised / [CLS] rows.  Assembled directly in the bf16 buffer the
+        # encoder backward reads (a row normally belongs to one head; where two heads meet the sum is formed in bf16)
+        g16 = bufs.g[:Mr]
+        g16.zero_()
         wg = lambda dy, x, dw, db: dict(dy=dy, x=x, dw=dw, db=db, accumulate=acc)
         dec_w_is_tied = pr.decoder.weight is emb.word_embeddings.weight
         word_grad = self._grad(emb.word_embeddings.weight)
@@ -618,7 +620,7 @@ class PretrainEngine(object):
                                      ws=bufs.ws_t["ln_partial"], accumulate=acc)
             g_ht = ops.dgelu_mul(g_t1, h_t)
             ops.wgrad([wg(g_ht, seq_w, self._grad(pr.transform.dense.weight), self._grad(pr.transform.dense.bias))], Ml)
-            g32.index_add_(0, rows_w, ops.linear(g_ht, self.head_t["tr"]).float())
+            g16.index_add_(0, rows_w, ops.linear(g_ht, self.head_t["tr"]))
         elif not acc:
             # no supervised MLM row (the loss is NaN, as the reference's): the head's gradients must not keep the
             # previous step's values (the tied decoder weight / bias were zeroed above)
@@ -627,7 +629,7 @@ class PretrainEngine(object):
                 self._grad(prm).zero_()
         if Mt > 0:
             ops.wgrad([wg(dlt[:, :C], seq_t, self._grad(lin_tok.weight), self._grad(lin_tok.bias))], Mt)
-            g32.index_add_(0, rows_t, ops.linear(dlt, self.head_t["tok"]).float())
+            g16.index_add_(0, rows_t, ops.linear(dlt, self.head_t["tok"]))
         elif not acc:
             self._grad(lin_tok.weight).zero_()
             self._grad(lin_tok.bias).zero_()
@@ -646,17 +648,18 @@ class PretrainEngine(object):
             ops.wgrad([dict(dy=g_z, x=seq.view(B, S * H)[:, :H] if lay is None else cls_seq,
                             dw=self._grad(m.bert.pooler.dense.weight), db=self._grad(m.bert.pooler.dense.bias),
                             accumulate=acc)], B)
-            g32.index_add_(0, cls_rows, ops.linear(g_z, self.head_t["pool"]).float())
+            g16.index_add_(0, cls_rows, ops.linear(g_z, self.head_t["pool"]))
         elif not acc:
             for prm in (m.next_action.linear.weight, m.next_action.linear.bias, m.bert.pooler.dense.weight,
                         m.bert.pooler.dense.bias):
                 self._grad(prm).zero_()
-        self._trunk_bwd(st, g32, acc, comm, word_grad_ready=True)
+        self._trunk_bwd(st, None, acc, comm, word_grad_ready=True)
         return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
 
     def _trunk_bwd(self, st, g32, acc, comm=None, word_grad_ready=False):
-        """Back through the trunk: g32 fp32 [rows, H] = dL/d(sequence output) in the layout of the forward (st); the
-        gradients of the encoder layers, the embeddings and the region projection land in the flat slab."""
+        """Back through the trunk: g32 fp32 [rows, H] = dL/d(sequence output) in the layout of the forward (st), or None
+        when the caller has already put it (bf16) into bufs.g; the gradients of the encoder layers, the embeddings and the
+        region projection land in the flat slab."""
         if st.serial != self._fwd_serial:
             raise RuntimeError("the activations of this forward were overwritten by a later forward of the same engine; "
                                "run backward before the next forward")
@@ -669,7 +672,8 @@ class PretrainEngine(object):
         if not acc and not word_grad_ready:
             word_grad.zero_()
         g = bufs.g[:Mr]
-        g.copy_(g32)
+        if g32 is not None:
+            g.copy_(g32)
         if ops.profiling() or hs is not None:
             self._encoder_backward_unrolled(bufs, x_enc, enc_mask, g, B, S, acc, p_h, p_a, seed, lay, mask_additive, hs)
         elif comm is None:
@@ -697,9 +701,9 @@ class PretrainEngine(object):
                 comm["done"].extend(rng)
                 hi = lo
         if lay is not None:   # dL/dx0 back in the padded row order (zero at the padding rows, as in the padded run)
-            g_c, g = g, bufs.g_pad
-            g.zero_()
-            g.index_copy_(0, lay.index, g_c)
+            # one gather: padded row -> its compact row, or the zero row kept behind the compact rows (Mr < M here)
+            bufs.g[Mr].zero_()
+            g = torch.index_select(bufs.g[:Mr + 1], 0, lay.gather_index(Mr), out=bufs.g_pad)
         # embeddings: text rows
         de = ops.embed_layernorm_bwd(ids, tt, pos_ids, emb.word_embeddings.weight.detach(),
                                      emb.position_embeddings.weight.detach(), emb.token_type_embeddings.weight.detach(),
@@ -710,18 +714,19 @@ class PretrainEngine(object):
         if not acc:
             pos_grad.zero_()
             type_grad.zero_()
-        flat_ids = ids.reshape(-1)
-        pad = emb.word_embeddings.padding_idx
-        de_w = de if pad is None else de * (flat_ids != pad)[:, None]
-        word_grad.index_add_(0, flat_ids, de_w)
+        # the three table gradients without float atomics (sorted ids, one workgroup per run: ops.embed_table_grad); the
+        # default position / type ids need no lookup at all: position t collects the batch's rows t, type 0 everything
+        ops.embed_table_grad(ids.reshape(-1), de, word_grad, skip_id=emb.word_embeddings.padding_idx)
+        pos_sum = None
         if pos_ids is None:
-            pos_grad[:T].add_(de.view(B, T, H).sum(0))
+            pos_sum = de.view(B, T, H).sum(0)
+            pos_grad[:T].add_(pos_sum)
         else:
-            pos_grad.index_add_(0, pos_ids.reshape(-1), de)
+            ops.embed_table_grad(pos_ids.reshape(-1), de, pos_grad)
         if tt is None:
-            type_grad[0].add_(de.sum(0))
+            type_grad[0].add_(pos_sum.sum(0) if pos_sum is not None else de.sum(0))
         else:
-            type_grad.index_add_(0, tt.reshape(-1), de)
+            ops.embed_table_grad(tt.reshape(-1), de, type_grad)
         # region projection
         if img is not None:
             g_img = g.view(B, S, H)[:, T:].reshape(B * R, H)
