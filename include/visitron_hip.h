@@ -182,10 +182,11 @@ int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const in
 
 /* The table gradient of an embedding lookup (BertEmbeddings' three nn.Embedding backward passes inside loss.backward(),
  * tasks/viewpoint_select/pretrain.py:191; torch: one float atomic per element and row): grad[id, :] += sum of the rows of
- * `de` that looked `id` up.  The caller passes the ids stably sorted (sorted_ids) with the sort's permutation (perm: sorted
+ * `de` that looked `id` up.  The caller passes the ids stably sorted (sorted_ids, int32: a radix sort over half the key bytes)
+ * with the sort's permutation (perm: sorted
  * position -> row of de); every run of equal ids is added by one workgroup in the rows' original order -- no atomics,
  * bitwise reproducible.  Rows whose id equals skip_id (nn.Embedding's padding_idx; -1 = none) contribute nothing. */
-int vt_embed_table_grad(const int64_t* sorted_ids, const int64_t* perm, const float* de, int64_t ld_de, float* grad,
+int vt_embed_table_grad(const int32_t* sorted_ids, const int64_t* perm, const float* de, int64_t ld_de, float* grad,
                         int64_t ld_grad, int64_t n, int H, int64_t n_rows_table, int64_t skip_id, vt_stream_t stream);
 
 /* Fused AdamW over a flat fp32 slab of n parameters (n % 4 == 0), the pytorch-transformers rule of

@@ -46,7 +46,7 @@ int vt_assemble_regions_dispatch(const float* img_feats, const int64_t* region_c
                                  const int64_t* text_mask, const int64_t* text_token_classes, float* feats_out, float* loc_out,
                                  int64_t* labels_out, int64_t* mask_out, int64_t* token_labels_out, int B, int T, int R,
                                  int R_in, int D, hipStream_t stream);
-int vt_embed_table_grad_dispatch(const long* sorted_ids, const long* perm, const float* de, long ld_de, float* grad, long ld_grad,
+int vt_embed_table_grad_dispatch(const int* sorted_ids, const long* perm, const float* de, long ld_de, float* grad, long ld_grad,
                                  long n, int H, long n_rows_table, long skip_id, hipStream_t stream);
 int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale,
                                 const float* lse, float* probs, int B, int S, int nh, int head_size, hipStream_t stream);
@@ -124,9 +124,9 @@ const char* vt_error_string(int code) {
 
 int vt_abi_version(void) { return 6; }
 
-int vt_embed_table_grad(const int64_t* sorted_ids, const int64_t* perm, const float* de, int64_t ld_de, float* grad,
+int vt_embed_table_grad(const int32_t* sorted_ids, const int64_t* perm, const float* de, int64_t ld_de, float* grad,
                         int64_t ld_grad, int64_t n, int H, int64_t n_rows_table, int64_t skip_id, vt_stream_t stream) {
-  return vt_embed_table_grad_dispatch((const long*)sorted_ids, (const long*)perm, de, ld_de, grad, ld_grad, n, H, n_rows_table,
+  return vt_embed_table_grad_dispatch((const int*)sorted_ids, (const long*)perm, de, ld_de, grad, ld_grad, n, H, n_rows_table,
                                       skip_id, (hipStream_t)stream);
 }
 

@@ -1113,7 +1113,7 @@ int vt_dropout_mask_dispatch(uint8_t* out, long n, const DropCfg& d, hipStream_t
 // index whose rows torch.nn.Embedding leaves without gradient), and then owns that table row: plain loads and stores, the
 // rows of the run added in their original order (bitwise reproducible).  Runs are short (a token id seldom repeats in a
 // batch; [CLS] repeats B times: 4 waves x 64 rows).
-__global__ __launch_bounds__(256) void embed_table_grad_runs(const long* __restrict__ sorted_ids, const long* __restrict__ perm,
+__global__ __launch_bounds__(256) void embed_table_grad_runs(const int* __restrict__ sorted_ids, const long* __restrict__ perm,
                                                              const float* __restrict__ de, long ld_de, float* __restrict__ grad,
                                                              long ld_grad, long n, int H, long n_rows_table, long skip_id) {
   __shared__ int s_len;
@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(256) void embed_table_grad_runs(const long* __restr
   }
 }
 
-int vt_embed_table_grad_dispatch(const long* sorted_ids, const long* perm, const float* de, long ld_de, float* grad, long ld_grad,
+int vt_embed_table_grad_dispatch(const int* sorted_ids, const long* perm, const float* de, long ld_de, float* grad, long ld_grad,
                                  long n, int H, long n_rows_table, long skip_id, hipStream_t stream) {
   if (!sorted_ids || !perm || !de || !grad) return VT_ERR_NULL;
   if (n <= 0 || H <= 0 || (H & 3) || n_rows_table <= 0 || n > 0x7fffffffL) return VT_ERR_BAD_SHAPE;

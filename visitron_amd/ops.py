@@ -437,6 +437,12 @@ class SeqLayout(object):
             self._gather = (zero_row, torch.where(self.inverse < 0, torch.full_like(self.inverse, zero_row), self.inverse))
         return self._gather[1]
 
+    def gather_index_split(self, zero_row, T):
+        """The same index as two lists: the first T positions of every sequence, and the rest (text | regions) -- each
+        part then lands contiguous, [B*T, H] and [B*(S-T), H]."""
+        idx = self.gather_index(zero_row).view(self.B, self.S)
+        return idx[:, :T].reshape(-1), idx[:, T:].reshape(-1)
+
 
 def keep_words(B, nh, S):
     """Words of a dropout keep buffer (VT_KEEP_WORDS in include/visitron_hip.h): one per (batch, head, 32-query block, key)."""
@@ -614,7 +620,7 @@ def embed_table_grad(ids, de, grad, skip_id=None):
     _require_hip(ids, de, grad)
     assert ids.dtype == torch.int64 and de.dtype == torch.float32 and grad.dtype == torch.float32
     assert de.stride(1) == 1 and grad.stride(1) == 1 and ids.numel() == de.shape[0] and de.shape[1] == grad.shape[1]
-    sorted_ids, perm = torch.sort(ids.reshape(-1), stable=True)
+    sorted_ids, perm = torch.sort(ids.reshape(-1).to(torch.int32), stable=True)   # (table rows < 2^31)
     rc = _lib.load().vt_embed_table_grad(_ptr(sorted_ids), _ptr(perm), _ptr(de), de.stride(0), _ptr(grad), grad.stride(0),
                                          ids.numel(), de.shape[1], grad.shape[0], -1 if skip_id is None else int(skip_id),
                                          _stream())

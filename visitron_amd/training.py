@@ -701,13 +701,19 @@ class PretrainEngine(object):
                 comm["done"].extend(rng)
                 hi = lo
         if lay is not None:   # dL/dx0 back in the padded row order (zero at the padding rows, as in the padded run)
-            # one gather: padded row -> its compact row, or the zero row kept behind the compact rows (Mr < M here)
+            # gathers: padded row -> its compact row, or the zero row kept behind the compact rows (Mr < M here); the text
+            # and the region positions land in two contiguous blocks (what the embedding and the region backward read)
             bufs.g[Mr].zero_()
-            g = torch.index_select(bufs.g[:Mr + 1], 0, lay.gather_index(Mr), out=bufs.g_pad)
+            gi_text, gi_reg = lay.gather_index_split(Mr, T)
+            g_text = torch.index_select(bufs.g[:Mr + 1], 0, gi_text, out=bufs.g_pad[:B * T])
+            g_reg = torch.index_select(bufs.g[:Mr + 1], 0, gi_reg, out=bufs.g_pad[B * T:B * S]) if img is not None else None
+            g_pitch = T
+        else:
+            g_text, g_reg, g_pitch = g, None, S
         # embeddings: text rows
         de = ops.embed_layernorm_bwd(ids, tt, pos_ids, emb.word_embeddings.weight.detach(),
                                      emb.position_embeddings.weight.detach(), emb.token_type_embeddings.weight.detach(),
-                                     emb.LayerNorm.weight.detach(), eps, g, S, self._grad(emb.LayerNorm.weight),
+                                     emb.LayerNorm.weight.detach(), eps, g_text, g_pitch, self._grad(emb.LayerNorm.weight),
                                      self._grad(emb.LayerNorm.bias), ws=bufs.ws_t["ln_partial"], accumulate=acc,
                                      drop=(p_h, seed, ops.SITE_EMB))
         pos_grad, type_grad = self._grad(emb.position_embeddings.weight), self._grad(emb.token_type_embeddings.weight)
@@ -729,7 +735,7 @@ class PretrainEngine(object):
             ops.embed_table_grad(tt.reshape(-1), de, type_grad)
         # region projection
         if img is not None:
-            g_img = g.view(B, S, H)[:, T:].reshape(B * R, H)
+            g_img = g_reg if g_reg is not None else g.view(B, S, H)[:, T:].reshape(B * R, H)
             if p_h > 0.0:
                 ops.apply_dropout(g_img, (p_h, seed, ops.SITE_IMG))   # g is not read again after this point
             if img_pre is not None:   # back through the image LayerNorm
