@@ -416,7 +416,8 @@ class SeqLayout(object):
     every activation; `rows` real rows in all, at most S per sequence.  index = the kept rows' positions in the padded
     [B*S] order (int64), inverse[padded position] = compact row or -1."""
 
-    def __init__(self, keep):
+    def __init__(self, keep, rows=None):
+        """rows: the number of kept positions when the caller already knows it (no host synchronisation here then)."""
         assert keep.dim() == 2 and keep.dtype == torch.bool
         B, S = keep.shape
         lens = keep.sum(1)
@@ -424,8 +425,12 @@ class SeqLayout(object):
         self.length = lens.to(torch.int32).contiguous()
         self.start = (torch.cumsum(lens, 0) - lens).to(torch.int32).contiguous()
         flat = keep.reshape(-1)
-        self.index = torch.nonzero(flat).flatten()
-        self.rows = int(self.index.numel())                     # host sync (the step has one for the labels anyway)
+        if rows is None:
+            self.index = torch.nonzero(flat).flatten()
+            self.rows = int(self.index.numel())                 # host sync
+        else:
+            self.rows = int(rows)
+            self.index = torch.nonzero_static(flat, size=self.rows).flatten()
         inv = torch.cumsum(flat.to(torch.int64), 0) - 1
         self.inverse = torch.where(flat, inv, torch.full_like(inv, -1))
         self._gather = None
