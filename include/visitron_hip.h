@@ -180,6 +180,20 @@ int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const in
                            int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
                            int accumulate, float drop_p, uint64_t drop_seed, vt_stream_t stream);
 
+/* What the host must know about a pretrain batch before it can size the step (pretrain.py:157-193 runs every position; this
+ * path runs the heads on the supervised rows and the encoder on the rows with a non-zero mask).  counts[5] = {err_flag[0],
+ * #(labels != -1), #(token_labels != -1), #(mask != 0), bad}, bad = the batch does not qualify for the compacted layout (a
+ * mask value other than 0 / 1, a [CLS] or a supervised position with mask 0).  labels / token_labels / mask / err_flag may
+ * each be NULL.  One launch, one 40-byte read-back. */
+int vt_batch_row_counts(const int64_t* labels, const int64_t* token_labels, const float* mask, const int32_t* err_flag, int B,
+                        int S, int64_t* counts, vt_stream_t stream);
+/* The row lists to the sizes vt_batch_row_counts reported (n_w, n_t, n_keep: nothing is written past them; ascending): idx_w / idx_t = positions with a label / token label;
+ * index = positions with a non-zero mask, inverse[position] = its rank among them or -1, start / length [B] = each sequence's
+ * first compact row and number of kept rows (needs every position b*S kept).  One launch. */
+int vt_batch_row_lists(const int64_t* labels, const int64_t* token_labels, const float* mask, int B, int S, int64_t n_w,
+                       int64_t n_t, int64_t n_keep, int64_t* idx_w, int64_t* idx_t, int64_t* index, int64_t* inverse,
+                       int32_t* start, int32_t* length, vt_stream_t stream);
+
 /* The table gradient of an embedding lookup (BertEmbeddings' three nn.Embedding backward passes inside loss.backward(),
  * tasks/viewpoint_select/pretrain.py:191; torch: one float atomic per element and row): grad[id, :] += sum of the rows of
  * `de` that looked `id` up.  The caller passes the ids stably sorted (sorted_ids, int32: a radix sort over half the key bytes)

@@ -551,3 +551,58 @@ def test_embed_table_grad_equals_index_add_and_is_reproducible(dev):
     ops.embed_table_grad(ids.to(dev), de.to(dev), grad)
     want2 = torch.zeros(V, H, dtype=torch.float64).index_add_(0, ids, de.double())
     assert float((grad.cpu().double() - want2).abs().max()) <= 1e-5 * float(want2.abs().max())
+
+
+@pytest.mark.parametrize("B,S,case", [(7, 33, "plain"), (256, 228, "plain"), (5, 40, "fraction"), (4, 20, "cls"), (3, 16, "label"),
+                                      (2, 700, "nolabels"), (6, 12, "allkept"), (3, 24, "zerolabels")])
+def test_batch_row_counts_and_lists_equal_the_torch_ops(dev, B, S, case):
+    """What a pretrain step needs from its batch before it can size its launches (supervised rows, rows with a non-zero
+    mask, whether the compacted layout applies, the embedding range flag): two launches against the torch ops they replace
+    (sum / any / nonzero / cumsum / where), including the cases that must veto the compacted layout."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(B * 100 + S)
+    M = B * S
+    lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+    mask = (torch.arange(S)[None, :] < lens[:, None]).float()
+    if case == "allkept":
+        mask[:] = 1.0
+    lab = torch.full((M,), -1, dtype=torch.int64)
+    tl = torch.full((M,), -1, dtype=torch.int64)
+    kept = torch.nonzero(mask.reshape(-1)).flatten()
+    lab[kept[torch.randperm(kept.numel(), generator=g)[: max(1, kept.numel() // 7)]]] = 5
+    tl[kept[torch.randperm(kept.numel(), generator=g)[: max(1, kept.numel() // 9)]]] = 3
+    if case == "zerolabels":
+        lab[:] = -1
+    want_bad = 0
+    if case == "fraction":
+        mask[1, 2] = 0.5; want_bad = 1
+    if case == "cls":
+        mask[2, 0] = 0.0; want_bad = 1
+    if case == "label":
+        dropped = torch.nonzero(mask.reshape(-1) == 0).flatten()
+        lab[dropped[0]] = 9; want_bad = 1
+    use_labels = case != "nolabels"
+    err = torch.tensor([3 if case == "cls" else 0], dtype=torch.int32)
+    d = lambda t: t.to(dev)
+    vals = ops.batch_row_counts(d(lab) if use_labels else None, d(tl) if use_labels else None, d(mask), d(err), B, S)
+    keep = mask.reshape(-1) != 0
+    assert vals[0] == int(err[0])
+    assert vals[1] == (int((lab != -1).sum()) if use_labels else 0) and vals[2] == (int((tl != -1).sum()) if use_labels else 0)
+    assert vals[3] == int(keep.sum()) and bool(vals[4]) == bool(want_bad)
+    if want_bad:
+        return
+    idx_w, idx_t, lay = ops.batch_row_lists(d(lab) if use_labels else None, d(tl) if use_labels else None, d(mask), B, S,
+                                            vals[1], vals[2], vals[3])
+    torch.cuda.synchronize()
+    ref = ops.SeqLayout(d(mask != 0))
+    if use_labels:
+        assert torch.equal(idx_w.cpu(), torch.nonzero(lab != -1).flatten()) and torch.equal(idx_t.cpu(), torch.nonzero(tl != -1).flatten())
+    else:
+        assert idx_w is None and idx_t is None
+    assert lay.rows == ref.rows and torch.equal(lay.index, ref.index) and torch.equal(lay.inverse, ref.inverse)
+    assert torch.equal(lay.start, ref.start) and torch.equal(lay.length, ref.length)
+    # without a mask: the lists alone
+    if use_labels:
+        iw, it, none = ops.batch_row_lists(d(lab), d(tl), None, B, S, vals[1], vals[2], 0)
+        assert none is None and torch.equal(iw, idx_w) and torch.equal(it, idx_t)

@@ -1149,3 +1149,108 @@ int vt_embed_table_grad_dispatch(const int* sorted_ids, const long* perm, const 
                      H, n_rows_table, skip_id);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
+
+// ---- what the host must know about a training batch, and its row lists -------------------------------------------
+// The pretrain step runs its heads on the supervised rows only (labels != -1, token_labels != -1: encoder.py:377-385,
+// CrossEntropyLoss(ignore_index=-1)) and its encoder on the rows with a non-zero attention mask only; the host needs the
+// three counts to size those launches.  batch_row_counts reduces them -- with the verdict on the compacted layout (a 0/1
+// mask, every [CLS] and every supervised position kept) and the embedding kernel's out-of-range flag -- into five words the
+// host reads back in one synchronisation; batch_row_lists then writes the row lists (ascending), the padded -> compact
+// map and the per-sequence start / length.  Two launches where torch needed ~25 (sum, any, nonzero, cumsum, where ...).
+struct BatchRowsArgs {
+  const long* lab; const long* tl;      // [M] or null
+  const float* mask;                    // [B*S] fp32 or null (no compaction wanted)
+  const int* err;                       // the embedding kernel's flag or null
+  long M; int S; int B;
+  long* counts;                         // [5]: err, n_w, n_t, n_keep, bad
+  long* idx_w; long* idx_t;             // row lists
+  long* index; long* inverse;           // kept rows; padded position -> compact row or -1
+  int* start; int* length;              // [B]
+  long n_w, n_t, n_keep;                // capacities of the three lists (the counts batch_row_counts reported)
+};
+
+__global__ __launch_bounds__(1024) void batch_row_counts(BatchRowsArgs a) {
+  __shared__ long red[16][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long nw = 0, nt = 0, nk = 0, bad = 0;
+  for (long i = tid; i < a.M; i += 1024) {
+    const bool w = a.lab && a.lab[i] != -1, t = a.tl && a.tl[i] != -1;
+    bool k = true;
+    if (a.mask) {
+      const float m = a.mask[i];
+      k = m != 0.f;
+      if ((k && m != 1.f) || ((w || t) && !k) || (!k && (i % a.S) == 0)) bad = 1;
+    }
+    nw += w; nt += t; nk += k;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    nw += __shfl_xor(nw, o, 64); nt += __shfl_xor(nt, o, 64); nk += __shfl_xor(nk, o, 64); bad |= __shfl_xor(bad, o, 64);
+  }
+  if (lane == 0) { red[wave][0] = nw; red[wave][1] = nt; red[wave][2] = nk; red[wave][3] = bad; }
+  __syncthreads();
+  if (tid == 0) {
+    long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int w = 0; w < 16; ++w) { s0 += red[w][0]; s1 += red[w][1]; s2 += red[w][2]; s3 |= red[w][3]; }
+    a.counts[0] = a.err ? (long)a.err[0] : 0;
+    a.counts[1] = s0; a.counts[2] = s1; a.counts[3] = s2; a.counts[4] = s3;
+  }
+}
+
+// blockIdx.x: 0 = labels list, 1 = token-labels list, 2 = kept rows + inverse map + per-sequence start / length
+__global__ __launch_bounds__(1024) void batch_row_lists(BatchRowsArgs a) {
+  __shared__ int wsum[16];
+  const int which = blockIdx.x;
+  if ((which == 0 && !a.lab) || (which == 1 && !a.tl) || (which == 2 && !a.mask)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long chunk = (a.M + 1023) / 1024;
+  const long i0 = tid * chunk, i1 = (i0 + chunk < a.M) ? i0 + chunk : a.M;
+  auto flag = [&](long i) -> bool {
+    return which == 0 ? a.lab[i] != -1 : (which == 1 ? a.tl[i] != -1 : a.mask[i] != 0.f);
+  };
+  int cnt = 0;
+  for (long i = i0; i < i1; ++i) cnt += flag(i);
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < 16; ++w) { if (w < wave) base += wsum[w]; total += wsum[w]; }
+  long pos = base + incl - cnt;
+  long* out = which == 0 ? a.idx_w : (which == 1 ? a.idx_t : a.index);
+  const long cap = which == 0 ? a.n_w : (which == 1 ? a.n_t : a.n_keep);   // (a stale count must not write past a list)
+  for (long i = i0; i < i1; ++i) {
+    const bool f = flag(i);
+    if (f && pos < cap) out[pos] = i;
+    if (which == 2) a.inverse[i] = f ? pos : -1;
+    pos += f;
+  }
+  if (which == 2) {
+    __threadfence_block();
+    __syncthreads();
+    for (int b = tid; b < a.B; b += 1024) {
+      const long s0 = a.inverse[(long)b * a.S];
+      const long s1 = b + 1 < a.B ? a.inverse[(long)(b + 1) * a.S] : (long)total;
+      a.start[b] = (int)s0;
+      a.length[b] = (int)(s1 - s0);
+    }
+  }
+}
+
+int vt_batch_rows_dispatch(const BatchRowsArgs& a, int lists, hipStream_t stream) {
+  if (a.M <= 0 || a.S <= 0 || a.B <= 0 || (long)a.B * a.S != a.M) return VT_ERR_BAD_SHAPE;
+  if (!lists) {
+    if (!a.counts) return VT_ERR_NULL;
+    hipLaunchKernelGGL(batch_row_counts, dim3(1), dim3(1024), 0, stream, a);
+  } else {
+    if ((a.lab && a.n_w > 0 && !a.idx_w) || (a.tl && a.n_t > 0 && !a.idx_t) ||
+        (a.mask && ((a.n_keep > 0 && !a.index) || !a.inverse || !a.start || !a.length))) return VT_ERR_NULL;
+    if (a.n_w < 0 || a.n_t < 0 || a.n_keep < 0) return VT_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(batch_row_lists, dim3(3), dim3(1024), 0, stream, a);
+  }
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

@@ -435,6 +435,15 @@ class SeqLayout(object):
         self.inverse = torch.where(flat, inv, torch.full_like(inv, -1))
         self._gather = None
 
+    @classmethod
+    def from_parts(cls, B, S, rows, index, inverse, start, length):
+        """A layout whose tensors were built elsewhere (ops.batch_row_lists): no kernels, no synchronisation."""
+        self = cls.__new__(cls)
+        self.B, self.S, self.rows = int(B), int(S), int(rows)
+        self.index, self.inverse, self.start, self.length = index, inverse, start, length
+        self._gather = None
+        return self
+
     def gather_index(self, zero_row):
         """int64 [B*S]: for every padded position its compact row, or `zero_row` (a row the caller keeps at zero) where the
         position was dropped -- un-compaction as ONE index_select instead of a fill + index_copy."""
@@ -616,6 +625,40 @@ def embed_layernorm_bwd(ids, type_ids, pos_ids, word, pos, typ, gamma, eps, g, S
         float(eps), 1 if accumulate else 0, float(drop[0]), int(drop[1]), _stream())
     _lib.check(rc, "vt_embed_layernorm_bwd")
     return de
+
+
+def batch_row_counts(labels, token_labels, mask, err_flag, B, S):
+    """-> [err, #labels != -1, #token_labels != -1, #mask != 0, bad] as Python ints: the one host synchronisation of a
+    training step (labels / token_labels int64 [B*S] or None, mask fp32 [B,S] or None, err_flag int32 [1] or None)."""
+    _require_hip(labels, token_labels, mask, err_flag)
+    ref = next(t for t in (labels, token_labels, mask, err_flag) if t is not None)
+    for t in (labels, token_labels):
+        assert t is None or (t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B * S)
+    assert mask is None or (mask.dtype == torch.float32 and mask.is_contiguous() and mask.numel() == B * S)
+    out = torch.empty(5, dtype=torch.int64, device=ref.device)
+    rc = _lib.load().vt_batch_row_counts(_ptr(labels), _ptr(token_labels), _ptr(mask), _ptr(err_flag), B, S, _ptr(out), _stream())
+    _lib.check(rc, "vt_batch_row_counts")
+    return out.tolist()
+
+
+def batch_row_lists(labels, token_labels, mask, B, S, n_w, n_t, n_keep):
+    """The row lists to the counts batch_row_counts reported: (idx_w, idx_t, layout) -- idx_* int64 or None, layout a
+    SeqLayout over the positions with a non-zero mask or None (mask None)."""
+    _require_hip(labels, token_labels, mask)
+    ref = next(t for t in (labels, token_labels, mask) if t is not None)
+    i64 = lambda n: torch.empty(int(n), dtype=torch.int64, device=ref.device)
+    idx_w = i64(n_w) if labels is not None else None
+    idx_t = i64(n_t) if token_labels is not None else None
+    index = inverse = start = length = None
+    if mask is not None:
+        index, inverse = i64(n_keep), i64(B * S)
+        start = torch.empty(B, dtype=torch.int32, device=ref.device)
+        length = torch.empty(B, dtype=torch.int32, device=ref.device)
+    rc = _lib.load().vt_batch_row_lists(_ptr(labels), _ptr(token_labels), _ptr(mask), B, S, int(n_w), int(n_t), int(n_keep),
+                                        _ptr(idx_w), _ptr(idx_t), _ptr(index), _ptr(inverse), _ptr(start), _ptr(length), _stream())
+    _lib.check(rc, "vt_batch_row_lists")
+    lay = SeqLayout.from_parts(B, S, n_keep, index, inverse, start, length) if mask is not None else None
+    return idx_w, idx_t, lay
 
 
 def embed_table_grad(ids, de, grad, skip_id=None):

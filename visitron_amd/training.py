@@ -428,48 +428,34 @@ class PretrainEngine(object):
         # Everything the host must know about this batch before it can size the step -- the numbers of supervised rows
         # (the heads run on those only), the number of rows with a non-zero mask and whether the batch qualifies for the
         # compacted layout, the embedding kernel's out-of-range flag -- is reduced on the device and read back in ONE
-        # synchronisation, at the start of the step; the row lists are then built to their known sizes (nonzero_static).
+        # synchronisation, at the start of the step (ops.batch_row_counts); the row lists and the compacted layout are then
+        # written to their known sizes by a second launch (ops.batch_row_lists).
         lab = tl = idx_w = idx_t = None
         Ml = Mt = 0
-        counts = [err[0].to(torch.int64)]
-        vw = vt = None
         if labels is not None:
-            lab, tl = labels.reshape(-1), token_labels.reshape(-1)
-            vw, vt = lab != -1, tl != -1
-            counts += [vw.sum(), vt.sum()]
+            lab, tl = _i64(labels.reshape(-1)), _i64(token_labels.reshape(-1))
         # rows nothing in the step reads: positions with attention mask 0.  As keys they weigh exactly 0, so their
         # hidden states reach no loss and their gradient is exactly 0 -- drop them from every row-wise kernel.  Needs a
         # 0/1 mask, the [CLS] position and every supervised position kept; otherwise the padded path below.
         try_compact = (allow_compact and self.compact_rows and mask is not None and mask.dim() == 2 and hs is None
                        and M >= self.compact_min_rows)
-        keep = None
-        if try_compact:
-            keep = mask != 0
-            kf = keep.reshape(-1)
-            bad = ((mask != 0) & (mask != 1)).any() | (~keep[:, 0]).any()
-            if vw is not None:
-                bad = bad | (vw & ~kf).any() | (vt & ~kf).any()
-            counts += [kf.sum(), bad.to(torch.int64)]
-        vals = torch.stack(counts).tolist()          # the step's one host synchronisation
+        cmask = mask.contiguous() if try_compact else None
+        vals = ops.batch_row_counts(lab, tl, cmask, err, B, S)       # one launch, the step's one host synchronisation
         # out-of-range input_ids / position_ids / token_type_ids: the reference's embedding lookup raises IndexError
         # (checked before anything indexes the gradient tables with those ids)
         if vals[0] != 0:
             raise IndexError("index out of range in BertEmbeddings (input_ids / position_ids / token_type_ids)")
-        if labels is not None:
-            Ml, Mt = int(vals[1]), int(vals[2])
-            idx_w = torch.nonzero_static(vw, size=Ml).flatten()
-            idx_t = torch.nonzero_static(vt, size=Mt).flatten()
         # the previous step's weight gradients: a workgroup of the persistent wgrad kernel that gave up its bounded wait
         # for a dW tile added out of turn (never seen; a preempted / shared GPU could do it) -- fail loudly
         late = ops.wgrad_turn_timeouts()
         if late:
             raise RuntimeError("vt_wgrad_bf16: %d workgroup(s) ran out of their turn wait in an earlier launch; the weight "
                                "gradients of that step are unreliable" % late)
+        Ml, Mt = (int(vals[1]), int(vals[2])) if labels is not None else (0, 0)
+        compact = try_compact and int(vals[3]) < M and not vals[4]
         lay = None
-        if try_compact:
-            rows_kept, is_bad = int(vals[-2]), int(vals[-1])
-            if rows_kept < M and not is_bad:
-                lay = ops.SeqLayout(keep, rows=rows_kept)
+        if labels is not None or compact:   # one launch: the supervised-row lists and the compacted layout
+            idx_w, idx_t, lay = ops.batch_row_lists(lab, tl, cmask if compact else None, B, S, Ml, Mt, int(vals[3]))
         Mr = M if lay is None else lay.rows
         self.last_rows = Mr
         self.last_layout = lay
