@@ -194,6 +194,13 @@ int vt_batch_row_lists(const int64_t* labels, const int64_t* token_labels, const
                        int64_t n_t, int64_t n_keep, int64_t* idx_w, int64_t* idx_t, int64_t* index, int64_t* inverse,
                        int32_t* start, int32_t* length, vt_stream_t stream);
 
+/* The action head's loss, accuracy and gradient (NextActionPrediction = Linear + LogSoftmax, encoder.py:142-151, under
+ * CrossEntropyLoss(ignore_index=-1), :387-391, which applies log_softmax again): logits fp32 [B, >= A] (A <= 64),
+ * next_action int64 [B] (-1 = ignored) -> loss_acc[0] = -mean over valid rows of log_softmax(log_softmax(z))[y],
+ * loss_acc[1] = #(argmax == y) / B, dlogits bf16 [B, Ap] = d(grad_scale * loss)/dz (columns A..Ap-1 zero).  One launch. */
+int vt_action_head_f32(const float* logits, int64_t ld, const int64_t* next_action, int B, int A, float grad_scale, void* dlogits,
+                       int64_t ldd, int Ap, float* loss_acc, vt_stream_t stream);
+
 /* The table gradient of an embedding lookup (BertEmbeddings' three nn.Embedding backward passes inside loss.backward(),
  * tasks/viewpoint_select/pretrain.py:191; torch: one float atomic per element and row): grad[id, :] += sum of the rows of
  * `de` that looked `id` up.  The caller passes the ids stably sorted (sorted_ids, int32: a radix sort over half the key bytes)

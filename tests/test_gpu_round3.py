@@ -606,3 +606,31 @@ def test_batch_row_counts_and_lists_equal_the_torch_ops(dev, B, S, case):
     if use_labels:
         iw, it, none = ops.batch_row_lists(d(lab), d(tl), None, B, S, vals[1], vals[2], 0)
         assert none is None and torch.equal(iw, idx_w) and torch.equal(it, idx_t)
+
+
+@pytest.mark.parametrize("B,A,ignored", [(256, 36, 0), (37, 36, 9), (5, 36, 5), (64, 7, 3)])
+def test_action_head_equals_the_double_log_softmax_cross_entropy(dev, B, A, ignored):
+    """NextActionPrediction (Linear + LogSoftmax, encoder.py:142-151) under CrossEntropyLoss(ignore_index=-1) (:387-391, a
+    second log_softmax): the one-launch kernel against torch autograd in float64 -- loss, accuracy, gradient w.r.t. the
+    logits, ignored rows, and the NaN of a batch without a valid action."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(B + A)
+    Ap, gs = 64, 0.37
+    z = torch.randn(B, Ap, generator=g) * 2.0
+    y = torch.randint(0, A, (B,), generator=g)
+    y[:ignored] = -1
+    zz = z[:, :A].double().requires_grad_(True)
+    lsm = torch.log_softmax(zz, -1)
+    want_loss = torch.nn.functional.cross_entropy(lsm, y, ignore_index=-1)
+    loss, acc, dl = ops.action_head(z.to(dev), y.to(dev), A, gs, Ap)
+    torch.cuda.synchronize()
+    if ignored == B:
+        assert torch.isnan(loss) and torch.isnan(want_loss)
+        return
+    (gs * want_loss).backward()
+    assert abs(float(loss) - float(want_loss)) <= 1e-5 * max(1.0, abs(float(want_loss)))
+    assert abs(float(acc) - float((lsm.argmax(1) == y).sum()) / B) <= 1e-6
+    d = dl.float().cpu()
+    assert float(d[:, A:].abs().max()) == 0.0
+    assert float((d[:, :A].double() - zz.grad).abs().max()) <= 2.0 ** -8 * float(zz.grad.abs().max()) + 1e-9

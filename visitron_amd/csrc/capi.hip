@@ -53,6 +53,8 @@ struct BatchRowsArgs {
   long* index; long* inverse; int* start; int* length; long n_w, n_t, n_keep;
 };
 int vt_batch_rows_dispatch(const BatchRowsArgs& a, int lists, hipStream_t stream);
+int vt_action_head_dispatch(const float* z, long ldz, const long* y, int B, int A, float grad_scale, void* dz, long lddz, int Ap,
+                            float* out, hipStream_t stream);
 int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale,
                                 const float* lse, float* probs, int B, int S, int nh, int head_size, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
@@ -142,6 +144,12 @@ int vt_batch_row_lists(const int64_t* labels, const int64_t* token_labels, const
   BatchRowsArgs a = {(const long*)labels, (const long*)token_labels, mask, nullptr, (long)B * S, S, B, nullptr, (long*)idx_w,
                      (long*)idx_t, (long*)index, (long*)inverse, (int*)start, (int*)length, n_w, n_t, n_keep};
   return vt_batch_rows_dispatch(a, 1, (hipStream_t)stream);
+}
+
+int vt_action_head_f32(const float* logits, int64_t ld, const int64_t* next_action, int B, int A, float grad_scale, void* dlogits,
+                       int64_t ldd, int Ap, float* loss_acc, vt_stream_t stream) {
+  return vt_action_head_dispatch(logits, ld, (const long*)next_action, B, A, grad_scale, dlogits, ldd, Ap, loss_acc,
+                                 (hipStream_t)stream);
 }
 
 int vt_embed_table_grad(const int32_t* sorted_ids, const int64_t* perm, const float* de, int64_t ld_de, float* grad,

@@ -1254,3 +1254,70 @@ int vt_batch_rows_dispatch(const BatchRowsArgs& a, int lists, hipStream_t stream
   }
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
+
+// ---- the 1-in-A action head's loss, accuracy and gradient in one launch ------------------------------------------
+// NextActionPrediction = Linear + LogSoftmax (tasks/viewpoint_select/encoder.py:142-151) and the criterion
+// CrossEntropyLoss(ignore_index=-1) applies log_softmax AGAIN (encoder.py:387-391): on logits z [B, A] with targets y,
+//   l = log_softmax(z), m = log_softmax(l), loss = -sum_{valid b} m[b, y_b] / n_valid, accuracy = #(argmax l == y) / B,
+//   dz = g - exp(l) * rowsum(g),  g = (exp(m) - onehot(y)) * valid * grad_scale / n_valid
+// (torch: two log_softmax, gather, clamp, exp, scatter_add, several multiplies and reductions = ~20 launches on a [256, 36]
+// tensor).  One workgroup, one wave per row in turn; A <= 64.  n_valid = 0 gives the NaN torch gives.
+__global__ __launch_bounds__(1024) void action_head_rows(const float* __restrict__ z, long ldz, const long* __restrict__ y, int B,
+                                                         int A, float grad_scale, bf16_t* __restrict__ dz, long lddz, int Ap,
+                                                         float* __restrict__ out /* loss, accuracy */) {
+  __shared__ float red[16][2];
+  __shared__ int redn[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int nv = 0;
+  for (int b = tid; b < B; b += 1024) nv += y[b] != -1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o, 64);
+  if (lane == 0) redn[wave] = nv;
+  __syncthreads();
+  int n_valid = 0;
+  for (int w = 0; w < 16; ++w) n_valid += redn[w];
+  const float inv_n = 1.0f / (float)n_valid;          // inf when nothing is valid: loss 0 * inf = NaN, as torch's 0 / 0
+  float loss = 0.f, hits = 0.f;
+  for (int b = wave; b < B; b += 16) {
+    const float v = lane < A ? z[b * ldz + lane] : -INFINITY;
+    const float mx = wave_max(v);
+    const float e = lane < A ? __expf(v - mx) : 0.f;
+    const float l = v - mx - __logf(wave_sum(e));                     // log_softmax(z)
+    const float lm = lane < A ? l : -INFINITY;
+    const float mx2 = wave_max(lm);
+    const float e2 = lane < A ? __expf(lm - mx2) : 0.f;
+    const float m = lm - mx2 - __logf(wave_sum(e2));                  // log_softmax(log_softmax(z))
+    const long yb = y[b];
+    const bool valid = yb != -1;
+    const int yc = yb < 0 ? 0 : (int)yb;                              // torch: clamp(min=0) for the gather
+    // argmax of l (first maximum, as torch.argmax)
+    const unsigned long long atmax = __builtin_amdgcn_ballot_w64(lane < A && lm == mx2);
+    const int amax = __builtin_ctzll(atmax);
+    const float m_y = __shfl(m, yc < A ? yc : 0, 64);
+    if (lane == 0) {
+      if (valid) loss -= m_y;
+      hits += (long)amax == yb ? 1.f : 0.f;
+    }
+    // (exp(m) - onehot) * valid * (grad_scale / n_valid); an ignored row is 0 * (grad_scale / n_valid): NaN only when n_valid = 0
+    const float g = lane < A ? (__expf(m) - (lane == yc ? 1.f : 0.f)) * ((valid ? 1.f : 0.f) * (grad_scale * inv_n)) : 0.f;
+    const float gs = wave_sum(g);
+    const float d = g - __expf(l) * gs;
+    if (lane < Ap) dz[b * lddz + lane] = f32_to_bf16(lane < A ? d : 0.f);
+  }
+  if (lane == 0) { red[wave][0] = loss; red[wave][1] = hits; }
+  __syncthreads();
+  if (tid == 0) {
+    float ls = 0.f, hs = 0.f;
+    for (int w = 0; w < 16; ++w) { ls += red[w][0]; hs += red[w][1]; }
+    out[0] = ls * inv_n;
+    out[1] = hs / (float)B;
+  }
+}
+
+int vt_action_head_dispatch(const float* z, long ldz, const long* y, int B, int A, float grad_scale, void* dz, long lddz, int Ap,
+                            float* out, hipStream_t stream) {
+  if (!z || !y || !dz || !out) return VT_ERR_NULL;
+  if (B <= 0 || A <= 0 || A > 64 || Ap < A || Ap > 64 || ldz < A || lddz < Ap) return VT_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(action_head_rows, dim3(1), dim3(1024), 0, stream, z, ldz, y, B, A, grad_scale, (bf16_t*)dz, lddz, Ap, out);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}

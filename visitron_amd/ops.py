@@ -661,6 +661,20 @@ def batch_row_lists(labels, token_labels, mask, B, S, n_w, n_t, n_keep):
     return idx_w, idx_t, lay
 
 
+def action_head(logits, next_action, A, grad_scale, Ap):
+    """logits fp32 [B, >= A], next_action int64 [B] -> (loss 0-d, accuracy 0-d, dlogits bf16 [B, Ap]): the action head's
+    double log-softmax cross entropy with its gradient (encoder.py:142-151, 387-391) in one launch."""
+    _require_hip(logits, next_action)
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and next_action.dtype == torch.int64
+    B = logits.shape[0]
+    dl = torch.empty((B, Ap), dtype=BF16, device=logits.device)
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    rc = _lib.load().vt_action_head_f32(_ptr(logits), logits.stride(0), _ptr(next_action.contiguous()), B, int(A),
+                                        float(grad_scale), _ptr(dl), Ap, int(Ap), _ptr(out), _stream())
+    _lib.check(rc, "vt_action_head_f32")
+    return out[0], out[1], dl
+
+
 def embed_table_grad(ids, de, grad, skip_id=None):
     """grad[ids[i], :] += de[i, :] for every row i (ids int64 [n], de fp32 [n, H], grad fp32 [rows, H]) without atomics: a
     stable sort of the ids, then one workgroup per run of equal ids (bitwise reproducible; rows with id == skip_id add

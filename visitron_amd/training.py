@@ -577,14 +577,11 @@ class PretrainEngine(object):
         la = torch.empty((B, self.Ap), dtype=torch.float32, device=dev)
         ops.linear(pooled_bf, self._mirror(m.next_action.linear.weight), m.next_action.linear.bias.detach(), out=la,
                    out_f32=True)
-        lsm = torch.log_softmax(la[:, :A], dim=-1)
+        dla_bf = None
         if next_action is not None:
-            valid_a = next_action != -1
-            n_valid = valid_a.sum()
-            logp_a = torch.log_softmax(lsm, dim=-1)
-            picked = logp_a.gather(1, next_action.clamp(min=0)[:, None])[:, 0]
-            next_loss = -(picked * valid_a).sum() / n_valid
-            action_acc = (lsm.argmax(1) == next_action).sum().float() / B
+            # LogSoftmax head under a CrossEntropyLoss that applies log_softmax again (encoder.py:142-151, 387-391): loss,
+            # accuracy and d(grad_scale * loss)/d(logits) in one launch
+            next_loss, action_acc, dla_bf = ops.action_head(la, _i64(next_action), A, float(grad_scale), self.Ap)
         else:
             next_loss, action_acc = 0, 0
         loss = mask_loss + next_loss + token_loss
@@ -629,13 +626,6 @@ class PretrainEngine(object):
             self._grad(lin_tok.weight).zero_()
             self._grad(lin_tok.bias).zero_()
         if next_action is not None:
-            da = torch.exp(logp_a)
-            da.scatter_add_(1, next_action.clamp(min=0)[:, None], torch.full((B, 1), -1.0, device=dev))
-            da = da * (valid_a[:, None] * (gs / n_valid))
-            # log_softmax of log-probabilities is the identity map's Jacobian: d lsm -> d logits
-            dla = da - torch.exp(lsm) * da.sum(1, keepdim=True)
-            dla_bf = torch.zeros((B, self.Ap), dtype=BF16, device=dev)
-            dla_bf[:, :A] = dla.to(BF16)
             ops.wgrad([wg(dla_bf[:, :A], pooled_bf, self._grad(m.next_action.linear.weight),
                           self._grad(m.next_action.linear.bias))], B)
             g_pooled = ops.linear(dla_bf, self.head_t["act"], out_f32=True)
