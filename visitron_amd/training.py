@@ -598,14 +598,18 @@ class PretrainEngine(object):
         wg = lambda dy, x, dw, db: dict(dy=dy, x=x, dw=dw, db=db, accumulate=acc)
         dec_w_is_tied = pr.decoder.weight is emb.word_embeddings.weight
         word_grad = self._grad(emb.word_embeddings.weight)
-        if not acc:
-            # gradients that receive scatter-adds start from zero; the rest is overwritten by the kernels
+        # The word table's gradient receives the embedding backward's run sums later on (_trunk_bwd), so it must hold
+        # defined values before that: with a tied decoder and supervised rows the decoder's weight gradient -- the first
+        # thing written into it -- simply overwrites all of it (no 94 MB fill, no read-back by an accumulating launch)
+        dec_overwrites = dec_w_is_tied and Ml > 0 and pr.decoder.weight.shape[0] == emb.word_embeddings.weight.shape[0]
+        if not acc and not dec_overwrites:
             word_grad.zero_()
             if dec_w_is_tied:
                 self._grad(pr.bias).zero_()  # shares the accumulate flag of the tied decoder weight below
         if Ml > 0:
             dec_grad = self._grad(pr.decoder.weight)
-            ops.wgrad([dict(dy=dl[:, :V], x=t2, dw=dec_grad, db=self._grad(pr.bias), accumulate=acc or dec_w_is_tied)], Ml)
+            ops.wgrad([dict(dy=dl[:, :V], x=t2, dw=dec_grad, db=self._grad(pr.bias),
+                            accumulate=acc or (dec_w_is_tied and not dec_overwrites))], Ml)
             g_t2 = ops.linear(dl, self.head_t["dec"])
             g_t1 = ops.layernorm_bwd(t1, g_t2, pr.transform.LayerNorm.weight.detach(), pr.transform.LayerNorm.variance_epsilon,
                                      self._grad(pr.transform.LayerNorm.weight), self._grad(pr.transform.LayerNorm.bias),
