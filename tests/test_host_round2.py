@@ -272,3 +272,37 @@ def test_gelu_polynomial_of_the_epilogues_meets_its_stated_error():
         exact_phi = 0.5 * (1 + erf(x64 / np.sqrt(2)))
         assert np.abs(phi - exact_phi).max() <= 2.6e-5, fn
         assert np.abs(x * phi - x64 * exact_phi).max() <= 1.2e-4, fn
+
+
+def test_keep_word_count_and_layout_gather_indices():
+    """Host-side helpers of round 3: the size of a dropout keep buffer (VT_KEEP_WORDS in include/visitron_hip.h) and the
+    un-compaction indices of a SeqLayout (padded position -> compact row, or the caller's zero row), whole and split into the
+    text / region blocks."""
+    import re
+
+    from visitron_amd import ops
+
+    assert ops.keep_words(2, 12, 228) == 2 * 12 * 8 * 256 and ops.keep_words(1, 1, 32) == 32 and ops.keep_words(1, 1, 33) == 2 * 64
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "visitron_hip.h")).read()
+    assert re.search(r"#define VT_KEEP_WORDS\(B, nh, S\) \(\(int64_t\)\(B\) \* \(nh\) \* \(\(\(S\) \+ 31\) / 32\) \* \(\(\(S\) \+ 31\) / 32 \* 32\)\)", hdr)
+
+    keep = torch.tensor([[1, 1, 1, 0, 1, 0], [1, 0, 0, 1, 1, 1]], dtype=torch.bool)
+    lay = ops.SeqLayout(keep)
+    assert lay.rows == 8 and lay.start.tolist() == [0, 4] and lay.length.tolist() == [4, 4]
+    assert lay.index.tolist() == [0, 1, 2, 4, 6, 9, 10, 11]
+    g = lay.gather_index(8)
+    assert g.tolist() == [0, 1, 2, 8, 3, 8, 4, 8, 8, 5, 6, 7]
+    compact = torch.arange(1, 10, dtype=torch.float32)[:, None].repeat(1, 2)      # rows 1..8 and the zero row
+    compact[8] = 0
+    padded = compact.index_select(0, g)
+    want = torch.zeros(12, 2)
+    want.index_copy_(0, lay.index, compact[:8])
+    assert torch.equal(padded, want)
+    text, reg = lay.gather_index_split(8, 4)
+    assert text.tolist() == [0, 1, 2, 8, 4, 8, 8, 5] and reg.tolist() == [3, 8, 6, 7]
+    # a layout built from ready-made parts carries the same indices
+    lay2 = ops.SeqLayout.from_parts(2, 6, 8, lay.index, lay.inverse, lay.start, lay.length)
+    assert lay2.gather_index(8).tolist() == g.tolist() and lay2.rows == 8
+    # known row count: no synchronising nonzero, same index
+    lay3 = ops.SeqLayout(keep, rows=8)
+    assert torch.equal(lay3.index, lay.index) and torch.equal(lay3.inverse, lay.inverse)
