@@ -947,14 +947,100 @@ __global__ __launch_bounds__(256) void ce_softmax_rows(const float* __restrict__
   }
 }
 
+// The same with the row held in registers (V <= 32 768: 32 x f32x4 per thread of a 256-thread workgroup): the logits are
+// read from HBM ONCE, the maximum is taken without exponentials, exp(z - max) is computed once per element and kept, the
+// gradient is that value times scale / sum (no second exponential, no second read).  Against the two-pass kernel above
+// (one exponential pair per element in the online pass, a third in the gradient pass, the row read twice): 440 -> ~170 us
+// for [4 272, 30 522] at B = 256.
+template <int NV>
+__global__ __launch_bounds__(256) void ce_softmax_rows_reg(const float* __restrict__ z, long ldz, const int64_t* __restrict__ y,
+                                                           float* __restrict__ loss_row, int64_t* __restrict__ amax,
+                                                           bf16_t* __restrict__ dz, long lddz, int V, int Vpad, float scale) {
+  __shared__ float red_a[4], red_b[4];
+  __shared__ int red_i[4];
+  const long row = blockIdx.x;
+  const float* zp = z + row * ldz;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  f32x4 v[NV];
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = tid * 4 + k * 1024;
+    if (c + 4 <= V) v[k] = *(const f32x4*)(zp + c);
+    else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[k][i] = (c + i < V) ? zp[c + i] : -INFINITY;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (v[k][i] > bv) { bv = v[k][i]; bi = tid * 4 + k * 1024 + i; }   // (ascending columns per thread: first maximum)
+  // block argmax (value, then smaller index: torch.argmax's first maximum)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float bv2 = __shfl_xor(bv, o, 64);
+    const int bi2 = __shfl_xor(bi, o, 64);
+    if (bv2 > bv || (bv2 == bv && bi2 < bi)) { bv = bv2; bi = bi2; }
+  }
+  if (lane == 0) { red_a[wave] = bv; red_i[wave] = bi; }
+  __syncthreads();
+  bv = red_a[0]; bi = red_i[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (red_a[w] > bv || (red_a[w] == bv && red_i[w] < bi)) { bv = red_a[w]; bi = red_i[w]; }
+  const float m = bv;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[k][i] = __expf(v[k][i] - m); s += v[k][i]; }   // (-inf columns: 0)
+  s = wave_sum(s);
+  if (lane == 0) red_b[wave] = s;
+  __syncthreads();
+  s = red_b[0] + red_b[1] + red_b[2] + red_b[3];
+  const float lse = m + __logf(s);
+  const int64_t label = y[row];
+  if (tid == 0) {
+    loss_row[row] = lse - zp[label];
+    amax[row] = bi;
+  }
+  if (!dz) return;
+  bf16_t* dp = dz + row * lddz;
+  const float f = scale / s;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = tid * 4 + k * 1024;
+    if (c < Vpad) {
+      float g[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = (c + i < V) ? v[k][i] * f - ((c + i == (int)label) ? scale : 0.f) : 0.f;
+      u32x2 o;
+      o[0] = pack_bf16x2(g[0], g[1]);
+      o[1] = pack_bf16x2(g[2], g[3]);
+      *(u32x2*)(dp + c) = o;
+    }
+  }
+}
+
 int vt_ce_softmax_dispatch(const float* z, long ldz, const int64_t* y, float* loss_row, int64_t* amax, void* dz, long lddz,
                            long rows, int V, int Vpad, float scale, hipStream_t stream) {
   if (!z || !y || !loss_row || !amax) return VT_ERR_NULL;
   if (!dz) { Vpad = (V + 7) / 8 * 8; lddz = Vpad; }   // no gradient row wanted
   if (rows <= 0 || V <= 0 || Vpad < V || (Vpad % 8) || lddz < Vpad) return VT_ERR_BAD_SHAPE;
   if ((ldz % 4) || (lddz % 8) || (((uintptr_t)z | (uintptr_t)dz) & 15)) return VT_ERR_BAD_ALIGN;
-  hipLaunchKernelGGL(ce_softmax_rows, dim3((unsigned)rows), dim3(256), 0, stream, z, ldz, y, loss_row, amax, (bf16_t*)dz, lddz,
-                     V, Vpad, scale);
+  const int need = (Vpad + 1023) / 1024;   // f32x4 per thread
+  if (need <= 8)
+    hipLaunchKernelGGL(ce_softmax_rows_reg<8>, dim3((unsigned)rows), dim3(256), 0, stream, z, ldz, y, loss_row, amax, (bf16_t*)dz,
+                       lddz, V, Vpad, scale);
+  else if (need <= 32)
+    hipLaunchKernelGGL(ce_softmax_rows_reg<32>, dim3((unsigned)rows), dim3(256), 0, stream, z, ldz, y, loss_row, amax, (bf16_t*)dz,
+                       lddz, V, Vpad, scale);
+  else
+    hipLaunchKernelGGL(ce_softmax_rows, dim3((unsigned)rows), dim3(256), 0, stream, z, ldz, y, loss_row, amax, (bf16_t*)dz, lddz,
+                       V, Vpad, scale);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
