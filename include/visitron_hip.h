@@ -184,15 +184,17 @@ int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const in
  * path runs the heads on the supervised rows and the encoder on the rows with a non-zero mask).  counts[5] = {err_flag[0],
  * #(labels != -1), #(token_labels != -1), #(mask != 0), bad}, bad = the batch does not qualify for the compacted layout (a
  * mask value other than 0 / 1, a [CLS] or a supervised position with mask 0).  labels / token_labels / mask / err_flag may
- * each be NULL.  One launch, one 40-byte read-back. */
+ * each be NULL.  counts must be zero on entry; tile_counts = 3 * ceil(B*S / 1024) ints of scratch that vt_batch_row_lists
+ * reads back (one workgroup per tile of 1024 positions).  One launch, one 40-byte read-back. */
 int vt_batch_row_counts(const int64_t* labels, const int64_t* token_labels, const float* mask, const int32_t* err_flag, int B,
-                        int S, int64_t* counts, vt_stream_t stream);
+                        int S, int64_t* counts, int32_t* tile_counts, vt_stream_t stream);
 /* The row lists to the sizes vt_batch_row_counts reported (n_w, n_t, n_keep: nothing is written past them; ascending): idx_w / idx_t = positions with a label / token label;
  * index = positions with a non-zero mask, inverse[position] = its rank among them or -1, start / length [B] = each sequence's
- * first compact row and number of kept rows (needs every position b*S kept).  One launch. */
+ * first compact row and number of kept rows (needs every position b*S kept); tile_counts as vt_batch_row_counts left them
+ * (same labels / token_labels / mask).  Two launches. */
 int vt_batch_row_lists(const int64_t* labels, const int64_t* token_labels, const float* mask, int B, int S, int64_t n_w,
-                       int64_t n_t, int64_t n_keep, int64_t* idx_w, int64_t* idx_t, int64_t* index, int64_t* inverse,
-                       int32_t* start, int32_t* length, vt_stream_t stream);
+                       int64_t n_t, int64_t n_keep, const int32_t* tile_counts, int64_t* idx_w, int64_t* idx_t, int64_t* index,
+                       int64_t* inverse, int32_t* start, int32_t* length, vt_stream_t stream);
 
 /* The action head's loss, accuracy and gradient (NextActionPrediction = Linear + LogSoftmax, encoder.py:142-151, under
  * CrossEntropyLoss(ignore_index=-1), :387-391, which applies log_softmax again): logits fp32 [B, >= A] (A <= 64),

@@ -585,7 +585,7 @@ def test_batch_row_counts_and_lists_equal_the_torch_ops(dev, B, S, case):
     use_labels = case != "nolabels"
     err = torch.tensor([3 if case == "cls" else 0], dtype=torch.int32)
     d = lambda t: t.to(dev)
-    vals = ops.batch_row_counts(d(lab) if use_labels else None, d(tl) if use_labels else None, d(mask), d(err), B, S)
+    vals, tiles = ops.batch_row_counts(d(lab) if use_labels else None, d(tl) if use_labels else None, d(mask), d(err), B, S)
     keep = mask.reshape(-1) != 0
     assert vals[0] == int(err[0])
     assert vals[1] == (int((lab != -1).sum()) if use_labels else 0) and vals[2] == (int((tl != -1).sum()) if use_labels else 0)
@@ -593,7 +593,7 @@ def test_batch_row_counts_and_lists_equal_the_torch_ops(dev, B, S, case):
     if want_bad:
         return
     idx_w, idx_t, lay = ops.batch_row_lists(d(lab) if use_labels else None, d(tl) if use_labels else None, d(mask), B, S,
-                                            vals[1], vals[2], vals[3])
+                                            vals[1], vals[2], vals[3], tiles)
     torch.cuda.synchronize()
     ref = ops.SeqLayout(d(mask != 0))
     if use_labels:
@@ -604,7 +604,7 @@ def test_batch_row_counts_and_lists_equal_the_torch_ops(dev, B, S, case):
     assert torch.equal(lay.start, ref.start) and torch.equal(lay.length, ref.length)
     # without a mask: the lists alone
     if use_labels:
-        iw, it, none = ops.batch_row_lists(d(lab), d(tl), None, B, S, vals[1], vals[2], 0)
+        iw, it, none = ops.batch_row_lists(d(lab), d(tl), None, B, S, vals[1], vals[2], 0, tiles)
         assert none is None and torch.equal(iw, idx_w) and torch.equal(it, idx_t)
 
 

@@ -49,8 +49,8 @@ int vt_assemble_regions_dispatch(const float* img_feats, const int64_t* region_c
 int vt_embed_table_grad_dispatch(const int* sorted_ids, const long* perm, const float* de, long ld_de, float* grad, long ld_grad,
                                  long n, int H, long n_rows_table, long skip_id, hipStream_t stream);
 struct BatchRowsArgs {
-  const long* lab; const long* tl; const float* mask; const int* err; long M; int S; int B; long* counts; long* idx_w; long* idx_t;
-  long* index; long* inverse; int* start; int* length; long n_w, n_t, n_keep;
+  const long* lab; const long* tl; const float* mask; const int* err; long M; int S; int B; long* counts; int* tile_counts;
+  long* idx_w; long* idx_t; long* index; long* inverse; int* start; int* length; long n_w, n_t, n_keep;
 };
 int vt_batch_rows_dispatch(const BatchRowsArgs& a, int lists, hipStream_t stream);
 int vt_action_head_dispatch(const float* z, long ldz, const long* y, int B, int A, float grad_scale, void* dz, long lddz, int Ap,
@@ -132,17 +132,18 @@ const char* vt_error_string(int code) {
 int vt_abi_version(void) { return 6; }
 
 int vt_batch_row_counts(const int64_t* labels, const int64_t* token_labels, const float* mask, const int32_t* err_flag, int B,
-                        int S, int64_t* counts, vt_stream_t stream) {
+                        int S, int64_t* counts, int32_t* tile_counts, vt_stream_t stream) {
   BatchRowsArgs a = {(const long*)labels, (const long*)token_labels, mask, (const int*)err_flag, (long)B * S, S, B, (long*)counts,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+                     (int*)tile_counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
   return vt_batch_rows_dispatch(a, 0, (hipStream_t)stream);
 }
 
 int vt_batch_row_lists(const int64_t* labels, const int64_t* token_labels, const float* mask, int B, int S, int64_t n_w,
-                       int64_t n_t, int64_t n_keep, int64_t* idx_w, int64_t* idx_t, int64_t* index, int64_t* inverse,
-                       int32_t* start, int32_t* length, vt_stream_t stream) {
-  BatchRowsArgs a = {(const long*)labels, (const long*)token_labels, mask, nullptr, (long)B * S, S, B, nullptr, (long*)idx_w,
-                     (long*)idx_t, (long*)index, (long*)inverse, (int*)start, (int*)length, n_w, n_t, n_keep};
+                       int64_t n_t, int64_t n_keep, const int32_t* tile_counts, int64_t* idx_w, int64_t* idx_t, int64_t* index,
+                       int64_t* inverse, int32_t* start, int32_t* length, vt_stream_t stream) {
+  BatchRowsArgs a = {(const long*)labels, (const long*)token_labels, mask, nullptr, (long)B * S, S, B, nullptr,
+                     (int*)tile_counts, (long*)idx_w, (long*)idx_t, (long*)index, (long*)inverse, (int*)start, (int*)length, n_w,
+                     n_t, n_keep};
   return vt_batch_rows_dispatch(a, 1, (hipStream_t)stream);
 }
 

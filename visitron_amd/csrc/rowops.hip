@@ -1195,34 +1195,63 @@ int vt_dropout_mask_dispatch(uint8_t* out, long n, const DropCfg& d, hipStream_t
 // grad[id[i], :] += sum of de[perm[j], :] over the rows j whose id equals id[i], for the sorted id list `sorted_ids`
 // (perm = the stable sort's permutation): the scatter-add of BertEmbeddings' backward (torch: index_add_ = 25 M float
 // atomics for the word table at B = 256, 179 us, and an order of additions that changes from run to run).  One workgroup
-// per sorted position; it works only if its position starts a run of equal ids (and the id is not `skip_id`, the padding
+// (one wave) per sorted position; it works only if its position starts a run of equal ids (and the id is not `skip_id`, the padding
 // index whose rows torch.nn.Embedding leaves without gradient), and then owns that table row: plain loads and stores, the
 // rows of the run added in their original order (bitwise reproducible).  Runs are short (a token id seldom repeats in a
 // batch; [CLS] repeats B times: 4 waves x 64 rows).
 __global__ __launch_bounds__(256) void embed_table_grad_runs(const int* __restrict__ sorted_ids, const long* __restrict__ perm,
                                                              const float* __restrict__ de, long ld_de, float* __restrict__ grad,
                                                              long ld_grad, long n, int H, long n_rows_table, long skip_id) {
-  __shared__ int s_len;
-  const long i = blockIdx.x;
+  // one WAVE per sorted position (four per workgroup: 8 192 workgroups for 32 768 ids instead of 32 768 -- the launch rate
+  // of one-row workgroups was the kernel's time); lane l adds columns 4l .. 4l+3 of every 256-column block
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
   const long id = sorted_ids[i];
-  if (id == skip_id || id < 0 || id >= n_rows_table) return;          // uniform per workgroup
+  if (id == skip_id || id < 0 || id >= n_rows_table) return;          // uniform per wave
   if (i > 0 && sorted_ids[i - 1] == id) return;                       // not the head of its run
-  if (threadIdx.x == 0) {
-    long j = i + 1;
-    while (j < n && sorted_ids[j] == id) ++j;
-    s_len = (int)(j - i);
-  }
-  __syncthreads();
-  const int len = s_len;
+  long len = 1;
+  while (i + len < n && sorted_ids[i + len] == id) ++len;             // (uniform scalar loop; runs are short)
   float* gr = grad + id * ld_grad;
-  for (int c = threadIdx.x * 4; c < H; c += 1024) {
-    f32x4 acc = *(const f32x4*)(gr + c);
-    for (int j = 0; j < len; ++j) {
-      const f32x4 v = *(const f32x4*)(de + perm[i + j] * ld_de + c);
+  for (int c0 = 0; c0 < H; c0 += 768) {                               // three f32x4 per lane and pass
+    f32x4 acc[3];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    for (int k = 0; k < 3; ++k) {
+      const int c = c0 + 256 * k + 4 * lane;
+      acc[k] = c < H ? *(const f32x4*)(gr + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    *(f32x4*)(gr + c) = acc;
+    // the run's rows, 64 permutation entries per vector load and four rows in flight at a time (a run's rows are added in
+    // their original order all the same: the four loads are issued together, the sums taken one after the other)
+    for (long j0 = 0; j0 < len; j0 += 64) {
+      const long left = len - j0 < 64 ? len - j0 : 64;
+      const long pv = lane < left ? perm[i + j0 + lane] : 0;
+      for (int j = 0; j < (int)left; j += 4) {
+        f32x4 v[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool on = j + r < (int)left;
+          const long pr = ((long)__builtin_amdgcn_readlane((int)(pv >> 32), on ? j + r : 0) << 32) |
+                          (unsigned)__builtin_amdgcn_readlane((int)pv, on ? j + r : 0);
+          const float* row = de + pr * ld_de;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int c = c0 + 256 * k + 4 * lane;
+            v[r][k] = (on && c < H) ? *(const f32x4*)(row + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[k][e] += v[r][k][e];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = c0 + 256 * k + 4 * lane;
+      if (c < H) *(f32x4*)(gr + c) = acc[k];
+    }
   }
 }
 
@@ -1231,7 +1260,7 @@ int vt_embed_table_grad_dispatch(const int* sorted_ids, const long* perm, const 
   if (!sorted_ids || !perm || !de || !grad) return VT_ERR_NULL;
   if (n <= 0 || H <= 0 || (H & 3) || n_rows_table <= 0 || n > 0x7fffffffL) return VT_ERR_BAD_SHAPE;
   if ((ld_de & 3) || (ld_grad & 3) || (((uintptr_t)de | (uintptr_t)grad) & 15)) return VT_ERR_BAD_ALIGN;
-  hipLaunchKernelGGL(embed_table_grad_runs, dim3((unsigned)n), dim3(256), 0, stream, sorted_ids, perm, de, ld_de, grad, ld_grad, n,
+  hipLaunchKernelGGL(embed_table_grad_runs, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, sorted_ids, perm, de, ld_de, grad, ld_grad, n,
                      H, n_rows_table, skip_id);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
@@ -1242,101 +1271,112 @@ int vt_embed_table_grad_dispatch(const int* sorted_ids, const long* perm, const 
 // three counts to size those launches.  batch_row_counts reduces them -- with the verdict on the compacted layout (a 0/1
 // mask, every [CLS] and every supervised position kept) and the embedding kernel's out-of-range flag -- into five words the
 // host reads back in one synchronisation; batch_row_lists then writes the row lists (ascending), the padded -> compact
-// map and the per-sequence start / length.  Two launches where torch needed ~25 (sum, any, nonzero, cumsum, where ...).
+// map and the per-sequence start / length.  Three short launches where torch needed ~25 (sum, any, nonzero, cumsum, where ...).
 struct BatchRowsArgs {
   const long* lab; const long* tl;      // [M] or null
   const float* mask;                    // [B*S] fp32 or null (no compaction wanted)
   const int* err;                       // the embedding kernel's flag or null
   long M; int S; int B;
-  long* counts;                         // [5]: err, n_w, n_t, n_keep, bad
+  long* counts;                         // [5]: err, n_w, n_t, n_keep, bad   (zeroed by the caller)
+  int* tile_counts;                     // [ntiles][3]: per 1024-position tile (written by the counts kernel, read by the lists kernel)
   long* idx_w; long* idx_t;             // row lists
   long* index; long* inverse;           // kept rows; padded position -> compact row or -1
   int* start; int* length;              // [B]
   long n_w, n_t, n_keep;                // capacities of the three lists (the counts batch_row_counts reported)
 };
 
+// one workgroup per tile of 1024 positions (one position per thread: coalesced)
 __global__ __launch_bounds__(1024) void batch_row_counts(BatchRowsArgs a) {
-  __shared__ long red[16][4];
+  __shared__ int red[16][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  long nw = 0, nt = 0, nk = 0, bad = 0;
-  for (long i = tid; i < a.M; i += 1024) {
-    const bool w = a.lab && a.lab[i] != -1, t = a.tl && a.tl[i] != -1;
-    bool k = true;
+  const long i = (long)blockIdx.x * 1024 + tid;
+  int w = 0, t = 0, k = 0, bad = 0;
+  if (i < a.M) {
+    w = a.lab && a.lab[i] != -1;
+    t = a.tl && a.tl[i] != -1;
+    k = 1;
     if (a.mask) {
       const float m = a.mask[i];
       k = m != 0.f;
       if ((k && m != 1.f) || ((w || t) && !k) || (!k && (i % a.S) == 0)) bad = 1;
     }
-    nw += w; nt += t; nk += k;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    nw += __shfl_xor(nw, o, 64); nt += __shfl_xor(nt, o, 64); nk += __shfl_xor(nk, o, 64); bad |= __shfl_xor(bad, o, 64);
-  }
-  if (lane == 0) { red[wave][0] = nw; red[wave][1] = nt; red[wave][2] = nk; red[wave][3] = bad; }
+  const int nw = __builtin_popcountll(__builtin_amdgcn_ballot_w64(w != 0)), nt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(t != 0));
+  const int nk = __builtin_popcountll(__builtin_amdgcn_ballot_w64(k != 0)), nb = __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+  if (lane == 0) { red[wave][0] = nw; red[wave][1] = nt; red[wave][2] = nk; red[wave][3] = nb; }
   __syncthreads();
   if (tid == 0) {
-    long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int w = 0; w < 16; ++w) { s0 += red[w][0]; s1 += red[w][1]; s2 += red[w][2]; s3 |= red[w][3]; }
-    a.counts[0] = a.err ? (long)a.err[0] : 0;
-    a.counts[1] = s0; a.counts[2] = s1; a.counts[3] = s2; a.counts[4] = s3;
+    int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int v = 0; v < 16; ++v) { s0 += red[v][0]; s1 += red[v][1]; s2 += red[v][2]; s3 |= red[v][3]; }
+    a.tile_counts[3 * blockIdx.x + 0] = s0; a.tile_counts[3 * blockIdx.x + 1] = s1; a.tile_counts[3 * blockIdx.x + 2] = s2;
+    // (integer atomics: the totals do not depend on the order)
+    if (s0) atomicAdd((unsigned long long*)&a.counts[1], (unsigned long long)s0);
+    if (s1) atomicAdd((unsigned long long*)&a.counts[2], (unsigned long long)s1);
+    if (s2) atomicAdd((unsigned long long*)&a.counts[3], (unsigned long long)s2);
+    if (s3) atomicOr((unsigned long long*)&a.counts[4], 1ull);
+    if (blockIdx.x == 0 && a.err) a.counts[0] = (long)a.err[0];
   }
 }
 
-// blockIdx.x: 0 = labels list, 1 = token-labels list, 2 = kept rows + inverse map + per-sequence start / length
+// grid (ntiles, 3): blockIdx.y 0 = labels list, 1 = token-labels list, 2 = kept rows + inverse map.  A tile's first output
+// slot is the sum of the earlier tiles' counts; inside the tile the slots follow the positions (ballot prefix per wave,
+// the waves' totals through LDS).
 __global__ __launch_bounds__(1024) void batch_row_lists(BatchRowsArgs a) {
   __shared__ int wsum[16];
-  const int which = blockIdx.x;
+  __shared__ long s_base;
+  const int which = blockIdx.y;
   if ((which == 0 && !a.lab) || (which == 1 && !a.tl) || (which == 2 && !a.mask)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long chunk = (a.M + 1023) / 1024;
-  const long i0 = tid * chunk, i1 = (i0 + chunk < a.M) ? i0 + chunk : a.M;
-  auto flag = [&](long i) -> bool {
-    return which == 0 ? a.lab[i] != -1 : (which == 1 ? a.tl[i] != -1 : a.mask[i] != 0.f);
-  };
-  int cnt = 0;
-  for (long i = i0; i < i1; ++i) cnt += flag(i);
-  int incl = cnt;
+  // base: counts of the tiles before this one (<= a few hundred values)
+  long part = 0;
+  for (int t = tid; t < (int)blockIdx.x; t += 1024) part += a.tile_counts[3 * t + which];
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
-  }
-  if (lane == 63) wsum[wave] = incl;
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) wsum[wave] = (int)part;
   __syncthreads();
-  int base = 0, total = 0;
-  for (int w = 0; w < 16; ++w) { if (w < wave) base += wsum[w]; total += wsum[w]; }
-  long pos = base + incl - cnt;
+  if (tid == 0) { long b = 0; for (int v = 0; v < 16; ++v) b += wsum[v]; s_base = b; }
+  __syncthreads();
+  const long base = s_base;
+  const long i = (long)blockIdx.x * 1024 + tid;
+  bool f = false;
+  if (i < a.M) f = which == 0 ? a.lab[i] != -1 : (which == 1 ? a.tl[i] != -1 : a.mask[i] != 0.f);
+  const unsigned long long bal = __builtin_amdgcn_ballot_w64(f);
+  const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+  __syncthreads();                       // (wsum is reused)
+  if (lane == 0) wsum[wave] = __builtin_popcountll(bal);
+  __syncthreads();
+  int wbase = 0;
+  for (int v = 0; v < wave; ++v) wbase += wsum[v];
+  const long pos = base + wbase + before;
   long* out = which == 0 ? a.idx_w : (which == 1 ? a.idx_t : a.index);
   const long cap = which == 0 ? a.n_w : (which == 1 ? a.n_t : a.n_keep);   // (a stale count must not write past a list)
-  for (long i = i0; i < i1; ++i) {
-    const bool f = flag(i);
-    if (f && pos < cap) out[pos] = i;
-    if (which == 2) a.inverse[i] = f ? pos : -1;
-    pos += f;
-  }
-  if (which == 2) {
-    __threadfence_block();
-    __syncthreads();
-    for (int b = tid; b < a.B; b += 1024) {
-      const long s0 = a.inverse[(long)b * a.S];
-      const long s1 = b + 1 < a.B ? a.inverse[(long)(b + 1) * a.S] : (long)total;
-      a.start[b] = (int)s0;
-      a.length[b] = (int)(s1 - s0);
-    }
-  }
+  if (f && pos < cap) out[pos] = i;
+  if (which == 2 && i < a.M) a.inverse[i] = f ? pos : -1;
+}
+
+// per-sequence first compact row and number of kept rows, from the finished inverse map ([CLS] of every sequence kept)
+__global__ __launch_bounds__(256) void batch_seq_starts(BatchRowsArgs a) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const long s0 = a.inverse[(long)b * a.S];
+  const long s1 = b + 1 < a.B ? a.inverse[(long)(b + 1) * a.S] : a.n_keep;
+  a.start[b] = (int)s0;
+  a.length[b] = (int)(s1 - s0);
 }
 
 int vt_batch_rows_dispatch(const BatchRowsArgs& a, int lists, hipStream_t stream) {
   if (a.M <= 0 || a.S <= 0 || a.B <= 0 || (long)a.B * a.S != a.M) return VT_ERR_BAD_SHAPE;
+  if (!a.tile_counts) return VT_ERR_NULL;
+  const unsigned ntiles = (unsigned)((a.M + 1023) / 1024);
   if (!lists) {
     if (!a.counts) return VT_ERR_NULL;
-    hipLaunchKernelGGL(batch_row_counts, dim3(1), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(batch_row_counts, dim3(ntiles), dim3(1024), 0, stream, a);
   } else {
     if ((a.lab && a.n_w > 0 && !a.idx_w) || (a.tl && a.n_t > 0 && !a.idx_t) ||
         (a.mask && ((a.n_keep > 0 && !a.index) || !a.inverse || !a.start || !a.length))) return VT_ERR_NULL;
     if (a.n_w < 0 || a.n_t < 0 || a.n_keep < 0) return VT_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(batch_row_lists, dim3(3), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(batch_row_lists, dim3(ntiles, 3), dim3(1024), 0, stream, a);
+    if (a.mask) hipLaunchKernelGGL(batch_seq_starts, dim3((a.B + 255) / 256), dim3(256), 0, stream, a);
   }
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }

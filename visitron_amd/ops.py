@@ -628,22 +628,25 @@ def embed_layernorm_bwd(ids, type_ids, pos_ids, word, pos, typ, gamma, eps, g, S
 
 
 def batch_row_counts(labels, token_labels, mask, err_flag, B, S):
-    """-> [err, #labels != -1, #token_labels != -1, #mask != 0, bad] as Python ints: the one host synchronisation of a
-    training step (labels / token_labels int64 [B*S] or None, mask fp32 [B,S] or None, err_flag int32 [1] or None)."""
+    """-> ([err, #labels != -1, #token_labels != -1, #mask != 0, bad] as Python ints, per-tile counts for batch_row_lists):
+    the one host synchronisation of a training step (labels / token_labels int64 [B*S] or None, mask fp32 [B,S] or None,
+    err_flag int32 [1] or None)."""
     _require_hip(labels, token_labels, mask, err_flag)
     ref = next(t for t in (labels, token_labels, mask, err_flag) if t is not None)
     for t in (labels, token_labels):
         assert t is None or (t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B * S)
     assert mask is None or (mask.dtype == torch.float32 and mask.is_contiguous() and mask.numel() == B * S)
-    out = torch.empty(5, dtype=torch.int64, device=ref.device)
-    rc = _lib.load().vt_batch_row_counts(_ptr(labels), _ptr(token_labels), _ptr(mask), _ptr(err_flag), B, S, _ptr(out), _stream())
+    out = torch.zeros(5, dtype=torch.int64, device=ref.device)
+    tiles = torch.empty(3 * ((B * S + 1023) // 1024), dtype=torch.int32, device=ref.device)
+    rc = _lib.load().vt_batch_row_counts(_ptr(labels), _ptr(token_labels), _ptr(mask), _ptr(err_flag), B, S, _ptr(out), _ptr(tiles),
+                                         _stream())
     _lib.check(rc, "vt_batch_row_counts")
-    return out.tolist()
+    return out.tolist(), tiles
 
 
-def batch_row_lists(labels, token_labels, mask, B, S, n_w, n_t, n_keep):
-    """The row lists to the counts batch_row_counts reported: (idx_w, idx_t, layout) -- idx_* int64 or None, layout a
-    SeqLayout over the positions with a non-zero mask or None (mask None)."""
+def batch_row_lists(labels, token_labels, mask, B, S, n_w, n_t, n_keep, tiles):
+    """The row lists to the counts batch_row_counts reported (tiles: its second return value, same labels / mask):
+    (idx_w, idx_t, layout) -- idx_* int64 or None, layout a SeqLayout over the positions with a non-zero mask or None."""
     _require_hip(labels, token_labels, mask)
     ref = next(t for t in (labels, token_labels, mask) if t is not None)
     i64 = lambda n: torch.empty(int(n), dtype=torch.int64, device=ref.device)
@@ -655,7 +658,8 @@ def batch_row_lists(labels, token_labels, mask, B, S, n_w, n_t, n_keep):
         start = torch.empty(B, dtype=torch.int32, device=ref.device)
         length = torch.empty(B, dtype=torch.int32, device=ref.device)
     rc = _lib.load().vt_batch_row_lists(_ptr(labels), _ptr(token_labels), _ptr(mask), B, S, int(n_w), int(n_t), int(n_keep),
-                                        _ptr(idx_w), _ptr(idx_t), _ptr(index), _ptr(inverse), _ptr(start), _ptr(length), _stream())
+                                        _ptr(tiles), _ptr(idx_w), _ptr(idx_t), _ptr(index), _ptr(inverse), _ptr(start),
+                                        _ptr(length), _stream())
     _lib.check(rc, "vt_batch_row_lists")
     lay = SeqLayout.from_parts(B, S, n_keep, index, inverse, start, length) if mask is not None else None
     return idx_w, idx_t, lay

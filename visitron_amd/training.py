@@ -440,7 +440,7 @@ class PretrainEngine(object):
         try_compact = (allow_compact and self.compact_rows and mask is not None and mask.dim() == 2 and hs is None
                        and M >= self.compact_min_rows)
         cmask = mask.contiguous() if try_compact else None
-        vals = ops.batch_row_counts(lab, tl, cmask, err, B, S)       # one launch, the step's one host synchronisation
+        vals, tiles = ops.batch_row_counts(lab, tl, cmask, err, B, S)   # one launch, the step's one host synchronisation
         # out-of-range input_ids / position_ids / token_type_ids: the reference's embedding lookup raises IndexError
         # (checked before anything indexes the gradient tables with those ids)
         if vals[0] != 0:
@@ -455,7 +455,7 @@ class PretrainEngine(object):
         compact = try_compact and int(vals[3]) < M and not vals[4]
         lay = None
         if labels is not None or compact:   # one launch: the supervised-row lists and the compacted layout
-            idx_w, idx_t, lay = ops.batch_row_lists(lab, tl, cmask if compact else None, B, S, Ml, Mt, int(vals[3]))
+            idx_w, idx_t, lay = ops.batch_row_lists(lab, tl, cmask if compact else None, B, S, Ml, Mt, int(vals[3]), tiles)
         Mr = M if lay is None else lay.rows
         self.last_rows = Mr
         self.last_layout = lay
