@@ -203,6 +203,13 @@ int vt_batch_row_lists(const int64_t* labels, const int64_t* token_labels, const
 int vt_action_head_f32(const float* logits, int64_t ld, const int64_t* next_action, int B, int A, float grad_scale, void* dlogits,
                        int64_t ldd, int Ap, float* loss_acc, vt_stream_t stream);
 
+/* y[M,N] (bf16) = x[M,K] w[N,K]^T for a LONG reduction and few output tiles (the MLM decoder's dgrad inside loss.backward(),
+ * pretrain.py:191: d(transform output) = d(logits)[Ml, 30528] . W_dec[30528, 768] -- 51 tiles of 256 x 256): the K-steps are
+ * split over ksplit copies of the tile list, each writing an fp32 plane of ws (ksplit * M * N floats), and summed.  No
+ * bias / activation / residual.  K % 64 == 0, N % 4 == 0, 2 <= ksplit <= K / 64. */
+int vt_linear_splitk_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, float* ws, int M, int N,
+                          int K, int ksplit, vt_stream_t stream);
+
 /* The table gradient of an embedding lookup (BertEmbeddings' three nn.Embedding backward passes inside loss.backward(),
  * tasks/viewpoint_select/pretrain.py:191; torch: one float atomic per element and row): grad[id, :] += sum of the rows of
  * `de` that looked `id` up.  The caller passes the ids stably sorted (sorted_ids, int32: a radix sort over half the key bytes)

@@ -634,3 +634,32 @@ def test_action_head_equals_the_double_log_softmax_cross_entropy(dev, B, A, igno
     d = dl.float().cpu()
     assert float(d[:, A:].abs().max()) == 0.0
     assert float((d[:, :A].double() - zz.grad).abs().max()) <= 2.0 ** -8 * float(zz.grad.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(4272, 768, 30528, 5), (300, 768, 4096, 4), (1000, 512, 2048, 3), (257, 264, 640, 10)])
+def test_linear_splitk_equals_the_fp32_product(dev, M, N, K, ks):
+    """The split-K form of the NT GEMM (the MLM decoder's dgrad shape first: 51 output tiles, 477 K-steps over 5 ranges of
+    96 / 96 / 96 / 96 / 93) against the fp32 product of the same bf16 operands; uneven K-ranges, ragged M / N, and a split
+    count equal to the number of K-steps."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dev, BF16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev, BF16)
+    got = ops.linear_splitk(a, w, ks).float()
+    torch.cuda.synchronize()
+    want = a.float() @ w.float().t()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2.0 ** -8 * scale + 1e-6
+    # the plain kernel on the same operands rounds the same fp32 sums (up to the order of the partial sums)
+    plain = ops.linear(a, w).float()
+    assert float((got - plain).abs().max()) <= 2.0 ** -7 * scale
+
+
+def test_splitk_heuristic():
+    from visitron_amd import ops
+
+    assert ops.splitk_for(4272, 768, 30528) == 5          # 51 tiles -> 255 workgroups
+    assert ops.splitk_for(50845, 768, 3072) == 0          # plenty of tiles
+    assert ops.splitk_for(256, 768, 1024) == 0            # short K
+    assert ops.splitk_for(1024, 768, 30528) == 21         # 12 tiles

@@ -62,6 +62,8 @@ SIGNATURES = {
     "vt_batch_row_lists": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vt_action_head_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_float, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "vt_linear_splitk_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
     "vt_embed_table_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int64, c_int64,
                                     c_void_p]),
     "vt_debug_set_gemm_variant": (None, [c_int]),

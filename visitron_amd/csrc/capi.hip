@@ -55,6 +55,8 @@ struct BatchRowsArgs {
 int vt_batch_rows_dispatch(const BatchRowsArgs& a, int lists, hipStream_t stream);
 int vt_action_head_dispatch(const float* z, long ldz, const long* y, int B, int A, float grad_scale, void* dz, long lddz, int Ap,
                             float* out, hipStream_t stream);
+int vt_gemm_splitk_dispatch(const void* A, long lda, const void* W, long ldw, void* C, long ldc, float* ws, int M, int N, int K,
+                            int ksplit, hipStream_t stream);
 int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale,
                                 const float* lse, float* probs, int B, int S, int nh, int head_size, hipStream_t stream);
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
@@ -151,6 +153,11 @@ int vt_action_head_f32(const float* logits, int64_t ld, const int64_t* next_acti
                        int64_t ldd, int Ap, float* loss_acc, vt_stream_t stream) {
   return vt_action_head_dispatch(logits, ld, (const long*)next_action, B, A, grad_scale, dlogits, ldd, Ap, loss_acc,
                                  (hipStream_t)stream);
+}
+
+int vt_linear_splitk_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, float* ws, int M, int N,
+                          int K, int ksplit, vt_stream_t stream) {
+  return vt_gemm_splitk_dispatch(x, ldx, w, ldw, y, ldy, ws, M, N, K, ksplit, (hipStream_t)stream);
 }
 
 int vt_embed_table_grad(const int32_t* sorted_ids, const int64_t* perm, const float* de, int64_t ld_de, float* grad,

@@ -840,7 +840,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   if (drop) g.drop = *drop; else { g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f; }
   g.trace = (unsigned long long*)g_gemm_trace;
   g.ln_mode = 0; g.ln_np = 0; g.ln_rows = 0; g.ln_inv_n = 0.f; g.ln_eps = 0.f; g.ln_stats = nullptr; g.colv = nullptr;
-  g.Rs = nullptr; g.Cs = nullptr; g.stats_out = nullptr; g.ldrs = 0; g.ldcs = 0;
+  g.Rs = nullptr; g.Cs = nullptr; g.stats_out = nullptr; g.ldrs = 0; g.ldcs = 0; g.ksplit = 0; g.c_plane = 0;
   if (g.drop.thresh && (long)M * N >= (1L << 32)) return VT_ERR_UNSUPPORTED;
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
@@ -916,7 +916,53 @@ int vt_gemm_ln_dispatch(const void* A, long lda, const void* W, long ldw, const 
   g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f;
   g.ln_mode = ln_mode; g.ln_np = np; g.ln_rows = (int)stat_rows; g.ln_inv_n = 1.0f / (float)row_len; g.ln_eps = eps;
   g.ln_stats = stats_in; g.colv = colv; g.Rs = (const uint16_t*)Rs; g.Cs = (uint16_t*)Cs; g.stats_out = stats_out; g.ldrs = ldrs; g.ldcs = ldcs;
+  g.ksplit = 0; g.c_plane = 0;
   int variant = g_gemm_variant >= 0 ? g_gemm_variant : vt_gemm_pick_variant(M, N, K, VT_TUNE_KIND(act, 0, 0, 0, ln_mode));
   if (variant != 15 && variant != 16 && (variant < 18 || variant > 23)) variant = 16;   // only the 256x256-tile kernels
   return vt_gemm_ln_launch(g, act, variant, stream);
+}
+
+// ---- split-K: C[M,N] (bf16) = A[M,K] W[N,K]^T for a long K and few output tiles --------------------------------------
+// ksplit copies of the 256x256 tile list of the one-tile-per-workgroup kernel, each over its share of the K-steps, write fp32
+// planes into `ws` (ksplit * M * N floats); splitk_reduce_bf16 sums them.  No bias / activation / residual.
+int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn);
+
+__global__ __launch_bounds__(256) void splitk_reduce_bf16(const float* __restrict__ ws, long plane, int ksplit, bf16_t* __restrict__ C,
+                                                          long ldc, long M, int N) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;   // element index in [M, N] (N % 4 == 0)
+  if (i >= M * N) return;
+  f32x4 acc = *(const f32x4*)(ws + i);
+  for (int s = 1; s < ksplit; ++s) {
+    const f32x4 v = *(const f32x4*)(ws + (long)s * plane + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += v[e];
+  }
+  const long row = i / N;
+  const int col = (int)(i - row * N);
+  u32x2 o;
+  o[0] = pack_bf16x2(acc[0], acc[1]);
+  o[1] = pack_bf16x2(acc[2], acc[3]);
+  *(u32x2*)(C + row * ldc + col) = o;
+}
+
+int vt_gemm_splitk_dispatch(const void* A, long lda, const void* W, long ldw, void* C, long ldc, float* ws, int M, int N, int K,
+                            int ksplit, hipStream_t stream) {
+  if (!A || !W || !C || !ws) return VT_ERR_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 64) || (N % 4) || ksplit < 2 || ksplit > 64 || ksplit > K / 64) return VT_ERR_BAD_SHAPE;
+  if ((lda % 8) || (ldw % 8) || (ldc % 4) || (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)ws) & 15)) return VT_ERR_BAD_ALIGN;
+  GemmArgs g;
+  g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.bias = nullptr; g.R = nullptr; g.C = ws; g.C2 = nullptr;
+  g.lda = lda; g.ldw = ldw; g.ldr = 0; g.ldc = N; g.ldc2 = 0;
+  g.M = M; g.N = N; g.K = K; g.grp_rows = 0; g.grp_stride = 0; g.tiles_m = 0; g.tiles_n = 0;
+  g.trace = nullptr;
+  g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f;
+  g.ln_mode = 0; g.ln_np = 0; g.ln_rows = 0; g.ln_inv_n = 0.f; g.ln_eps = 0.f; g.ln_stats = nullptr; g.colv = nullptr;
+  g.Rs = nullptr; g.Cs = nullptr; g.stats_out = nullptr; g.ldrs = 0; g.ldcs = 0;
+  g.ksplit = ksplit; g.c_plane = (long)M * N;
+  const int rc = vt_gemm_v7_launch(g, ACT_NONE, 1, stream, 8);
+  if (rc) return rc;
+  const long n4 = ((long)M * N + 3) / 4;
+  hipLaunchKernelGGL(splitk_reduce_bf16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, ws, (long)M * N, ksplit,
+                     (bf16_t*)C, ldc, (long)M, N);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }

@@ -37,6 +37,12 @@ struct GemmArgs {
   uint16_t* Cs;              // mode 2: the fp16 stream out (row stride ldcs)
   float* stats_out;          // mode 2: [N / 128][ln_rows][2]
   long ldrs, ldcs;
+  // ---- split-K (one-tile-per-workgroup kernel, fp32 partial planes): workgroup (tile, s) reduces K-steps
+  // [s * kq, min((s + 1) * kq, K / 64)), kq = ceil(K / 64 / ksplit), and writes plane s of C (c_plane elements apart);
+  // a reduce pass sums the planes.  For the shapes whose tile count leaves most of the chip idle and whose K is long:
+  // the MLM decoder's dgrad, [4 272, 30 528] x [30 528, 768] = 51 tiles of 256 x 256 with 477 K-steps each.
+  int ksplit;                // 0 / 1: off
+  long c_plane;
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_MUL = 3 };  // MUL: out = acc * R (R = saved gelu'(pre-activation))

@@ -68,7 +68,7 @@ static int launch_v7(const GemmArgs& g, hipStream_t stream, int mtn) {
 #undef V7_PICK
   else return VT_ERR_UNSUPPORTED;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES) != hipSuccess) return VT_ERR_HIP;
-  hipLaunchKernelGGL(kern, dim3(g7.tiles_m * g7.tiles_n), dim3(256), V7_LDS_BYTES, stream, g7);
+  hipLaunchKernelGGL(kern, dim3(g7.tiles_m * g7.tiles_n * (g7.ksplit > 1 ? g7.ksplit : 1)), dim3(256), V7_LDS_BYTES, stream, g7);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 

@@ -315,7 +315,19 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   const int nwg = gridDim.x;
   const int b = blockIdx.x;
   const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-  const int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  int t_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  // split-K (GemmArgs::ksplit): the grid holds ksplit copies of the tile list, copy s takes its share of the K-steps
+  int ks_k0 = 0, ks_nk = g.K >> 6;
+  if (g.ksplit > 1) {
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int split = t_id / ntile;
+    t_id -= split * ntile;
+    const int kq = ((g.K >> 6) + g.ksplit - 1) / g.ksplit;
+    ks_k0 = split * kq;
+    ks_nk = (g.K >> 6) - ks_k0 < kq ? (g.K >> 6) - ks_k0 : kq;
+    if (ks_nk < 0) ks_nk = 0;
+    g.C = (float*)g.C + (long)split * g.c_plane;
+  }
   const int band_tiles = 8 * g.tiles_n;
   const int band = t_id / band_tiles;
   const int within = t_id - band * band_tiles;
@@ -329,11 +341,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   // lane -> row 8p + (lane>>3), 16-B chunk (lane&7) ^ swz(row), swz(row) = (4*(i&1) + (lane>>4)) & 7.
   const int rows_x = g.M - m0 < TH ? g.M - m0 : TH;
   const int rows_w = g.N - n0 < 256 ? g.N - n0 : 256;
-  const bf16_t* xbase = g.A + (long)m0 * g.lda;
-  const bf16_t* wbase = g.W + (long)n0 * g.ldw;
-  // bytes of the tile's row panel that may be read: full rows except the last one, which holds K elements
-  const unsigned xbytes = (unsigned)(((long)(rows_x - 1) * g.lda + g.K) * 2);
-  const unsigned wbytes = (unsigned)(((long)(rows_w - 1) * g.ldw + g.K) * 2);
+  const bf16_t* xbase = g.A + (long)m0 * g.lda + 64 * ks_k0;
+  const bf16_t* wbase = g.W + (long)n0 * g.ldw + 64 * ks_k0;
+  // bytes of the tile's row panel that may be read: full rows except the last one, which holds this workgroup's K elements
+  const unsigned xbytes = (unsigned)(((long)(rows_x - 1) * g.lda + 64L * ks_nk) * 2);
+  const unsigned wbytes = (unsigned)(((long)(rows_w - 1) * g.ldw + 64L * ks_nk) * 2);
   int vx[2], vw[2];
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
     sx[i] = (wave * 8 + i) * 8 * (int)g.lda * 2;
     sw[i] = (64 * wave + 32 * (i & 1) + 4 * (i >> 1)) * (int)g.ldw * 2;
   }
-  const int nk = g.K >> 6;
+  const int nk = ks_nk;
 
   // ---- fragment addresses: X image row 128*wm + 16*mt + (lane&15), W image row 128*wn + 16*nt + (lane&15);
   // chunk (lane>>4) ^ swz(row) for k-substep 0, the same ^ 4 (address ^ 64) for substep 1

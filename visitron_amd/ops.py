@@ -679,6 +679,32 @@ def action_head(logits, next_action, A, grad_scale, Ap):
     return out[0], out[1], dl
 
 
+def linear_splitk(a, w, ksplit, out=None):
+    """a [M,K] bf16, w [N,K] bf16 -> a w^T [M,N] bf16 with the reduction split over `ksplit` copies of the 256x256 tile list
+    (fp32 partial planes, then a sum): for a long K and so few output tiles that one copy leaves most CUs idle."""
+    _require_hip(a, w, out)
+    assert a.dtype == BF16 and w.dtype == BF16 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    ws = torch.empty(int(ksplit) * M * N, dtype=torch.float32, device=a.device)
+    with _timed("gemm_nt_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
+        rc = _lib.load().vt_linear_splitk_bf16(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), _ptr(ws), M, N,
+                                               K, int(ksplit), _stream())
+    _lib.check(rc, "vt_linear_splitk_bf16")
+    return out
+
+
+def splitk_for(M, N, K, cus=256):
+    """How many K-ranges to give the 256x256 tile list of an [M, N] output so that it covers the chip about once (0: none --
+    enough tiles already, or a short K)."""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles * 2 > cus or K < 64 * 32 or os.environ.get("VT_SPLITK", "1") == "0":
+        return 0
+    return max(2, min(cus // tiles, K // (64 * 8)))
+
+
 def embed_table_grad(ids, de, grad, skip_id=None):
     """grad[ids[i], :] += de[i, :] for every row i (ids int64 [n], de fp32 [n, H], grad fp32 [rows, H]) without atomics: a
     stable sort of the ids, then one workgroup per run of equal ids (bitwise reproducible; rows with id == skip_id add

@@ -610,7 +610,9 @@ class PretrainEngine(object):
             dec_grad = self._grad(pr.decoder.weight)
             ops.wgrad([dict(dy=dl[:, :V], x=t2, dw=dec_grad, db=self._grad(pr.bias),
                             accumulate=acc or (dec_w_is_tied and not dec_overwrites))], Ml)
-            g_t2 = ops.linear(dl, self.head_t["dec"])
+            # d(logits)[Ml, Vp] . W_dec[Vp, H]: 51 output tiles for 477 K-steps -- the K-steps are split over the chip
+            ks = ops.splitk_for(Ml, H, self.Vp)
+            g_t2 = ops.linear_splitk(dl, self.head_t["dec"], ks) if ks else ops.linear(dl, self.head_t["dec"])
             g_t1 = ops.layernorm_bwd(t1, g_t2, pr.transform.LayerNorm.weight.detach(), pr.transform.LayerNorm.variance_epsilon,
                                      self._grad(pr.transform.LayerNorm.weight), self._grad(pr.transform.LayerNorm.bias),
                                      ws=bufs.ws_t["ln_partial"], accumulate=acc)
