@@ -1,7 +1,7 @@
 """A few hundred optimizer steps of the pretrain engine on a small fixed pool of synthetic batches (BASELINE configs[2]
 shape, dropout 0.1, the reference's AdamW + warm-up schedule): the loss must stay finite and come down, the persistent
 weight-gradient kernel must report no timed-out turn, and the eval-mode inference path must see the trained weights.
-Usage: python tools/soak.py [steps] [batch]      (prints one line per 25 steps; exit code 1 on a failed check)"""
+Usage: python tools/soak.py [steps] [batch] [text] [regions]      (prints one line per 25 steps; exit code 1 on a failed check)"""
 import os
 import sys
 import time
@@ -19,12 +19,14 @@ from visitron_amd.training import PretrainEngine  # noqa: E402
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+    R = int(sys.argv[4]) if len(sys.argv) > 4 else 100
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     cfg = BertConfig(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
     model = PreTrainOscar(cfg).to(dev).train()
     eng = PretrainEngine(model, lr=1e-4, warmup_steps=20, t_total=steps + 50)
-    pool = [{k: v.to(dev) for k, v in make_batch(cfg, B, seed=100 + i).items()} for i in range(4)]
+    pool = [{k: v.to(dev) for k, v in make_batch(cfg, B, T, R, seed=100 + i).items()} for i in range(4)]
     model.eval()
     with torch.no_grad():
         before = float(model(**pool[0])[0])
