@@ -215,9 +215,13 @@ int vt_linear_splitk_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw
  * `de` that looked `id` up.  The caller passes the ids stably sorted (sorted_ids, int32: a radix sort over half the key bytes)
  * with the sort's permutation (perm: sorted
  * position -> row of de); every run of equal ids is added by one workgroup in the rows' original order -- no atomics,
- * bitwise reproducible.  Rows whose id equals skip_id (nn.Embedding's padding_idx; -1 = none) contribute nothing. */
+ * bitwise reproducible.  Rows whose id equals skip_id (nn.Embedding's padding_idx; -1 = none) contribute nothing.  A run is
+ * cut at the multiples of 32 of the sorted order: a token repeated thousands of times ([MASK]) is added by many waves into
+ * `scratch` (n * H floats, only the rows of such segments are touched) and joined in segment order by a second launch;
+ * flag: one int of scratch. */
 int vt_embed_table_grad(const int32_t* sorted_ids, const int64_t* perm, const float* de, int64_t ld_de, float* grad,
-                        int64_t ld_grad, int64_t n, int H, int64_t n_rows_table, int64_t skip_id, vt_stream_t stream);
+                        int64_t ld_grad, int64_t n, int H, int64_t n_rows_table, int64_t skip_id, float* scratch, int32_t* flag,
+                        vt_stream_t stream);
 
 /* Fused AdamW over a flat fp32 slab of n parameters (n % 4 == 0), the pytorch-transformers rule of
  * tasks/viewpoint_select/pretrain.py:128-130: m,v moments; p -= step_size * m / (sqrt(v) + eps) with

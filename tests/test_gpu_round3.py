@@ -553,6 +553,57 @@ def test_embed_table_grad_equals_index_add_and_is_reproducible(dev):
     assert float((grad.cpu().double() - want2).abs().max()) <= 1e-5 * float(want2.abs().max())
 
 
+@pytest.mark.parametrize("H", [768, 64])
+def test_embed_table_grad_long_runs_are_cut_into_segments(dev, H):
+    """A token that repeats thousands of times in a batch ([MASK] after oscar_tasks.py's masking): its run is cut at the
+    multiples of 32 of the sorted order, the segments are added by different waves and joined in order.  Runs of 1, 31,
+    32, 33, 64, 65 and 4001 rows, placed so that some start on a boundary and some straddle one; against float64, and
+    against the same order of additions in float32 on the host (bitwise)."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    lens = {5: 1, 9: 31, 12: 32, 13: 33, 20: 64, 21: 65, 103: 4001, 200: 3, 201: 32, 202: 29, 203: 96}
+    ids = torch.cat([torch.full((c,), i) for i, c in lens.items()])
+    ids = ids[torch.randperm(ids.numel(), generator=g)]
+    n, V = ids.numel(), 256
+    de = torch.randn(n, H, generator=g)
+    base = torch.randn(V, H, generator=g)
+    want = base.double().clone().index_add_(0, ids, de.double())
+    # the kernel's order: stable sort, per segment a running float32 sum from zero (from the table row if the run is one
+    # segment), then the segment sums added to the table row in order
+    sid, perm = torch.sort(ids.to(torch.int32), stable=True)
+    emu = base.clone()
+    i = 0
+    while i < n:
+        e = i
+        while e < n and sid[e] == sid[i]:
+            e += 1
+        cuts = [i] + [c for c in range((i // 32 + 1) * 32, e, 32)] + [e]
+        row = emu[int(sid[i])].clone()
+        if len(cuts) == 2:
+            for j in range(i, e):
+                row += de[perm[j]]
+        else:
+            for a0, a1 in zip(cuts[:-1], cuts[1:]):
+                part = torch.zeros(H)
+                for j in range(a0, a1):
+                    part += de[perm[j]]
+                row += part
+        emu[int(sid[i])] = row
+        i = e
+    outs = []
+    for _ in range(2):
+        grad = base.clone().to(dev)
+        ops.embed_table_grad(ids.to(dev), de.to(dev), grad)
+        torch.cuda.synchronize()
+        outs.append(grad.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0].double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert torch.equal(outs[0], emu)
+    untouched = [r for r in range(V) if r not in lens]
+    assert torch.equal(outs[0][untouched], base[untouched])
+
+
 @pytest.mark.parametrize("B,S,case", [(7, 33, "plain"), (256, 228, "plain"), (5, 40, "fraction"), (4, 20, "cls"), (3, 16, "label"),
                                       (2, 700, "nolabels"), (6, 12, "allkept"), (3, 24, "zerolabels")])
 def test_batch_row_counts_and_lists_equal_the_torch_ops(dev, B, S, case):

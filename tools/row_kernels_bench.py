@@ -28,3 +28,8 @@ de = torch.randn(ids.numel(), 768, device=dev)
 grad = torch.zeros(cfg.vocab_size, 768, device=dev)
 print("embed_table_grad (sort + runs): %.1f us" % timed(lambda: ops.embed_table_grad(ids, de, grad, skip_id=0)))
 print("  of which torch.sort(int32, stable): %.1f us" % timed(lambda: torch.sort(ids.to(torch.int32), stable=True)))
+ids_m = ids.clone(); ids_m[torch.randperm(ids.numel(), device=dev)[:4000]] = 103   # [MASK] 4000 times
+print("embed_table_grad, 4000 x [MASK]: %.1f us" % timed(lambda: ops.embed_table_grad(ids_m, de, grad, skip_id=0)))
+pos = (torch.arange(ids.numel(), device=dev) % 128)
+g2 = torch.zeros(512, 768, device=dev)
+print("embed_table_grad, position table (128 runs of %d): %.1f us" % (ids.numel() // 128, timed(lambda: ops.embed_table_grad(pos, de, g2))))

@@ -65,7 +65,7 @@ SIGNATURES = {
     "vt_linear_splitk_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p]),
     "vt_embed_table_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int64, c_int64,
-                                    c_void_p]),
+                                    c_void_p, c_void_p, c_void_p]),
     "vt_debug_set_gemm_variant": (None, [c_int]),
     "vt_debug_set_gemm_trace": (None, [c_void_p]),
     "vt_debug_set_wgrad_kernel": (None, [c_int]),

@@ -47,7 +47,7 @@ int vt_assemble_regions_dispatch(const float* img_feats, const int64_t* region_c
                                  int64_t* labels_out, int64_t* mask_out, int64_t* token_labels_out, int B, int T, int R,
                                  int R_in, int D, hipStream_t stream);
 int vt_embed_table_grad_dispatch(const int* sorted_ids, const long* perm, const float* de, long ld_de, float* grad, long ld_grad,
-                                 long n, int H, long n_rows_table, long skip_id, hipStream_t stream);
+                                 long n, int H, long n_rows_table, long skip_id, float* scratch, int* flag, hipStream_t stream);
 struct BatchRowsArgs {
   const long* lab; const long* tl; const float* mask; const int* err; long M; int S; int B; long* counts; int* tile_counts;
   long* idx_w; long* idx_t; long* index; long* inverse; int* start; int* length; long n_w, n_t, n_keep;
@@ -161,9 +161,10 @@ int vt_linear_splitk_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw
 }
 
 int vt_embed_table_grad(const int32_t* sorted_ids, const int64_t* perm, const float* de, int64_t ld_de, float* grad,
-                        int64_t ld_grad, int64_t n, int H, int64_t n_rows_table, int64_t skip_id, vt_stream_t stream) {
+                        int64_t ld_grad, int64_t n, int H, int64_t n_rows_table, int64_t skip_id, float* scratch, int32_t* flag,
+                        vt_stream_t stream) {
   return vt_embed_table_grad_dispatch((const int*)sorted_ids, (const long*)perm, de, ld_de, grad, ld_grad, n, H, n_rows_table,
-                                      skip_id, (hipStream_t)stream);
+                                      skip_id, scratch, (int*)flag, (hipStream_t)stream);
 }
 
 void vt_debug_set_gemm_variant(int variant) { vt_gemm_set_variant(variant); }

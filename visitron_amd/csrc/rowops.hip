@@ -1194,58 +1194,127 @@ int vt_dropout_mask_dispatch(uint8_t* out, long n, const DropCfg& d, hipStream_t
 // ---- table gradients of an embedding lookup without atomics ------------------------------------------------------
 // grad[id[i], :] += sum of de[perm[j], :] over the rows j whose id equals id[i], for the sorted id list `sorted_ids`
 // (perm = the stable sort's permutation): the scatter-add of BertEmbeddings' backward (torch: index_add_ = 25 M float
-// atomics for the word table at B = 256, 179 us, and an order of additions that changes from run to run).  One workgroup
-// (one wave) per sorted position; it works only if its position starts a run of equal ids (and the id is not `skip_id`, the padding
-// index whose rows torch.nn.Embedding leaves without gradient), and then owns that table row: plain loads and stores, the
-// rows of the run added in their original order (bitwise reproducible).  Runs are short (a token id seldom repeats in a
-// batch; [CLS] repeats B times: 4 waves x 64 rows).
+// atomics for the word table at B = 256, 179 us, and an order of additions that changes from run to run).  No atomics
+// here: a table row is written by one wave, the rows of a run added in their original order (bitwise reproducible); the
+// padding index `skip_id`, whose row torch.nn.Embedding leaves without gradient, is passed over.  Most runs are short (a
+// token id seldom repeats in a batch), [CLS] repeats B times, and [MASK] may repeat thousands of times: hence the segments.
+#define ETG_SEG 32   // rows one wave adds at most: a run of equal ids is cut at the multiples of ETG_SEG of the sorted order
+
+// the rows [i, e) of the sorted order (one id), added in their original order into acc[3] (columns c0 + 256 k + 4 lane):
+// 64 permutation entries per vector load, four rows in flight at a time
+__device__ __forceinline__ void etg_sum_rows(const long* __restrict__ perm, const float* __restrict__ de, long ld_de, long i, long len,
+                                             int c0, int H, int lane, f32x4 (&acc)[3]) {
+  for (long j0 = 0; j0 < len; j0 += 64) {
+    const long left = len - j0 < 64 ? len - j0 : 64;
+    const long pv = lane < left ? perm[i + j0 + lane] : 0;
+    for (int j = 0; j < (int)left; j += 4) {
+      f32x4 v[4][3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool on = j + r < (int)left;
+        const long pr = ((long)__builtin_amdgcn_readlane((int)(pv >> 32), on ? j + r : 0) << 32) |
+                        (unsigned)__builtin_amdgcn_readlane((int)pv, on ? j + r : 0);
+        const float* row = de + pr * ld_de;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int c = c0 + 256 * k + 4 * lane;
+          v[r][k] = (on && c < H) ? *(const f32x4*)(row + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[k][e] += v[r][k][e];
+    }
+  }
+}
+
+// Pass 1, one WAVE per sorted position (four per workgroup).  A position works if it starts a SEGMENT: a run of equal ids, cut
+// at every multiple of ETG_SEG of the sorted order (so that a token repeated thousands of times in a batch -- [MASK] -- is
+// added by many waves, not by one).  A run that is one segment is added straight into its table row (plain loads and
+// stores: the wave owns the row); the segments of a longer run park their sums in `scratch` (row = the segment's first
+// sorted position) for pass 2.
 __global__ __launch_bounds__(256) void embed_table_grad_runs(const int* __restrict__ sorted_ids, const long* __restrict__ perm,
                                                              const float* __restrict__ de, long ld_de, float* __restrict__ grad,
-                                                             long ld_grad, long n, int H, long n_rows_table, long skip_id) {
-  // one WAVE per sorted position (four per workgroup: 8 192 workgroups for 32 768 ids instead of 32 768 -- the launch rate
-  // of one-row workgroups was the kernel's time); lane l adds columns 4l .. 4l+3 of every 256-column block
+                                                             long ld_grad, long n, int H, long n_rows_table, long skip_id,
+                                                             float* __restrict__ scratch, int* __restrict__ any_long) {
   const int lane = threadIdx.x & 63;
   const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const long id = sorted_ids[i];
   if (id == skip_id || id < 0 || id >= n_rows_table) return;          // uniform per wave
-  if (i > 0 && sorted_ids[i - 1] == id) return;                       // not the head of its run
-  long len = 1;
-  while (i + len < n && sorted_ids[i + len] == id) ++len;             // (uniform scalar loop; runs are short)
+  const bool run_head = i == 0 || sorted_ids[i - 1] != id;
+  if (!run_head && (i % ETG_SEG) != 0) return;                        // not the first row of a segment
+  const long bound = (i / ETG_SEG + 1) * ETG_SEG < n ? (i / ETG_SEG + 1) * ETG_SEG : n;
+  long e = i + 1;
+  while (e < bound && sorted_ids[e] == id) ++e;                       // (uniform scalar loop, <= ETG_SEG steps)
+  const bool run_ends = e == n || sorted_ids[e] != id;
+  const bool whole_run = run_head && run_ends;
+  if (!whole_run && lane == 0) *any_long = 1;
+  float* dst = whole_run ? grad + id * ld_grad : scratch + i * (long)H;
+  for (int c0 = 0; c0 < H; c0 += 768) {
+    f32x4 acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = c0 + 256 * k + 4 * lane;
+      acc[k] = (whole_run && c < H) ? *(const f32x4*)(dst + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    etg_sum_rows(perm, de, ld_de, i, e - i, c0, H, lane, acc);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = c0 + 256 * k + 4 * lane;
+      if (c < H) *(f32x4*)(dst + c) = acc[k];
+    }
+  }
+}
+
+// Pass 2 (does nothing unless pass 1 met a run of several segments): the head of such a run adds its segments' sums, in
+// the order of the segments, into the table row.
+__global__ __launch_bounds__(256) void embed_table_grad_join(const int* __restrict__ sorted_ids, float* __restrict__ grad, long ld_grad,
+                                                             long n, int H, long n_rows_table, long skip_id,
+                                                             const float* __restrict__ scratch, const int* __restrict__ any_long) {
+  if (*any_long == 0) return;
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const long id = sorted_ids[i];
+  if (id == skip_id || id < 0 || id >= n_rows_table) return;
+  if (i > 0 && sorted_ids[i - 1] == id) return;                       // not a run head
+  const long b1 = (i / ETG_SEG + 1) * ETG_SEG;                        // the run's second segment would start here
+  if (b1 >= n || sorted_ids[b1] != id) return;                        // one segment: pass 1 added it straight into the table
   float* gr = grad + id * ld_grad;
-  for (int c0 = 0; c0 < H; c0 += 768) {                               // three f32x4 per lane and pass
+  for (int c0 = 0; c0 < H; c0 += 768) {
     f32x4 acc[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int c = c0 + 256 * k + 4 * lane;
       acc[k] = c < H ? *(const f32x4*)(gr + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    // the run's rows, 64 permutation entries per vector load and four rows in flight at a time (a run's rows are added in
-    // their original order all the same: the four loads are issued together, the sums taken one after the other)
-    for (long j0 = 0; j0 < len; j0 += 64) {
-      const long left = len - j0 < 64 ? len - j0 : 64;
-      const long pv = lane < left ? perm[i + j0 + lane] : 0;
-      for (int j = 0; j < (int)left; j += 4) {
-        f32x4 v[4][3];
+    // the first segment starts at i, the others at the multiples of ETG_SEG after it; four sums in flight at a time
+    long sgm = i;
+    while (sgm < n && sorted_ids[sgm] == id) {
+      f32x4 v[4][3];
+      bool on[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool on = j + r < (int)left;
-          const long pr = ((long)__builtin_amdgcn_readlane((int)(pv >> 32), on ? j + r : 0) << 32) |
-                          (unsigned)__builtin_amdgcn_readlane((int)pv, on ? j + r : 0);
-          const float* row = de + pr * ld_de;
+      for (int r = 0; r < 4; ++r) {
+        on[r] = sgm < n && sorted_ids[sgm] == id;
+        const float* src = scratch + (on[r] ? sgm : i) * (long)H;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int c = c0 + 256 * k + 4 * lane;
-            v[r][k] = (on && c < H) ? *(const f32x4*)(row + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
+        for (int k = 0; k < 3; ++k) {
+          const int c = c0 + 256 * k + 4 * lane;
+          v[r][k] = (on[r] && c < H) ? *(const f32x4*)(src + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        if (on[r]) sgm = (sgm / ETG_SEG + 1) * ETG_SEG;
+      }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
+        if (on[r])
 #pragma unroll
           for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[k][e] += v[r][k][e];
-      }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1256,12 +1325,16 @@ __global__ __launch_bounds__(256) void embed_table_grad_runs(const int* __restri
 }
 
 int vt_embed_table_grad_dispatch(const int* sorted_ids, const long* perm, const float* de, long ld_de, float* grad, long ld_grad,
-                                 long n, int H, long n_rows_table, long skip_id, hipStream_t stream) {
-  if (!sorted_ids || !perm || !de || !grad) return VT_ERR_NULL;
+                                 long n, int H, long n_rows_table, long skip_id, float* scratch, int* flag, hipStream_t stream) {
+  if (!sorted_ids || !perm || !de || !grad || !scratch || !flag) return VT_ERR_NULL;
   if (n <= 0 || H <= 0 || (H & 3) || n_rows_table <= 0 || n > 0x7fffffffL) return VT_ERR_BAD_SHAPE;
-  if ((ld_de & 3) || (ld_grad & 3) || (((uintptr_t)de | (uintptr_t)grad) & 15)) return VT_ERR_BAD_ALIGN;
-  hipLaunchKernelGGL(embed_table_grad_runs, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, sorted_ids, perm, de, ld_de, grad, ld_grad, n,
-                     H, n_rows_table, skip_id);
+  if ((ld_de & 3) || (ld_grad & 3) || (((uintptr_t)de | (uintptr_t)grad | (uintptr_t)scratch) & 15)) return VT_ERR_BAD_ALIGN;
+  if (hipMemsetAsync(flag, 0, sizeof(int), stream) != hipSuccess) return VT_ERR_HIP;
+  const unsigned nwg = (unsigned)((n + 3) / 4);
+  hipLaunchKernelGGL(embed_table_grad_runs, dim3(nwg), dim3(256), 0, stream, sorted_ids, perm, de, ld_de, grad, ld_grad, n, H,
+                     n_rows_table, skip_id, scratch, flag);
+  hipLaunchKernelGGL(embed_table_grad_join, dim3(nwg), dim3(256), 0, stream, sorted_ids, grad, ld_grad, n, H, n_rows_table, skip_id,
+                     scratch, flag);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 

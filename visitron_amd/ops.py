@@ -713,9 +713,12 @@ def embed_table_grad(ids, de, grad, skip_id=None):
     assert ids.dtype == torch.int64 and de.dtype == torch.float32 and grad.dtype == torch.float32
     assert de.stride(1) == 1 and grad.stride(1) == 1 and ids.numel() == de.shape[0] and de.shape[1] == grad.shape[1]
     sorted_ids, perm = torch.sort(ids.reshape(-1).to(torch.int32), stable=True)   # (table rows < 2^31)
+    # partial sums of the runs that span several 32-row segments (rows of such segments only are touched), and one flag
+    scratch = torch.empty((ids.numel(), de.shape[1]), dtype=torch.float32, device=de.device)
+    flag = torch.empty(1, dtype=torch.int32, device=de.device)
     rc = _lib.load().vt_embed_table_grad(_ptr(sorted_ids), _ptr(perm), _ptr(de), de.stride(0), _ptr(grad), grad.stride(0),
                                          ids.numel(), de.shape[1], grad.shape[0], -1 if skip_id is None else int(skip_id),
-                                         _stream())
+                                         _ptr(scratch), _ptr(flag), _stream())
     _lib.check(rc, "vt_embed_table_grad")
     return grad
 
