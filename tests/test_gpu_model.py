@@ -3,6 +3,7 @@ and weights.  Tolerance from BASELINE.json north_star: 5e-2 for the bf16 path.""
 import pytest
 import torch
 
+import visitron_amd
 from helpers import check_close, maxabs, model_pair
 
 pytestmark = pytest.mark.gpu
@@ -86,8 +87,11 @@ def test_trunk_defaults_and_errors(dev):
     assert torch.equal(a[0], b[0])
     with pytest.raises(NotImplementedError):
         prod(ids, attention_mask=torch.ones(2, 1, 1, 8, device=dev))  # rank not in {2,3}: encoder.py:230-231
-    with pytest.raises(IndexError):
+    with pytest.raises(IndexError):   # reported like a GPU nn.Embedding's device-side assert: asynchronously
         prod(torch.full((2, 8), cfg.vocab_size + 1, device=dev))
+        visitron_amd.check_errors()
+    prod(ids)                          # the flag was consumed: the module is usable afterwards
+    visitron_amd.check_errors()
     with pytest.raises(RuntimeError):
         prod(ids.cpu())  # no CPU fallback
 
