@@ -283,15 +283,21 @@ def test_embed_layernorm_matches_fp32(dev):
     assert int(err.item()) == 1
 
 
-def test_pack_concat(dev):
+@pytest.mark.parametrize("d0,d1,kpad,shift", [(2054, 128, 2240, 0), (2054, 128, 2240, 1), (2053, 128, 2240, 0), (2054, 127, 2240, 0),
+                                              (40, 0, 40, 0), (6, 2, 8, 0)])
+def test_pack_concat(dev, d0, d1, kpad, shift):
+    """[src0 | src1 | zeros] -> bf16 (the region features next to their location embedding, encoder.py:277-279): even widths
+    on 8-byte bases take the float2 reads, odd widths and a base that is only 4-byte aligned (shift) the element-wise path."""
     from visitron_amd import ops
 
     g = torch.Generator().manual_seed(4)
-    a, b = _rand((11, 2054), g), _rand((11, 128), g)
-    got = ops.pack_concat(a.to(dev), b.to(dev), 2240).float().cpu()
-    assert torch.equal(got[:, :2054], bf16_round(a))
-    assert torch.equal(got[:, 2054:2182], bf16_round(b))
-    assert float(got[:, 2182:].abs().max()) == 0.0
+    rows = 11
+    a, b = _rand((rows, d0), g), _rand((rows, max(d1, 1)), g)[:, :d1]
+    a_dev = torch.empty(rows * d0 + shift, device=dev)[shift:].view(rows, d0).copy_(a)
+    got = ops.pack_concat(a_dev, b.contiguous().to(dev), kpad).float().cpu()
+    assert torch.equal(got[:, :d0], bf16_round(a))
+    assert torch.equal(got[:, d0:d0 + d1], bf16_round(b))
+    assert got.shape[1] == kpad and (kpad == d0 + d1 or float(got[:, d0 + d1:].abs().max()) == 0.0)
 
 
 @pytest.mark.parametrize("M", [456, 64, 1000, 14592])

@@ -246,7 +246,10 @@ int vt_embed_layernorm_dispatch(const int64_t* ids, const int64_t* type_ids, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// out[row, :] = bf16([src0[row, 0:d0] | src1[row, 0:d1] | zeros up to kpad]); 8 columns per thread.
+// out[row, :] = bf16([src0[row, 0:d0] | src1[row, 0:d1] | zeros up to kpad]); 8 columns per thread.  A group that lies
+// inside one source reads it as four float2 (d0 = 2054: the rows of the region features are 8-byte, not 16-byte, aligned);
+// only the group that straddles the seam (and any source with an odd width) takes the element-wise path.
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void pack_concat_bf16(const float* __restrict__ s0, int d0, const float* __restrict__ s1,
                                                         int d1, bf16_t* __restrict__ out, int kpad, long rows) {
   const int cpr = kpad >> 3;  // 8-column groups per row
@@ -255,13 +258,27 @@ __global__ __launch_bounds__(256) void pack_concat_bf16(const float* __restrict_
   const long row = gid / cpr;
   const int col = (int)(gid - row * cpr) * 8;
   float v[8];
+  const float* src = nullptr;
+  if (PAIRS) {
+    if (col + 8 <= d0) src = s0 + row * d0 + col;
+    else if (col >= d0 && col + 8 <= d0 + d1) src = s1 + row * d1 + (col - d0);
+  }
+  if (src) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = col + i;
-    float x = 0.f;
-    if (c < d0) x = s0[row * d0 + c];
-    else if (c < d0 + d1) x = s1[row * d1 + (c - d0)];
-    v[i] = x;
+    for (int i = 0; i < 4; ++i) {
+      const float2 t = *(const float2*)(src + 2 * i);
+      v[2 * i] = t.x;
+      v[2 * i + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = col + i;
+      float x = 0.f;
+      if (c < d0) x = s0[row * d0 + c];
+      else if (c < d0 + d1) x = s1[row * d1 + (c - d0)];
+      v[i] = x;
+    }
   }
   u32x4 w;
 #pragma unroll
@@ -275,8 +292,12 @@ int vt_pack_concat_dispatch(const float* s0, int d0, const float* s1, int d1, vo
   if (rows <= 0 || d0 <= 0 || d1 < 0 || kpad < d0 + d1 || (kpad % 8)) return VT_ERR_BAD_SHAPE;
   if (((uintptr_t)out) & 15) return VT_ERR_BAD_ALIGN;
   const long n = rows * (kpad >> 3);
-  hipLaunchKernelGGL(pack_concat_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s0, d0, s1, d1,
-                     (bf16_t*)out, kpad, rows);
+  // float2 reads need even widths (every row and the seam then start on 8 bytes) and 8-byte aligned bases
+  const bool pairs = !(d0 & 1) && !(d1 & 1) && !(((uintptr_t)s0 | (uintptr_t)s1) & 7);
+  if (pairs) hipLaunchKernelGGL(pack_concat_bf16<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s0, d0, s1, d1,
+                                (bf16_t*)out, kpad, rows);
+  else hipLaunchKernelGGL(pack_concat_bf16<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s0, d0, s1, d1,
+                          (bf16_t*)out, kpad, rows);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
