@@ -385,6 +385,13 @@ int vt_transpose_batch_bf16(const void* const* in, const int64_t* ldi, void* con
 int vt_pack_concat_bf16(const float* s0, int d0, const float* s1, int d1, void* out, int kpad,
                         int64_t rows, vt_stream_t stream);
 
+/* The per-key attention mask [B, S] as the attention kernels take it: out = float(mask) - rowmax(float(mask)) + 1, fp32
+ * contiguous.  (1 - m) * -10000 (encoder.py:238-241) then differs by one constant per sequence, which the softmax over the
+ * keys does not see (oscar/modeling_bert.py:55-58); a 0/1 mask with a kept key is unchanged bit for bit, the rollout
+ * caller's inverted uint8 mask (254 / 255, agent_models.py:267) becomes 0 / 1.  kind: 0 float32, 1 int64, 2 int32,
+ * 3 one byte (bool / uint8); ldm = row pitch of mask in elements. */
+int vt_center_mask(const void* mask, int kind, int64_t ldm, float* out, int B, int S, vt_stream_t stream);
+
 /* Weight (and bias) gradients of nn.Linear layers -- the wgrad half of loss.backward()
  * (tasks/viewpoint_select/pretrain.py:191):  dW[N,K] (+)= dY[M,N]^T . X[M,K],  db[N] (+)= colsum(dY).
  * dY, X bf16 row-major over the same M token rows; dW, db fp32.  Up to 8 problems sharing M are

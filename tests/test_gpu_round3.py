@@ -714,3 +714,29 @@ def test_splitk_heuristic():
     assert ops.splitk_for(50845, 768, 3072) == 0          # plenty of tiles
     assert ops.splitk_for(256, 768, 1024) == 0            # short K
     assert ops.splitk_for(1024, 768, 30528) == 21         # 12 tiles
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.int64, torch.int32, torch.bool, torch.uint8, torch.float16])
+def test_center_mask_equals_the_torch_expression(dev, dtype):
+    """The per-key mask as the attention kernels take it (m - rowmax(m) + 1 in fp32, encoder.py:238-241 up to one constant
+    per sequence) in ONE launch from the dtypes callers pass, against the torch expression it replaces -- bitwise; with the
+    rollout caller's inverted uint8 mask (254 / 255, agent_models.py:267), a row pitch, and rows without any kept key."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    B, S = 9, 228
+    m = (torch.rand(B, S, generator=g) < 0.8)
+    m[3] = False                                            # nothing kept: max 0 -> all ones
+    if dtype == torch.uint8:
+        m = ~m.to(torch.uint8)                              # 254 / 255
+    elif dtype in (torch.float32, torch.float16):
+        m = m.to(dtype) * 0.5 + torch.rand(B, S, generator=g).to(dtype) * (dtype == torch.float32)
+    else:
+        m = m.to(dtype)
+    wide = torch.zeros(B, S + 12, dtype=m.dtype)
+    wide[:, :S] = m
+    for src in (m.to(dev), wide.to(dev)[:, :S]):            # contiguous, and a view with a row pitch
+        got = ops.center_mask(src)
+        f = src.to(torch.float32)
+        want = f - f.amax(dim=1, keepdim=True) + 1.0
+        assert got.dtype == torch.float32 and got.is_contiguous() and torch.equal(got, want)

@@ -58,6 +58,7 @@ class WgradProblem(ctypes.Structure):  # vt_wgrad_problem
 SIGNATURES = {
     "vt_error_string": (ctypes.c_char_p, [c_int]),
     "vt_abi_version": (c_int, []),
+    "vt_center_mask": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_void_p]),
     "vt_batch_row_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vt_batch_row_lists": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -46,6 +46,7 @@ int vt_assemble_regions_dispatch(const float* img_feats, const int64_t* region_c
                                  const int64_t* text_mask, const int64_t* text_token_classes, float* feats_out, float* loc_out,
                                  int64_t* labels_out, int64_t* mask_out, int64_t* token_labels_out, int B, int T, int R,
                                  int R_in, int D, hipStream_t stream);
+int vt_center_mask_dispatch(const void* mask, int kind, long ldm, float* out, int B, int S, hipStream_t stream);
 int vt_embed_table_grad_dispatch(const int* sorted_ids, const long* perm, const float* de, long ld_de, float* grad, long ld_grad,
                                  long n, int H, long n_rows_table, long skip_id, float* scratch, int* flag, hipStream_t stream);
 struct BatchRowsArgs {
@@ -131,7 +132,7 @@ const char* vt_error_string(int code) {
   }
 }
 
-int vt_abi_version(void) { return 6; }
+int vt_abi_version(void) { return 7; }
 
 int vt_batch_row_counts(const int64_t* labels, const int64_t* token_labels, const float* mask, const int32_t* err_flag, int B,
                         int S, int64_t* counts, int32_t* tile_counts, vt_stream_t stream) {
@@ -511,6 +512,10 @@ int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_
 int vt_pack_concat_bf16(const float* s0, int d0, const float* s1, int d1, void* out, int kpad, int64_t rows,
                         vt_stream_t stream) {
   return vt_pack_concat_dispatch(s0, d0, s1, d1, out, kpad, rows, (hipStream_t)stream);
+}
+
+int vt_center_mask(const void* mask, int kind, int64_t ldm, float* out, int B, int S, vt_stream_t stream) {
+  return vt_center_mask_dispatch(mask, kind, ldm, out, B, S, (hipStream_t)stream);
 }
 
 // ---- fp32 parity path (fp32_path.hip) ----------------------------------------------------------------------------

@@ -1359,6 +1359,37 @@ int vt_embed_table_grad_dispatch(const int* sorted_ids, const long* perm, const 
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
+// ---- the per-key attention mask as the kernels take it ---------------------------------------------------------------
+// out[b, :] = float(mask[b, :]) - max_s float(mask[b, s]) + 1 (modeling._centered_mask: one constant per sequence off the
+// additive bias (1 - m) * -10000 of encoder.py:238-241, a bitwise no-op for a 0/1 mask with a kept key), from the dtypes
+// callers pass (float32, int64, int32, one-byte bool / uint8): one launch where torch took a cast, amax, sub and add.
+template <typename T>
+__global__ __launch_bounds__(256) void center_mask_rows(const T* __restrict__ m, long ldm, float* __restrict__ out, int S) {
+  __shared__ float red[4];
+  const T* row = m + (long)blockIdx.x * ldm;
+  float mx = -INFINITY;
+  for (int s = threadIdx.x; s < S; s += 256) mx = fmaxf(mx, (float)row[s]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  for (int s = threadIdx.x; s < S; s += 256) out[(long)blockIdx.x * S + s] = ((float)row[s] - mx) + 1.0f;
+}
+
+// kind: 0 float32, 1 int64, 2 int32, 3 one byte (bool / uint8)
+int vt_center_mask_dispatch(const void* mask, int kind, long ldm, float* out, int B, int S, hipStream_t stream) {
+  if (!mask || !out) return VT_ERR_NULL;
+  if (B <= 0 || S <= 0 || ldm < S) return VT_ERR_BAD_SHAPE;
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(center_mask_rows<float>, dim3(B), dim3(256), 0, stream, (const float*)mask, ldm, out, S); break;
+    case 1: hipLaunchKernelGGL(center_mask_rows<long>, dim3(B), dim3(256), 0, stream, (const long*)mask, ldm, out, S); break;
+    case 2: hipLaunchKernelGGL(center_mask_rows<int>, dim3(B), dim3(256), 0, stream, (const int*)mask, ldm, out, S); break;
+    case 3: hipLaunchKernelGGL(center_mask_rows<unsigned char>, dim3(B), dim3(256), 0, stream, (const unsigned char*)mask, ldm, out, S); break;
+    default: return VT_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
 // ---- what the host must know about a training batch, and its row lists -------------------------------------------
 // The pretrain step runs its heads on the supervised rows only (labels != -1, token_labels != -1: encoder.py:377-385,
 // CrossEntropyLoss(ignore_index=-1)) and its encoder on the rows with a non-zero attention mask only; the host needs the

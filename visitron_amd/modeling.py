@@ -354,7 +354,7 @@ def _refuse_data_parallel_replica(module):
                                   "(DistributedDataParallel, or PretrainEngine with torch.distributed)")
 
 
-def _centered_mask(mask_f32):
+def _centered_mask(mask_f32):   # (any dtype ops.center_mask takes; fp32 out)
     """A per-key mask [B, S] shifted so that each sequence's largest value is 1: (1 - m) * -10000 then changes by one
     constant per sequence, which a softmax over the keys does not see (encoder.py:238-241; oscar/modeling_bert.py:55-58).
     A 0/1 mask with a kept key is unchanged bit for bit.  What it is for: the rollout caller's `~mask` of a uint8 tensor
@@ -362,7 +362,7 @@ def _centered_mask(mask_f32):
     own softmax is then computed on scores rounded to that grid, and a log-sum-exp of that size cannot carry the backward's
     recomputation.  Shifted, the same mask is 0 / 1 and every kernel sees well-scaled numbers.  bf16 paths only: the fp32
     parity path keeps the literal arithmetic and reproduces the reference's rounded scores (tests/test_gpu_fp32.py)."""
-    return (mask_f32 - mask_f32.amax(dim=1, keepdim=True) + 1.0).contiguous()
+    return ops.center_mask(mask_f32)   # (mask - mask.amax(1, keepdim) + 1 in fp32, from the caller's dtype, one launch)
 
 
 def _additive_mask_2d(attention_mask, B, S):
@@ -989,9 +989,10 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                     raise RuntimeError(
                         "attention_mask shape %s does not match [batch, history+text+region] = [%d, %d]"
                         % (tuple(attention_mask.shape), B, Sh + S))
-                mask_f32 = attention_mask.to(device=dev, dtype=torch.float32).contiguous()
-                if not _is_fp32(self):   # (the fp32 path adds the literal bias in fp32 like the reference, rounding and all)
-                    mask_f32 = _centered_mask(mask_f32)
+                if _is_fp32(self):   # (the fp32 path adds the literal bias in fp32 like the reference, rounding and all)
+                    mask_f32 = attention_mask.to(device=dev, dtype=torch.float32).contiguous()
+                else:
+                    mask_f32 = _centered_mask(attention_mask.to(device=dev))
             elif attention_mask.dim() == 3:   # encoder.py:228-229 + :238-241: per-query mask -> additive bias [B,S,S]
                 if attention_mask.shape != (B, S, S):
                     raise RuntimeError("3-D attention_mask shape %s does not match [%d, %d, %d]"

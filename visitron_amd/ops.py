@@ -539,6 +539,25 @@ def embed_layernorm(ids, type_ids, pos_ids, word, pos, typ, gamma, beta, eps, ou
     return out
 
 
+_MASK_KINDS = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.bool: 3, torch.uint8: 3}
+
+
+def center_mask(mask):
+    """fp32 [B, S] = mask - rowmax(mask) + 1 for a per-key attention mask of any of the dtypes callers pass (one launch;
+    other dtypes are cast to fp32 first).  See modeling._centered_mask for what the shift is for."""
+    _require_hip(mask)
+    assert mask.dim() == 2
+    if mask.dtype not in _MASK_KINDS:
+        mask = mask.to(torch.float32)
+    if mask.stride(1) != 1:
+        mask = mask.contiguous()
+    B, S = mask.shape
+    out = torch.empty((B, S), dtype=torch.float32, device=mask.device)
+    rc = _lib.load().vt_center_mask(_ptr(mask), _MASK_KINDS[mask.dtype], mask.stride(0), _ptr(out), B, S, _stream())
+    _lib.check(rc, "vt_center_mask")
+    return out
+
+
 def pack_concat(s0, s1, kpad, out=None):
     """bf16([s0 | s1 | 0-pad]) row-wise; s0 [rows,d0], s1 [rows,d1] fp32 contiguous."""
     _require_hip(s0, s1, out)
