@@ -123,7 +123,8 @@ __device__ __forceinline__ void gelu_erf_both4(f32x4 x, f32x4& g, f32x4& dg) {
 }
 // erf-GELU without transcendentals, four elements at a time, for the bf16 epilogues of the INFERENCE path (the training
 // forward keeps gelu_erf_both4: a polynomial form with the derivative measured no faster there -- 314-320 us either way at
-// M = 51 200: that epilogue waits on its second store stream, not on the VALU; the fp32 path keeps gelu_erf).  Phi(x) = 0.5 + xc P(xc^2) with
+// M = 51 200: Phi and x phi(x) as two polynomials are as many issue slots as the reciprocal and the exponential both results
+// share; the fp32 path keeps gelu_erf).  Phi(x) = 0.5 + xc P(xc^2) with
 // xc = x clamped to +-4.5 and P a degree-8 minimax fit of (Phi(x) - 0.5) / x over |x| <= 4.5 (weighted for the absolute
 // error of Phi); evaluated in fp32 by Horner: |Phi - exact| <= 2.6e-5, |gelu - exact| <= 1.2e-4 over all x (checked on a
 // 2e6-point grid over [-9, 9]; the rounding of the result to bf16 is 2e-3 relative).  Packed fma / mul on pairs of
