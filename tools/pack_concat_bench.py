@@ -1,5 +1,6 @@
-import sys, torch
-sys.path.insert(0, "/root/repo")
+"""Times vt_pack_concat_bf16 at the region-projection shapes (B x 100 rows of 2054 + 128 floats -> 2240 bf16)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visitron_amd import ops
 dev = torch.device("cuda:0")
 for B in (64, 256):
