@@ -270,6 +270,37 @@ def test_gradients_match_oracle_long_sequence(dev):
     _check_grads("mini S=300 train", prod, {n: p.grad for n, p in ref.named_parameters()})
 
 
+def test_gradients_with_a_token_repeated_hundreds_of_times(dev):
+    """A real pretrain batch repeats [MASK] thousands of times (data_loader_pretrain.py:549-613 replaces 80 % of the masked
+    positions by one id): the word-table gradient of that id is a run of several 32-row segments in the sorted order (the
+    two-pass path of vt_embed_table_grad), the position table's runs are B rows each.  Every gradient against the
+    oracle's autograd, and the table rows of the repeated ids one by one."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config()
+    ref, prod, eng = _engine_pair(cfg, 17, dev)
+    b = make_batch(cfg, 8, text_len=64, region_len=10, seed=21)
+    g = torch.Generator().manual_seed(2)
+    ids = b["input_ids"]
+    real = ids != 0
+    hit = (torch.rand(ids.shape, generator=g) < 0.7) & real
+    hit[:, 0] = False                                      # [CLS] stays: a second, shorter run (8 rows)
+    ids[hit] = 7                                           # "[MASK]": ~300 rows of one id
+    ids[0, 1:34][real[0, 1:34]] = 9                        # a run of ~33: one full segment and a bit
+    assert int((ids == 7).sum()) > 200
+    want = ref(**b)
+    want[0].backward()
+    got = eng.forward_backward({k: v.to(dev) for k, v in b.items()})
+    torch.cuda.synchronize()
+    _check_losses("mini repeated-token train", got, want)
+    _check_grads("mini repeated-token train", prod, {n: p.grad for n, p in ref.named_parameters()})
+    w = ref.bert.embeddings.word_embeddings.weight.grad
+    gq = prod.bert.embeddings.word_embeddings.weight.grad.cpu()
+    for tok in (7, 9, int(ids[0, 0])):
+        assert _rel(gq[tok], w[tok]) < GRAD_TOL, tok
+
+
 def _dropout_cfg(p_h, p_a):
     from visitron_amd.config import mini_config
 
