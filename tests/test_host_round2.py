@@ -122,14 +122,17 @@ def test_data_parallel_gradient_ranges_are_aligned_and_tile_the_slab():
 
 
 def test_centered_mask_is_the_same_softmax_and_a_noop_for_plain_masks():
-    """modeling._centered_mask (the per-key mask shifted by one constant per sequence): bit-identical for 0/1 masks with a
-    kept key, 254/255 (the rollout's ~uint8 mask, agent_models.py:267) becomes 0/1, and the oracle trunk evaluated in float64
-    gives the same output for the raw and the centred mask."""
-    import copy
-
+    """The per-key mask shifted by one constant per sequence, m - rowmax(m) + 1 (modeling._centered_mask; since round 3 one
+    HIP launch, vt_center_mask, held bitwise to this expression by tests/test_gpu_round3.py::
+    test_center_mask_equals_the_torch_expression): bit-identical for 0/1 masks with a kept key, 254/255 (the rollout's ~uint8
+    mask, agent_models.py:267) becomes 0/1, and the oracle trunk evaluated in float64 gives the same output for the raw and
+    the centred mask."""
     from oracle.modeling import BertImgModelwithLocationEmbeds as OTrunk
     from visitron_amd.config import mini_config
-    from visitron_amd.modeling import _centered_mask
+
+    def _centered_mask(m):
+        m = m.to(torch.float32)
+        return m - m.amax(dim=1, keepdim=True) + 1.0
 
     m = torch.tensor([[1, 1, 1, 0, 0], [1, 0, 1, 1, 1]], dtype=torch.float32)
     assert torch.equal(_centered_mask(m), m)
