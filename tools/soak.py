@@ -27,6 +27,14 @@ def main():
     model = PreTrainOscar(cfg).to(dev).train()
     eng = PretrainEngine(model, lr=1e-4, warmup_steps=20, t_total=steps + 50)
     pool = [{k: v.to(dev) for k, v in make_batch(cfg, B, T, R, seed=100 + i).items()} for i in range(4)]
+    # as the reference's loader leaves them (data_loader_pretrain.py:549-613): 80 % of the supervised positions carry [MASK]
+    # (id 103), thousands of times per batch -- the long runs of the embedding-gradient kernel
+    g = torch.Generator(device=dev).manual_seed(5)
+    for b in pool:
+        sup = b["labels"][:, :T] != -1
+        hit = sup & (torch.rand(sup.shape, generator=g, device=dev) < 0.8)
+        b["input_ids"][hit] = 103
+    print("[MASK] positions per batch: %s" % [int((b["input_ids"] == 103).sum()) for b in pool], flush=True)
     model.eval()
     with torch.no_grad():
         before = float(model(**pool[0])[0])
