@@ -740,3 +740,38 @@ def test_center_mask_equals_the_torch_expression(dev, dtype):
         f = src.to(torch.float32)
         want = f - f.amax(dim=1, keepdim=True) + 1.0
         assert got.dtype == torch.float32 and got.is_contiguous() and torch.equal(got, want)
+
+
+def test_trunk_forward_replayed_from_a_hip_graph_is_bitwise_the_direct_call(dev):
+    """The inference trunk forward (text + regions, deferred-LayerNorm layer loop) captured into a HIP graph after a warm-up
+    on a side stream and replayed: the same bits as the direct call.  Inside a capture the asynchronous out-of-range check
+    stands down (events cannot be queried there); outside it still reports."""
+    import visitron_amd
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config()
+    torch.manual_seed(3)
+    trunk = BertImgModelwithLocationEmbeds(cfg).eval().to(dev)
+    b = make_batch(cfg, 4, text_len=24, region_len=9, seed=2, device=dev, with_labels=False)
+    with torch.no_grad():
+        want = trunk(**b)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                trunk(**b)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = trunk(**b)
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+        bad = dict(b)
+        bad["input_ids"] = torch.full_like(b["input_ids"], cfg.vocab_size + 1)
+        with pytest.raises(IndexError):
+            trunk(**bad)
+            visitron_amd.check_errors()

@@ -304,6 +304,8 @@ def _post_index_flag(err):
 
 
 def _poll_index_flags(block=False):
+    if not _PENDING_FLAGS or torch.cuda.is_current_stream_capturing():
+        return
     bad, i = False, 0
     while i < len(_PENDING_FLAGS):
         ev, host = _PENDING_FLAGS[i]
@@ -330,6 +332,8 @@ def _check_index_error(emb):
     if err is None:
         return
     emb._last_err = None
+    if torch.cuda.is_current_stream_capturing():
+        return   # a forward being captured into a HIP graph: no host-side look at the flag (events cannot be queried there)
     _post_index_flag(err)
     _poll_index_flags(block=os.environ.get("VT_SYNC_ERRORS") == "1")
 
