@@ -91,8 +91,11 @@ def test_cfg0_reference_init_b2_every_output_within_5e2(dev):
         got7 = prod(**_to(b, dev))
     for i, n in enumerate(("loss", "mask_loss", "next_loss", "token_loss")):
         check_close("cfg0 reference-init B=2 %s" % n, float(got7[i]), float(want7[i]), TOL)
+    # the accuracies are counts of matching argmaxes over the supervised positions (encoder.py:398-431): at most ONE flipped
+    # argmax per head is tolerated (a near-tie decided the other way in bf16), i.e. a difference of 1 / supervised count
+    counts = {4: int((b["labels"] != -1).sum()), 5: int(b["next_action"].shape[0]), 6: int((b["token_labels"] != -1).sum())}
     for i, n in ((4, "words_accuracy"), (5, "action_accuracy"), (6, "token_accuracy")):
-        assert abs(float(got7[i]) - float(want7[i])) <= 0.1, (n, float(got7[i]), float(want7[i]))
+        assert abs(float(got7[i]) - float(want7[i])) <= 1.0 / max(counts[i], 1) + 1e-6, (n, float(got7[i]), float(want7[i]), counts[i])
 
 
 def test_cfg1_reference_init_b64_slice_within_5e2(dev):

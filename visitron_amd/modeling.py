@@ -554,7 +554,9 @@ class _PackedEncoderLn(object):
         def fold(W, b, gamma, beta):
             W = W.detach().float()
             wf = (W * gamma[None, :]).to(BF16).contiguous()
-            return wf, wf.float().sum(1).contiguous(), (W @ beta + b.detach().float()).contiguous()
+            # h = W beta + b as an elementwise product and a row sum (torch's `W @ beta` would be the one vendor-BLAS
+            # kernel, rocblas_gemvt, in a trace of this library; weight prep only, cached per weights generation)
+            return wf, wf.float().sum(1).contiguous(), ((W * beta[None, :]).sum(1) + b.detach().float()).contiguous()
 
         for i, layer in enumerate(encoder.layer):
             att, so = layer.attention.self, layer.attention.output
