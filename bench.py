@@ -349,6 +349,9 @@ def main():
                                "trunk forward (embeddings + region projection + encoder + pooler) [BASELINE configs[1]]"),
                 "global_batch": world * a.batch, "seq_len": S,
                 "parallelism": ("dp%d (flat-slab gradient all-reduce over RCCL)" if train else "dp%d (replicas, no collective)") % world,
+                # what the NT GEMM does beside the collective's kernels (ops.multi_rank_gemm_policy: decided from the
+                # environment RCCL reads, no hand-set knob)
+                "gemm_beside_collective": (engine.gemm_policy if train else None),
                 # the data-parallel exchange moves a bf16 copy of the gradient slab by default (VT_GRAD_COMM=fp32: the fp32 slab)
                 "grad_comm_dtype": (engine.grad_comm_dtype if (train and world > 1) else None),
                 "weights": "random init N(0,0.02), seed 0",

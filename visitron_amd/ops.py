@@ -213,6 +213,31 @@ def set_gemm_variant(v):
 # one-tile-per-workgroup forms of the same kernel (15, 22, 23) are within 1 % over the step and simply queue their tiles.
 PERSISTENT_GEMM_OK = True
 PERSISTENT_VARIANTS = (16, 18, 19, 20, 21)
+
+
+def multi_rank_gemm_policy(environ=None):
+    """What the NT GEMM does under more than one rank, decided from the environment alone (no knob has to be set by hand):
+    -> (k, text).  k > 0: the persistent kernels stay in the candidate list and launch on CUs - k workgroups, leaving k
+    compute units to the collective's kernels; k == 0: they stand down and the one-tile-per-workgroup forms (15, 22, 23:
+    within 0-0.8 % over the step on one GPU) queue their tiles behind whatever RCCL occupies.
+      * VT_GEMM_RESERVE_CUS=k   explicit: k > 0 reserves, 0 turns the persistent kernels off;
+      * NCCL_MAX_NCHANNELS=c    RCCL runs one workgroup per channel, so a pinned channel count bounds the CUs it can hold:
+                                k = c (NCCL_MIN_NCHANNELS larger than that wins, as in RCCL);
+      * neither                 the channel count is RCCL's own choice per topology and message size (not knowable here
+                                before the first collective): persistent kernels off."""
+    env = os.environ if environ is None else environ
+    v = env.get("VT_GEMM_RESERVE_CUS")
+    if v is not None and str(v).strip() != "":
+        k = max(0, int(v))
+        return k, ("persistent GEMM on CUs - %d (VT_GEMM_RESERVE_CUS)" % k if k else
+                   "persistent GEMM off beside the collective (VT_GEMM_RESERVE_CUS=0): one-tile-per-workgroup kernels")
+    ch = [int(env[n]) for n in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS") if str(env.get(n, "")).strip().isdigit()]
+    if "NCCL_MAX_NCHANNELS" in env and ch:
+        k = max(ch)
+        if 0 < k <= 64:
+            return k, "persistent GEMM on CUs - %d (one CU per RCCL channel: NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS)" % k
+    return 0, ("persistent GEMM off beside the collective (RCCL's channel count is not pinned: NCCL_MAX_NCHANNELS unset): "
+               "one-tile-per-workgroup kernels")
 _tuned = {}
 _forced_variant = None
 

@@ -217,6 +217,7 @@ class PretrainEngine(object):
         if grad_comm_dtype not in ("bf16", "fp32"):
             raise ValueError("grad_comm_dtype must be 'bf16' or 'fp32'")
         self.grad_comm_dtype = grad_comm_dtype
+        self.gemm_policy = "persistent GEMM on every CU (one rank, no collective beside it)"
         self.g16 = None
         if self.world > 1 and grad_comm_dtype == "bf16":
             self.g16 = torch.zeros(self.flat.total, dtype=BF16, device=self.flat.p.device)
@@ -355,10 +356,10 @@ class PretrainEngine(object):
             b = _TrainBuffers(cfg.num_hidden_layers, B * S, B, S, cfg.hidden_size, cfg.intermediate_size,
                               cfg.num_attention_heads, self.flat.p.device)
             if self.world > 1:
-                # collectives share the CUs with the backward (see ops.py): by default the persistent GEMM stands down;
-                # VT_GEMM_RESERVE_CUS=k keeps it and launches it on (CUs - k) workgroups instead, leaving k compute units to
-                # the RCCL kernels (not measured on a multi-GPU node yet: opt-in)
-                k = int(os.environ.get("VT_GEMM_RESERVE_CUS", "0"))
+                # collectives share the CUs with the backward: ops.multi_rank_gemm_policy decides once, from the
+                # environment RCCL itself reads, whether the persistent GEMM keeps running (on CUs - k workgroups, k = one
+                # CU per RCCL channel) or stands down for the one-tile-per-workgroup kernels; bench.py prints the choice
+                k, self.gemm_policy = ops.multi_rank_gemm_policy()
                 if k > 0:
                     _lib.load().vt_gemm_reserve_cus(k)
                 else:
@@ -644,8 +645,32 @@ class PretrainEngine(object):
             for prm in (m.next_action.linear.weight, m.next_action.linear.bias, m.bert.pooler.dense.weight,
                         m.bert.pooler.dense.bias):
                 self._grad(prm).zero_()
+        if comm is not None:
+            # data-parallel: the head / pooler gradients are final here, before the encoder backward has started -- their
+            # all-reduce goes out first and hides under the whole backward (round 3 reduced them last, with the embeddings)
+            rng = self._param_ranges([pr.transform.dense.weight, pr.transform.dense.bias, pr.transform.LayerNorm.weight,
+                                      pr.transform.LayerNorm.bias, pr.bias, lin_tok.weight, lin_tok.bias,
+                                      m.next_action.linear.weight, m.next_action.linear.bias, m.bert.pooler.dense.weight,
+                                      m.bert.pooler.dense.bias] + ([] if dec_w_is_tied else [pr.decoder.weight]))
+            comm["launch"](rng)
+            comm["done"].extend(rng)
         self._trunk_bwd(st, None, acc, comm, word_grad_ready=True)
         return (loss, mask_loss, next_loss, token_loss, words_acc, action_acc, token_acc)
+
+    def _param_ranges(self, params):
+        """Slab ranges [start, end) of the given parameters, ends rounded up to the alignment granule (the padding belongs
+        to no parameter), sorted and merged where they touch."""
+        f, spans = self.flat, []
+        for prm in params:
+            o, cnt, _ = f.off[self._name_of(prm)]
+            spans.append((o, min(round_up(o + cnt, ALIGN), f.total)))
+        out = []
+        for s_, e_ in sorted(spans):
+            if out and s_ <= out[-1][1]:
+                out[-1] = (out[-1][0], max(out[-1][1], e_))
+            else:
+                out.append((s_, e_))
+        return out
 
     def _trunk_bwd(self, st, g32, acc, comm=None, word_grad_ready=False):
         """Back through the trunk: g32 fp32 [rows, H] = dL/d(sequence output) in the layout of the forward (st), or None
