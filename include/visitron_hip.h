@@ -93,7 +93,7 @@ int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, co
 int vt_apply_dropout_bf16(void* x, int64_t ld, int64_t rows, int cols, float drop_p, uint64_t drop_seed,
                           uint32_t drop_site, vt_stream_t stream);
 /* Test hook: out[i] = 1 if element i of the site is kept (head_index = b*nh + h for attention sites where
- * element i = q * S + key, else -1). */
+ * element i = q * S' + key, S' = the sequence's length rounded up to an even number, else -1). */
 int vt_debug_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, uint32_t drop_site,
                           int head_index, vt_stream_t stream);
 

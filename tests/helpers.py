@@ -109,6 +109,9 @@ def inject_dropout_masks(ref, p_hidden, p_attn, seed, B, T, R, device="cuda:0", 
     def keep(n, p, site, head=-1):
         return ops.dropout_mask(n, (p, seed, site), head_index=head, device=device).cpu()
 
+    def attn_keep(n, site, head):   # [n, n] of one (batch, head): element (q, k) = index q * n' + k, n' = n rounded up to even
+        return ops.attn_dropout_mask(n, (p_attn, seed, site), head, device=device).cpu()
+
     def setmod(name, mod):
         parent = ref
         parts = name.split(".")
@@ -130,12 +133,12 @@ def inject_dropout_masks(ref, p_hidden, p_attn, seed, B, T, R, device="cuda:0", 
 
     def attn_site(site):
         if layout is None:
-            return torch.stack([keep(S * S, p_attn, site, head=i).view(S, S) for i in range(B * nh)]).view(B, nh, S, S)
+            return torch.stack([attn_keep(S, site, i) for i in range(B * nh)]).view(B, nh, S, S)
         full = torch.ones(B, nh, S, S, dtype=torch.uint8)
         for b in range(B):
             n = length[b]
             for h in range(nh):
-                blk = keep(n * n, p_attn, site, head=b * nh + h).view(n, n)
+                blk = attn_keep(n, site, b * nh + h)
                 full[b, h][pos[b][:, None], pos[b][None, :]] = blk
         return full
 

@@ -563,7 +563,7 @@ def test_apply_dropout_and_layernorm_bwd_dropped_copy(dev):
 
 
 def _attn_keep(ops, B, nh, S, drop, dev):
-    return torch.stack([ops.dropout_mask(S * S, drop, head_index=i, device=dev).view(S, S)
+    return torch.stack([ops.attn_dropout_mask(S, drop, i, device=dev)
                         for i in range(B * nh)]).view(B, nh, S, S).float().cpu()
 
 
@@ -745,7 +745,7 @@ def test_attention_dropout_on_compacted_rows_matches_autograd(dev):
         x = qkv[off:off + n].to(BF16).float().requires_grad_(True)
         t = x.view(n, 3, nh, 64).permute(1, 2, 0, 3)
         p = torch.softmax(t[0] @ t[1].transpose(-1, -2) / 8.0, -1)
-        km = torch.stack([ops.dropout_mask(n * n, drop, head_index=b * nh + h, device=dev).view(n, n) for h in range(nh)]).float().cpu()
+        km = torch.stack([ops.attn_dropout_mask(n, drop, b * nh + h, device=dev) for h in range(nh)]).float().cpu()
         o = ((p * km / 0.8) @ t[2]).permute(1, 0, 2).reshape(n, H)
         o.backward(dctx[off:off + n].to(BF16).float())
         assert maxabs(ctx[off:off + n], o.detach()) < 3e-2

@@ -483,7 +483,7 @@ def test_attention_keep_words_are_the_hash_mask_and_drive_the_backward(dev, B, S
     torch.cuda.synchronize()
     assert torch.equal(ctx0, ctx1) and torch.equal(lse0, lse1)
     got = _unpack_keep_words(words, B, nh, S)[:, :S, :S]
-    want = torch.stack([ops.dropout_mask(S * S, drop, head_index=i, device=dev).view(S, S) for i in range(B * nh)]).bool().cpu()
+    want = torch.stack([ops.attn_dropout_mask(S, drop, i, device=dev) for i in range(B * nh)]).bool().cpu()
     assert torch.equal(got, want)
     d0 = ops.attention_bwd(qkv, dctx, ctx0, lse0, B, S, nh, mask=mask, drop=drop)
     d1 = ops.attention_bwd(qkv, dctx, ctx1, lse1, B, S, nh, mask=mask, drop=drop, keep_bits=words)
@@ -519,7 +519,7 @@ def test_attention_keep_words_on_compacted_rows(dev):
     for b in range(B):
         n = int(lens[b])
         for h in range(nh):
-            want = ops.dropout_mask(n * n, drop, head_index=b * nh + h, device=dev).view(n, n).bool().cpu()
+            want = ops.attn_dropout_mask(n, drop, b * nh + h, device=dev).bool().cpu()
             assert torch.equal(got[b * nh + h, :n, :n], want), (b, h)
 
 

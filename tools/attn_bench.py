@@ -44,3 +44,16 @@ if p > 0 and hasattr(ops, "keep_words"):   # the forward writing its keep words,
     tfk = timeit(lambda: ops.attention_fwd(qkv, B, S, nh, mask=mask, lse=lse, drop=drop, keep_bits=kb))
     tbk = timeit(lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=mask, out=out, delta_ws=delta, drop=drop, keep_bits=kb))
     print("    with keep words: fwd %.1f us  bwd %.1f us" % (tfk, tbk))
+if p > 0 and S == 228:   # the training step's layout: real rows only, per-sequence lengths as bench.py's synthetic batch draws them
+    g = torch.Generator().manual_seed(0)
+    lens = (128 - torch.randint(0, 33, (B,), generator=g)) + torch.randint(75, 101, (B,), generator=g)
+    keepm = torch.arange(S)[None, :] < lens[:, None]
+    seq = ops.SeqLayout(keepm.to(dev))
+    qc, dc = qkv[:seq.rows].contiguous(), dctx[:seq.rows].contiguous()
+    kb = torch.zeros(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev)
+    ctxc = ops.attention_fwd(qc, B, S, nh, lse=lse, drop=drop, seq=seq, keep_bits=kb)
+    outc = torch.empty(seq.rows, 3 * H, device=dev, dtype=torch.bfloat16)
+    tfc = timeit(lambda: ops.attention_fwd(qc, B, S, nh, lse=lse, drop=drop, seq=seq, keep_bits=kb))
+    tbc = timeit(lambda: ops.attention_bwd(qc, dc, ctxc, lse, B, S, nh, out=outc, delta_ws=delta, drop=drop, seq=seq, keep_bits=kb))
+    print("    compacted rows (%d of %d, %d odd lengths), keep words: fwd %.1f us  bwd %.1f us" % (
+        seq.rows, B * S, int((lens % 2).sum()), tfc, tbc))

@@ -15,7 +15,7 @@ torch.cuda.synchronize()
 nqb = 2
 w = words.view(nqb, nqb * 32).cpu().to(torch.int64) & 0xFFFFFFFF
 bits = ((w[:, None, :] >> torch.arange(32)[None, :, None]) & 1).reshape(64, 64).bool()   # [query][key]
-want = ops.dropout_mask(S * S, drop, head_index=0, device=dev).view(S, S).bool().cpu()
+want = ops.attn_dropout_mask(S, drop, 0, device=dev).bool().cpu()
 print("equal frac", (bits == want).float().mean().item(), "transposed", (bits.t() == want).float().mean().item())
 print("keep rate got", bits.float().mean().item(), "want", want.float().mean().item())
 # per key column agreement

@@ -34,7 +34,10 @@ struct AttnArgs {
   int B, S, nh;
   float scale;              // 1 / sqrt(head_size)
   DropCfg drop;             // dropout on the attention probabilities (oscar/modeling_bert.py:62); per (b,h) the
-                            // seed is hash32(drop.seed, b*nh+h) and the element index is q * S + key
+                            // seed is hash32(drop.seed, b*nh+h) and the element index is q * S' + key, S' = the sequence's
+                            // length rounded up to an EVEN number: the keys 2m, 2m+1 of a query then always share one hash
+                            // word (with pitch S an odd-length sequence -- every other one of a compacted batch -- paid a
+                            // whole hash per element: 13 instead of 4 issue slots)
   // compacted rows (training without the padding rows): sequence b holds seq_len[b] <= S rows starting at row
   // seq_start[b]; lse keeps its [B, nh, S] layout.  Null: every sequence has S rows, sequence b starts at row b * S.
   const int* seq_start;
@@ -71,7 +74,16 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
 }
 
 // KEEP: also write the dropout keep words (AttnArgs::keep_bits; training with probability dropout)
-template <bool KEEP>
+// MASK3: mask_additive == 2, an additive bias per (query, key) [B, S, S] (the reference's 3-D masks); the common kernels
+// carry none of its per-element loads and branches
+//
+// The softmax runs on the RAW accumulators: the per-key bias is staged in LDS divided by the scale (bias / scale: exact
+// for head size 64, scale = 1/8) and is the INITIAL VALUE of the score accumulators, so after the four MFMAs
+//   acc = q.k + bias / scale,   score * log2(e) = acc * scale2,   scale2 = scale * log2(e) > 0,
+// the running maximum is taken over acc itself and p = exp2(fma(acc, scale2, -max * scale2)): one fma per element where
+// round 3 spent a fma (scale + bias) and a subtract.  (The reference rounds fma(q.k, 1/8, mask) once; here a masked key's
+// q.k is added to -80 000 in fp32 -- its probability is 0 either way -- and an unmasked key's bias is 0: same values.)
+template <bool KEEP, bool MASK3>
 __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -101,12 +113,14 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
   f32x16 o0, o1;
 #pragma unroll
   for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;   // running maximum (exp2 domain) and running sum
+  float m_run = -INFINITY, l_run = 0.f;   // running maximum (of the raw accumulators) and running sum
   const float scale2 = a.scale * LOG2E;
+  const float inv_scale = 1.0f / a.scale;
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
-  const uint32_t q_elem = (uint32_t)(q0 + r) * (uint32_t)S;
-  const float* mrow3 = (a.mask && a.mask_additive == 2) ? a.mask + ((long)b * Smax + ((q0 + r) < S ? (q0 + r) : S - 1)) * Smax : nullptr;
+  const uint32_t Sp = (uint32_t)(S + 1) & ~1u;                        // even row pitch of the dropout element index
+  const uint32_t q_elem = (uint32_t)(q0 + r) * Sp;
+  const float* mrow3 = MASK3 ? a.mask + ((long)b * Smax + ((q0 + r) < S ? (q0 + r) : S - 1)) * Smax : nullptr;
 
   // lane-constant LDS offsets
   const int k_row_off = r * 128;                       // + kt*4096
@@ -136,11 +150,11 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
       float bias = -INFINITY;
       if (key < S) {
         float add = 0.f;
-        if (a.mask && a.mask_additive != 2) {
+        if (a.mask && !MASK3) {
           const float mval = a.mask[(long)b * Smax + key];
           add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
         }
-        bias = add * LOG2E;   // exp2 domain (see the softmax below)
+        bias = add * inv_scale;   // in units of the raw accumulator (see the kernel's header)
       }
       ((float*)(smem + ATT_SBIAS))[tid] = bias;
     }
@@ -155,52 +169,48 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
         keep_tile += ((((long)b * a.nh + head) * nqb + (q0 >> 5)) * nqb << 5) + kc;
       }
       for (int kt = 0; kt < ntiles; ++kt) {
-        // ---- S^T tile = K[32 keys] . Q^T ----
+        // ---- S^T tile = K[32 keys] . Q^T, on top of the bias ----
         f32x16 sacc;
+        const float* bp = (const float*)(smem + ATT_SBIAS) + kt * 32 + 4 * h2;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 bv = *(const f32x4*)(bp + 8 * g4);
+          if (MASK3) {   // per-query bias row of this lane's query; the LDS bias is 0 / -inf (key range)
+            const int key0 = kc + kt * 32 + 8 * g4 + 4 * h2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (key0 + e < S) bv[e] += mrow3[key0 + e] * inv_scale;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sacc[4 * g4 + e] = bv[e];
+        }
         const char* kp = smem + ATT_SK + kt * 4096 + k_row_off;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
           const bf16x8 kf = *(const bf16x8*)(kp + (((2 * ds + h2) ^ k_swz) << 4));
           sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc, 0, 0, 0);
         }
-        // ---- scale + mask, online softmax in the exp2 domain: s2 = (q.k / sqrt(d) + bias) * log2(e) in ONE fma per
-        // element (scale2 = log2(e) / sqrt(d), the bias row is staged pre-multiplied), p = exp2(s2 - m2).  The kernel is
-        // VALU-bound (profiles/r01/attention_sq_counters.txt): every instruction taken out of this loop shows. ----
-        const float* bp = (const float*)(smem + ATT_SBIAS) + kt * 32 + 4 * h2;
-        float tmax = -INFINITY;
+        // ---- online softmax in the exp2 domain on the raw accumulators.  The kernel is VALU-bound
+        // (profiles/r01/attention_sq_counters.txt): every instruction taken out of this loop shows. ----
+        float tmax = sacc[0];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          f32x4 bv = *(const f32x4*)(bp + 8 * g4);
-          if (mrow3) {   // per-query bias row of this lane's query; the LDS bias is 0 / -inf (key range)
-            const int key0 = kc + kt * 32 + 8 * g4 + 4 * h2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (key0 + e < S) bv[e] += mrow3[key0 + e] * LOG2E;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float s = fmaf(sacc[4 * g4 + e], scale2, bv[e]);
-            sacc[4 * g4 + e] = s;
-            tmax = fmaxf(tmax, s);
-          }
-        }
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sacc[i]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         // the running maximum moves in the first tile or two and then rarely: the rescale of the 32 output registers (and
         // its exp2) is skipped when no lane's maximum changed (wave-uniform branch; exact: alpha would be 1)
         if (__builtin_amdgcn_ballot_w64(tmax > m_run) != 0) {
           const float m_new = fmaxf(m_run, tmax);
-          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale2);
           m_run = m_new;
           l_run *= alpha;
 #pragma unroll
           for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
         }
+        const float negm = -m_run * scale2;
         float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(sacc[i] - m_run);
+          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[i], scale2, negm));
           sacc[i] = p;
           psum += p;
         }
@@ -213,15 +223,14 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
           u32x4 pbw;
           int kw = 0;   // lane 16 s2 + l, l < 16: the keep word of key 32 kt + 16 s2 + l over this wave's 32 queries
           if (dr.thresh) {  // drop probabilities AFTER the row sum was taken (the normaliser uses all of them)
-            // S even: the tile's eight key pairs sit at fixed offsets from one pair index -> one multiply per half tile
+            // the tile's eight key pairs sit at fixed offsets from one pair index -> one multiply per half tile (the
+            // element index q * S' + key of an even key is even: S' is even)
             const uint32_t xb = vt_hash_pre(dr.seed, (q_elem + (uint32_t)(kc + kt * 32 + 4 * h2)) >> 1);
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {   // elements i, i+1 are neighbouring keys: one hash for both (S even)
+            for (int j = 0; j < 8; j += 2) {   // elements i, i+1 are neighbouring keys: one hash for both
               const int i = 8 * s2 + j;
-              const uint32_t e = q_elem + (uint32_t)(kc + kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2);
               bool k0, k1;
-              if ((S & 1) == 0) vt_keep2_pre(dr, xb + (uint32_t)(((i & 3) + 8 * (i >> 2)) >> 1) * VT_HASH_C1, k0, k1);
-              else { k0 = vt_keep(dr, e); k1 = vt_keep(dr, e + 1); }
+              vt_keep2_pre(dr, xb + (uint32_t)(((i & 3) + 8 * (i >> 2)) >> 1) * VT_HASH_C1, k0, k1);
               sacc[i] = k0 ? sacc[i] : 0.f;          // the 1 / (1 - p) factor is uniform: applied once to O below
               sacc[i + 1] = k1 ? sacc[i + 1] : 0.f;
               if (KEEP) {
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
   if (q >= S) return;
   float inv = 1.0f / l_tot;
   if (dr.thresh) inv *= dr.scale;   // dropout's 1 / (1 - p)
-  if (a.lse && h2 == 0) a.lse[((long)b * a.nh + head) * Smax + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  if (a.lse && h2 == 0) a.lse[((long)b * a.nh + head) * Smax + q] = (m_run * scale2 + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
   if (a.head_scale) inv *= a.head_scale[head];
   bf16_t* op = a.ctx + (row0 + q) * a.ld_ctx + head * 64 + 16 * h2;
   u32x4 w0, w1, w2, w3;
@@ -279,9 +288,11 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
   if ((ld_qkv % 8) || (ld_ctx % 8) || ld_qkv < 3L * nh * 64 || ld_ctx < (long)nh * 64) return VT_ERR_BAD_ALIGN;
   if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return VT_ERR_BAD_ALIGN;
-  static VtLdsAttrOnce attr, attr_keep;
-  if (!attr.set((const void*)attention_fwd_d64<false>, ATT_LDS_BYTES)) return VT_ERR_HIP;
-  if (!attr_keep.set((const void*)attention_fwd_d64<true>, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  static VtLdsAttrOnce attr, attr_keep, attr_m3, attr_keep_m3;
+  if (!attr.set((const void*)attention_fwd_d64<false, false>, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  if (!attr_keep.set((const void*)attention_fwd_d64<true, false>, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  if (!attr_m3.set((const void*)attention_fwd_d64<false, true>, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  if (!attr_keep_m3.set((const void*)attention_fwd_d64<true, true>, ATT_LDS_BYTES)) return VT_ERR_HIP;
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = (bf16_t*)ctx; a.lse = lse;
   a.ld_qkv = ld_qkv; a.ld_ctx = ld_ctx; a.B = B; a.S = S; a.nh = nh;
@@ -292,8 +303,11 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   a.seq_start = seq_start; a.seq_len = seq_len;
   a.keep_bits = keep_bits;
   dim3 grid((S + 255) / 256, nh, B);
-  if (keep_bits && a.drop.thresh) hipLaunchKernelGGL(attention_fwd_d64<true>, grid, dim3(512), ATT_LDS_BYTES, stream, a);
-  else hipLaunchKernelGGL(attention_fwd_d64<false>, grid, dim3(512), ATT_LDS_BYTES, stream, a);
+  const bool keep = keep_bits && a.drop.thresh, m3 = mask && mask_additive == 2;
+  if (keep && m3) hipLaunchKernelGGL((attention_fwd_d64<true, true>), grid, dim3(512), ATT_LDS_BYTES, stream, a);
+  else if (keep) hipLaunchKernelGGL((attention_fwd_d64<true, false>), grid, dim3(512), ATT_LDS_BYTES, stream, a);
+  else if (m3) hipLaunchKernelGGL((attention_fwd_d64<false, true>), grid, dim3(512), ATT_LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL((attention_fwd_d64<false, false>), grid, dim3(512), ATT_LDS_BYTES, stream, a);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 

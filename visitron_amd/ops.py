@@ -858,6 +858,14 @@ def dropout_mask(n, drop, head_index=-1, device="cuda"):
     return out
 
 
+def attn_dropout_mask(n, drop, head_index, device="cuda"):
+    """uint8 [n, n]: the keep mask of the attention-probability dropout of one (batch, head) whose sequence has n rows
+    (test hook).  The attention kernels index element (query q, key k) as q * n' + k with n' = n rounded up to an even
+    number (csrc/attention_fwd.hip: the keys 2m, 2m + 1 of a query then always share a hash word)."""
+    pitch = (n + 1) & ~1
+    return dropout_mask(n * pitch, drop, head_index=head_index, device=device).view(n, pitch)[:, :n]
+
+
 def transpose(src, out):
     """out[c, r] = src[r, c] (bf16 2-D, row strides allowed)."""
     _require_hip(src, out)
