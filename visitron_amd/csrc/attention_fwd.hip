@@ -55,14 +55,26 @@ struct AttnArgs {
 #define ATT_SBIAS (2 * ATT_KCHUNK * 128)
 #define ATT_LDS_BYTES (2 * ATT_KCHUNK * 128 + ATT_KCHUNK * 4)
 
-// lanes L0..L3 (constants) of the VGPR `dst` = the wave-uniform values v0..v3 (hipcc has no builtin for v_writelane_b32).
-// The values are lane masks a v_cmp has just written: a VALU write of an SGPR needs wait states before v_writelane reads
-// it (measured: without them the first write of a group carried the previous compare's mask), and hipcc's hazard
-// recognizer does not look inside an asm statement -- hence the s_nop.
-#define ATT_WRITELANE4(dst, v0, v1, v2, v3, L0, L1, L2, L3)                                                    \
-  asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %6\n\t"                      \
-               "v_writelane_b32 %0, %3, %7\n\tv_writelane_b32 %0, %4, %8"                                      \
-               : "+v"(dst) : "s"(v0), "s"(v1), "s"(v2), "s"(v3), "n"(L0), "n"(L1), "n"(L2), "n"(L3))
+// Sixteen lanes of the VGPR `dst` = sixteen wave-uniform words (hipcc has no builtin for v_writelane_b32): ml[j] / mh[j] are
+// the low / high halves of the lane mask of compare j (j = 0 .. 7), written to lanes La_j / Lb_j.  The values are lane masks
+// v_cmp instructions have just written: a VALU write of an SGPR needs wait states before v_writelane reads it (measured:
+// without them the first write of a group carried the previous compare's mask), and hipcc's hazard recognizer does not look
+// inside an asm statement -- hence the s_nop, ONE for all sixteen (round 3 paid one per group of four).
+#define ATT_WL_STR2(x) #x
+#define ATT_WL_STR(x) ATT_WL_STR2(x)
+#define ATT_WRITELANE16(dst, ml, mh, A0, B0, A1, B1, A2, B2, A3, B3, A4, B4, A5, B5, A6, B6, A7, B7)                        \
+  asm volatile("s_nop 4\n\t"                                                                                               \
+               "v_writelane_b32 %0, %1, " ATT_WL_STR(A0) "\n\tv_writelane_b32 %0, %2, " ATT_WL_STR(B0) "\n\t"                 \
+               "v_writelane_b32 %0, %3, " ATT_WL_STR(A1) "\n\tv_writelane_b32 %0, %4, " ATT_WL_STR(B1) "\n\t"                 \
+               "v_writelane_b32 %0, %5, " ATT_WL_STR(A2) "\n\tv_writelane_b32 %0, %6, " ATT_WL_STR(B2) "\n\t"                 \
+               "v_writelane_b32 %0, %7, " ATT_WL_STR(A3) "\n\tv_writelane_b32 %0, %8, " ATT_WL_STR(B3) "\n\t"                 \
+               "v_writelane_b32 %0, %9, " ATT_WL_STR(A4) "\n\tv_writelane_b32 %0, %10, " ATT_WL_STR(B4) "\n\t"                \
+               "v_writelane_b32 %0, %11, " ATT_WL_STR(A5) "\n\tv_writelane_b32 %0, %12, " ATT_WL_STR(B5) "\n\t"               \
+               "v_writelane_b32 %0, %13, " ATT_WL_STR(A6) "\n\tv_writelane_b32 %0, %14, " ATT_WL_STR(B6) "\n\t"               \
+               "v_writelane_b32 %0, %15, " ATT_WL_STR(A7) "\n\tv_writelane_b32 %0, %16, " ATT_WL_STR(B7)                       \
+               : "+v"(dst)                                                                                                   \
+               : "s"(ml[0]), "s"(mh[0]), "s"(ml[1]), "s"(mh[1]), "s"(ml[2]), "s"(mh[2]), "s"(ml[3]), "s"(mh[3]),             \
+                 "s"(ml[4]), "s"(mh[4]), "s"(ml[5]), "s"(mh[5]), "s"(ml[6]), "s"(mh[6]), "s"(ml[7]), "s"(mh[7]))
 
 __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
   // two transposed 4x16 block reads (keys k..k+3 and k+8..k+11), 8 bf16 per lane
@@ -207,44 +219,56 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
           for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
         }
         const float negm = -m_run * scale2;
+        // (scalar arrays from here on: updating elements of the f32x16 accumulator tuple in place made hipcc copy the whole
+        // tuple -- 16 v_mov_b64 per tile -- to keep the undropped values for the row sum)
+        float pv[16];
         float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[i], scale2, negm));
-          sacc[i] = p;
-          psum += p;
+          pv[i] = __builtin_amdgcn_exp2f(fmaf(sacc[i], scale2, negm));
+          psum += pv[i];
         }
         l_run += psum;
+        // the tile's key pairs sit at fixed offsets from one pair index: the hash's first multiply once per tile (the element
+        // index q * S' + key of an even key is even: S' is even)
+        const uint32_t xb = dr.thresh ? vt_hash_pre(dr.seed, (q_elem + (uint32_t)(kc + kt * 32 + 4 * h2)) >> 1) : 0u;
 
         // ---- O^T += V^T . P^T ----
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           typedef __attribute__((ext_vector_type(8))) short short8v;
           u32x4 pbw;
-          int kw = 0;   // lane 16 s2 + l, l < 16: the keep word of key 32 kt + 16 s2 + l over this wave's 32 queries
+          float pm[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pm[j] = pv[8 * s2 + j];
           if (dr.thresh) {  // drop probabilities AFTER the row sum was taken (the normaliser uses all of them)
-            // the tile's eight key pairs sit at fixed offsets from one pair index -> one multiply per half tile (the
-            // element index q * S' + key of an even key is even: S' is even)
-            const uint32_t xb = vt_hash_pre(dr.seed, (q_elem + (uint32_t)(kc + kt * 32 + 4 * h2)) >> 1);
+            uint32_t ml[8], mh[8];   // lane masks of the eight compares: low half = this wave's 32 queries against key
+                                     // (i&3) + 8(i>>2), high half the same queries against that key + 4
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {   // elements i, i+1 are neighbouring keys: one hash for both
               const int i = 8 * s2 + j;
               bool k0, k1;
               vt_keep2_pre(dr, xb + (uint32_t)(((i & 3) + 8 * (i >> 2)) >> 1) * VT_HASH_C1, k0, k1);
-              sacc[i] = k0 ? sacc[i] : 0.f;          // the 1 / (1 - p) factor is uniform: applied once to O below
-              sacc[i + 1] = k1 ? sacc[i + 1] : 0.f;
+              pm[j] = k0 ? pm[j] : 0.f;          // the 1 / (1 - p) factor is uniform: applied once to O below
+              pm[j + 1] = k1 ? pm[j + 1] : 0.f;
               if (KEEP) {
-                // a compare's lane mask IS the word the backward wants: lanes 0..31 = this wave's queries against key
-                // (i&3) + 8(i>>2), lanes 32..63 the same queries against that key + 4; each goes to the lane of its key
                 const uint64_t m0 = __builtin_amdgcn_ballot_w64(k0), m1 = __builtin_amdgcn_ballot_w64(k1);
-                const int ki = (i & 3) + 8 * (i >> 2);
-                ATT_WRITELANE4(kw, (uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32), ki, ki + 4, ki + 1, ki + 5);
+                ml[j] = (uint32_t)m0; mh[j] = (uint32_t)(m0 >> 32); ml[j + 1] = (uint32_t)m1; mh[j + 1] = (uint32_t)(m1 >> 32);
               }
             }
+            if (KEEP) {
+              // a compare's lane mask IS the word the backward wants; each half goes to the lane of its key: lane 16 s2 + l,
+              // l < 16, ends up with the keep word of key 32 kt + 16 s2 + l over this wave's 32 queries.  All sixteen
+              // v_writelane_b32 behind ONE wait (a VALU write of an SGPR needs wait states before v_writelane reads it, and
+              // hipcc's hazard recognizer does not look inside an asm statement)
+              int kw = 0;
+              if (s2 == 0) ATT_WRITELANE16(kw, ml, mh, 0, 4, 1, 5, 2, 6, 3, 7, 8, 12, 9, 13, 10, 14, 11, 15);
+              else ATT_WRITELANE16(kw, ml, mh, 16, 20, 17, 21, 18, 22, 19, 23, 24, 28, 25, 29, 26, 30, 27, 31);
+              if ((lane >> 4) == s2) keep_tile[kt * 32 + lane] = (uint32_t)kw;
+            }
           }
-          if (KEEP && dr.thresh && (lane >> 4) == s2) keep_tile[kt * 32 + lane] = (uint32_t)kw;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) pbw[j] = pack_bf16x2(sacc[8 * s2 + 2 * j], sacc[8 * s2 + 2 * j + 1]);
+          for (int j = 0; j < 4; ++j) pbw[j] = pack_bf16x2(pm[2 * j], pm[2 * j + 1]);
           const bf16x8 pb = __builtin_bit_cast(bf16x8, pbw);
           const char* vp = smem + ATT_SV + (kt * 32 + 16 * s2 + v_row) * 128;
           const bf16x8 vf0 = tr_pair(vp + ((v_colb) ^ v_swz));
