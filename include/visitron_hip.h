@@ -77,7 +77,9 @@ int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const
 /* Same (same reference lines; in training also the dgrad GEMMs of loss.backward(), tasks/viewpoint_select/pretrain.py:191),
  * plus C2: optional second bf16 output saved for backward, row stride ldc2 -- gelu'(acc + bias)
  * when act == VT_ACT_GELU (what the backward of BertIntermediate multiplies by), else acc + bias --
- * and act == VT_ACT_MUL (out = acc * R). */
+ * and act == VT_ACT_MUL (out = acc * R).  out_f32 is a bit set (ABI 8): 1 = fp32 output; 2 = C written as FP16
+ * (saturating at +-65504) instead of bf16; 4 = the residual R holds FP16 -- the pre-LayerNorm sum and the residual operand
+ * of a layer that keeps fp16 copies of its residual stream (vt_layer_acts::ln1_h). */
 int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                       const void* R, int64_t ldr, void* C, int64_t ldc, void* C2, int64_t ldc2, int M, int N,
                       int K, int act, int out_f32, int grp_rows, int grp_stride, float drop_p, uint64_t drop_seed,
@@ -145,6 +147,11 @@ int vt_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
                       const float* beta, float* mean, float* rstd, int M, int H, float eps,
                       int grp_rows, int grp_stride, vt_stream_t stream);
 
+/* The same LayerNorm over FP16 input rows (the pre-LayerNorm sums of a layer that keeps fp16 copies of its residual
+ * stream, vt_layer_acts::ln1_h), written as bf16 (y) and, when y_f16 is not NULL, as fp16 too. */
+int vt_layernorm_h_bf16(const void* x_f16, int64_t ldx, void* y, int64_t ldy, void* y_f16, int64_t ldyh, const float* gamma,
+                        const float* beta, float* mean, float* rstd, int M, int H, float eps, vt_stream_t stream);
+
 /* Backward of vt_layernorm_bf16 (autograd of BertLayerNorm in BertSelfOutput / BertOutput, oscar/modeling_bert.py:94,120, and
  * of the image LayerNorm, encoder.py:280-281, inside loss.backward(), pretrain.py:191): dx, and dgamma / dbeta (fp32,
  * overwritten or accumulated).  x is the
@@ -155,6 +162,11 @@ int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ld
                           uint64_t drop_seed, uint32_t drop_site, vt_stream_t stream);
 /* (dx_dropped, optional: dx * mask / (1-p) of the given site = the gradient of the dense output that was
  * dropped out before the residual add.) */
+/* ... with the pre-LayerNorm input x held as FP16 (backward of vt_layernorm_h_bf16). */
+int vt_layernorm_bwd_h_bf16(const void* x_f16, int64_t ldx, const void* dy, int64_t ldy, const float* gamma,
+                            void* dx, int64_t lddx, float* dgamma, float* dbeta, float* partial_ws, int M, int H,
+                            float eps, int accumulate, void* dx_dropped, int64_t lddxd, float drop_p,
+                            uint64_t drop_seed, uint32_t drop_site, vt_stream_t stream);
 
 /* out = g * d, bf16, n elements (n % 8 == 0), d = saved gelu' values: the dGELU of the MLM-head transform
  * (BertOnlyMLMHead's dense + gelu, constructed at encoder.py:322, in loss.backward(), pretrain.py:191). */
@@ -490,6 +502,12 @@ typedef struct vt_layer_acts {
   float* lse;      /* [B,nh,S] or null */
   float* ln1_mean; float* ln1_rstd; float* ln2_mean; float* ln2_rstd; /* [M] or null */
   uint32_t* keep_bits; /* VT_KEEP_WORDS(B, nh, S) words or null: the attention dropout's keep decisions (see vt_attention_fwd_bf16) */
+  /* fp16 copies of the two LayerNorm outputs, [M,H] each, or both null (ABI 8).  Present: the layer keeps its residual
+   * stream at 11 significant bits -- attn_pre / out_pre then hold FP16 (same bytes), each LayerNorm writes its output as
+   * bf16 (attn_out / out: the next GEMM's operand, the backward's) and as fp16 (ln1_h / ln2_h: the next sub-layer's residual
+   * add reads this copy).  Transient: every layer may point at the same two buffers (ln2_h of layer l is read by layer
+   * l + 1's first residual add and overwritten after it).  The last layer's ln2_h is the encoder output at fp16 precision. */
+  void* ln1_h; void* ln2_h;
 } vt_layer_acts;
 
 /* x: [B*S, H] bf16 embedding output (layer-0 input).  head_scale: [L, nh] fp32 or null.

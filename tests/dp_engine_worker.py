@@ -36,14 +36,14 @@ def main():
                          max_position_embeddings=64)
         m = PreTrainOscar(cfg)
         m.load_state_dict(deterministic_state_dict(m, seed=5, weight_std=0.03))
-        bsz, text_len, region_len, per_chunk, bucket_mb, calls = 6, 40, 24, 1, 4.0, 3
+        bsz, text_len, region_len, per_chunk, bucket_mb, calls = 6, 40, 24, 1, 4.0, 4
     else:
         ops.force_gemm_variant(1)             # one kernel variant everywhere: the comparison is then order-exact
         ops.set_wgrad_kernel(-8)
         cfg = mini_config(num_hidden_layers=4)
         m = PreTrainOscar(cfg)
         m.load_state_dict(deterministic_state_dict(m, seed=5))
-        bsz, text_len, region_len, per_chunk, bucket_mb, calls = 3, 20, 10, 2, 0.05, 3
+        bsz, text_len, region_len, per_chunk, bucket_mb, calls = 3, 20, 10, 2, 0.05, 4
     m.tie_weights()
     m = m.to(dev).eval()
     eng = PretrainEngine(m, lr=1e-3, weight_decay=0.05, schedule="constant", warmup_steps=0, bucket_mb=bucket_mb,
@@ -74,7 +74,7 @@ def main():
     out = eng.train_step(shard, overlap=True, layers_per_chunk=per_chunk)
     torch.cuda.synchronize()
     assert abs(captured["scale"] - 1.0 / world) < 1e-12
-    assert bool(captured["cover"].all()) and captured["calls"] == calls   # the layer chunks + the tail
+    assert bool(captured["cover"].all()) and captured["calls"] == calls   # the heads (first), the layer chunks, the tail
     assert eng.step_count == 1 and eng.sched_step == 1
     metrics = all_reduce_metrics([v if torch.is_tensor(v) else torch.tensor(float(v), device=dev) for v in out])
     torch.save({"g": captured["g"], "p": eng.flat.p.detach().cpu(), "out": [float(v) for v in out],

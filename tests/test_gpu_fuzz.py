@@ -72,8 +72,12 @@ def test_random_shapes_inference_and_training_step(dev, seed):
         return                                      # PreTrainOscar's callers always pass regions
     with torch.no_grad():
         want7, got7 = ref(**b), prod(**bd)
+    # losses at 5e-2; the accuracies are counts of matching argmaxes over the supervised positions (encoder.py:398-431): at
+    # most ONE argmax per head may fall the other way (a near-tie among 1601 / 30522 random-weight logits decided in bf16)
+    n_sup = {4: int((b["labels"] != -1).sum()), 5: int(b["next_action"].shape[0]), 6: int((b["token_labels"] != -1).sum())}
+    tol7 = lambda i: 5e-2 if i < 4 else 1.0 / max(n_sup[i], 1) + 1e-6
     for i in range(7):
-        assert _close_or_both_nan(got7[i], want7[i], 5e-2 if i < 4 else 1e-6), (tag, i, float(got7[i]), float(want7[i]))
+        assert _close_or_both_nan(got7[i], want7[i], tol7(i)), (tag, i, float(got7[i]), float(want7[i]))
     prod.train()
     eng = PretrainEngine(prod)
     eng.compact_min_rows = 0 if seed % 2 else 1 << 30
@@ -82,7 +86,7 @@ def test_random_shapes_inference_and_training_step(dev, seed):
     o = eng.forward_backward(bd)
     torch.cuda.synchronize()
     for i in range(7):
-        assert _close_or_both_nan(o[i], w[i], 5e-2 if i < 4 else 1e-6), (tag, "train", i, float(o[i]), float(w[i]))
+        assert _close_or_both_nan(o[i], w[i], tol7(i)), (tag, "train", i, float(o[i]), float(w[i]))
     if float(w[0]) != float(w[0]):
         return                                      # NaN loss (no supervised row): nothing to differentiate
     w[0].backward()

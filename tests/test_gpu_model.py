@@ -166,8 +166,9 @@ def test_base_config_cfg1_matches_oracle(dev):
     # of the seven-launch layer); the deferred-LayerNorm path with its fp16 stream is what closed it.
     check_close("base cfg1 sequence_output", g_seq, w_seq, TOL_BF16)
     check_close("base cfg1 prediction_scores", g_scores, w_scores, TOL_BF16)
-    # the seven-launch layer (VT_DEFERRED_LN=0: what training-mode forwards and compacted rows still run), recorded with its
-    # round-2 bound; and its opt-in fp32 last layer
+    # the seven-launch layer (VT_DEFERRED_LN=0: what training-mode forwards and compacted rows run) at the same flat 5e-2:
+    # since round 4 it keeps its residual stream at fp16 precision (fp16 pre-LayerNorm sums, fp16 copies of the LayerNorm
+    # outputs for the residual adds; 5.8e-2 with the bf16 stream of rounds 1-3); and its opt-in fp32 last layer
     prod.bert.encoder.deferred_ln = False
     with torch.no_grad():
         g_seq7 = prod.bert(**{k: b[k].to(dev) for k in trunk_keys})[0]
@@ -175,8 +176,8 @@ def test_base_config_cfg1_matches_oracle(dev):
         g_seq2 = prod.bert(**{k: b[k].to(dev) for k in trunk_keys})[0]
     prod.bert.encoder.precise_final = False
     prod.bert.encoder.deferred_ln = True
-    check_close("base cfg1 sequence_output (seven-launch layer, bf16 residual stream)", g_seq7, w_seq, 8e-2)
-    check_close("base cfg1 sequence_output (seven-launch layer, precise_final)", g_seq2, w_seq, 7e-2)
+    check_close("base cfg1 sequence_output (seven-launch layer, fp16 residual stream)", g_seq7, w_seq, TOL_BF16)
+    check_close("base cfg1 sequence_output (seven-launch layer, fp16 stream, precise_final)", g_seq2, w_seq, TOL_BF16)
     check_close("base cfg1 pooled_output", g_pool, w_pool, TOL_BF16)
     check_close("base cfg1 action_scores", g_act, w_act, TOL_BF16)
     for i, n in enumerate(("loss", "mask_loss", "next_loss", "token_loss")):

@@ -427,9 +427,9 @@ def test_deferred_layernorm_path_equals_the_seven_launch_layer(dev):
         o_seq, o_pool = prod(**_to(b, dev))[:2]
         prod.encoder.deferred_ln = True
     e_new = check_close("deferred-LN trunk sequence_output (mini)", g_seq, w_seq, TOL)
-    # (the seven-launch layer rounds the residual stream to bf16 twice per sub-layer: on these weights it sits AT 5e-2 --
-    # measured 5.0e-2 -- which is what the deferred path is for; recorded, with the bound of the stress cases)
-    e_old = check_close("seven-launch layer trunk sequence_output (mini)", o_seq, w_seq, 8e-2)
+    # (the seven-launch layer: 5.0e-2 on these weights with the bf16 residual stream of rounds 1-3, asserted at 8e-2 then;
+    # with the fp16 copies of the stream -- round 4 -- it is held to the same flat bound as everything else)
+    e_old = check_close("seven-launch layer (fp16 stream) trunk sequence_output (mini)", o_seq, w_seq, TOL)
     check_close("deferred-LN trunk pooled_output (mini)", g_pool, w_pool, TOL)
     print("deferred-LN max error %.3e, seven-launch layer %.3e" % (e_new, e_old))
     assert e_new <= e_old + 5e-3, "the un-rounded residual stream should not be the less accurate of the two"

@@ -26,7 +26,7 @@ class LayerWeights(ctypes.Structure):  # vt_layer_weights
 class LayerActs(ctypes.Structure):  # vt_layer_acts
     _fields_ = [(n, c_void_p) for n in (
         "qkv", "ctx", "attn_pre", "attn_out", "mid_pre", "mid", "out_pre", "out", "lse",
-        "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd", "keep_bits")]
+        "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd", "keep_bits", "ln1_h", "ln2_h")]
 
 
 class LayerWeightsLn(ctypes.Structure):  # vt_layer_weights_ln
@@ -87,6 +87,9 @@ SIGNATURES = {
     "vt_layernorm_bwd_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_int64] + DROP
                               + [c_void_p]),
+    "vt_layernorm_bwd_h_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                        c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_int64] + DROP
+                                + [c_void_p]),
     "vt_embed_layernorm_bwd": (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_uint64, c_void_p]),
     "vt_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
@@ -159,6 +162,8 @@ SIGNATURES = {
                                       c_int, c_int, c_int, c_int] + DROP + [c_void_p, c_void_p]),
     "vt_layernorm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "vt_layernorm_h_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_int, c_float, c_void_p]),
     "vt_embed_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p, c_float, c_uint64, c_void_p]),

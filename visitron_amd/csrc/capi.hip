@@ -13,7 +13,8 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
                               long rows_total = 0, const uint32_t* keep_bits = nullptr);
 int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
-                              hipStream_t stream, void* dx2 = nullptr, long lddx2 = 0, const DropCfg* drop = nullptr);
+                              hipStream_t stream, void* dx2 = nullptr, long lddx2 = 0, const DropCfg* drop = nullptr,
+                              int x_f16 = 0);
 int vt_apply_dropout_dispatch(void* x, long ld, long rows, int cols, const DropCfg& d, hipStream_t stream);
 int vt_dropout_mask_dispatch(uint8_t* out, long n, const DropCfg& d, hipStream_t stream);
 int vt_dgelu_mul_dispatch(const void* g, const void* h, void* out, long n, hipStream_t stream);
@@ -66,7 +67,7 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
                               uint32_t* keep_bits = nullptr);
 int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
                           float* mean, float* rstd, int M, int H, float eps, int grp_rows, int grp_stride,
-                          hipStream_t stream);
+                          hipStream_t stream, int x_f16 = 0, void* y_f16 = nullptr, long ldyh = 0);
 int vt_embed_layernorm_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                                 const float* pos, const float* type, const float* gamma, const float* beta, void* y,
                                 long ldy, int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
@@ -132,7 +133,7 @@ const char* vt_error_string(int code) {
   }
 }
 
-int vt_abi_version(void) { return 7; }
+int vt_abi_version(void) { return 8; }
 
 int vt_batch_row_counts(const int64_t* labels, const int64_t* token_labels, const float* mask, const int32_t* err_flag, int B,
                         int S, int64_t* counts, int32_t* tile_counts, vt_stream_t stream) {
@@ -236,6 +237,15 @@ int vt_layernorm_bwd_bf16(const void* x, int64_t ldx, const void* dy, int64_t ld
   const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_layernorm_bwd_dispatch(x, ldx, dy, ldy, gamma, dx, lddx, dgamma, dbeta, partial_ws, M, H, eps, accumulate,
                                    (hipStream_t)stream, dx_dropped, lddxd, &d);
+}
+
+int vt_layernorm_bwd_h_bf16(const void* x_f16, int64_t ldx, const void* dy, int64_t ldy, const float* gamma, void* dx,
+                            int64_t lddx, float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps,
+                            int accumulate, void* dx_dropped, int64_t lddxd, float drop_p, uint64_t drop_seed,
+                            uint32_t drop_site, vt_stream_t stream) {
+  const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
+  return vt_layernorm_bwd_dispatch(x_f16, ldx, dy, ldy, gamma, dx, lddx, dgamma, dbeta, partial_ws, M, H, eps, accumulate,
+                                   (hipStream_t)stream, dx_dropped, lddxd, &d, 1);
 }
 
 int vt_embed_layernorm_bwd(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
@@ -500,6 +510,11 @@ int vt_layernorm_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
                                (hipStream_t)stream);
 }
 
+int vt_layernorm_h_bf16(const void* x_f16, int64_t ldx, void* y, int64_t ldy, void* y_f16, int64_t ldyh, const float* gamma,
+                        const float* beta, float* mean, float* rstd, int M, int H, float eps, vt_stream_t stream) {
+  return vt_layernorm_dispatch(x_f16, ldx, y, ldy, gamma, beta, mean, rstd, M, H, eps, 0, 0, (hipStream_t)stream, 1, y_f16, ldyh);
+}
+
 int vt_embed_layernorm(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                        const float* pos, const float* type, const float* gamma, const float* beta, void* y,
                        int64_t ldy, int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
@@ -648,6 +663,7 @@ static int encoder_forward_impl(const vt_layer_weights* layers, const vt_layer_a
   if (rows && (!seq_start || !seq_len || mask || rows < 0 || rows > (long)B * S)) return VT_ERR_BAD_SHAPE;
   const int M = rows ? (int)rows : B * S;
   const void* cur = x;
+  const void* cur_h = nullptr;   // fp16 copy of `cur` (the previous layer's output), when that layer kept one
   for (int l = 0; l < num_layers; ++l) {
     const vt_layer_weights& w = layers[l];
     const vt_layer_acts& a = acts[l];
@@ -662,18 +678,30 @@ static int encoder_forward_impl(const vt_layer_weights* layers, const vt_layer_a
                                    a.lse, B, S, nh, 64, stream, &d_att, rows ? seq_start : nullptr, rows ? seq_len : nullptr,
                                    a.keep_bits);
     if (rc) return rc;
-    rc = vt_gemm_dispatch(a.ctx, H, w.w_ao, H, w.b_ao, cur, H, a.attn_pre, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream, nullptr, 0, &d_so);
+    // The residual stream.  Plain form: every tensor bf16.  With the layer's fp16 copies present (ln1_h / ln2_h non-null,
+    // vt_layer_acts): the pre-LayerNorm sums attn_pre / out_pre are written and read as fp16, each LayerNorm writes its
+    // output twice -- bf16 for the next GEMM's A operand (and the backward), fp16 for the next sub-layer's residual add --
+    // so the stream itself is rounded to 11 significant bits instead of 8 (north_star's 5e-2 on the hidden states of the
+    // path training runs: 5.8e-2 with the bf16 stream on the stress weights).
+    const bool h16 = a.ln1_h && a.ln2_h;
+    const void* res = cur_h ? cur_h : cur;
+    rc = vt_gemm_dispatch(a.ctx, H, w.w_ao, H, w.b_ao, res, H, a.attn_pre, H, M, H, H, VT_ACT_NONE,
+                          (h16 ? 2 : 0) | (cur_h ? 4 : 0), 0, 0, stream, nullptr, 0, &d_so);
     if (rc) return rc;
-    rc = vt_layernorm_dispatch(a.attn_pre, H, a.attn_out, H, w.ln1_g, w.ln1_b, a.ln1_mean, a.ln1_rstd, M, H, ln_eps, 0, 0, stream);
+    rc = vt_layernorm_dispatch(a.attn_pre, H, a.attn_out, H, w.ln1_g, w.ln1_b, a.ln1_mean, a.ln1_rstd, M, H, ln_eps, 0, 0, stream,
+                               h16 ? 1 : 0, h16 ? a.ln1_h : nullptr, H);
     if (rc) return rc;
     rc = vt_gemm_dispatch(a.attn_out, H, w.w_in, H, w.b_in, nullptr, 0, a.mid, I, M, I, H, VT_ACT_GELU, 0, 0, 0, stream,
                           a.mid_pre, I);
     if (rc) return rc;
-    rc = vt_gemm_dispatch(a.mid, I, w.w_out, I, w.b_out, a.attn_out, H, a.out_pre, H, M, H, I, VT_ACT_NONE, 0, 0, 0, stream, nullptr, 0, &d_out);
+    rc = vt_gemm_dispatch(a.mid, I, w.w_out, I, w.b_out, h16 ? a.ln1_h : a.attn_out, H, a.out_pre, H, M, H, I, VT_ACT_NONE,
+                          h16 ? 6 : 0, 0, 0, stream, nullptr, 0, &d_out);
     if (rc) return rc;
-    rc = vt_layernorm_dispatch(a.out_pre, H, a.out, H, w.ln2_g, w.ln2_b, a.ln2_mean, a.ln2_rstd, M, H, ln_eps, 0, 0, stream);
+    rc = vt_layernorm_dispatch(a.out_pre, H, a.out, H, w.ln2_g, w.ln2_b, a.ln2_mean, a.ln2_rstd, M, H, ln_eps, 0, 0, stream,
+                               h16 ? 1 : 0, h16 ? a.ln2_h : nullptr, H);
     if (rc) return rc;
     cur = a.out;
+    cur_h = h16 ? a.ln2_h : nullptr;
   }
   return VT_OK;
 }
@@ -765,8 +793,9 @@ static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_
     void* g_pre_dn = p_hidden > 0.f ? ws->g_pre_d : ws->g_pre;
     void* g_pre2_dn = p_hidden > 0.f ? ws->g_pre2_d : ws->g_pre2;
     // LayerNorm 2 backward: dL/d(out_pre)
+    const int h16 = (a.ln1_h && a.ln2_h) ? 1 : 0;   // the forward kept the pre-LayerNorm sums as fp16 (see encoder_forward_impl)
     rc = vt_layernorm_bwd_dispatch(a.out_pre, H, g, H, w.ln2_g, ws->g_pre, H, d.d_ln2_g, d.d_ln2_b, ws->ln_partial, M, H,
-                                   ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre_d : nullptr, H, &d_out);
+                                   ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre_d : nullptr, H, &d_out, h16);
     if (rc) return rc;
     // through output.dense and the GELU: g_mid = (g_pre . W_out) * gelu'(pre-activation) (saved in mid_pre)
     rc = vt_gemm_dispatch(g_pre_dn, H, wt.wt_out, H, nullptr, a.mid_pre, I, ws->g_mid, I, M, I, H, VT_ACT_MUL, 0, 0, 0, stream);
@@ -776,7 +805,7 @@ static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_
     if (rc) return rc;
     // LayerNorm 1 backward: dL/d(attn_pre)
     rc = vt_layernorm_bwd_dispatch(a.attn_pre, H, g, H, w.ln1_g, ws->g_pre2, H, d.d_ln1_g, d.d_ln1_b, ws->ln_partial, M, H,
-                                   ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre2_d : nullptr, H, &d_so);
+                                   ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre2_d : nullptr, H, &d_so, h16);
     if (rc) return rc;
     // through attention.output.dense: dL/d(ctx)
     rc = vt_gemm_dispatch(g_pre2_dn, H, wt.wt_ao, H, nullptr, nullptr, 0, ws->g_ctx, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream);

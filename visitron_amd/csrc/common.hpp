@@ -40,6 +40,23 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// ---- fp16 (the higher-precision copies of the residual stream: 11 significant bits against bf16's 8) ----------------
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float f16lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+__device__ __forceinline__ float f16hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+// two fp32 -> one dword of fp16, round to nearest even, saturating at the largest finite fp16 (a pre-LayerNorm sum of that
+// size does not occur in a BERT-class model; it must not become an infinity that the next LayerNorm turns into NaN)
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  lo = __builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f);
+  hi = __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f);
+  const f16x2_t v = __builtin_convertvector((f32x2){lo, hi}, f16x2_t);
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint16_t f32_to_f16bits(float f) {
+  return __builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
+}
+__device__ __forceinline__ float f16bits_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), enough for fp32-tolerance parity
 // (1e-3) and far below bf16 resolution; ~12 VALU ops instead of libm's erff.
 __device__ __forceinline__ float fast_erf(float x) {

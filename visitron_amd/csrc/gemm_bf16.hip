@@ -826,8 +826,12 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
 
 // Host entry used by the C ABI (capi.hip).  Returns a VT_* code; never synchronises.
 int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const void* R, long ldr,
-                     void* C, long ldc, int M, int N, int K, int act, int out_f32, int grp_rows, int grp_stride,
+                     void* C, long ldc, int M, int N, int K, int act, int out_mode, int grp_rows, int grp_stride,
                      hipStream_t stream, void* C2 = nullptr, long ldc2 = 0, const DropCfg* drop = nullptr) {
+  // out_mode: bit 0 fp32 output; bit 1 C written as fp16 (saturating) instead of bf16; bit 2 the residual R holds fp16
+  // (GemmArgs::c_f16 / r_f16: the training layer's higher-precision residual stream)
+  const int out_f32 = out_mode & 1, c_f16 = (out_mode >> 1) & 1, r_f16 = (out_mode >> 2) & 1;
+  if ((out_mode & ~7) || (c_f16 && out_f32) || (r_f16 && (!R || act == ACT_MUL))) return VT_ERR_UNSUPPORTED;
   if (!A || !W || !C) return VT_ERR_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || (K % GEMM_BK) != 0) return VT_ERR_BAD_SHAPE;
   if ((lda % 8) || (ldw % 8) || (R && (ldr % 8)) || (ldc % (out_f32 ? 4 : 8)) || (C2 && (ldc2 % 8))) return VT_ERR_BAD_ALIGN;
@@ -843,11 +847,13 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   g.trace = (unsigned long long*)g_gemm_trace;
   g.ln_mode = 0; g.ln_np = 0; g.ln_rows = 0; g.ln_inv_n = 0.f; g.ln_eps = 0.f; g.ln_stats = nullptr; g.colv = nullptr;
   g.Rs = nullptr; g.Cs = nullptr; g.stats_out = nullptr; g.ldrs = 0; g.ldcs = 0; g.ksplit = 0; g.c_plane = 0;
+  g.r_f16 = r_f16; g.c_f16 = c_f16;
   if (g.drop.thresh && (long)M * N >= (1L << 32)) return VT_ERR_UNSUPPORTED;
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-  const int variant = g_gemm_variant >= 0 ? g_gemm_variant
-                                          : vt_gemm_pick_variant(M, N, K, VT_TUNE_KIND(act, R != nullptr, C2 != nullptr, out_f32 != 0, 0));
+  int variant = g_gemm_variant >= 0 ? g_gemm_variant
+                                    : vt_gemm_pick_variant(M, N, K, VT_TUNE_KIND(act, R != nullptr, C2 != nullptr, out_f32 != 0, 0));
+  if ((r_f16 || c_f16) && (variant == 9 || variant == 10)) variant = 1;   // the 256 x 192 / 256 kernels' grouped epilogue reads / writes bf16 only
   auto launch = [&](const GemmArgs& ga, int v) {
     switch (act * 2 + (out_f32 ? 1 : 0)) {
       case 0: return launch_gemm<ACT_NONE, false>(ga, v, stream);
@@ -918,7 +924,7 @@ int vt_gemm_ln_dispatch(const void* A, long lda, const void* W, long ldw, const 
   g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f;
   g.ln_mode = ln_mode; g.ln_np = np; g.ln_rows = (int)stat_rows; g.ln_inv_n = 1.0f / (float)row_len; g.ln_eps = eps;
   g.ln_stats = stats_in; g.colv = colv; g.Rs = (const uint16_t*)Rs; g.Cs = (uint16_t*)Cs; g.stats_out = stats_out; g.ldrs = ldrs; g.ldcs = ldcs;
-  g.ksplit = 0; g.c_plane = 0;
+  g.ksplit = 0; g.c_plane = 0; g.r_f16 = 0; g.c_f16 = 0;
   int variant = g_gemm_variant >= 0 ? g_gemm_variant : vt_gemm_pick_variant(M, N, K, VT_TUNE_KIND(act, 0, 0, 0, ln_mode));
   if (variant != 15 && variant != 16 && (variant < 18 || variant > 23)) variant = 16;   // only the 256x256-tile kernels
   return vt_gemm_ln_launch(g, act, variant, stream);
@@ -960,7 +966,7 @@ int vt_gemm_splitk_dispatch(const void* A, long lda, const void* W, long ldw, vo
   g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f;
   g.ln_mode = 0; g.ln_np = 0; g.ln_rows = 0; g.ln_inv_n = 0.f; g.ln_eps = 0.f; g.ln_stats = nullptr; g.colv = nullptr;
   g.Rs = nullptr; g.Cs = nullptr; g.stats_out = nullptr; g.ldrs = 0; g.ldcs = 0;
-  g.ksplit = ksplit; g.c_plane = (long)M * N;
+  g.ksplit = ksplit; g.c_plane = (long)M * N; g.r_f16 = 0; g.c_f16 = 0;
   const int rc = vt_gemm_v7_launch(g, ACT_NONE, 1, stream, 8);
   if (rc) return rc;
   const long n4 = ((long)M * N + 3) / 4;

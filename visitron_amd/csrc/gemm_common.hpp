@@ -43,6 +43,11 @@ struct GemmArgs {
   // the MLM decoder's dgrad, [4 272, 30 528] x [30 528, 768] = 51 tiles of 256 x 256 with 477 K-steps each.
   int ksplit;                // 0 / 1: off
   long c_plane;
+  // ---- fp16 copies of the residual stream in the seven-launch (training) layer ------------------------------------
+  // r_f16: the residual operand R holds fp16 (the previous LayerNorm's output, kept beside its bf16 copy);
+  // c_f16: C is written as fp16 (saturating): the pre-LayerNorm sum dense(h) + bias + residual.  Same bytes as bf16, three
+  // more significant bits where the stream is rounded twice per sub-layer.
+  int r_f16, c_f16;
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_MUL = 3 };  // MUL: out = acc * R (R = saved gelu'(pre-activation))
@@ -121,10 +126,10 @@ __device__ __forceinline__ void epi_row_values(const GemmArgs& g, const f32x4 (&
     float rv[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      rv[2 * i] = bf16lo(r0[i]);
-      rv[2 * i + 1] = bf16hi(r0[i]);
-      rv[8 + 2 * i] = bf16lo(r1[i]);
-      rv[8 + 2 * i + 1] = bf16hi(r1[i]);
+      rv[2 * i] = g.r_f16 ? f16lo(r0[i]) : bf16lo(r0[i]);
+      rv[2 * i + 1] = g.r_f16 ? f16hi(r0[i]) : bf16hi(r0[i]);
+      rv[8 + 2 * i] = g.r_f16 ? f16lo(r1[i]) : bf16lo(r1[i]);
+      rv[8 + 2 * i + 1] = g.r_f16 ? f16hi(r1[i]) : bf16hi(r1[i]);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = (ACT == ACT_MUL) ? v[i] * rv[i] : v[i] + rv[i];
@@ -161,8 +166,8 @@ __device__ __forceinline__ void epi_row_direct(const GemmArgs& g, const f32x4 (&
       u32x4 o0, o1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-        o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+        o0[i] = g.c_f16 ? pack_f16x2(v[2 * i], v[2 * i + 1]) : pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        o1[i] = g.c_f16 ? pack_f16x2(v[8 + 2 * i], v[8 + 2 * i + 1]) : pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
       }
       cp[0] = o0;
       cp[1] = o1;
@@ -176,11 +181,12 @@ __device__ __forceinline__ void epi_row_direct(const GemmArgs& g, const f32x4 (&
         float x = apply_act<ACT>(pre);
         if (g.drop.thresh) x = vt_keep(g.drop, (uint32_t)m * (uint32_t)g.N + (uint32_t)(nb + i)) ? x * g.drop.scale : 0.f;
         if (g.R) {
-          const float rr = bf16_to_f32(g.R[orow * g.ldr + nb + i]);
+          const uint16_t rb = g.R[orow * g.ldr + nb + i];
+          const float rr = g.r_f16 ? f16bits_to_f32(rb) : bf16_to_f32(rb);
           x = (ACT == ACT_MUL) ? x * rr : x + rr;
         }
         if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;
-        else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = f32_to_bf16(x);
+        else ((bf16_t*)g.C)[orow * g.ldc + nb + i] = g.c_f16 ? f32_to_f16bits(x) : f32_to_bf16(x);
       }
     }
   }

@@ -134,7 +134,8 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
       asm volatile("" : "+v"(rq[MT][0]), "+v"(rq[MT][1]));                                                \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
         const u32x4 q0 = rq[MT][0], q1 = rq[MT][1];                                                       \
-        const float r0 = bf16lo(q0[i]), r1 = bf16hi(q0[i]), r2 = bf16lo(q1[i]), r3 = bf16hi(q1[i]);       \
+        const float r0 = r_f16 ? f16lo(q0[i]) : bf16lo(q0[i]), r1 = r_f16 ? f16hi(q0[i]) : bf16hi(q0[i]); \
+        const float r2 = r_f16 ? f16lo(q1[i]) : bf16lo(q1[i]), r3 = r_f16 ? f16hi(q1[i]) : bf16hi(q1[i]); \
         if (ACT == ACT_MUL) { v[2 * i] *= r0; v[2 * i + 1] *= r1; v[8 + 2 * i] *= r2; v[8 + 2 * i + 1] *= r3; } \
         else { v[2 * i] += r0; v[2 * i + 1] += r1; v[8 + 2 * i] += r2; v[8 + 2 * i + 1] += r3; }          \
       }                                                                                                   \
@@ -145,9 +146,16 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
       }                                                                                                   \
     }                                                                                                     \
     u32x4 o0, o1;                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
-      o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);                                                        \
-      o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);                                                \
+    if (c_f16) {   /* the pre-LayerNorm sum of the training layer as fp16 (wave-uniform branch) */           \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        o0[i] = pack_f16x2(v[2 * i], v[2 * i + 1]);                                                       \
+        o1[i] = pack_f16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);                                               \
+      }                                                                                                   \
+    } else {                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+        o0[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);                                                      \
+        o1[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);                                              \
+      }                                                                                                   \
     }                                                                                                     \
     v7_buf_store16(o0, rs_c, vo_c, so_row * ldc_b + ec * 2);                                              \
     v7_buf_store16_o16(o1, rs_c, vo_c, so_row * ldc_b + ec * 2);                                          \
@@ -166,6 +174,7 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
   const int gq = lane >> 4, j = lane & 15;
   const int vo_c = j * ldc_b + gq * 32, vo_c2 = j * ldc2_b + gq * 32, vo_r = j * ldr_b + gq * 32;
   const bool has_c2 = g.C2 != nullptr;
+  const bool r_f16 = g.r_f16 != 0, c_f16 = g.c_f16 != 0;
   u32x4 rq[8][2];   // residual ring: the next eight slabs (one column half), two 8-column halves each
   // the two 64-column halves spelled out: a rolled (or not fully unrolled) loop would index the accumulators
   // dynamically and demote them to scratch

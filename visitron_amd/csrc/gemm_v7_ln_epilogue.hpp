@@ -31,17 +31,6 @@
 // emulation of the forward with an fp16 stream gives the same error against the fp32 reference as an fp32 stream:
 // 2.2e-2 against 2.1e-2 on the base config, where the bf16 stream of the seven-launch layer gives 7.4e-2.)
 #define V7_LN_RING 8
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float f16lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
-__device__ __forceinline__ float f16hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
-// two fp32 -> one dword of fp16, round to nearest even, saturating at the largest finite fp16 (a pre-LayerNorm sum of that
-// size does not occur in a BERT-class model; it must not become an infinity that the next LayerNorm turns into NaN)
-__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
-  lo = __builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f);
-  hi = __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f);
-  const f16x2_t v = __builtin_convertvector((f32x2){lo, hi}, f16x2_t);
-  return __builtin_bit_cast(uint32_t, v);
-}
 // VMEM operations younger than slab s's ring loads at the moment slab s waits for them (T slabs; LD loads and ST stores
 // per slab; issue order per slab: wait, arithmetic, loads of slab s + RING, stores of slab s; prologue: slabs 0 .. RING-1)
 constexpr int v7_ln_vmcnt(int s, int T) {

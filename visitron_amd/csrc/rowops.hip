@@ -12,8 +12,9 @@
 #include "common.hpp"
 
 struct LnArgs {
-  const bf16_t* x; long ldx;
+  const bf16_t* x; long ldx;   // bf16, or fp16 (template parameter XF16: the training layer's pre-LayerNorm sums)
   bf16_t* y; long ldy;
+  uint16_t* yh; long ldyh;     // optional second output: the same rows as fp16 (the next sub-layer's residual operand)
   const float* gamma; const float* beta;
   float* mean; float* rstd;  // optional [M] outputs for backward
   int M, H;
@@ -21,8 +22,10 @@ struct LnArgs {
   float eps;
 };
 
-template <int CH>
+template <int CH, bool XF16>
 __global__ __launch_bounds__(256) void layernorm_rows(LnArgs a) {
+  auto lo = [](uint32_t w) { return XF16 ? f16lo(w) : bf16lo(w); };
+  auto hi = [](uint32_t w) { return XF16 ? f16hi(w) : bf16hi(w); };
   // One wave = LN_ROWS consecutive rows at once: their loads are all in flight together and the scale / shift vectors
   // (6 KiB of fp32 against 1.5 KiB per row) are fetched once per wave instead of once per row.
   constexpr int LN_ROWS = 4;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void layernorm_rows(LnArgs a) {
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s += bf16lo(w[r][c][i]) + bf16hi(w[r][c][i]);   // columns past H hold zeros
+      for (int i = 0; i < 4; ++i) s += lo(w[r][c][i]) + hi(w[r][c][i]);   // columns past H hold zeros
     u[r] = s;
   }
 #pragma unroll
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void layernorm_rows(LnArgs a) {
       if (col < a.H) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float d0 = bf16lo(w[r][c][i]) - u[r], d1 = bf16hi(w[r][c][i]) - u[r];
+          const float d0 = lo(w[r][c][i]) - u[r], d1 = hi(w[r][c][i]) - u[r];
           ss += d0 * d0 + d1 * d1;
         }
       }
@@ -105,14 +108,16 @@ __global__ __launch_bounds__(256) void layernorm_rows(LnArgs a) {
     for (int c = 0; c < CH; ++c) {
       const int col = (lane + 64 * c) * 8;
       if (col < a.H) {
-        u32x4 o4;
+        u32x4 o4, h4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float o0 = (bf16lo(w[r][c][i]) - u[r]) * rstd * gam[c][2 * i] + bet[c][2 * i];
-          const float o1 = (bf16hi(w[r][c][i]) - u[r]) * rstd * gam[c][2 * i + 1] + bet[c][2 * i + 1];
+          const float o0 = (lo(w[r][c][i]) - u[r]) * rstd * gam[c][2 * i] + bet[c][2 * i];
+          const float o1 = (hi(w[r][c][i]) - u[r]) * rstd * gam[c][2 * i + 1] + bet[c][2 * i + 1];
           o4[i] = pack_bf16x2(o0, o1);
+          h4[i] = pack_f16x2(o0, o1);
         }
         *(u32x4*)(yp + col) = o4;
+        if (a.yh) *(u32x4*)(a.yh + prow[r] * a.ldyh + col) = h4;
       }
     }
   }
@@ -120,19 +125,25 @@ __global__ __launch_bounds__(256) void layernorm_rows(LnArgs a) {
 
 int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
                           float* mean, float* rstd, int M, int H, float eps, int grp_rows, int grp_stride,
-                          hipStream_t stream) {
+                          hipStream_t stream, int x_f16 = 0, void* y_f16 = nullptr, long ldyh = 0) {
   if (!x || !y || !gamma || !beta) return VT_ERR_NULL;
   if (M <= 0 || H <= 0 || (H % 8) || H > 64 * 8 * 4) return VT_ERR_BAD_SHAPE;
   if ((ldx % 8) || (ldy % 8) || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15)) return VT_ERR_BAD_ALIGN;
+  if (y_f16 && ((ldyh % 8) || ((uintptr_t)y_f16 & 15))) return VT_ERR_BAD_ALIGN;
   LnArgs a;
   a.x = (const bf16_t*)x; a.ldx = ldx; a.y = (bf16_t*)y; a.ldy = ldy; a.gamma = gamma; a.beta = beta;
+  a.yh = (uint16_t*)y_f16; a.ldyh = ldyh;
   a.mean = mean; a.rstd = rstd; a.M = M; a.H = H; a.grp_rows = grp_rows; a.grp_stride = grp_stride; a.eps = eps;
   const dim3 grid((M + 15) / 16), block(256);   // 4 waves x 4 rows per workgroup
   const int ch = (H + 511) / 512;
-  if (ch == 1) hipLaunchKernelGGL(layernorm_rows<1>, grid, block, 0, stream, a);
-  else if (ch == 2) hipLaunchKernelGGL(layernorm_rows<2>, grid, block, 0, stream, a);
-  else if (ch == 3) hipLaunchKernelGGL(layernorm_rows<3>, grid, block, 0, stream, a);
-  else hipLaunchKernelGGL(layernorm_rows<4>, grid, block, 0, stream, a);
+#define VT_LN_LAUNCH(CH_)                                                                     \
+  if (x_f16) hipLaunchKernelGGL((layernorm_rows<CH_, true>), grid, block, 0, stream, a);      \
+  else hipLaunchKernelGGL((layernorm_rows<CH_, false>), grid, block, 0, stream, a)
+  if (ch == 1) { VT_LN_LAUNCH(1); }
+  else if (ch == 2) { VT_LN_LAUNCH(2); }
+  else if (ch == 3) { VT_LN_LAUNCH(3); }
+  else { VT_LN_LAUNCH(4); }
+#undef VT_LN_LAUNCH
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
@@ -321,7 +332,7 @@ struct LnBwdArgs {
   float eps;
 };
 
-template <int CH>
+template <int CH, bool XF16>
 __global__ __launch_bounds__(256) void layernorm_bwd_rows(LnBwdArgs a) {
   __shared__ float red[4][2][CH * 512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows(LnBwdArgs a) {
         const u32x4 d = *(const u32x4*)(a.dy + row * a.ldy + col);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          xv[c][2 * i] = bf16lo(w[i]); xv[c][2 * i + 1] = bf16hi(w[i]);
+          xv[c][2 * i] = XF16 ? f16lo(w[i]) : bf16lo(w[i]); xv[c][2 * i + 1] = XF16 ? f16hi(w[i]) : bf16hi(w[i]);
           gv[c][2 * i] = bf16lo(d[i]); gv[c][2 * i + 1] = bf16hi(d[i]);
         }
 #pragma unroll
@@ -466,7 +477,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ p
 #define LN_BWD_MAX_BLOCKS 1024
 int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
-                              hipStream_t stream, void* dx2 = nullptr, long lddx2 = 0, const DropCfg* drop = nullptr) {
+                              hipStream_t stream, void* dx2 = nullptr, long lddx2 = 0, const DropCfg* drop = nullptr,
+                              int x_f16 = 0) {
   if (!x || !dy || !gamma || !dx || !dgamma || !dbeta || !partial_ws) return VT_ERR_NULL;
   if (M <= 0 || H <= 0 || (H % 8) || H > 1024) return VT_ERR_BAD_SHAPE;
   if ((ldx % 8) || (ldy % 8) || (lddx % 8) || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15)) return VT_ERR_BAD_ALIGN;
@@ -478,8 +490,13 @@ int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy,
   if (dx2 && ((lddx2 % 8) || ((uintptr_t)dx2 & 15))) return VT_ERR_BAD_ALIGN;
   int nblocks = (M + 3) / 4;
   if (nblocks > LN_BWD_MAX_BLOCKS) nblocks = LN_BWD_MAX_BLOCKS;
-  if (H <= 512) hipLaunchKernelGGL(layernorm_bwd_rows<1>, dim3(nblocks), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(layernorm_bwd_rows<2>, dim3(nblocks), dim3(256), 0, stream, a);
+  if (H <= 512) {
+    if (x_f16) hipLaunchKernelGGL((layernorm_bwd_rows<1, true>), dim3(nblocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((layernorm_bwd_rows<1, false>), dim3(nblocks), dim3(256), 0, stream, a);
+  } else {
+    if (x_f16) hipLaunchKernelGGL((layernorm_bwd_rows<2, true>), dim3(nblocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((layernorm_bwd_rows<2, false>), dim3(nblocks), dim3(256), 0, stream, a);
+  }
   hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 15) / 16), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
                      dbeta, H, accumulate);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;

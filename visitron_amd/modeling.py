@@ -732,6 +732,9 @@ class CaptionBertEncoder(nn.Module):
         H, I, L = self._hidden, self._inter, len(self.layer)
         mk = lambda n: torch.empty((M, n), dtype=BF16, device=device)
         shared = dict(qkv=mk(3 * H), ctx=mk(H), attn_pre=mk(H), attn_out=mk(H), mid=mk(I), out_pre=mk(H))
+        if ops.F16_STREAM:   # the residual stream at fp16 precision: pre-LayerNorm sums + the LayerNorm outputs' second copies
+            mkh = lambda: torch.empty((M, H), dtype=ops.F16, device=device)
+            shared.update(attn_pre=mkh(), out_pre=mkh(), ln1_h=mkh(), ln2_h=mkh())
         outs = [mk(H) for _ in range(L)] if keep_all else [mk(H)] * L
         table = (_lib.LayerActs * L)()
         for i in range(L):
@@ -776,6 +779,8 @@ class CaptionBertEncoder(nn.Module):
         if seq is not None or not self.precise_final:
             ops.encoder_forward(pk.table, ws["table"], x_bf16, mask_f32, mask_additive, head_scale, B, S,
                                 self._hidden, self._heads, self._inter, self._eps, seq=seq)
+            if seq is None and "ln2_h" in ws["shared"]:   # the caller's hidden states from the fp16 copy of the last LayerNorm
+                self._final_f32, self._final_f32_fresh = ws["shared"]["ln2_h"], False
             return ws["outs"]
         # The hidden states this call returns are handed to the caller in fp32.  Layers 0 .. L-2 run in the C loop; the
         # last layer is issued here with its two pre-LayerNorm sums kept in fp32 and its LayerNorm written twice from
@@ -797,7 +802,8 @@ class CaptionBertEncoder(nn.Module):
         ops.linear(cur, t["w_qkv"], t["b_qkv"], out=sh["qkv"])
         ops.attention_fwd(sh["qkv"], B, S, self._heads, mask=mask_f32, mask_additive=mask_additive, head_scale=hs_l,
                           out=sh["ctx"])
-        ops.linear(sh["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=ws["pre32"], out_f32=True)
+        res = sh["ln2_h"] if (L > 1 and "ln2_h" in sh) else cur   # the previous layer's output at fp16 precision
+        ops.linear(sh["ctx"], t["w_ao"], t["b_ao"], residual=res, out=ws["pre32"], out_f32=True)
         ops.layernorm_rows(ws["pre32"], t["ln1_g"], t["ln1_b"], eps, out=sh["attn_out"])
         ops.linear(sh["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=sh["mid"])
         ops.linear(sh["mid"], t["w_out"], t["b_out"], residual=sh["attn_out"], out=ws["pre32"], out_f32=True)
@@ -810,7 +816,7 @@ class CaptionBertEncoder(nn.Module):
         """The launch sequence of vt_encoder_forward_bf16 issued op by op (same kernels, same buffers); with `probs` (a
         list) also each layer's attention probabilities (output_attentions)."""
         sh, nh, eps = ws["shared"], self._heads, self._eps
-        cur = x
+        cur, cur_h = x, None
         lse = torch.empty((B, nh, S), dtype=torch.float32, device=x.device) if probs is not None else None
         for i, t in enumerate(pk.tensors):
             out = ws["outs"][i]
@@ -828,12 +834,16 @@ class CaptionBertEncoder(nn.Module):
                 if probs is not None:
                     probs.append(ops.attention_probs(sh["qkv"], lse, B, S, nh, mask=mask, mask_additive=mask_additive,
                                                      head_scale=hs_i))
-            ops.linear(sh["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=sh["attn_pre"])
-            ops.layernorm(sh["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=sh["attn_out"])
+            # (with the fp16 copies of the stream -- ops.F16_STREAM -- attn_pre / out_pre are fp16 tensors and every
+            # LayerNorm also writes ln1_h / ln2_h, which the residual adds read: the library learns it from the dtypes)
+            ops.linear(sh["ctx"], t["w_ao"], t["b_ao"], residual=cur if cur_h is None else cur_h, out=sh["attn_pre"])
+            ops.layernorm(sh["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=sh["attn_out"], out_h=sh.get("ln1_h"))
             ops.linear(sh["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=sh["mid"])
-            ops.linear(sh["mid"], t["w_out"], t["b_out"], residual=sh["attn_out"], out=sh["out_pre"])
-            ops.layernorm(sh["out_pre"], t["ln2_g"], t["ln2_b"], eps, out=out)
-            cur = out
+            ops.linear(sh["mid"], t["w_out"], t["b_out"], residual=sh.get("ln1_h", sh["attn_out"]), out=sh["out_pre"])
+            ops.layernorm(sh["out_pre"], t["ln2_g"], t["ln2_b"], eps, out=out, out_h=sh.get("ln2_h"))
+            cur, cur_h = out, sh.get("ln2_h")
+        if "ln2_h" in sh:
+            self._final_f32, self._final_f32_fresh = sh["ln2_h"], False
         return ws["outs"]
 
     def run_f32(self, x, B, S, mask_f32, mask_additive, head_scale=None, history=None):

@@ -96,6 +96,13 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
+F16 = torch.float16
+# The seven-launch layer (training, compacted-row and diagnostic forwards) keeps its residual stream at fp16 precision: the
+# pre-LayerNorm sums are written as fp16 and every LayerNorm output also as an fp16 copy that the next residual add reads
+# (include/visitron_hip.h, vt_layer_acts::ln1_h).  VT_F16_STREAM=0: every tensor bf16, as through round 3 (A/B switch).
+F16_STREAM = os.environ.get("VT_F16_STREAM", "1") != "0"
+
+
 def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False, grp_rows=0, grp_stride=0,
            M=None, lda=None, ldc=None, pre_act_out=None, drop=NO_DROP):
     """out = act(a @ w.T + bias) (+ residual).  a [M,K] bf16 (row stride lda), w [N,K] bf16.
@@ -114,16 +121,18 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
     if ldc is None:
         ldc = out.stride(0)
     ldr = residual.stride(0) if residual is not None else 0
+    # an fp16 `out` / `residual` (the training layer's higher-precision residual stream) is told to the library by bits 1 / 2
+    # of its output-mode argument
+    assert out.dtype == (torch.float32 if out_f32 else out.dtype) and out.dtype in (BF16, F16, torch.float32)
+    assert residual is None or residual.dtype in (BF16, F16)
+    out_f32 = (1 if out_f32 else 0) | (2 if out.dtype == F16 else 0) | (4 if (residual is not None and residual.dtype == F16) else 0)
     with _timed("gemm_nt_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
         rc = _lib.load().vt_linear_bf16_ex(
             _ptr(a), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(residual), ldr, _ptr(out), ldc,
             _ptr(pre_act_out), 0 if pre_act_out is None else pre_act_out.stride(0),
-            M, N, K, act, 1 if out_f32 else 0, grp_rows, grp_stride, float(drop[0]), int(drop[1]), int(drop[2]), _stream())
+            M, N, K, act, int(out_f32), grp_rows, grp_stride, float(drop[0]), int(drop[1]), int(drop[2]), _stream())
     _lib.check(rc, "vt_linear_bf16_ex")
     return out
-
-
-F16 = torch.float16
 
 
 def linear_ln(a, w, bias, colv, stats, eps, ln_mode, act=ACT_NONE, out=None, rs=None, out_s=None, stats_out=None, M=None):
@@ -530,14 +539,25 @@ def attention_probs(qkv, lse, B, S, nh, mask=None, mask_additive=False, head_sca
     return probs
 
 
-def layernorm(x, gamma, beta, eps, out=None, mean=None, rstd=None, M=None, grp_rows=0, grp_stride=0):
-    _require_hip(x, gamma, beta, out)
-    assert x.dtype == BF16 and gamma.dtype == torch.float32
+def layernorm(x, gamma, beta, eps, out=None, mean=None, rstd=None, M=None, grp_rows=0, grp_stride=0, out_h=None):
+    """BertLayerNorm over bf16 rows -> bf16; or over FP16 rows (the pre-LayerNorm sums of a layer that keeps fp16 copies of
+    its residual stream) -> bf16 (out) and, with out_h, the same values as fp16 (the next sub-layer's residual operand)."""
+    _require_hip(x, gamma, beta, out, out_h)
+    assert x.dtype in (BF16, F16) and gamma.dtype == torch.float32
     H = gamma.numel()
     if M is None:
         M = x.shape[0]
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    if x.dtype == F16:
+        assert grp_rows == 0 and (out_h is None or out_h.dtype == F16)
+        with _timed("layernorm_rows", 0.0, (4.0 if out_h is None else 6.0) * M * H):
+            rc = _lib.load().vt_layernorm_h_bf16(
+                _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(out_h), 0 if out_h is None else out_h.stride(0),
+                _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), M, H, float(eps), _stream())
+        _lib.check(rc, "vt_layernorm_h_bf16")
+        return out
+    assert out_h is None
     with _timed("layernorm_rows", 0.0, 4.0 * M * H):
         rc = _lib.load().vt_layernorm_bf16(
             _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
@@ -645,12 +665,13 @@ def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta, dx=None, ws=None, accumulate
         dx = torch.empty((M, H), dtype=BF16, device=x.device)
     if ws is None:
         ws = torch.empty(LN_BWD_WS_ROWS * 2 * H, dtype=torch.float32, device=x.device)
+    fn = "vt_layernorm_bwd_h_bf16" if x.dtype == F16 else "vt_layernorm_bwd_bf16"   # x: the pre-LayerNorm sums, bf16 or fp16
     with _timed("layernorm_bwd_rows", 0.0, 6.0 * M * H):
-        rc = _lib.load().vt_layernorm_bwd_bf16(
+        rc = getattr(_lib.load(), fn)(
             _ptr(x), x.stride(0), _ptr(dy), dy.stride(0), _ptr(gamma), _ptr(dx), dx.stride(0), _ptr(dgamma),
             _ptr(dbeta), _ptr(ws), M, H, float(eps), 1 if accumulate else 0, _ptr(dx_dropped),
             0 if dx_dropped is None else dx_dropped.stride(0), float(drop[0]), int(drop[1]), int(drop[2]), _stream())
-    _lib.check(rc, "vt_layernorm_bwd_bf16")
+    _lib.check(rc, fn)
     return dx
 
 

@@ -118,11 +118,18 @@ class _TrainBuffers(object):
 
     def __init__(self, L, M, B, S, H, I, nh, dev):
         mk = lambda n: torch.empty((M, n), dtype=BF16, device=dev)
+        # the residual stream at fp16 precision (ops.F16_STREAM): the pre-LayerNorm sums are fp16 tensors (the LayerNorm
+        # backward reads them) and every LayerNorm output has a second, fp16 copy that the next residual add reads -- those
+        # copies are transient: ONE pair of buffers serves all layers (include/visitron_hip.h, vt_layer_acts::ln1_h)
+        mkpre = (lambda: torch.empty((M, H), dtype=ops.F16, device=dev)) if ops.F16_STREAM else (lambda: mk(H))
+        self.ln_h = (mkpre(), mkpre()) if ops.F16_STREAM else None
         self.layers = []
         self.acts = (_lib.LayerActs * L)()
         for i in range(L):
-            d = dict(qkv=mk(3 * H), ctx=mk(H), attn_pre=mk(H), attn_out=mk(H), mid_pre=mk(I), mid=mk(I),
-                     out_pre=mk(H), out=mk(H), lse=torch.empty((B, nh, S), dtype=torch.float32, device=dev))
+            d = dict(qkv=mk(3 * H), ctx=mk(H), attn_pre=mkpre(), attn_out=mk(H), mid_pre=mk(I), mid=mk(I),
+                     out_pre=mkpre(), out=mk(H), lse=torch.empty((B, nh, S), dtype=torch.float32, device=dev))
+            if self.ln_h is not None:
+                d["ln1_h"], d["ln2_h"] = self.ln_h
             if KEEP_BITS:   # the attention dropout's keep decisions, forward -> backward (25 MB per layer at B = 256)
                 d["keep_bits"] = torch.empty(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev)
             self.layers.append(d)
@@ -778,11 +785,14 @@ class PretrainEngine(object):
         if training is None:
             training = self.model.bert.training
         st = self._trunk_fwd(batch, head_mask, None, None, bool(training), bool(unmasked_only))
+        # the caller's hidden states come from the fp16 copy of the last LayerNorm's output where the layer keeps one (the
+        # bf16 copy is the heads' / pooler's GEMM operand)
+        last = st.seq if st.bufs.ln_h is None else st.bufs.ln_h[1][:st.seq.shape[0]]
         if st.lay is None:
-            seq = st.seq.float().view(st.B, st.S, st.H)
+            seq = last.float().view(st.B, st.S, st.H)
         else:
             seq = torch.zeros((st.M, st.H), dtype=torch.float32, device=st.dev)
-            seq.index_copy_(0, st.lay.index, st.seq.float())
+            seq.index_copy_(0, st.lay.index, last.float())
             seq = seq.view(st.B, st.S, st.H)
         return seq, st.pooled.clone(), st
 
@@ -822,7 +832,7 @@ class PretrainEngine(object):
                                   hs=None):
         cfg = self.cfg
         nh, eps = cfg.num_attention_heads, cfg.layer_norm_eps
-        cur = x0
+        cur, cur_h = x0, None
         n = x0.shape[0]
         for l, ((t, _), a) in enumerate(zip(self._keep, bufs.layers)):
             a = {k: (v if k in ("lse", "keep_bits") else v[:n]) for k, v in a.items()}   # the rows in use (all, or the compacted ones)
@@ -838,13 +848,16 @@ class PretrainEngine(object):
                 ops.attention_fwd(a["qkv"], B, S, nh, mask=mask, mask_additive=mask_additive, out=raw, lse=a["lse"],
                                   drop=(p_a, seed, ops.site_attn(l)), seq=lay, keep_bits=kb)
                 ops.scale_heads(raw, hs[l].contiguous(), out=a["ctx"])
-            ops.linear(a["ctx"], t["w_ao"], t["b_ao"], residual=cur, out=a["attn_pre"], drop=(p_h, seed, ops.site_selfout(l)))
-            ops.layernorm(a["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=a["attn_out"])
+            # (fp16 copies of the stream, ops.F16_STREAM: attn_pre / out_pre are fp16 tensors, the residual adds read the
+            # LayerNorm outputs' fp16 copies ln1_h / ln2_h -- the library learns all of it from the dtypes)
+            ops.linear(a["ctx"], t["w_ao"], t["b_ao"], residual=cur if cur_h is None else cur_h, out=a["attn_pre"],
+                       drop=(p_h, seed, ops.site_selfout(l)))
+            ops.layernorm(a["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=a["attn_out"], out_h=a.get("ln1_h"))
             ops.linear(a["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=a["mid"], pre_act_out=a["mid_pre"])
-            ops.linear(a["mid"], t["w_out"], t["b_out"], residual=a["attn_out"], out=a["out_pre"],
+            ops.linear(a["mid"], t["w_out"], t["b_out"], residual=a.get("ln1_h", a["attn_out"]), out=a["out_pre"],
                        drop=(p_h, seed, ops.site_out(l)))
-            ops.layernorm(a["out_pre"], t["ln2_g"], t["ln2_b"], eps, out=a["out"])
-            cur = a["out"]
+            ops.layernorm(a["out_pre"], t["ln2_g"], t["ln2_b"], eps, out=a["out"], out_h=a.get("ln2_h"))
+            cur, cur_h = a["out"], a.get("ln2_h")
 
     def _overlap_kw(self, bufs):
         """Second workspace set + side stream for the wgrad / dgrad overlap (off: overlap_wgrad = False)."""
