@@ -102,7 +102,7 @@ def test_attention_kernels_register_budgets_and_the_writelane_hazard(tmp_path):
     asm = _device_asm(os.path.join(CSRC, "attention_fwd.hip"), tmp_path)
     ks = _kernels(asm)
     fwd = {n: t for n, t in ks.items() if "attention_fwd_d64" in n}
-    assert len(fwd) == 2
+    assert len(fwd) == 4                                        # (keep words | none) x (per-query bias | none)
     for name, text in fwd.items():
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", text).group(1)) <= 128, name
         keep = "ILb1E" in name
@@ -112,7 +112,7 @@ def test_attention_kernels_register_budgets_and_the_writelane_hazard(tmp_path):
         else:
             lines = [l.strip() for l in text.splitlines() if l.strip() and not l.strip().startswith(";")]
             idx = [i for i, l in enumerate(lines) if l.startswith("v_writelane_b32")]
-            assert len(idx) == 32, (name, len(idx))            # 16 compares x 2 half-waves per 32-key tile
+            assert len(idx) == 32, (name, len(idx))            # 16 compares x 2 half-waves per 32-key tile, in two groups of 16
             for i in idx:
                 j = i
                 while lines[j].startswith("v_writelane_b32"):
