@@ -772,6 +772,270 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   }
 }
 
+// ================================================================================================
+// 16-wave form (round 4): wave w owns the 16 keys 16w .. 16w+15, every product on v_mfma_f32_16x16x32_bf16, <= 128
+// registers, FOUR waves per SIMD.  The 8-wave kernel above sits at 235 registers and 83 KB of LDS -- one workgroup per CU,
+// two waves per SIMD that reach the slice barrier together, 40 % of their cycles parked at waits
+// (profiles/r03/attention_sq_counters.txt) -- and spends ~13 vector instructions per score element.  Here:
+//   * a wave's S / dP / P / dS tiles are 16 keys x 32 queries (8 elements per lane); its K and V fragments (B operands,
+//     lane = key) are 16 registers, its dK^T / dV^T accumulators 32;
+//   * one iteration = 64 queries in two sub-slices of 32 (S, dP, element-wise, dV^T, dK^T per sub-slice), then ONE barrier
+//     and the dQ product of all 64 queries: 16 output tiles of 16 d x 16 queries, one per wave -- half as many barriers
+//     per (batch, head) as with 32-query slices;
+//   * element-wise work per score element: c = key bias - lse (per element: the two live on different axes), p =
+//     exp2(fma(acc, scale * log2 e, c)) -- the scale, the bias, the log-sum-exp and the change of base in ONE fma --, the
+//     keep bit (bit-field extract, two ands), dS = p (m dP - delta): 9-10 instructions.
+// The A operands that contract over the queries (dO^T, Q^T for dV^T, dK^T) come from the row-major slices by
+// ds_read_b64_tr_b16 in the k-slot order the accumulators already have: lane group g of a P / dS tile pair holds the queries
+// {4g..4g+3, 16+4g..16+4g+3} of the sub-slice, so B = (tile 0 registers | tile 1 registers) needs no lane movement.
+// dS crosses LDS once, in the [4-query group][key][4 queries] image of the kernels above.  Serves S <= 256 (one key block),
+// per-key masks or none, dropout through the forward's keep words (or none), delta formed in the kernel; everything else
+// stays with the kernels above.
+#define AW_K 0                       // [256 keys][128 B]
+#define AW_Q 32768                   // [256 q][128 B]: the whole sequence's Q rows (this head)
+#define AW_DO (AW_Q + 32768)         // [256 q][128 B]: its dO rows
+#define AW_DS (AW_DO + 32768)        // [16 q-groups][256 keys][8 B]: the dS of one iteration (64 queries)
+#define AW_ROW (AW_DS + 32768)       // lse2[256] | delta[256] fp32
+#define AW_LDS_BYTES (AW_ROW + 2048)
+
+// Everything a (batch, head) needs is fetched ONCE, in the prologue, and stays in LDS (K, Q, dO: 3 x 32 KB at S <= 256): a
+// workgroup that owns a whole compute unit has nothing to hide a global load behind, and the slice-by-slice kernels above pay
+// one exposed load latency per slice (8 per (batch, head): 25 us per workgroup for ~5 us of MFMA and ~5 us of vector work).
+template <bool BITS>
+__global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kl = lane & 15, g = lane >> 4;          // this lane's key inside the wave's 16; k-slot group
+  const int b = blockIdx.y, head = blockIdx.x;
+  const int Smax = a.S, H = a.nh * 64;
+  const int S = a.seq_len ? a.seq_len[b] : a.S;
+  const long row0 = a.seq_start ? (long)a.seq_start[b] : (long)b * a.S;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // wave-uniform bases (64-bit, in SGPRs) + 32-bit per-lane byte offsets: per-lane 64-bit pointers cost two registers each
+  // in a kernel that has none to spare
+  const bf16_t* base = a.qkv + row0 * a.ld_qkv + head * 64;
+  const char* qb8 = (const char*)base;
+  const char* dob8 = (const char*)(a.dctx + row0 * a.ld_d + head * 64);
+  const char* ob8 = (const char*)(a.ctx + row0 * a.ld_ctx + head * 64);
+  char* dq8 = (char*)(a.dqkv + row0 * a.ld_dqkv + head * 64);
+  const unsigned ldq_b = (unsigned)a.ld_qkv * 2u, ldd_b = (unsigned)a.ld_d * 2u, ldo_b = (unsigned)a.ld_ctx * 2u, lddq_b = (unsigned)a.ld_dqkv * 2u;
+  const float* lse_p = a.lse + ((long)b * a.nh + head) * Smax;
+  const int niter = (S + 63) >> 6;
+  const int nkt = (S + 31) >> 5;                   // 32-key steps of the dQ product
+  const float drop_scale = a.drop.thresh ? a.drop.scale : 1.0f;
+  const float ds_scale = a.scale * drop_scale;     // 1 / sqrt(d) times dropout's 1 / (1-p): applied to dK once and to dQ per tile
+  const float scale2 = a.scale * LOG2E;
+
+  // ---- prologue.  Register loads first (row constants, the dO / O chunks of delta), then the DMA, then the LDS stores: an
+  // LDS access behind an LDS-DMA makes hipcc wait for the DMA, which would put a second load latency behind the first.
+  float* rowc = (float*)(smem + AW_ROW);
+  const float lse_v = (tid < 256 && tid < S) ? lse_p[tid] * LOG2E : INFINITY;   // +inf past the sequence: P = 0
+  u32x2 xd[4], xo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                      // thread t: query 64 i + (t >> 4), head columns 4 (t & 15) .. + 3
+    const int qi = 64 * i + (tid >> 4);
+    const unsigned q = qi < S ? qi : S - 1;
+    xd[i] = *(const u32x2*)(dob8 + (q * ldd_b + 8u * (tid & 15)));
+    xo[i] = *(const u32x2*)(ob8 + (q * ldo_b + 8u * (tid & 15)));
+  }
+  // K rows (image of the kernels above), Q rows and dO rows (chunk swizzle (row >> 1) & 7) -> LDS by DMA, 8-row pieces of
+  // 1 KiB; rows past the sequence repeat its last row (their P is 0)
+  for (int j = wave; j < nkt * 4; j += 16) {
+    const int row = 8 * j + (lane >> 3);
+    const int kr = row < S ? row : S - 1;
+    const int cs = lane & 7;
+    const int sw = (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
+    glds16(base + (long)kr * a.ld_qkv + H + ((cs ^ sw) << 3), smem + AW_K + j * 1024);
+  }
+  for (int j = wave; j < niter * 8; j += 16) {
+    const int row = 8 * j + (lane >> 3);
+    const unsigned q = row < S ? row : S - 1;
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    glds16(qb8 + (q * ldq_b + 16u * c), smem + AW_Q + j * 1024);
+    glds16(dob8 + (q * ldd_b + 16u * c), smem + AW_DO + j * 1024);
+  }
+  // the keep words of this lane's key: one per 32-query sub-slice, fetched an iteration ahead
+  const int key = 16 * wave + kl;
+  const unsigned keep_step = (unsigned)((Smax + 31) >> 5) << 5;
+  const uint32_t* keep_u = BITS ? a.keep_bits + ((long)b * a.nh + head) * ((Smax + 31) >> 5) * (long)keep_step : nullptr;   // uniform
+  const unsigned keep_k = (unsigned)key < keep_step ? (unsigned)key : keep_step - 1u;
+  auto keep_word = [&](int qb) -> uint32_t { return keep_u[(unsigned)qb * keep_step + keep_k]; };
+  const int nqb_s = (S + 31) >> 5;                 // sub-slices that hold queries of this sequence
+  uint32_t kwn0 = BITS ? keep_word(0) : 0u, kwn1 = (BITS && nqb_s > 1) ? keep_word(1) : 0u;
+
+  // ---- this wave's K and V fragments (B operands: lane = key, 8 head columns at 32 ks + 8 g) and its key bias ----
+  const int kr = key < S ? key : S - 1;
+  bf16x8 kf[2], vf[2];
+  {
+    const bf16_t* kp = base + (long)kr * a.ld_qkv + H + 8 * g;
+    const bf16_t* vp = base + (long)kr * a.ld_qkv + 2 * H + 8 * g;
+    kf[0] = *(const bf16x8*)kp; kf[1] = *(const bf16x8*)(kp + 32);
+    vf[0] = *(const bf16x8*)vp; vf[1] = *(const bf16x8*)(vp + 32);
+  }
+  float kb2 = -INFINITY;                           // key bias in the exp2 domain; -inf: a key past the sequence (p = 0)
+  if (key < S) {
+    float add = 0.f;
+    if (a.mask) {
+      const float mval = a.mask[(long)b * Smax + key];
+      add = a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
+    }
+    kb2 = add * LOG2E;
+  }
+  f32x4 dv[4], dk[4];   // [d tile]: lane = key, register j <-> head column 16 dt + 4 g + j
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  // lane-constant addressing.  Row reads (A of S, dP): row 16 t + kl of the sub-slice, 16-byte chunk 4 ks + g, chunk
+  // swizzle (row >> 1) & 7.  Transposed reads (A of dV^T, dK^T): lane 4 q' + p of a 16-lane group supplies row 4 g + q' (+ 16 t),
+  // head columns 16 dt + 4 p .. + 3.
+  const int qp = kl >> 2, pp = kl & 3;
+  const int tr_row = 4 * g + qp;
+  const int dq_dt = wave >> 2, dq_qt = wave & 3;   // this wave's 16 (d) x 16 (q) tile of the iteration's dQ^T
+
+  // row constants of every query -> LDS: lse2 = lse log2(e), delta = rowsum(dO o O) x (1 - p_drop) (sum over the 16 lanes of a
+  // query, one DPP row: xor 1, xor 2, mirror within 8, mirror within 16)
+  if (tid < 256) rowc[tid] = lse_v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float v = bf16lo(xd[i][0]) * bf16lo(xo[i][0]) + bf16hi(xd[i][0]) * bf16hi(xo[i][0]) + bf16lo(xd[i][1]) * bf16lo(xo[i][1]) +
+              bf16hi(xd[i][1]) * bf16hi(xo[i][1]);
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));
+    if ((tid & 15) == 0) rowc[256 + 64 * i + (tid >> 4)] = v * a.delta_mul;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int it = 0; it < niter; ++it) {
+    const unsigned sQ = lds0 + AW_Q + it * 8192, sDO = lds0 + AW_DO + it * 8192;
+    const float* rowv = rowc + 64 * it;
+    char* sDS = smem + AW_DS;
+    const uint32_t kw0 = kwn0, kw1 = kwn1;
+    if (BITS && it + 1 < niter) {                   // the next iteration's keep words
+      kwn0 = keep_word(2 * it + 2);
+      kwn1 = (2 * it + 3 < nqb_s) ? keep_word(2 * it + 3) : 0u;
+    }
+
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      if (it * 64 + ss * 32 >= S) break;           // uniform: the sub-slice holds no query of this sequence
+      const unsigned qb_ = sQ + ss * 4096, db_ = sDO + ss * 4096;
+      // ---- S = Q K^T and dP = dO V^T for this wave's 16 keys (lane = key; register j of tile t <-> query 16 t + 4 g + j) ----
+      f32x4 sacc[2], dpacc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = 16 * t + kl;
+        const unsigned ro = row * 128, sw = (row >> 1) & 7;
+        const bf16x8 q0 = *(const bf16x8*)(smem + (qb_ - lds0) + ro + (((0 + g) ^ sw) << 4));
+        const bf16x8 q1 = *(const bf16x8*)(smem + (qb_ - lds0) + ro + (((4 + g) ^ sw) << 4));
+        const bf16x8 d0 = *(const bf16x8*)(smem + (db_ - lds0) + ro + (((0 + g) ^ sw) << 4));
+        const bf16x8 d1 = *(const bf16x8*)(smem + (db_ - lds0) + ro + (((4 + g) ^ sw) << 4));
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf[0], z, 0, 0, 0);
+        sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf[1], sacc[t], 0, 0, 0);
+        dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf[0], z, 0, 0, 0);
+        dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf[1], dpacc[t], 0, 0, 0);
+      }
+      // ---- P = exp2(acc scale2 + key bias - lse2);  dS = P (keep dP - delta) ----
+      const uint32_t kw = (ss == 0 ? kw0 : kw1) >> (4 * g);   // bit 16 t + j = the keep flag of query 16 t + 4 g + j
+      float pm[8], dsv[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 l4 = *(const f32x4*)(rowv + 32 * ss + 16 * t + 4 * g);
+        const f32x4 e4 = *(const f32x4*)(rowv + 256 + 32 * ss + 16 * t + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[t][j], scale2, kb2 - l4[j]));
+          float dpv = dpacc[t][j], pv = p;
+          if (BITS) {   // (launched only with dropout on)
+            const int km = __builtin_amdgcn_sbfe((int)kw, 16 * t + j, 1);   // 0 / -1
+            dpv = __int_as_float(__float_as_int(dpv) & km);
+            pv = __int_as_float(__float_as_int(p) & km);
+          }
+          pm[4 * t + j] = pv;
+          dsv[4 * t + j] = p * (dpv - e4[j]);        // up to ds_scale; delta arrives times (1 - p_drop), see the kernels above
+        }
+      }
+      u32x4 pw4, sw4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pw4[i] = pack_bf16x2(pm[2 * i], pm[2 * i + 1]);
+        sw4[i] = pack_bf16x2(dsv[2 * i], dsv[2 * i + 1]);
+      }
+      const bf16x8 pb = __builtin_bit_cast(bf16x8, pw4), sb = __builtin_bit_cast(bf16x8, sw4);
+      // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries, k-slot order = the tiles' own) ----
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int cb = 32 * dt + 8 * pp;            // byte offset of head columns 16 dt + 4 pp inside the 128-byte row
+        const int r0 = tr_row, r1 = tr_row + 16;
+        const unsigned o0 = r0 * 128 + ((((cb >> 4) ^ ((r0 >> 1) & 7)) << 4) | (cb & 8));
+        const unsigned o1 = r1 * 128 + ((((cb >> 4) ^ ((r1 >> 1) & 7)) << 4) | (cb & 8));
+        const bf16x8 dot = tr_pair_b(db_ + o0, (int)(o1 - o0));
+        const bf16x8 qt = tr_pair_b(qb_ + o0, (int)(o1 - o0));
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pb, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, sb, dk[dt], 0, 0, 0);
+      }
+      // ---- dS -> LDS image [q-group G][key][4 q] (8 B per (G, key)), key index XOR-swizzled by G ----
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int G = 8 * ss + 4 * t + g;
+        const int kx = key ^ (((G >> 1) & 1) << 2) ^ ((G & 1) << 4);
+        u32x2 w;
+        w[0] = sw4[2 * t]; w[1] = sw4[2 * t + 1];
+        *(u32x2*)(sDS + (G * 256 + kx) * 8) = w;
+      }
+    }
+
+    __syncthreads();   // every wave's dS is in the image
+
+    // ---- dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: this wave's tile = head columns 16 dq_dt .., queries 16 dq_qt .. ----
+    if (it * 64 + 16 * dq_qt < S) {                    // uniform: the tile holds a query of this sequence
+      f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+      const unsigned kbase = lds0 + AW_K, dsb = lds0 + AW_DS;
+      const int G = 4 * dq_qt + pp;
+      const int gsw = (((G >> 1) & 1) << 2) ^ ((G & 1) << 4);
+      for (int ks = 0; ks < nkt; ++ks) {
+        const int krow = 32 * ks + 8 * g + qp;         // first block row; second block = +4
+        const int ksw = ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 5);
+        const int ksw2 = (((((krow + 4) >> 1) & 1) | ((((krow + 4) >> 3) & 1) << 1)) << 5);
+        const int kcol = 2 * (16 * dq_dt) + 8 * pp;
+        const bf16x8 ka = tr_pair_b(kbase + krow * 128 + (kcol ^ ksw), 4 * 128 + ((kcol ^ ksw2) - (kcol ^ ksw)));
+        const unsigned s0a = dsb + (G * 256 + (krow ^ gsw)) * 8, s1a = dsb + (G * 256 + ((krow + 4) ^ gsw)) * 8;
+        const bf16x8 sbq = tr_pair_b(s0a, (int)(s1a - s0a));
+        dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, sbq, dq, 0, 0, 0);
+      }
+      const int q = it * 64 + 16 * dq_qt + kl;         // lane (query kl of the tile, g): head columns 16 dq_dt + 4 g .. + 3
+      if (q < S) {
+        u32x2 w;
+        w[0] = pack_bf16x2(dq[0] * ds_scale, dq[1] * ds_scale);
+        w[1] = pack_bf16x2(dq[2] * ds_scale, dq[3] * ds_scale);
+        *(u32x2*)(dq8 + ((unsigned)q * lddq_b + 2u * (16 * dq_dt + 4 * g))) = w;
+      }
+    }
+    if (it + 1 < niter) __syncthreads();               // the (single) dS image is rewritten by the next iteration
+  }
+
+  // ---- dK, dV of this wave's keys: lane = key, register j of tile dt <-> head column 16 dt + 4 g + j ----
+  if (key < S) {
+    char* orow = dq8 + ((unsigned)key * lddq_b + 8u * g);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      u32x2 kq, vq;
+      kq[0] = pack_bf16x2(dk[dt][0] * ds_scale, dk[dt][1] * ds_scale);
+      kq[1] = pack_bf16x2(dk[dt][2] * ds_scale, dk[dt][3] * ds_scale);
+      vq[0] = pack_bf16x2(dv[dt][0] * drop_scale, dv[dt][1] * drop_scale);
+      vq[1] = pack_bf16x2(dv[dt][2] * drop_scale, dv[dt][3] * drop_scale);
+      *(u32x2*)(orow + 2 * (H + 16 * dt)) = kq;
+      *(u32x2*)(orow + 2 * (2 * H + 16 * dt)) = vq;
+    }
+  }
+}
+
 // delta[b,h,s] = mul * sum_d dO[b,s,h,d] * O[b,s,h,d]   (one wave per token row; 64 d per head = 8 lanes x 8).
 // grid = (ceil(S / 4), B): row s of sequence b, which starts at seq_start[b] (or b * S) and has seq_len[b] (or S) rows.
 __global__ __launch_bounds__(256) void attn_delta_rows(const bf16_t* __restrict__ d_o, long ld_d, const bf16_t* __restrict__ o,
@@ -815,8 +1079,9 @@ __global__ __launch_bounds__(256) void attn_dq_round(const float* __restrict__ d
 
 // 8 (default): the 8-wave kernel forming delta = rowsum(dO o O) itself; 10: the same kernel behind a separate
 // attn_delta_rows pass (the form before round 3's last change: 330-338 against 320 us per launch at B = 256); 4: the 4-wave kernel
-static int g_attn_bwd_waves = 8;
-void vt_attn_bwd_set_waves(int w) { g_attn_bwd_waves = (w == 4 || w == 10) ? w : 8; }
+// 16 (default): the 16-wave kernel where it serves (one key block, no per-query bias, keep words or no dropout), else as 8
+static int g_attn_bwd_waves = 16;
+void vt_attn_bwd_set_waves(int w) { g_attn_bwd_waves = (w == 4 || w == 10 || w == 8) ? w : 16; }
 
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
@@ -838,7 +1103,8 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   if (seq_start && (mask || rows_total <= 0)) return VT_ERR_UNSUPPORTED;   // compacted rows carry no masked keys
   const long rows = seq_start ? rows_total : (long)B * S;
   const float delta_mul = (drop && drop->thresh) ? 1.0f / drop->scale : 1.0f;
-  if (g_attn_bwd_waves != 8)
+  const bool w16 = g_attn_bwd_waves == 16 && nkb == 1 && mask_additive != 2 && (keep_bits || !(drop && drop->thresh));
+  if (g_attn_bwd_waves != 8 && g_attn_bwd_waves != 16)
     hipLaunchKernelGGL(attn_delta_rows, dim3((unsigned)((S + 3) / 4), B), dim3(256), 0, stream, (const bf16_t*)dctx, ld_d,
                        (const bf16_t*)ctx, ld_ctx, delta_ws, B, S, nh, seq_start, seq_len, delta_mul);
   AttnBwdArgs a;
@@ -852,7 +1118,13 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
   a.keep_bits = a.drop.thresh ? keep_bits : nullptr;
   a.ctx = (const bf16_t*)ctx; a.ld_ctx = ld_ctx; a.delta_mul = delta_mul;
-  if (g_attn_bwd_waves == 4) {
+  if (w16) {
+    static VtLdsAttrOnce attr16, attr16b;
+    if (!attr16.set((const void*)attention_bwd_d64_w16<false>, AW_LDS_BYTES)) return VT_ERR_HIP;
+    if (!attr16b.set((const void*)attention_bwd_d64_w16<true>, AW_LDS_BYTES)) return VT_ERR_HIP;
+    if (a.keep_bits) hipLaunchKernelGGL((attention_bwd_d64_w16<true>), dim3(nh, B), dim3(1024), AW_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((attention_bwd_d64_w16<false>), dim3(nh, B), dim3(1024), AW_LDS_BYTES, stream, a);
+  } else if (g_attn_bwd_waves == 4) {
     hipLaunchKernelGGL(attention_bwd_d64, dim3(nh, B, nkb), dim3(256), AB_LDS_BYTES, stream, a);
   } else {
     static VtLdsAttrOnce attr8, attr8b, attr8d, attr8bd;
@@ -861,7 +1133,7 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
     if (!attr8d.set((const void*)attention_bwd_d64_w8<false, true>, AB_LDS_BYTES)) return VT_ERR_HIP;
     if (!attr8bd.set((const void*)attention_bwd_d64_w8<true, true>, AB_LDS_BYTES)) return VT_ERR_HIP;
     const dim3 grid(nh, B, nkb);
-    if (g_attn_bwd_waves == 8) {
+    if (g_attn_bwd_waves == 8 || g_attn_bwd_waves == 16) {
       if (a.keep_bits) hipLaunchKernelGGL((attention_bwd_d64_w8<true, true>), grid, dim3(512), AB_LDS_BYTES, stream, a);
       else hipLaunchKernelGGL((attention_bwd_d64_w8<false, true>), grid, dim3(512), AB_LDS_BYTES, stream, a);
     } else {
