@@ -125,3 +125,31 @@ def test_seven_launch_layer_keeps_the_stream_at_fp16_precision(dev):
     prod.encoder._ws.clear()
     print("seven-launch layer, 4 base layers: max error fp16 stream %.3e, bf16 stream %.3e" % (errs[True], errs[False]))
     assert errs[True] <= 5e-2 and errs[True] < errs[False]
+
+
+def test_two_rank_loss_curve_bf16_exchange_follows_fp32_exchange(dev, tmp_path):
+    """The data-parallel gradient exchange moves a bf16 copy of the gradient slab by default where the reference's DDP
+    (tasks/viewpoint_select/pretrain.py:96-102,191) reduces fp32 buckets: six optimizer steps under two ranks with either
+    exchange, same kernels, same data -- the loss curves must stay together (the bf16 sum over ranks rounds each gradient to 8
+    significant bits once) and both must fall."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "dp_curve_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=root)
+    res = {}
+    for comm, port in (("fp32", "29681"), ("bf16", "29683")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", port, script, str(tmp_path), comm]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+        res[comm] = torch.load(os.path.join(str(tmp_path), "curve_%s.pt" % comm))
+    a, b = torch.tensor(res["fp32"]["curve"]), torch.tensor(res["bf16"]["curve"])
+    print("two-rank loss curve, fp32 exchange:", [round(float(v), 4) for v in a[:, 0]])
+    print("two-rank loss curve, bf16 exchange:", [round(float(v), 4) for v in b[:, 0]])
+    assert float(a[-2:, 0].mean()) < float(a[:2, 0].mean()) and float(b[-2:, 0].mean()) < float(b[:2, 0].mean())
+    assert float((a[:, :4] - b[:, :4]).abs().max()) <= 2e-2 * float(a[:, 0].abs().max())
+    pa, pb = res["fp32"]["p"], res["bf16"]["p"]
+    assert float((pa - pb).norm() / pa.norm()) <= 2e-3
