@@ -293,10 +293,8 @@ def main():
             here = os.path.dirname(os.path.abspath(__file__))
             # (the PMC passes of THIS configuration: train B=256 or forward B=64, default shapes; newest round first)
             default_shape = a.text == 128 and a.regions == 100 and a.batch == (256 if train else 64)
-            rels = (("profiles/r04/train_b256_pmc_hbm_traffic.json", "profiles/r03/train_b256_pmc_hbm_traffic_v5.json", "profiles/r03/train_b256_pmc_hbm_traffic_v4.json", "profiles/r03/train_b256_pmc_hbm_traffic_v3.json", "profiles/r03/train_b256_pmc_hbm_traffic_v2.json", "profiles/r03/train_b256_pmc_hbm_traffic.json", "profiles/r02/train_b256_pmc_hbm_traffic_v3.json",
-                     "profiles/r01/train_b256_pmc_hbm_traffic_v6.json") if train else
-                    ("profiles/r04/fwd_b64_pmc_hbm_traffic.json", "profiles/r03/fwd_b64_pmc_hbm_traffic_v3.json", "profiles/r03/fwd_b64_pmc_hbm_traffic_v2.json",
-                     "profiles/r03/fwd_b64_pmc_hbm_traffic.json"))
+            rels = (("profiles/r04/train_b256_pmc_hbm_traffic.json", "profiles/r03/train_b256_pmc_hbm_traffic_v5.json") if train else
+                    ("profiles/r04/fwd_b64_pmc_hbm_traffic.json", "profiles/r03/fwd_b64_pmc_hbm_traffic_v3.json"))
             for rel in rels:
                 tp = os.path.join(here, rel)
                 if default_shape and os.path.exists(tp):

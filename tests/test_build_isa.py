@@ -121,6 +121,8 @@ def test_attention_kernels_register_budgets_and_the_writelane_hazard(tmp_path):
                 assert m and int(m.group(1)) >= 4, (name, lines[j])
     ks = _kernels(_device_asm(os.path.join(CSRC, "attention_bwd.hip"), tmp_path))
     bwd = {n: t for n, t in ks.items() if "attention_bwd_d64" in n}
-    assert len(bwd) == 5                                        # 4 waves; 8 waves x (hash | keep words) x (delta pass | in-kernel)
+    assert len(bwd) == 7        # 4 waves; 8 waves x (hash | keep words) x (delta pass | in-kernel); 16 waves x (keep words | none)
     for name, text in bwd.items():
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", text).group(1)) == 0, name
+        if "w16" in name:       # sixteen waves per workgroup = four per SIMD: 128 registers is the whole budget
+            assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", text).group(1)) <= 128, name
