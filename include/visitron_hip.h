@@ -95,7 +95,8 @@ int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, co
 int vt_apply_dropout_bf16(void* x, int64_t ld, int64_t rows, int cols, float drop_p, uint64_t drop_seed,
                           uint32_t drop_site, vt_stream_t stream);
 /* Test hook: out[i] = 1 if element i of the site is kept (head_index = b*nh + h for attention sites where
- * element i = q * S' + key, S' = the sequence's length rounded up to an even number, else -1). */
+ * element i = q * S' + key, S' = the sequence's length rounded up to a multiple of 4, and the keep decision is byte
+ * (i & 3) of the hash word of i >> 2 against p quantised to 1/256 -- the attention sites' form, ABI 8 --, else -1). */
 int vt_debug_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, uint32_t drop_site,
                           int head_index, vt_stream_t stream);
 

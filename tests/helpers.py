@@ -147,7 +147,8 @@ def inject_dropout_masks(ref, p_hidden, p_attn, seed, B, T, R, device="cuda:0", 
         setmod("bert.dropout", FixedMaskDropout(keep(B * R * H, p_hidden, ops.SITE_IMG).view(B, R, H), p_hidden))
     for l in range(cfg.num_hidden_layers):
         pre = "bert.encoder.layer.%d." % l
-        setmod(pre + "attention.self.dropout", FixedMaskDropout(attn_site(ops.site_attn(l)), p_attn))
+        # (the attention sites run p quantised to 1/256 and scale by the quantised value: ops.attn_drop_p)
+        setmod(pre + "attention.self.dropout", FixedMaskDropout(attn_site(ops.site_attn(l)), ops.attn_drop_p(p_attn)))
         setmod(pre + "attention.output.dropout", FixedMaskDropout(rows_site(ops.site_selfout(l)), p_hidden))
         setmod(pre + "output.dropout", FixedMaskDropout(rows_site(ops.site_out(l)), p_hidden))
     return ref

@@ -584,7 +584,7 @@ def test_attention_dropout_fwd_bwd_match_autograd(dev, B, S, nh, waves):
     keep = _attn_keep(ops, B, nh, S, drop, dev)
     t = qkv.view(B, S, 3, nh, 64).permute(2, 0, 3, 1, 4)
     s = t[0] @ t[1].transpose(-1, -2) / 8.0 + ((1.0 - mask) * -10000.0)[:, None, None, :]
-    ctx_ref = ((torch.softmax(s, dim=-1) * keep / (1 - p)) @ t[2]).permute(0, 2, 1, 3).reshape(B * S, H)
+    ctx_ref = ((torch.softmax(s, dim=-1) * keep / (1 - ops.attn_drop_p(p))) @ t[2]).permute(0, 2, 1, 3).reshape(B * S, H)
     ctx_ref.backward(dctx)
     want = qkv.grad
     qd = qkv.detach().to(dev, BF16)
@@ -749,7 +749,7 @@ def test_attention_dropout_on_compacted_rows_matches_autograd(dev):
         t = x.view(n, 3, nh, 64).permute(1, 2, 0, 3)
         p = torch.softmax(t[0] @ t[1].transpose(-1, -2) / 8.0, -1)
         km = torch.stack([ops.attn_dropout_mask(n, drop, b * nh + h, device=dev) for h in range(nh)]).float().cpu()
-        o = ((p * km / 0.8) @ t[2]).permute(1, 0, 2).reshape(n, H)
+        o = ((p * km / (1.0 - ops.attn_drop_p(0.2))) @ t[2]).permute(1, 0, 2).reshape(n, H)
         o.backward(dctx[off:off + n].to(BF16).float())
         assert maxabs(ctx[off:off + n], o.detach()) < 3e-2
         assert maxabs(dq[off:off + n], x.grad) < 3e-2 * (1 + float(x.grad.abs().max()))

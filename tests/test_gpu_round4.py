@@ -153,3 +153,36 @@ def test_two_rank_loss_curve_bf16_exchange_follows_fp32_exchange(dev, tmp_path):
     assert float((a[:, :4] - b[:, :4]).abs().max()) <= 2e-2 * float(a[:, 0].abs().max())
     pa, pb = res["fp32"]["p"], res["bf16"]["p"]
     assert float((pa - pb).norm() / pa.norm()) <= 2e-3
+
+
+def test_attention_dropout_mask_is_bernoulli_per_key_and_decorrelated(dev):
+    """The attention sites' keep function (csrc/common.hpp, vt_keep_attn: one hash word per four neighbouring keys, a byte
+    each against an 8-bit threshold): keep rate 1 - p_q for the quantised probability, the four bytes of a word and
+    neighbouring words uncorrelated, different (batch, head) streams and different sites uncorrelated, rows decorrelated."""
+    import math
+
+    from visitron_amd import ops
+
+    n = 1024
+    for p in (0.1, 0.5, 0.2):
+        pq = ops.attn_drop_p(p)
+        assert abs(pq - p) <= 1.0 / 512 + 1e-9
+        m = ops.attn_dropout_mask(n, (p, 4321, ops.site_attn(3)), 5, device=dev).float().cpu()
+        N = m.numel()
+        tol = 4.5 * math.sqrt(pq * (1 - pq) / N)
+        assert abs(float(m.mean()) - (1.0 - pq)) < tol, (p, float(m.mean()))
+        c = m - m.mean()
+        var = float((c * c).mean())
+        for lag in (1, 2, 3, 4, 5, 8, 32):           # along the keys: inside a hash word (1..3) and across words
+            r = float((c[:, :-lag] * c[:, lag:]).mean()) / var
+            assert abs(r) < 5.0 / math.sqrt(N), (p, "key lag", lag, r)
+        for lag in (1, 2, 7):                         # along the queries
+            r = float((c[:-lag] * c[lag:]).mean()) / var
+            assert abs(r) < 5.0 / math.sqrt(N), (p, "query lag", lag, r)
+        for other in (dict(head=6), dict(site=ops.site_attn(4)), dict(seed=4322)):
+            m2 = ops.attn_dropout_mask(n, (p, other.get("seed", 4321), other.get("site", ops.site_attn(3))), other.get("head", 5),
+                                       device=dev).float().cpu()
+            r = float(((m2 - m2.mean()) * c).mean()) / var
+            assert abs(r) < 5.0 / math.sqrt(N), (p, other, r)
+        for e in range(4):                            # every byte position of the word has the same rate
+            assert abs(float(m[:, e::4].mean()) - (1.0 - pq)) < 2.0 * tol * 2.0, (p, e)

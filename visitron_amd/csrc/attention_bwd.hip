@@ -73,27 +73,19 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-// Keep flags of a lane's 16 score elements in the backward tiles: element i = query qbase + (i&3) + 8*(i>>2), this
-// lane's key.  vt_keep pairs the elements (q, 2m) and (q, 2m+1) on one hash word (S even), and here those two sit in
-// NEIGHBOURING LANES (the row pitch of the element index is even), so each lane hashes 8 of its 16 queries and takes the other 8 words from lane ^ 1 (DPP
-// quad_perm [1,0,3,2]) instead of hashing all 16.  Needs every lane active (the callers' control flow is uniform).
+// Keep flags of a lane's 16 score elements in the backward tiles, re-derived from the hash (the path without the forward's
+// keep words: tests, VT_ATTN_KEEP_BITS=0): element i = query qbase + (i&3) + 8*(i>>2), this lane's key.  The attention
+// sites' function (common.hpp, vt_keep_attn): byte key & 3 of the hash word of (query, key >> 2), row pitch Sp = the
+// sequence's length rounded up to a multiple of 4.  The word index is linear in the query, so the hash's first multiply is
+// taken once and the other queries are reached by adding multiples of (Sp / 4) * C1.
 __device__ __forceinline__ void attn_bwd_keep16(const DropCfg& dr, uint32_t qbase, uint32_t key, uint32_t Sp, bool (&keep)[16]) {
-  // Sp: the even row pitch of the element index (the sequence's length rounded up to even, as in attention_fwd.hip)
-  const uint32_t par = key & 1u;
-  const bool odd = par != 0;
-  const uint32_t fsh = par << 4;   // this key's 16-bit field of the shared word
-  // pair index of (query q, this key) = q * (Sp/2) + (key >> 1): linear in q, so the hash's first multiply is taken
-  // once (for query qbase + par) and the other seven queries are reached by adding multiples of (Sp/2) * C1
-  const uint32_t qstep = (Sp >> 1) * VT_HASH_C1;
-  const uint32_t x0 = vt_hash_pre(dr.seed, (qbase + par) * (Sp >> 1) + (key >> 1));
+  const uint32_t sh = 8u * (key & 3u);
+  const uint32_t qstep = (Sp >> 2) * VT_HASH_C1;
+  const uint32_t x0 = vt_hash_pre(dr.seed, qbase * (Sp >> 2) + (key >> 2));
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const uint32_t hm = vt_hash_fin(x0 + (uint32_t)(((2 * j) & 3) + 8 * ((2 * j) >> 2)) * qstep);   // element 2j + par
-    const uint32_t hp = (uint32_t)__builtin_amdgcn_mov_dpp((int)hm, 0xB1, 0xF, 0xF, true);   // the neighbour's: element 2j + 1 - par
-    const uint32_t h0 = odd ? hp : hm, h1 = odd ? hm : hp;
-    // this key's field moved to the high half: one shift (by 16 or 0), one compare
-    keep[2 * j] = vt_keep_hi(h0 << (16u - fsh), dr.thresh);
-    keep[2 * j + 1] = vt_keep_hi(h1 << (16u - fsh), dr.thresh);
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t h = vt_hash_fin(x0 + (uint32_t)((i & 3) + 8 * (i >> 2)) * qstep);
+    keep[i] = ((h >> sh) & 0xffu) >= dr.thresh;
   }
 }
 
@@ -278,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
       // P = exp(s/8 + mask - lse);  dS = P (dP - delta) / 8
       f32x16 pacc;
       bool keep[16];
-      if (dr.thresh) attn_bwd_keep16(dr, (uint32_t)(sl * 32 + 4 * h2), (uint32_t)(kb0 + 64 * wave + 32 * kt + r), (uint32_t)(S + 1) & ~1u, keep);
+      if (dr.thresh) attn_bwd_keep16(dr, (uint32_t)(sl * 32 + 4 * h2), (uint32_t)(kb0 + 64 * wave + 32 * kt + r), (uint32_t)(S + 3) & ~3u, keep);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
@@ -628,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       // P = exp(s/8 + mask - lse);  dS = P (dP - delta) / 8
       f32x16 pacc;
       bool keep[16];
-      if (!BITS && dr.thresh) attn_bwd_keep16(dr, (uint32_t)(sl * 32 + 4 * h2), (uint32_t)(kb0 + 32 * wave + r), (uint32_t)(S + 1) & ~1u, keep);
+      if (!BITS && dr.thresh) attn_bwd_keep16(dr, (uint32_t)(sl * 32 + 4 * h2), (uint32_t)(kb0 + 32 * wave + r), (uint32_t)(S + 3) & ~3u, keep);
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const f32x4 lse4_g = *(const f32x4*)(rowv + 8 * g4 + 4 * h2);

@@ -33,11 +33,12 @@ struct AttnArgs {
   long ld_qkv, ld_ctx;
   int B, S, nh;
   float scale;              // 1 / sqrt(head_size)
-  DropCfg drop;             // dropout on the attention probabilities (oscar/modeling_bert.py:62); per (b,h) the
-                            // seed is hash32(drop.seed, b*nh+h) and the element index is q * S' + key, S' = the sequence's
-                            // length rounded up to an EVEN number: the keys 2m, 2m+1 of a query then always share one hash
-                            // word (with pitch S an odd-length sequence -- every other one of a compacted batch -- paid a
-                            // whole hash per element: 13 instead of 4 issue slots)
+  DropCfg drop;             // dropout on the attention probabilities (oscar/modeling_bert.py:62), the attention sites'
+                            // form (common.hpp, vt_keep_attn): per (b,h) the seed is hash32(drop.seed, b*nh+h), the element
+                            // index is q * S' + key with S' = the sequence's length rounded up to a MULTIPLE OF 4, and the
+                            // keys 4m .. 4m+3 of a query share one hash word (byte j >= drop.thresh = p * 2^8).  (With
+                            // pitch S an odd-length sequence -- every other one of a compacted batch -- paid a whole hash
+                            // per element in round 3.)
   // compacted rows (training without the padding rows): sequence b holds seq_len[b] <= S rows starting at row
   // seq_start[b]; lse keeps its [B, nh, S] layout.  Null: every sequence has S rows, sequence b starts at row b * S.
   const int* seq_start;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
   const float inv_scale = 1.0f / a.scale;
   DropCfg dr = a.drop;
   dr.seed = vt_hash32(a.drop.seed, (uint32_t)(b * a.nh + head));
-  const uint32_t Sp = (uint32_t)(S + 1) & ~1u;                        // even row pitch of the dropout element index
+  const uint32_t Sp = (uint32_t)(S + 3) & ~3u;                        // row pitch of the dropout element index: a multiple of 4
   const uint32_t q_elem = (uint32_t)(q0 + r) * Sp;
   const float* mrow3 = MASK3 ? a.mask + ((long)b * Smax + ((q0 + r) < S ? (q0 + r) : S - 1)) * Smax : nullptr;
 
@@ -229,9 +230,10 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
           psum += pv[i];
         }
         l_run += psum;
-        // the tile's key pairs sit at fixed offsets from one pair index: the hash's first multiply once per tile (the element
-        // index q * S' + key of an even key is even: S' is even)
-        const uint32_t xb = dr.thresh ? vt_hash_pre(dr.seed, (q_elem + (uint32_t)(kc + kt * 32 + 4 * h2)) >> 1) : 0u;
+        // a lane's elements 4 g4 .. 4 g4 + 3 are the four neighbouring keys 8 g4 + 4 h2 .. + 3: ONE hash word each (q * S' and
+        // the key offsets are multiples of 4); the words of a tile sit at fixed offsets from one word index, so the hash's
+        // first multiply is paid once per tile
+        const uint32_t xb = dr.thresh ? vt_hash_pre(dr.seed, (q_elem + (uint32_t)(kc + kt * 32 + 4 * h2)) >> 2) : 0u;
 
         // ---- O^T += V^T . P^T ----
 #pragma unroll
@@ -245,15 +247,17 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
             uint32_t ml[8], mh[8];   // lane masks of the eight compares: low half = this wave's 32 queries against key
                                      // (i&3) + 8(i>>2), high half the same queries against that key + 4
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {   // elements i, i+1 are neighbouring keys: one hash for both
-              const int i = 8 * s2 + j;
-              bool k0, k1;
-              vt_keep2_pre(dr, xb + (uint32_t)(((i & 3) + 8 * (i >> 2)) >> 1) * VT_HASH_C1, k0, k1);
-              pm[j] = k0 ? pm[j] : 0.f;          // the 1 / (1 - p) factor is uniform: applied once to O below
-              pm[j + 1] = k1 ? pm[j + 1] : 0.f;
-              if (KEEP) {
-                const uint64_t m0 = __builtin_amdgcn_ballot_w64(k0), m1 = __builtin_amdgcn_ballot_w64(k1);
-                ml[j] = (uint32_t)m0; mh[j] = (uint32_t)(m0 >> 32); ml[j + 1] = (uint32_t)m1; mh[j + 1] = (uint32_t)(m1 >> 32);
+            for (int j = 0; j < 8; j += 4) {   // elements i .. i + 3 are four neighbouring keys: one hash word, a byte each
+              const int i = 8 * s2 + j;          // key offset of element i: 8 (i >> 2) + 4 h2, word index + 2 (i >> 2)
+              const uint32_t hw = vt_hash_fin(xb + (uint32_t)(2 * (i >> 2)) * VT_HASH_C1);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const bool k = ((hw >> (8 * e)) & 0xffu) >= dr.thresh;   // (an SDWA byte compare: no shift, no mask)
+                pm[j + e] = k ? pm[j + e] : 0.f;     // the 1 / (1 - p) factor is uniform: applied once to O below
+                if (KEEP) {
+                  const uint64_t m = __builtin_amdgcn_ballot_w64(k);
+                  ml[j + e] = (uint32_t)m; mh[j + e] = (uint32_t)(m >> 32);
+                }
               }
             }
             if (KEEP) {

@@ -260,6 +260,25 @@ __host__ __forceinline__ DropCfg vt_make_drop(float p, uint64_t step_seed, uint3
   d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   return d;
 }
+// ---- attention-probability dropout (oscar/modeling_bert.py:62): one hash word per FOUR neighbouring keys ------------------
+// The attention forward is bound by vector issue and half of its slots were this decision.  For the attention sites a hash
+// word serves the keys 4m .. 4m+3 of a query -- byte j against an 8-bit threshold, one SDWA byte compare each, no shifts --
+// which needs the row pitch of the element index (q * pitch + key) to be a multiple of 4 (the sequence's length rounded up)
+// and quantises the drop probability to 1/256: p = 0.1 runs as 26/256 = 0.1016, and the scale 1/(1-p) uses the quantised
+// value (unbiased).  DropCfg::thresh then holds p * 2^8.  Everything else (hidden-state dropout in the GEMM epilogues, the
+// embeddings) keeps the 16-bit pairs above.
+__host__ __device__ __forceinline__ bool vt_keep_attn(const DropCfg& d, uint32_t idx) {
+  return ((vt_hash32(d.seed, idx >> 2) >> (8u * (idx & 3u))) & 0xffu) >= d.thresh;
+}
+__host__ __forceinline__ float vt_attn_drop_p(float p) { return p > 0.f ? (float)(uint32_t)(p * 256.0f + 0.5f) / 256.0f : 0.f; }
+__host__ __forceinline__ DropCfg vt_make_drop_attn(float p, uint64_t step_seed, uint32_t site) {
+  DropCfg d;
+  const float pq = vt_attn_drop_p(p);
+  d.thresh = (uint32_t)(pq * 256.0f + 0.5f);
+  d.seed = vt_site_seed(step_seed, site);
+  d.scale = pq > 0.f ? 1.0f / (1.0f - pq) : 1.0f;
+  return d;
+}
 // dropout sites: layer l uses 8*l + {0: attention probs, 1: attention.output dropout, 2: output dropout};
 // 0xE0 = embeddings, 0xE1 = image embedding
 #define VT_SITE_ATTN(l) (8u * (l) + 0u)

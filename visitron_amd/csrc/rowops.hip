@@ -1217,15 +1217,18 @@ int vt_apply_dropout_dispatch(void* x, long ld, long rows, int cols, const DropC
 }
 
 // out[i] = 1 if element i of the site is kept (tests: lets the CPU oracle run with the SAME masks)
+// ATTN: the attention sites' function (a hash word per four keys, 8-bit thresholds: vt_keep_attn)
+template <bool ATTN>
 __global__ __launch_bounds__(256) void dropout_mask_dump(uint8_t* __restrict__ out, long n, DropCfg d) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = vt_keep(d, (uint32_t)i) ? 1 : 0;
+  if (i < n) out[i] = (ATTN ? vt_keep_attn(d, (uint32_t)i) : vt_keep(d, (uint32_t)i)) ? 1 : 0;
 }
 
-int vt_dropout_mask_dispatch(uint8_t* out, long n, const DropCfg& d, hipStream_t stream) {
+int vt_dropout_mask_dispatch(uint8_t* out, long n, const DropCfg& d, hipStream_t stream, int attn) {
   if (!out) return VT_ERR_NULL;
   if (n <= 0 || n >= (1L << 32)) return VT_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(dropout_mask_dump, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, n, d);
+  if (attn) hipLaunchKernelGGL(dropout_mask_dump<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, n, d);
+  else hipLaunchKernelGGL(dropout_mask_dump<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, n, d);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 

@@ -882,10 +882,17 @@ def dropout_mask(n, drop, head_index=-1, device="cuda"):
 
 def attn_dropout_mask(n, drop, head_index, device="cuda"):
     """uint8 [n, n]: the keep mask of the attention-probability dropout of one (batch, head) whose sequence has n rows
-    (test hook).  The attention kernels index element (query q, key k) as q * n' + k with n' = n rounded up to an even
-    number (csrc/attention_fwd.hip: the keys 2m, 2m + 1 of a query then always share a hash word)."""
-    pitch = (n + 1) & ~1
+    (test hook).  The attention kernels index element (query q, key k) as q * n' + k with n' = n rounded up to a multiple of 4
+    (csrc/common.hpp, vt_keep_attn: the keys 4m .. 4m + 3 of a query share a hash word, a byte each against an 8-bit
+    threshold -- the drop probability runs quantised to 1/256, attn_drop_p)."""
+    pitch = (n + 3) & ~3
     return dropout_mask(n * pitch, drop, head_index=head_index, device=device).view(n, pitch)[:, :n]
+
+
+def attn_drop_p(p):
+    """The attention-probability dropout's effective probability: p quantised to 1/256 (0.1 -> 26/256 = 0.1016); kept
+    probabilities are scaled by 1 / (1 - attn_drop_p(p))."""
+    return float(int(p * 256.0 + 0.5)) / 256.0 if p > 0 else 0.0
 
 
 def transpose(src, out):
