@@ -354,10 +354,14 @@ def main():
                 "grad_comm_dtype": (engine.grad_comm_dtype if (train and world > 1) else None),
                 "weights": "random init N(0,0.02), seed 0",
                 "dropout": a.dropout if train else 0.0,
+                # the attention-probability dropout runs p quantised to 1/256 (one hash word per four keys)
+                "attention_dropout_effective": (ops.attn_drop_p(a.dropout) if train else 0.0),
                 # bf16 operands on the matrix cores, fp32 accumulation everywhere.  Inference keeps the residual stream
                 # between sub-layers in fp16 (+ a bf16 copy for the next GEMM) and defers every LayerNorm into the GEMM
-                # epilogues that consume it; training keeps bf16 activations and LayerNorm passes (its backward reads them)
-                "residual_stream": ("bf16 (seven-launch layer, LayerNorm passes)" if train else
+                # epilogues that consume it; training keeps bf16 activations and LayerNorm passes (its backward reads them) with
+                # the pre-LayerNorm sums and the residual operands as fp16 (VT_F16_STREAM=0: all bf16)
+                "residual_stream": (("fp16 copies beside the bf16 GEMM operands (seven-launch layer, LayerNorm passes)" if ops.F16_STREAM
+                                     else "bf16 (seven-launch layer, LayerNorm passes)") if train else
                                     ("fp16, LayerNorms deferred into the GEMM epilogues" if trunk.encoder.serves_deferred_ln()
                                      else "bf16 (seven-launch layer, LayerNorm passes)")),
                 # training computes the real rows only: positions with attention mask 0 (text tails, missing regions;
