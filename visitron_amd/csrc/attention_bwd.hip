@@ -619,12 +619,25 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       }
       // P = exp(s/8 + mask - lse);  dS = P (dP - delta) / 8
       f32x16 pacc;
-      bool keep[16];
-      if (!BITS && dr.thresh) attn_bwd_keep16(dr, (uint32_t)(sl * 32 + 4 * h2), (uint32_t)(kb0 + 32 * wave + r), (uint32_t)(S + 3) & ~3u, keep);
+      // hash path (no keep words): the flags of a group of four queries are derived right before their use -- sixteen flags
+      // held across the tile cost three spilled registers at this kernel's 128-register budget
+      uint32_t hx0 = 0, hstep = 0, hsh = 0;
+      if (!BITS && dr.thresh) {
+        const uint32_t Sp4 = ((uint32_t)(S + 3) & ~3u) >> 2, key = (uint32_t)(kb0 + 32 * wave + r);
+        hsh = 8u * (key & 3u);
+        hstep = Sp4 * VT_HASH_C1;
+        hx0 = vt_hash_pre(dr.seed, (uint32_t)(sl * 32 + 4 * h2) * Sp4 + (key >> 2));
+      }
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const f32x4 lse4_g = *(const f32x4*)(rowv + 8 * g4 + 4 * h2);
         const f32x4 del4_g = *(const f32x4*)(rowv + 32 + 8 * g4 + 4 * h2);
+        bool keep[16];
+        if (!BITS && dr.thresh) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            keep[4 * g4 + e] = ((vt_hash_fin(hx0 + (uint32_t)(e + 8 * g4) * hstep) >> hsh) & 0xffu) >= dr.thresh;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g4 + e;
