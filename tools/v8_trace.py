@@ -15,7 +15,7 @@ bias = torch.zeros(N, device=dev) if MODE != "plain" else None
 pre = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if MODE == "gelu_pre" else None
 res = torch.randn(M, N, device=dev).to(torch.bfloat16) if MODE == "res" else None
 kw = dict(bias=bias, residual=res, act=1 if MODE == "gelu_pre" else 0, pre_act_out=pre)
-ops.set_gemm_variant(16)
+ops.set_gemm_variant(int(os.environ.get("VARIANT", "16")))
 for _ in range(3):
     ops.linear(x, w, out=y, **kw)
 torch.cuda.synchronize()
