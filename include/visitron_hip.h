@@ -563,6 +563,14 @@ int vt_encoder_forward_ln_bf16(const vt_layer_weights_ln* layers, int num_layers
                                void* s16_b, void* sf_b, float* stats_b, void* qkv, void* ctx, void* mid, const float* mask,
                                int mask_additive, const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps,
                                int64_t stat_rows, vt_stream_t stream);
+/* The same loop over COMPACTED rows (the layout of vt_encoder_forward_seq_bf16: `rows` token rows without the masked
+ * positions, sequence b = rows seq_start[b] .. seq_start[b] + seq_len[b], every key of a sequence attended, no mask): the
+ * rollout's eval forward (agent_models.py:256-277 calling oscar/modeling_bert.py:140-169) on the rows that exist.  The
+ * streams / scratch hold `rows` rows, stat_rows >= rows. */
+int vt_encoder_forward_ln_seq_bf16(const vt_layer_weights_ln* layers, int num_layers, void* s16_a, void* sf_a, float* stats_a,
+                                   void* s16_b, void* sf_b, float* stats_b, void* qkv, void* ctx, void* mid,
+                                   const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps, int64_t stat_rows,
+                                   int64_t rows, const int32_t* seq_start, const int32_t* seq_len, vt_stream_t stream);
 
 /* ---- backward of the encoder stack (the encoder part of loss.backward(), pretrain.py:191) ------ */
 typedef struct vt_layer_weights_t { /* transposed bf16 copies consumed by the dgrad GEMMs */

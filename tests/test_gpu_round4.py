@@ -127,6 +127,54 @@ def test_seven_launch_layer_keeps_the_stream_at_fp16_precision(dev):
     assert errs[True] <= 5e-2 and errs[True] < errs[False]
 
 
+def test_compacted_rows_run_the_deferred_layernorm_loop(dev):
+    """run_trunk(keep=...) -- the rollout's eval forward on the rows that exist (agent_models.py:256-277) -- goes through the
+    deferred-LayerNorm loop over compacted rows (vt_encoder_forward_ln_seq_bf16): against the oracle's masked forward at the
+    kept positions (flat 5e-2), against the padded deferred loop (same arithmetic, masked keys instead of absent ones) and
+    not less accurate than the seven-launch layer it replaces there; text + regions, ragged lengths down to one token."""
+    from oracle.modeling import BertImgModelwithLocationEmbeds as OTrunk
+    from helpers import model_pair
+    from visitron_amd.config import BertConfig
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.synth import make_batch
+
+    cfg = BertConfig(num_hidden_layers=3, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ref, prod = model_pair(OTrunk, BertImgModelwithLocationEmbeds, cfg, seed=8, device=dev, weight_std=0.03)
+    B, T, R = 5, 40, 12
+    b = make_batch(cfg, B, text_len=T, region_len=R, seed=31)
+    lens_t = torch.tensor([40, 33, 17, 2, 1])
+    lens_r = torch.tensor([12, 0, 5, 12, 1])
+    keep = torch.cat([torch.arange(T)[None, :] < lens_t[:, None], torch.arange(R)[None, :] < lens_r[:, None]], 1)
+    mask = keep.to(torch.int64)
+    args = dict(input_ids=b["input_ids"], img_feats=b["img_feats"], img_location_embeddings=b["img_location_embeddings"])
+    with torch.no_grad():
+        want, want_pooled = ref(attention_mask=mask, **args)[:2]
+        dargs = {k: v.to(dev) for k, v in args.items()}
+        outs, pooled, _, _, _ = prod.run_trunk(dargs["input_ids"], img_feats=dargs["img_feats"],
+                                               img_location_embeddings=dargs["img_location_embeddings"], keep=keep.to(dev))
+        lay = prod._last_layout
+        got_c = outs[-1][:lay.rows].float().cpu()
+        pooled_c = pooled.float().cpu()
+        padded = prod(attention_mask=mask.to(dev), **dargs)
+        prod.encoder.deferred_ln = False
+        outs7, _, _, _, _ = prod.run_trunk(dargs["input_ids"], img_feats=dargs["img_feats"],
+                                           img_location_embeddings=dargs["img_location_embeddings"], keep=keep.to(dev))
+        got_7 = outs7[-1][:lay.rows].float().cpu()
+        prod.encoder.deferred_ln = True
+    assert lay.rows == int(keep.sum())
+    H = cfg.hidden_size
+    want_rows = want.reshape(-1, H)[keep.reshape(-1)]
+    e_c = maxabs(got_c, want_rows)
+    e_7 = maxabs(got_7, want_rows)
+    e_p = maxabs(padded[0].reshape(-1, H).float().cpu()[keep.reshape(-1)], got_c)
+    print("compacted deferred-LN loop: max error %.3e (seven-launch layer %.3e); against the padded deferred loop %.3e"
+          % (e_c, e_7, e_p))
+    assert e_c <= 5e-2 and e_c <= e_7 + 5e-3
+    # absent keys against keys at -10000: the same stream arithmetic, one bf16 rounding step of the largest outputs apart
+    assert e_p <= max(2e-2, float(want_rows.abs().max()) * 2.0 ** -7)
+    assert maxabs(pooled_c, want_pooled) <= 5e-2
+
+
 def test_two_rank_loss_curve_bf16_exchange_follows_fp32_exchange(dev, tmp_path):
     """The data-parallel gradient exchange moves a bf16 copy of the gradient slab by default where the reference's DDP
     (tasks/viewpoint_select/pretrain.py:96-102,191) reduces fp32 buckets: six optimizer steps under two ranks with either

@@ -190,6 +190,8 @@ SIGNATURES = {
                                   c_int, c_float, c_void_p]),
     "vt_encoder_forward_ln_bf16": (c_int, [ctypes.POINTER(LayerWeightsLn), c_int] + [c_void_p] * 10 + [
         c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int64, c_void_p]),
+    "vt_encoder_forward_ln_seq_bf16": (c_int, [ctypes.POINTER(LayerWeightsLn), c_int] + [c_void_p] * 9 + [
+        c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "vt_encoder_forward_bf16": (c_int, [ctypes.POINTER(LayerWeights), ctypes.POINTER(LayerActs), c_int, c_void_p,
                                         c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                         c_float, c_float, c_uint64, c_void_p]),

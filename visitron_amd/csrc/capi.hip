@@ -133,7 +133,7 @@ const char* vt_error_string(int code) {
   }
 }
 
-int vt_abi_version(void) { return 8; }
+int vt_abi_version(void) { return 9; }
 
 int vt_batch_row_counts(const int64_t* labels, const int64_t* token_labels, const float* mask, const int32_t* err_flag, int B,
                         int S, int64_t* counts, int32_t* tile_counts, vt_stream_t stream) {
@@ -615,17 +615,22 @@ int vt_ln_stream_init(const float* x, int64_t ldx, void* x_f16, int64_t lds, voi
 }
 
 // CaptionBertEncoder.forward (oscar/modeling_bert.py:140-169) in eval mode with the LayerNorms deferred: five launches per
-// layer (no LayerNorm pass; the residual stream stays fp32):
+// layer (no LayerNorm pass; the residual stream stays fp16):
 //   qkv GEMM (LN of the incoming stream folded in) -> fused attention -> out-proj GEMM (+ LN(stream) as residual; new
 //   stream + statistics) -> FFN-up GEMM (LN folded in, GELU) -> FFN-down GEMM (+ LN(stream); new stream + statistics)
-int vt_encoder_forward_ln_bf16(const vt_layer_weights_ln* layers, int num_layers, void* s16_a, void* sf_a, float* stats_a,
-                               void* s16_b, void* sf_b, float* stats_b, void* qkv, void* ctx, void* mid, const float* mask,
-                               int mask_additive, const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps,
-                               int64_t stat_rows, vt_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+// rows != 0: the streams hold `rows` compacted token rows, sequence b = rows seq_start[b] .. + seq_len[b], every key of a
+// sequence attended (no mask) -- the layout of vt_encoder_forward_seq_bf16.
+}  // extern "C"
+
+static int encoder_forward_ln_impl(const vt_layer_weights_ln* layers, int num_layers, void* s16_a, void* sf_a, float* stats_a,
+                                   void* s16_b, void* sf_b, float* stats_b, void* qkv, void* ctx, void* mid, const float* mask,
+                                   int mask_additive, const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps,
+                                   int64_t stat_rows, hipStream_t stream, long rows, const int* seq_start, const int* seq_len) {
   if (!layers || !s16_a || !sf_a || !stats_a || !s16_b || !sf_b || !stats_b || !qkv || !ctx || !mid) return VT_ERR_NULL;
   if (num_layers <= 0 || B <= 0 || S <= 0 || nh <= 0 || H != nh * 64 || (H % 128) || (I % 128) || H > 1024) return VT_ERR_BAD_SHAPE;
-  const int M = B * S, np = H / 128;
+  if (rows && (!seq_start || !seq_len || mask || rows < 0 || rows > (long)B * S)) return VT_ERR_BAD_SHAPE;
+  const int M = rows ? (int)rows : B * S, np = H / 128;
+  if (stat_rows < M) return VT_ERR_BAD_SHAPE;
   for (int l = 0; l < num_layers; ++l) {
     const vt_layer_weights_ln& w = layers[l];
     int rc;
@@ -634,7 +639,7 @@ int vt_encoder_forward_ln_bf16(const vt_layer_weights_ln* layers, int num_layers
     if (rc) return rc;
     const DropCfg nodrop = vt_make_drop(0.f, 0, 0);
     rc = vt_attention_fwd_dispatch(qkv, 3L * H, mask, mask_additive, head_scale ? head_scale + (long)l * nh : nullptr, ctx, H,
-                                   nullptr, B, S, nh, 64, stream, &nodrop);
+                                   nullptr, B, S, nh, 64, stream, &nodrop, rows ? seq_start : nullptr, rows ? seq_len : nullptr);
     if (rc) return rc;
     rc = vt_gemm_ln_dispatch(ctx, H, w.w_ao, H, w.cb_ao, w.gamma_in, stats_a, np, stat_rows, ln_eps, 2, sf_a, H, s16_b, H, sf_b,
                              H, stats_b, M, H, H, VT_ACT_NONE, stream);
@@ -647,6 +652,25 @@ int vt_encoder_forward_ln_bf16(const vt_layer_weights_ln* layers, int num_layers
     if (rc) return rc;
   }
   return VT_OK;
+}
+
+extern "C" {
+
+int vt_encoder_forward_ln_bf16(const vt_layer_weights_ln* layers, int num_layers, void* s16_a, void* sf_a, float* stats_a,
+                               void* s16_b, void* sf_b, float* stats_b, void* qkv, void* ctx, void* mid, const float* mask,
+                               int mask_additive, const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps,
+                               int64_t stat_rows, vt_stream_t stream) {
+  return encoder_forward_ln_impl(layers, num_layers, s16_a, sf_a, stats_a, s16_b, sf_b, stats_b, qkv, ctx, mid, mask, mask_additive,
+                                 head_scale, B, S, H, nh, I, ln_eps, stat_rows, (hipStream_t)stream, 0, nullptr, nullptr);
+}
+
+int vt_encoder_forward_ln_seq_bf16(const vt_layer_weights_ln* layers, int num_layers, void* s16_a, void* sf_a, float* stats_a,
+                                   void* s16_b, void* sf_b, float* stats_b, void* qkv, void* ctx, void* mid,
+                                   const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps, int64_t stat_rows,
+                                   int64_t rows, const int32_t* seq_start, const int32_t* seq_len, vt_stream_t stream) {
+  if (rows <= 0) return VT_ERR_BAD_SHAPE;
+  return encoder_forward_ln_impl(layers, num_layers, s16_a, sf_a, stats_a, s16_b, sf_b, stats_b, qkv, ctx, mid, nullptr, 0,
+                                 head_scale, B, S, H, nh, I, ln_eps, stat_rows, (hipStream_t)stream, (long)rows, seq_start, seq_len);
 }
 
 // CaptionBertEncoder.forward (oscar/modeling_bert.py:140-169): the Python loop over layers, each

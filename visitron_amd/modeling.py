@@ -660,8 +660,8 @@ class CaptionBertEncoder(nn.Module):
         return self._packed_ln
 
     def serves_deferred_ln(self, history=None, seq=None):
-        """The deferred-LayerNorm loop serves the plain eval forward: hidden size a multiple of 128 (<= 1024: eight
-        statistics slices), no per-layer outputs asked for, every row present."""
+        """The deferred-LayerNorm loop serves the plain eval forward (padded rows with a mask, or compacted rows: run_ln's
+        seq): hidden size a multiple of 128 (<= 1024: eight statistics slices), no per-layer outputs asked for."""
         return (self.deferred_ln and history is None and seq is None and not self.output_attentions
                 and not self.output_hidden_states and self._hidden == self._heads * 64 and self._hidden % 128 == 0
                 and self._hidden <= 1024 and self._inter % 128 == 0)
@@ -685,9 +685,11 @@ class CaptionBertEncoder(nn.Module):
         self._ws[key] = ws
         return ws
 
-    def run_ln(self, x32, B, S, mask_f32, mask_additive, head_scale=None):
+    def run_ln(self, x32, B, S, mask_f32, mask_additive, head_scale=None, seq=None):
         """The deferred-LayerNorm layer loop: x32 fp32 [B*S, H] (the embedding output) -> (sequence output bf16 [B*S, H], the
-        same in fp32).  Both live in the workspace and are rewritten by the next call."""
+        same in fp32).  Both live in the workspace and are rewritten by the next call.  seq (ops.SeqLayout): x32 holds the
+        compacted rows [seq.rows, H] (no masked positions, no mask) and so do the first seq.rows rows of the bf16 output;
+        no fp32 copy is made then."""
         for layer in self.layer:
             _no_train_dropout(layer, layer.attention.self.dropout.p)
             _no_train_dropout(layer, layer.output.dropout.p)
@@ -696,8 +698,19 @@ class CaptionBertEncoder(nn.Module):
         ws = self._workspace_ln(M, x32.device)
         sa, sb = ws["a"], ws["b"]
         H, nh, I, eps = self._hidden, self._heads, self._inter, self._eps
-        ops.ln_stream_init(x32, sa[1], sa[0], sa[2], eps)
         self._last_attentions = None
+        if seq is not None:
+            if mask_f32 is not None or x32.shape[0] != seq.rows:
+                raise ValueError("compacted rows: [seq.rows, H] without a mask")
+            # the row count decides the tile quantisation: tuned once per 2048-row bucket (the nearest tuned M is used)
+            ops.autotune_encoder_shapes_ln(min(M, round_up(seq.rows, 2048)), H, I, device=x32.device)
+            ops.ln_stream_init(x32, sa[1], sa[0], sa[2], eps)
+            ops.encoder_forward_ln(pk.table, sa, sb, ws["qkv"], ws["ctx"], ws["mid"], None, False, head_scale, B, S, H, nh, I, eps,
+                                   seq=seq)
+            ops.ln_apply(sa[1], sa[2], pk.final_gamma, pk.final_beta, eps, out16=ws["out16"], M=seq.rows)
+            self._final_f32, self._final_f32_fresh = None, False
+            return ws["out16"], None
+        ops.ln_stream_init(x32, sa[1], sa[0], sa[2], eps)
         if ops.profiling():   # bench.py's per-kernel timing: the same launches, issued one by one
             for i, t in enumerate(pk.tensors):
                 hs_i = None if head_scale is None else head_scale[i].contiguous()
@@ -1024,7 +1037,7 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                 raise NotImplementedError("compacted rows are served by the bf16 path")
             return self._run_trunk_f32(input_ids, token_type_ids, position_ids, img_feats, img_location_embeddings,
                                        encoder_history_states, mask_f32, mask_is_additive, hs, B, T, R, S, H)
-        if keep is None and self.encoder.serves_deferred_ln(history=encoder_history_states):
+        if (keep is None or not ops.profiling()) and self.encoder.serves_deferred_ln(history=encoder_history_states):
             # default inference path: the embedding output in fp32, the encoder's residual stream in fp16 (not bf16)
             emb = self.embeddings
             _no_train_dropout(emb, emb.dropout.p)
@@ -1046,6 +1059,14 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                     ops.layernorm_rows(x32[T:], _f32(self.LayerNorm.weight), _f32(self.LayerNorm.bias),
                                        self.LayerNorm.variance_epsilon, out=x32[T:], M=B * R, grp_rows=R, grp_stride=S)
             self._last_layout = None
+            if keep is not None:   # compacted rows (the rollout's eval forward): the same loop on the rows that exist
+                lay = ops.SeqLayout(keep.to(device=dev, dtype=torch.bool))
+                self._last_layout = lay
+                out16, _ = self.encoder.run_ln(x32.index_select(0, lay.index), B, S, None, False, hs, seq=lay)
+                cls = out16[:lay.rows].index_select(0, lay.start.to(torch.int64))
+                pooled = self.pooler.pooled(cls, B, 1)
+                _check_index_error(emb)
+                return [out16], pooled, x32, B, S
             out16, _ = self.encoder.run_ln(x32, B, S, mask_f32, mask_is_additive, hs)
             pooled = self.pooler.pooled(out16, B, S)
             _check_index_error(emb)

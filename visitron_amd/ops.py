@@ -192,10 +192,21 @@ def ln_stream_init(x32, xs, x16, stats, eps, M=None):
     _lib.check(rc, "vt_ln_stream_init")
 
 
-def encoder_forward_ln(layer_weights, stream_a, stream_b, qkv, ctx, mid, mask, mask_additive, head_scale, B, S, H, nh, I, eps):
-    """The deferred-LayerNorm layer loop in C.  stream_x = (bf16 copy, fp16 rows, statistics)."""
+def encoder_forward_ln(layer_weights, stream_a, stream_b, qkv, ctx, mid, mask, mask_additive, head_scale, B, S, H, nh, I, eps,
+                       seq=None):
+    """The deferred-LayerNorm layer loop in C.  stream_x = (bf16 copy, fp16 rows, statistics).  seq (SeqLayout): the
+    streams hold its compacted rows (no mask)."""
     _require_hip(stream_a[0], mask, head_scale)
     rows = stream_a[2].shape[1]
+    if seq is not None:
+        if mask is not None:
+            raise ValueError("compacted rows carry no mask")
+        rc = _lib.load().vt_encoder_forward_ln_seq_bf16(
+            layer_weights, len(layer_weights), _ptr(stream_a[0]), _ptr(stream_a[1]), _ptr(stream_a[2]), _ptr(stream_b[0]),
+            _ptr(stream_b[1]), _ptr(stream_b[2]), _ptr(qkv), _ptr(ctx), _ptr(mid), _ptr(head_scale), B, S, H, nh, I, float(eps),
+            rows, seq.rows, _ptr(seq.start), _ptr(seq.length), _stream())
+        _lib.check(rc, "vt_encoder_forward_ln_seq_bf16")
+        return
     rc = _lib.load().vt_encoder_forward_ln_bf16(
         layer_weights, len(layer_weights), _ptr(stream_a[0]), _ptr(stream_a[1]), _ptr(stream_a[2]), _ptr(stream_b[0]),
         _ptr(stream_b[1]), _ptr(stream_b[2]), _ptr(qkv), _ptr(ctx), _ptr(mid), _ptr(mask), _mask_mode(mask, mask_additive, B, S),
