@@ -274,6 +274,7 @@ def main():
     # ---- live per-kernel timing (HIP events on the launch stream), outside the timed region ----
     roofline = None
     kernels = None
+    hbm_step_bytes, traffic_src = None, None
     if rank == 0 and not a.no_kernel_timing:
         ops.profile_begin()
         for _ in range(3):
@@ -293,12 +294,18 @@ def main():
             here = os.path.dirname(os.path.abspath(__file__))
             # (the PMC passes of THIS configuration: train B=256 or forward B=64, default shapes; newest round first)
             default_shape = a.text == 128 and a.regions == 100 and a.batch == (256 if train else 64)
-            rels = (("profiles/r04/train_b256_pmc_hbm_traffic.json", "profiles/r03/train_b256_pmc_hbm_traffic_v5.json") if train else
-                    ("profiles/r04/fwd_b64_pmc_hbm_traffic.json", "profiles/r03/fwd_b64_pmc_hbm_traffic_v3.json"))
+            rels = ()
+            if default_shape:
+                rels = (("profiles/r04/train_b256_pmc_hbm_traffic.json", "profiles/r03/train_b256_pmc_hbm_traffic_v5.json") if train else
+                        ("profiles/r04/fwd_b64_pmc_hbm_traffic.json", "profiles/r03/fwd_b64_pmc_hbm_traffic_v3.json"))
+            elif train and a.text == 512 and a.regions == 144 and a.batch == 64:   # BASELINE configs[4]'s shape on one GPU
+                rels = ("profiles/r04/cfg5_pmc_hbm_traffic.json",)
             for rel in rels:
                 tp = os.path.join(here, rel)
-                if default_shape and os.path.exists(tp):
-                    traffic, traffic_src = json.load(open(tp))["hbm_bytes_per_launch"], rel
+                if os.path.exists(tp):
+                    pmc = json.load(open(tp))
+                    traffic, traffic_src = pmc["hbm_bytes_per_launch"], rel
+                    hbm_step_bytes = pmc.get("all_kernels_hbm_bytes_per_step")
                     break
             roofline = {
                 "kernel": "gemm_nt_bf16 (NT GEMM family; per shape the autotuner picks among the persistent 256x256-tile "
@@ -383,6 +390,12 @@ def main():
             "mfma_frac_whole_forward": (None if (train and fwd_value is None) else
                                         round(f_enc * (fwd_value if train else value) / world / (PEAK_BF16_TFLOPS * 1e12), 4)),
             "roofline": roofline,
+            # the whole step's HBM traffic (every kernel of the committed PMC passes of this command, FETCH_SIZE doubled per
+            # the gfx950 correction, Infinity-Cache hits included in FETCH_SIZE: an upper bound on DRAM bytes) over the time
+            # measured here, against the 8 TB/s peak; null without a committed profile of this configuration
+            "hbm": None if hbm_step_bytes is None else {
+                "bytes_per_step": hbm_step_bytes, "gbps": round(hbm_step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                "peak_gbps": 8000.0, "frac": round(hbm_step_bytes / (ms_per_step * 1e-3) / 8e12, 4), "source": traffic_src},
             # the autotuner's pick per (M, N, K, kind) -- kind = act | 16 residual | 32 second output | 64 fp32 out |
             # deferred-LayerNorm mode << 8; kernel variant numbers as in csrc/gemm_bf16.hip
             "gemm_variants": {"%d,%d,%d,%d" % k: v for k, v in sorted(ops._tuned.items())},

@@ -2,7 +2,10 @@
 per-kernel HBM traffic table and the per-launch figure bench.py reports as roofline.traffic for the NT GEMM family.
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B, so it is doubled
 (MI355X_MICROARCH.md, HBM / rocprofv3 section).
-usage: python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_prefix>"""
+The JSON also carries the sum over EVERY kernel of the passes divided by the steps they ran (`steps`, default 3 = bench.py
+--steps 2 --warmup 1 with the side measurements switched off): the whole step's HBM bytes, which bench.py turns into
+HBM GB/s against the 8 TB/s peak (BASELINE configs[4] asks for that figure).
+usage: python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_prefix> [steps]"""
 import collections
 import csv
 import json
@@ -19,6 +22,7 @@ def agg(path, ctr):
 
 
 fetch, write, prefix = sys.argv[1:4]
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 f, w = agg(fetch, "FETCH_SIZE"), agg(write, "WRITE_SIZE")
 rows = []
 for name in set(f) | set(w):
@@ -35,7 +39,9 @@ with open(prefix + ".csv", "w", newline="") as fh:
 nt = [r for r in rows if "gemm_nt_bf16" in r["kernel"]]
 n = sum(r["launches"] for r in nt)
 tot = sum((r["read_MB_per_launch"] + r["write_MB_per_launch"]) * r["launches"] for r in nt) * 1e6
+every = sum((r["read_MB_per_launch"] + r["write_MB_per_launch"]) * r["launches"] for r in rows) * 1e6
 json.dump({"kernel_family": "gemm_nt_bf16*", "launches": n, "hbm_bytes_per_launch": round(tot / n),
+           "all_kernels_hbm_bytes_per_step": round(every / steps), "steps_in_the_passes": steps,
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1, "
                      "FETCH_SIZE doubled (gfx950)"}, open(prefix + ".json", "w"), indent=1)
-print("NT GEMM family: %d launches, %.1f MB per launch" % (n, tot / n / 1e6))
+print("NT GEMM family: %d launches, %.1f MB per launch; every kernel: %.1f MB per step" % (n, tot / n / 1e6, every / steps / 1e6))
