@@ -36,3 +36,8 @@ t = timeit(lambda: ops.layernorm(x, g, b, 1e-12, out=y))
 print("layernorm fwd  M=%d: %6.1f us  %.2f TB/s" % (M, t, 4.0 * M * H / t / 1e6))
 t = timeit(lambda: ops.layernorm_bwd(x, dy, g, 1e-12, dg, db, dx=dx, ws=ws))
 print("layernorm bwd  M=%d: %6.1f us  %.2f TB/s" % (M, t, 6.0 * M * H / t / 1e6))
+# the training step's form: fp16 pre-LayerNorm sums in, dx written twice (plain + dropout-masked for the dense branch)
+xh = x.to(torch.float16)
+dxd = torch.empty_like(dx)
+t = timeit(lambda: ops.layernorm_bwd(xh, dy, g, 1e-12, dg, db, dx=dx, ws=ws, dx_dropped=dxd, drop=(0.1, 4242, ops.site_out(1))))
+print("layernorm bwd  M=%d, fp16 x, dx + dropped dx: %6.1f us  %.2f TB/s" % (M, t, 8.0 * M * H / t / 1e6))
