@@ -22,6 +22,7 @@ torch.cuda.synchronize()
 buf = torch.zeros(256 * 64 + 8, dtype=torch.int64, device=dev)
 buf[256 * 64] = int(float(sys.argv[3]) * 100) if len(sys.argv) > 3 else 0   # stagger window in us
 buf[256 * 64 + 1] = int(sys.argv[5]) if len(sys.argv) > 5 else 0             # 1: every tile fetches tile (0,0)'s operands
+buf[256 * 64 + 2] = int(os.environ.get("V11_DBG", "0"))   # variant 25 only: group B paused (1), + 288 / 768 fmas per step (2 / 3)
 _lib.load().vt_debug_set_gemm_trace(buf.data_ptr())
 ops.linear(x, w, out=y, **kw)
 torch.cuda.synchronize()

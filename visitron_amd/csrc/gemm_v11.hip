@@ -52,7 +52,33 @@
     xa0 ^= V7_STAGE; xa1 ^= V7_STAGE; wa0 ^= V7_STAGE; wa1 ^= V7_STAGE; dst ^= V7_STAGE;                  \
   }
 
-template <int ACT, bool HAS_R>
+// Timing experiment (GemmArgs::trace slot 256*64+2 != 0; results are NOT valid then): group B "paused" -- its waves keep
+// the step's three barriers and their eight DMA pieces but issue no MFMAs and read no fragments, optionally running
+// `fill` x 8 independent v_fma_f32 in each of the three gaps (the vector work of an epilogue cut into pieces).  It measures
+// what the opposite-phase design rests on: the K-step of one group computing alone, and what a partner doing vector work at
+// the same barrier cadence costs it.
+#define V11_FILL(n)                                                                                       \
+  for (int r_ = 0; r_ < (n); ++r_)                                                                        \
+    asm volatile("v_fma_f32 %0, %8, %9, %0\n\tv_fma_f32 %1, %8, %9, %1\n\tv_fma_f32 %2, %8, %9, %2\n\tv_fma_f32 %3, %8, %9, %3\n\t" \
+                 "v_fma_f32 %4, %8, %9, %4\n\tv_fma_f32 %5, %8, %9, %5\n\tv_fma_f32 %6, %8, %9, %6\n\tv_fma_f32 %7, %8, %9, %7"     \
+                 : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]), "+v"(fl[4]), "+v"(fl[5]), "+v"(fl[6]), "+v"(fl[7])     \
+                 : "v"(fc1), "v"(fc2))
+#define V11_PSTEP_(VMW)                                                                                   \
+  {                                                                                                       \
+    asm volatile("" : "+v"(vx[0]), "+v"(vx[1]), "+v"(vw[0]), "+v"(vw[1]));                                \
+    V11_FILL(fill);                                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) V11_DMA_X(rx, dst, i);                                  \
+    V11_FILL(fill);                                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) V11_DMA_W(rw, dst, i);                                  \
+    V11_FILL(fill);                                                                                       \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    xa0 ^= V7_STAGE; xa1 ^= V7_STAGE; wa0 ^= V7_STAGE; wa1 ^= V7_STAGE; dst ^= V7_STAGE;                  \
+  }
+
+template <int ACT, bool HAS_R, bool DBG = false>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_v11(GemmArgs g) {
   constexpr int MTN = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,6 +155,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_v11(GemmArgs g) {
   u32x4 xf[2][8], wf[2][8];
 
   if (first >= c1) return;
+  const int dbg = DBG && g.trace ? (int)g.trace[256 * 64 + 2] : 0;   // timing experiment (see V11_PSTEP_): its own instantiation
+  const bool paused = DBG && dbg != 0 && grp == 1;
+  const int fill = dbg == 2 ? 12 : dbg == 3 ? 32 : 0;
+  float fl[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  float fc1 = 0.5f + lane * 1e-3f, fc2 = 0.25f;   // (distinct source registers: one register three times costs bank-conflict cycles)
+  asm volatile("" : "+v"(fc1), "+v"(fc2));
   unsigned long long* tr = g.trace ? g.trace + (long)b * 64 : nullptr;
   int tri = 2;
 #define V11_TRACE_RT() { if (tr && tid == 0 && tri < 40) tr[tri++] = __builtin_amdgcn_s_memrealtime(); }
@@ -157,6 +189,26 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_v11(GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
+  if (DBG && paused) {
+    // the paused group's whole tile walk, kept apart from the computing path (a branch per step made the compiler park the
+    // accumulators in scratch): the same steps, barriers and pieces, no MFMAs, no epilogue
+    for (int t = first; t < c1; t += nx) {
+      int m0, n0;
+      tile_origin(t, m0, n0);
+      for (int kt = 0; kt < nk; ++kt) {
+        __amdgpu_buffer_rsrc_t rx = V8_RSRC_X(), rw = V8_RSRC_W();
+        cursor_next();
+        if (kt == 0) {
+          const int bn_ = g.N - n0 < 256 ? g.N - n0 : 256;
+          __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.bias ? g.bias + n0 : nullptr), 0, g.bias ? bn_ * 4 : 0, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, LDS_PTR(smem + 2 * V7_STAGE + wave * 1024), 16, lane * 16, 0, 0, 0);
+        }
+        V11_PSTEP_(8)
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   for (int t = first; t < c1; t += nx) {
     int m0, n0;
     tile_origin(t, m0, n0);
@@ -201,6 +253,7 @@ static int launch_v11(const GemmArgs& g, hipStream_t stream) {
   const int grid = (int)(tiles < cus ? tiles : cus);
   const bool has_r = g.R || ACT == ACT_MUL;
   void (*kern)(GemmArgs) = has_r ? gemm_nt_bf16_v11<ACT, true> : gemm_nt_bf16_v11<ACT, ACT == ACT_MUL>;
+  if (g.trace && ACT == ACT_NONE && !has_r) kern = gemm_nt_bf16_v11<ACT_NONE, false, true>;   // tools/v8_trace.py: with the paused-group modes
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V11_LDS_BYTES) != hipSuccess) return VT_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), V11_LDS_BYTES, stream, ga);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
