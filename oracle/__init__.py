@@ -13,15 +13,23 @@ algorithm for the one hot path this repo accelerates:
   * ``oracle.optim``        -- the pytorch-transformers AdamW rule and warm-up
     schedules used by ``tasks/viewpoint_select/pretrain.py:108-139``.
 
-PARITY UNPINNED by the reference's own tests: the reference ships no tests,
-fixtures or golden vectors and its encoder cannot be
-imported in this container (``ModuleNotFoundError: transformers.
-pytorch_transformers`` -- an ordinary Python error, nothing was denied).  The
-strongest pin available is used instead: ``oracle/crosscheck_hf.py`` checks
-every block against the *independent* third-party implementation installed in
-this image (transformers 5.x ``BertEncoder``/``BertEmbeddings``/``BertPooler``/
-``BertOnlyMLMHead``, eager attention), plus analytic known-answer tests in
-``tests/test_oracle_kat.py``.
+PARITY STATUS.  The reference ships no tests, fixtures or golden vectors.  Since round 5 the
+oracle is pinned BY EXECUTION of the reference's own source in the build container:
+``tests/golden/make_golden_from_reference.py`` puts /root/reference on sys.path, imports ``oscar/modeling_bert.py``,
+``tasks/viewpoint_select/encoder.py``, ``agent_models.py`` and ``data_loader_pretrain.py`` as they lie, runs them on
+deterministic weights (mini, configs[0] B=2 128+100, S=656, the shipped 511+256 and text-only T=511 B=8; forward and
+``loss.backward()``; head_mask, 3-D / float / uint8 masks, history states, text_only, loss corners; OscarEncoder,
+SoftDotAttention, AttnDecoderLSTM; _mask_tokens / _preprocess_item) and writes ``tests/golden/ref_*.npz``.  In that
+process ``oracle.modeling`` / ``oracle.rollout`` / ``oracle.data`` agree with the reference BITWISE on every output and
+gradient (``tests/golden/ref_pin_report.json``); ``tests/test_oracle_reference_pin.py`` re-checks the oracle against
+the fixtures on every CPU run and the GPU tests read the same fixtures.
+
+WHAT REMAINS UNPINNED by the reference: ``oracle.bert_blocks`` and ``oracle.optim``.  The package they restate
+(``transformers.pytorch_transformers``) is an empty submodule, so the generator ran the reference over
+``oracle.bert_blocks`` as a flagged STAND-IN for it: the fixtures pin every line of the reference's files, not the
+arithmetic inside LayerNorm / erf-GELU / embeddings / pooler / MLM head / init / AdamW / schedules.  Those rest on
+``oracle/crosscheck_hf.py`` (every block, forward and gradients, against the independent transformers 5.x installed
+in this image) and the analytic known-answer tests in ``tests/test_oracle_kat.py``.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this package, and only as the checker.  The product package

@@ -2,10 +2,10 @@
 
     python tests/golden/make_golden.py
 
-The reference itself cannot run here (its pytorch-transformers dependency is an empty
-submodule), so the vectors come from the oracle -- which is pinned by oracle/crosscheck_hf.py
-against an independent implementation -- with weights from the hash-based deterministic
-generator (visitron_amd.synth.deterministic_state_dict), i.e. no RNG state is involved.
+SUPERSEDED for outputs and gradients by make_golden_from_reference.py (ref_*.npz: the reference's
+own source, executed).  What is left here is what the reference cannot give -- the AdamW step
+deltas of the un-vendored pytorch-transformers optimizer, restated in oracle/optim.py -- with
+weights from the hash-based deterministic generator (visitron_amd.synth.deterministic_state_dict), i.e. no RNG state is involved.
 Fixtures hold inputs and expected outputs only.
 """
 import os
@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle.modeling import PreTrainOscar  # noqa: E402
 from oracle.optim import AdamW, grouped_parameters  # noqa: E402
-from visitron_amd.config import BertConfig, mini_config  # noqa: E402
+from visitron_amd.config import mini_config  # noqa: E402
 from visitron_amd.synth import deterministic_state_dict, make_batch  # noqa: E402
 
 TRUNK_KEYS = ("input_ids", "attention_mask", "img_feats", "img_location_embeddings")
@@ -65,46 +65,5 @@ def mini():
     print("mini 7-tuple", out7)
 
 
-def base():
-    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    b = make_batch(cfg, 2, seed=1234)  # BASELINE config 1: B=2, 128 text + 100 region tokens
-    m, seq, pooled, scores, tokp, act, out7, grads = run(cfg, b, seed=0, weight_std=0.03)
-    names = sorted(grads)
-    np.savez_compressed(
-        os.path.join(HERE, "base_cfg1.npz"),
-        in_input_ids=b["input_ids"].numpy(), in_attention_mask=b["attention_mask"].numpy(),
-        in_labels=b["labels"].numpy(), in_token_labels=b["token_labels"].numpy(), in_next_action=b["next_action"].numpy(),
-        in_img_feats_checksum=np.array([float(b["img_feats"].double().sum()), float(b["img_feats"].double().abs().max())]),
-        in_loc_checksum=np.array([float(b["img_location_embeddings"].double().sum())]),
-        sequence_output_slice=seq[:, ::19, ::31].numpy(), sequence_output_absmax=np.array([float(seq.abs().max())]),
-        pooled_output=pooled.numpy(), prediction_scores_slice=scores[:, ::23, ::1009].numpy(),
-        prediction_scores_absmax=np.array([float(scores.abs().max())]),
-        token_probs_slice=tokp[:, ::23, ::97].numpy(), action_scores=act.numpy(),
-        tuple7=np.array(out7, dtype=np.float64),
-        grad_names=np.array(names), grad_norms=np.array([float(grads[n].norm()) for n in names]),
-    )
-    print("base 7-tuple", out7)
-
-
-def base_long():
-    """BASELINE configs[4] shape: 512 text + 144 region tokens (S = 656), base config, B = 2."""
-    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    b = make_batch(cfg, 2, text_len=512, region_len=144, seed=77)
-    m, seq, pooled, scores, tokp, act, out7, grads = run(cfg, b, seed=0, weight_std=0.03)
-    names = sorted(grads)
-    np.savez_compressed(
-        os.path.join(HERE, "base_cfg4.npz"),
-        in_input_ids=b["input_ids"].numpy(), in_attention_mask=b["attention_mask"].numpy(),
-        sequence_output_slice=seq[:, ::41, ::31].numpy(), sequence_output_absmax=np.array([float(seq.abs().max())]),
-        pooled_output=pooled.numpy(), prediction_scores_slice=scores[:, ::41, ::1009].numpy(),
-        prediction_scores_absmax=np.array([float(scores.abs().max())]), action_scores=act.numpy(),
-        tuple7=np.array(out7, dtype=np.float64),
-        grad_names=np.array(names), grad_norms=np.array([float(grads[n].norm()) for n in names]),
-    )
-    print("base S=656 7-tuple", out7)
-
-
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mini", "base", "base_long"]
-    for w in which:
-        {"mini": mini, "base": base, "base_long": base_long}[w]()
+    mini()

@@ -52,8 +52,8 @@ def test_base_config_long_dialog_cfg4_forward_backward(dev):
     check_close("base S=656 prediction_scores", g_scores, w_scores, 5e-2)
     check_close("base S=656 pooled_output", g_pool, w_pool, 5e-2)
     check_close("base S=656 action_scores", g_act, w_act, 5e-2)
-    # golden slice of the same case (no oracle call needed to check it)
-    g = np.load(os.path.join(GOLD, "base_cfg4.npz"))
+    # the REFERENCE's own outputs for the same case (tests/golden/make_golden_from_reference.py base_long)
+    g = np.load(os.path.join(GOLD, "ref_base_long.npz"))
     assert np.array_equal(g["in_input_ids"], b["input_ids"].numpy())
     check_close("base S=656 golden sequence_output slice", g_seq.float().cpu()[:, ::41, ::31], g["sequence_output_slice"], 5e-2)
     check_close("base S=656 golden prediction_scores slice", g_scores.float().cpu()[:, ::41, ::1009],

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import maxabs, model_pair
+from helpers import check_close, maxabs, model_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -54,6 +54,43 @@ def _check_grads(tag, prod, want_grads, bound=GRAD_TOL):
     assert not bad, (tag, sorted(bad.items(), key=lambda kv: -kv[1])[:10])
 
 
+def grad_slice(t, n=2048):
+    flat = t.detach().reshape(-1)
+    step = max(1, flat.numel() // n)
+    return flat[::step][:n]
+
+
+def _check_grad_slices(tag, prod, g, bound=GRAD_TOL, prefix=""):
+    """Gradients against a ref_*.npz fixture (tests/golden/make_golden_from_reference.py: per parameter the norm and a
+    2 048-element strided slice of the reference's gradient): relative L2 on the slice (floored like _rel) and the norm
+    within the same bound."""
+    import helpers
+
+    names, off = list(g[prefix + "grad_names"]), g[prefix + "grad_slice_offsets"]
+    params = dict(prod.named_parameters())
+    errs, nerrs = {}, {}
+    for i, n in enumerate(names):
+        p = params[n]
+        assert p.grad is not None, n
+        want = torch.from_numpy(g[prefix + "grad_slices"][off[i]:off[i + 1]])
+        errs[n] = _rel(grad_slice(p.grad), want)
+        wn = float(g[prefix + "grad_norms"][i])
+        nerrs[n] = abs(float(p.grad.float().norm()) - wn) / (wn + 2e-3 * (p.numel() ** 0.5))
+    vals = sorted(errs.values())
+    worst, nworst = max(errs, key=errs.get), max(nerrs, key=nerrs.get)
+    helpers._MEASURED.append((tag + " grad slices worst rel-L2 (" + worst + ")", "rel_l2", errs[worst], bound))
+    helpers._MEASURED.append((tag + " grad slices median rel-L2", "rel_l2", vals[len(vals) // 2], bound))
+    helpers._MEASURED.append((tag + " grad norms worst rel (" + nworst + ")", "rel", nerrs[nworst], bound))
+    print("PARITY %-58s rel_l2  worst %.3e (%s)  median %.3e  norms worst %.3e (%s)  bound %.3e" % (
+        tag + " grad slices", errs[worst], worst, vals[len(vals) // 2], nerrs[nworst], nworst, bound))
+    bad = {n: e for n, e in errs.items() if e > bound}
+    bad.update({n + " (norm)": e for n, e in nerrs.items() if e > bound})
+    assert not bad, (tag, sorted(bad.items(), key=lambda kv: -kv[1])[:10])
+
+
+LOSS_TOL = 5e-3   # absolute, on the four losses (measured ~1e-3 at base size: smoke 13.9457 against 13.9468)
+
+
 def _check_losses(tag, got, want, bound=5e-2, acc_bound=1e-6):
     from helpers import check_close
 
@@ -77,15 +114,13 @@ def test_gradients_match_oracle_mini(dev):
     torch.cuda.synchronize()
     _check_losses("mini train", got, want)
     _check_grads("mini train", prod, {n: p.grad for n, p in ref.named_parameters()})
-    # golden fixture cross-check (no oracle call)
+    # the REFERENCE's own gradients for this case (tests/golden/make_golden_from_reference.py mini), no oracle call
     import os
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mini_pretrain.npz"))
-    names = list(g["grad_names"])
-    norms = dict(zip(names, g["grad_norms"]))
-    for n, p in prod.named_parameters():
-        assert abs(float(p.grad.norm()) - norms[n]) < 0.08 * norms[n] + 2e-3 * (p.numel() ** 0.5), n
-    q0 = dict(prod.named_parameters())["bert.encoder.layer.0.attention.self.query.weight"].grad
-    assert _rel(q0, torch.from_numpy(g["grad_query0"])) < GRAD_TOL
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_mini.npz"))
+    for i in range(4):
+        check_close("mini train vs reference fixture tuple7[%d]" % i, float(got[i]), float(g["tuple7"][i]), 5e-2)
+    _check_grads("mini train vs reference fixture", prod,
+                 {n: torch.from_numpy(g["grad_%03d" % i]) for i, n in enumerate(list(g["grad_names"]))})
 
 
 def test_padding_row_and_tied_decoder_gradients(dev):
@@ -157,25 +192,27 @@ def test_training_reduces_loss_and_tracks_oracle(dev):
 
 
 def test_gradients_match_oracle_base_cfg1(dev):
+    """BASELINE configs[0] (12 layers, 30 522 words, B = 2, 128 + 100): the backward's DIRECTION.  Every parameter's
+    gradient against (a) the oracle's autograd run here, whole tensors, relative L2 <= 2e-2, and (b) the reference's own
+    gradients from tests/golden/ref_base_cfg0.npz (a 2 048-element strided slice and the norm per parameter);
+    losses at an absolute 5e-3."""
     from visitron_amd.config import BertConfig
     from visitron_amd.synth import make_batch
     import os
 
     cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    _, prod, eng = _engine_pair(cfg, 0, dev, std=0.03)
+    ref, prod, eng = _engine_pair(cfg, 0, dev, std=0.03)
     b = make_batch(cfg, 2, seed=1234)
     got = eng.forward_backward({k: v.to(dev) for k, v in b.items()})
     torch.cuda.synchronize()
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "base_cfg1.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_base_cfg0.npz"))
     for i in range(4):
-        assert abs(float(got[i]) - g["tuple7"][i]) < 5e-2 * max(1.0, abs(g["tuple7"][i]))
-    norms = dict(zip(list(g["grad_names"]), g["grad_norms"]))
-    bad = {}
-    for n, p in prod.named_parameters():
-        e = abs(float(p.grad.norm()) - norms[n]) / (norms[n] + 2e-3 * (p.numel() ** 0.5))
-        if e > 0.1:
-            bad[n] = (e, norms[n])
-    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:10]
+        check_close("base cfg0 train vs reference fixture tuple7[%d]" % i, float(got[i]), float(g["tuple7"][i]), LOSS_TOL)
+    want = ref(**b)
+    want[0].backward()
+    _check_losses("base cfg0 train", got, want, bound=LOSS_TOL)
+    _check_grads("base cfg0 train", prod, {n: p.grad for n, p in ref.named_parameters()})
+    _check_grad_slices("base cfg0 train vs reference fixture", prod, g)
 
 
 def test_reference_style_loop_with_torch_optimizer(dev):

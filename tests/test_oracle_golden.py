@@ -1,4 +1,6 @@
-"""CPU: the oracle reproduces the committed golden fixtures, and its un-vendored blocks agree with
+"""CPU: the oracle reproduces the mini fixture it wrote itself (kept for the AdamW step deltas -- the optimizer lives in the
+un-vendored dependency, so the reference cannot supply them; outputs and gradients are pinned by the reference in
+test_oracle_reference_pin.py), and its un-vendored blocks agree with
 the independent implementation recorded in tests/golden/hf_crosscheck.json."""
 import json
 import os
@@ -64,48 +66,6 @@ def test_mini_fixture_gradients_and_adamw_step():
     after = dict(m.named_parameters())
     np.testing.assert_allclose([float((after[n].detach() - before[n]).norm()) for n in names], g["adamw_delta_norms"],
                                rtol=1e-3, atol=1e-7)
-
-
-def test_base_cfg1_fixture_reproduced_by_oracle():
-    from visitron_amd.config import BertConfig
-    from visitron_amd.synth import make_batch
-
-    g = np.load(os.path.join(GOLD, "base_cfg1.npz"))
-    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    b = make_batch(cfg, 2, seed=1234)
-    assert np.array_equal(g["in_input_ids"], b["input_ids"].numpy())
-    assert np.array_equal(g["in_attention_mask"], b["attention_mask"].numpy())
-    assert abs(float(b["img_feats"].double().sum()) - g["in_img_feats_checksum"][0]) < 1e-6 * abs(g["in_img_feats_checksum"][0])
-    m = _oracle(cfg, 0, 0.03)
-    with torch.no_grad():
-        seq, pooled = m.bert(**{k: b[k] for k in TRUNK_KEYS})[:2]
-        scores, tokp, act = m.heads(seq, pooled)
-        out7 = m(**b)
-    np.testing.assert_allclose(seq[:, ::19, ::31].numpy(), g["sequence_output_slice"], atol=1e-4)
-    np.testing.assert_allclose(pooled.numpy(), g["pooled_output"], atol=1e-4)
-    np.testing.assert_allclose(scores[:, ::23, ::1009].numpy(), g["prediction_scores_slice"], atol=5e-4)
-    np.testing.assert_allclose(act.numpy(), g["action_scores"], atol=1e-4)
-    np.testing.assert_allclose([float(x) for x in out7], g["tuple7"], atol=5e-4)
-
-
-def test_base_cfg4_fixture_reproduced_by_oracle():
-    """BASELINE configs[4] shape (512 text + 144 regions): forward only here (the fixture's gradient norms come from
-    tests/golden/make_golden.py base_long)."""
-    from visitron_amd.config import BertConfig
-    from visitron_amd.synth import make_batch
-
-    g = np.load(os.path.join(GOLD, "base_cfg4.npz"))
-    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    b = make_batch(cfg, 2, text_len=512, region_len=144, seed=77)
-    assert np.array_equal(g["in_input_ids"], b["input_ids"].numpy())
-    assert np.array_equal(g["in_attention_mask"], b["attention_mask"].numpy())
-    m = _oracle(cfg, 0, 0.03)
-    with torch.no_grad():
-        seq, pooled = m.bert(**{k: b[k] for k in TRUNK_KEYS})[:2]
-        scores, _, act = m.heads(seq, pooled)
-    np.testing.assert_allclose(seq[:, ::41, ::31].numpy(), g["sequence_output_slice"], atol=1e-4)
-    np.testing.assert_allclose(scores[:, ::41, ::1009].numpy(), g["prediction_scores_slice"], atol=5e-4)
-    np.testing.assert_allclose(act.numpy(), g["action_scores"], atol=1e-4)
 
 
 def test_crosscheck_report_is_green():
