@@ -1,0 +1,341 @@
+// K-step laboratory for the persistent NT GEMM (gemm_nt_bf16_v8, variant 16): TIMING-ONLY builds of the product kernel's own
+// K-step stream with pieces removed, re-placed or stamped, to say where the step's non-MFMA time goes.  Not part of
+// libvisitron_hip.so; built by tools/experiments/Makefile into tools/experiments/bin/ (one binary per -D set).
+//
+//   LAB_DMA    1 (default) the 16 LDS-DMA pieces per wave and step are issued; 0: none (operands stale)
+//   LAB_VMW    1 the landing wait s_waitcnt vmcnt(13) is there; 0: removed (next tile may not have landed: wrong values)
+//   LAB_BAR    1 the three s_barrier of the step; 0: none
+//   LAB_READS  1 the 32 ds_read_b128 fragment reads; 0: none (fragments stale)
+//   LAB_LGKM   1 full lgkmcnt(0) drains at A.20 / A.50 / end (product); 0: none at A.20 / A.50
+//   LAB_SRC    0 product addressing; 1 every piece reads the workgroup's first 1 KiB of X (an L1 / L2 hit: delivery removed)
+//   LAB_STAMP  0 none; 1 A.20 (lgkmcnt drain, barrier) 2 A.50 (drain, barrier) 3 B.24 (vmcnt landing wait, barrier)
+//              4 end-of-step drain: two s_memtime deltas accumulated per workgroup (wave 0) over all K-steps
+//   LAB_SCHED  0 product placement; other values: candidate re-placements (see LAB_SCHED blocks below)
+// Results differ from the product's whenever a piece is removed; LAB_CHECK=1 builds (nothing removed) compare C with a
+// reference product of the same operands computed on the host for a few rows.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#ifndef LAB_DMA
+#define LAB_DMA 1
+#endif
+#ifndef LAB_VMW
+#define LAB_VMW 1
+#endif
+#ifndef LAB_BAR
+#define LAB_BAR 1
+#endif
+#ifndef LAB_READS
+#define LAB_READS 1
+#endif
+#ifndef LAB_LGKM
+#define LAB_LGKM 1
+#endif
+#ifndef LAB_SRC
+#define LAB_SRC 0
+#endif
+#ifndef LAB_STAMP
+#define LAB_STAMP 0
+#endif
+#ifndef LAB_SCHED
+#define LAB_SCHED 0
+#endif
+
+#define LAB_BARRIER() do { if (LAB_BAR) __builtin_amdgcn_s_barrier(); } while (0)
+#define LAB_T(v) do { v = __builtin_amdgcn_s_memtime(); } while (0)
+#if LAB_SRC
+#define LAB_DX(rs, d, i) do { if (LAB_DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(smem + (d) + (i) * 1024), 16, lab_v0, 0, 0, 0); } while (0)
+#define LAB_DW(rs, d, i) do { if (LAB_DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(smem + (d) + V7_WOFF + (i) * 1024), 16, lab_v0, 0, 0, 0); } while (0)
+#else
+#define LAB_DX(rs, d, i) do { if (LAB_DMA) V7_DMA_X(rs, d, i); } while (0)
+#define LAB_DW(rs, d, i) do { if (LAB_DMA) V7_DMA_W(rs, d, i); } while (0)
+#endif
+#define LAB_RD(dst, addr, off) do { if (LAB_READS) V7_LDSR(dst, addr, off); } while (0)
+
+#if LAB_SCHED == 0
+// ---- the product's stream (gemm_v7_kernels.hpp V7_STEP_), with the switches above -------------------------------------
+#define V7_STEP_(VMW, MFMA_A, HOOK)                                                                        \
+  {                                                                                                        \
+    const unsigned xn0 = xa0 ^ V7_STAGE, wn0 = wa0 ^ V7_STAGE;                                             \
+    unsigned long long t1_ = 0, t2_ = 0, t3_ = 0;                                                          \
+    asm volatile("" : "+v"(vx[0]), "+v"(vx[1]), "+v"(vw[0]), "+v"(vw[1]));                                \
+    _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
+      MFMA_A(0, i);                                                                                        \
+      if (i < 16 && (i & 1) && (i >> 1) < MTN) LAB_RD(xf[1][i >> 1], xa1, (i >> 1) * 2048);                \
+      if (i == 20) {                                                                                       \
+        if (LAB_STAMP == 1) LAB_T(t1_);                                                                    \
+        if (LAB_LGKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+        if (LAB_STAMP == 1) LAB_T(t2_);                                                                    \
+        LAB_BARRIER();                                                                                     \
+        if (LAB_STAMP == 1) LAB_T(t3_);                                                                    \
+      }                                                                                                    \
+      if (i >= 22 && i < 38 && !(i & 1)) LAB_DX(rx, dst, (i - 22) >> 1);                                   \
+      if (i >= 22 && i < 38 && (i & 1)) LAB_RD(wf[1][(i - 22) >> 1], wa1, ((i - 22) >> 1) * 2048);         \
+      if (i == 50) {                                                                                       \
+        if (LAB_STAMP == 2) LAB_T(t1_);                                                                    \
+        if (LAB_LGKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+        if (LAB_STAMP == 2) LAB_T(t2_);                                                                    \
+        LAB_BARRIER();                                                                                     \
+        if (LAB_STAMP == 2) LAB_T(t3_);                                                                    \
+      }                                                                                                    \
+      if (i >= 52 && !(i & 3)) LAB_DW(rw, dst, (i - 52) >> 2);                                             \
+      HOOK(i)                                                                                              \
+    }                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
+      V7_MFMA(1, i);                                                                                       \
+      if (i == 4) LAB_DW(rw, dst, 3);                                                                      \
+      if (i == 10) LAB_DW(rw, dst, 4);                                                                     \
+      if (i == 24) {                                                                                       \
+        if (LAB_STAMP == 3) LAB_T(t1_);                                                                    \
+        if (LAB_VMW && LAB_DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");                 \
+        if (LAB_STAMP == 3) LAB_T(t2_);                                                                    \
+        LAB_BARRIER();                                                                                     \
+        if (LAB_STAMP == 3) LAB_T(t3_);                                                                    \
+      }                                                                                                    \
+      if (i >= 26 && i < 58 && !(i & 1)) {                                                                 \
+        const int j = (i - 26) >> 1;                                                                       \
+        if (j < 8) { if (j < MTN) LAB_RD(xf[0][j], xn0, j * 2048); }                                       \
+        else LAB_RD(wf[0][j - 8], wn0, (j - 8) * 2048);                                                    \
+      }                                                                                                    \
+      if (i == 31) LAB_DW(rw, dst, 5);                                                                     \
+      if (i == 39) LAB_DW(rw, dst, 6);                                                                     \
+      if (i == 47) LAB_DW(rw, dst, 7);                                                                     \
+    }                                                                                                      \
+    if (LAB_STAMP == 4) LAB_T(t1_);                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    if (LAB_STAMP == 4) { LAB_T(t2_); t3_ = t2_; }                                                         \
+    if (LAB_STAMP) { lab_acc1 += (unsigned)(t2_ - t1_); lab_acc2 += (unsigned)(t3_ - t2_); ++lab_steps; }  \
+    xa0 ^= V7_STAGE; xa1 ^= V7_STAGE; wa0 ^= V7_STAGE; wa1 ^= V7_STAGE; dst ^= V7_STAGE;                   \
+  }
+#endif
+
+#if LAB_SCHED == 1
+// ---- candidate 1: counted lgkmcnt instead of full drains, fragment reads of the next sub-step issued BEFORE the barrier
+// that frees the image for the DMA (the read of stage s precedes its overwrite by the barrier + the landing latency), X
+// pieces spread over MFMA-only gaps instead of alternating with the W reads.
+//   A.1..15 (odd)   X reads substep 1 -> xf[1]            (8 reads)
+//   A.17..31 (odd)  W reads substep 1 -> wf[1]            (8 reads; the stage's last reads)
+//   A.36            lgkmcnt(0) + barrier: stage s (X and W images) is free   [ONE image-free barrier instead of two]
+//   A.38..62 step 4 X pieces 0..6 of tile kt+2   (7)
+//   B.2             X piece 7;  B.6..22 step 4: W pieces 0..4 (5)
+//   B.24            vmcnt(N) + barrier: tile kt+1 landed
+//   B.26..57 even   reads substep 0 of tile kt+1 -> set 0 (16 reads), W pieces 5..7 at B.31 / 39 / 47
+// vmcnt: at B.24 this step has issued 7 + 1 + 5 = 13 pieces -> vmcnt(13), as before.
+#define V7_STEP_(VMW, MFMA_A, HOOK)                                                                        \
+  {                                                                                                        \
+    const unsigned xn0 = xa0 ^ V7_STAGE, wn0 = wa0 ^ V7_STAGE;                                             \
+    asm volatile("" : "+v"(vx[0]), "+v"(vx[1]), "+v"(vw[0]), "+v"(vw[1]));                                \
+    _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
+      MFMA_A(0, i);                                                                                        \
+      if (i < 16 && (i & 1) && (i >> 1) < MTN) LAB_RD(xf[1][i >> 1], xa1, (i >> 1) * 2048);                \
+      if (i >= 16 && i < 32 && (i & 1)) LAB_RD(wf[1][(i - 16) >> 1], wa1, ((i - 16) >> 1) * 2048);         \
+      if (i == 36) {                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        LAB_BARRIER();                                                                                     \
+      }                                                                                                    \
+      if (i >= 38 && i < 64 && ((i - 38) & 3) == 0) LAB_DX(rx, dst, (i - 38) >> 2);                        \
+      HOOK(i)                                                                                              \
+    }                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
+      V7_MFMA(1, i);                                                                                       \
+      if (i == 2) LAB_DX(rx, dst, 7);                                                                      \
+      if (i >= 6 && i < 24 && ((i - 6) & 3) == 0) LAB_DW(rw, dst, (i - 6) >> 2);                           \
+      if (i == 24) {                                                                                       \
+        if (LAB_VMW && LAB_DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");                 \
+        LAB_BARRIER();                                                                                     \
+      }                                                                                                    \
+      if (i >= 26 && i < 58 && !(i & 1)) {                                                                 \
+        const int j = (i - 26) >> 1;                                                                       \
+        if (j < 8) { if (j < MTN) LAB_RD(xf[0][j], xn0, j * 2048); }                                       \
+        else LAB_RD(wf[0][j - 8], wn0, (j - 8) * 2048);                                                    \
+      }                                                                                                    \
+      if (i == 31) LAB_DW(rw, dst, 5);                                                                     \
+      if (i == 39) LAB_DW(rw, dst, 6);                                                                     \
+      if (i == 47) LAB_DW(rw, dst, 7);                                                                     \
+    }                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    xa0 ^= V7_STAGE; xa1 ^= V7_STAGE; wa0 ^= V7_STAGE; wa1 ^= V7_STAGE; dst ^= V7_STAGE;                   \
+  }
+#endif
+
+
+#if LAB_SCHED == 2
+// ---- candidate 2: ONE image-free barrier and evenly spread pieces.  The sixteen sub-step-1 fragment reads (X then W) go
+// out in the first sixteen MFMA gaps; one lgkmcnt(0) + barrier at A.22 then frees BOTH images of stage s (its sub-step-0
+// fragments were read in the previous step's phase B), and the sixteen pieces of tile kt+2 follow one per five MFMAs
+// (X: A.24 .. A.59; W: B.1 .. B.21, then B.31 / 39 / 47 between the next tile's reads) instead of eight pieces in sixteen
+// gaps right behind a barrier.  Landing wait + barrier at B.24 as in the product (13 pieces issued before it).
+#define V7_STEP_(VMW, MFMA_A, HOOK)                                                                        \
+  {                                                                                                        \
+    const unsigned xn0 = xa0 ^ V7_STAGE, wn0 = wa0 ^ V7_STAGE;                                             \
+    asm volatile("" : "+v"(vx[0]), "+v"(vx[1]), "+v"(vw[0]), "+v"(vw[1]));                                \
+    _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
+      MFMA_A(0, i);                                                                                        \
+      if (i < 8 && i < MTN) LAB_RD(xf[1][i], xa1, i * 2048);                                               \
+      if (i >= 8 && i < 16) LAB_RD(wf[1][i - 8], wa1, (i - 8) * 2048);                                     \
+      if (i == 22) {                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        LAB_BARRIER();                                                                                     \
+      }                                                                                                    \
+      if (i >= 24 && i < 64 && (i - 24) % 5 == 0) LAB_DX(rx, dst, (i - 24) / 5);                           \
+      HOOK(i)                                                                                              \
+    }                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
+      V7_MFMA(1, i);                                                                                       \
+      if (i >= 1 && i < 24 && (i - 1) % 5 == 0) LAB_DW(rw, dst, (i - 1) / 5);                              \
+      if (i == 24) {                                                                                       \
+        if (LAB_VMW && LAB_DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMW) : "memory");                 \
+        LAB_BARRIER();                                                                                     \
+      }                                                                                                    \
+      if (i >= 26 && i < 58 && !(i & 1)) {                                                                 \
+        const int j = (i - 26) >> 1;                                                                       \
+        if (j < 8) { if (j < MTN) LAB_RD(xf[0][j], xn0, j * 2048); }                                       \
+        else LAB_RD(wf[0][j - 8], wn0, (j - 8) * 2048);                                                    \
+      }                                                                                                    \
+      if (i == 31) LAB_DW(rw, dst, 5);                                                                     \
+      if (i == 39) LAB_DW(rw, dst, 6);                                                                     \
+      if (i == 47) LAB_DW(rw, dst, 7);                                                                     \
+    }                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    xa0 ^= V7_STAGE; xa1 ^= V7_STAGE; wa0 ^= V7_STAGE; wa1 ^= V7_STAGE; dst ^= V7_STAGE;                   \
+  }
+#endif
+
+#if LAB_SCHED == 3
+// ---- candidate 3: candidate 2 with the landing wait moved as late as the next tile's reads allow: the sub-step-0 reads
+// of tile kt+1 packed one per MFMA gap into B.46 .. B.61 behind a wait + barrier at B.44 (20 gaps later: the pieces get
+// 0.2 us more to land), the last three W pieces before it (B.26 / 31 / 36): 16 issued -> vmcnt(16).
+#define V7_STEP_(VMW, MFMA_A, HOOK)                                                                        \
+  {                                                                                                        \
+    const unsigned xn0 = xa0 ^ V7_STAGE, wn0 = wa0 ^ V7_STAGE;                                             \
+    asm volatile("" : "+v"(vx[0]), "+v"(vx[1]), "+v"(vw[0]), "+v"(vw[1]));                                \
+    _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
+      MFMA_A(0, i);                                                                                        \
+      if (i < 8 && i < MTN) LAB_RD(xf[1][i], xa1, i * 2048);                                               \
+      if (i >= 8 && i < 16) LAB_RD(wf[1][i - 8], wa1, (i - 8) * 2048);                                     \
+      if (i == 22) {                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        LAB_BARRIER();                                                                                     \
+      }                                                                                                    \
+      if (i >= 24 && i < 64 && (i - 24) % 5 == 0) LAB_DX(rx, dst, (i - 24) / 5);                           \
+      HOOK(i)                                                                                              \
+    }                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 64; ++i) {                                                      \
+      V7_MFMA(1, i);                                                                                       \
+      if (i >= 1 && i < 40 && (i - 1) % 5 == 0) LAB_DW(rw, dst, (i - 1) / 5);                              \
+      if (i == 44) {                                                                                       \
+        if (LAB_VMW && LAB_DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VMW) == 13 ? 16 : (VMW)) : "memory"); \
+        LAB_BARRIER();                                                                                     \
+      }                                                                                                    \
+      if (i >= 46 && i < 62) {                                                                             \
+        const int j = i - 46;                                                                              \
+        if (j < 8) { if (j < MTN) LAB_RD(xf[0][j], xn0, j * 2048); }                                       \
+        else LAB_RD(wf[0][j - 8], wn0, (j - 8) * 2048);                                                    \
+      }                                                                                                    \
+    }                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    xa0 ^= V7_STAGE; xa1 ^= V7_STAGE; wa0 ^= V7_STAGE; wa1 ^= V7_STAGE; dst ^= V7_STAGE;                   \
+  }
+#endif
+
+// stamp accumulators live in the kernel's scope (the header's V7_LAB_DECLS / V7_LAB_EXIT hooks, empty in the product);
+// wave 0 of each workgroup writes its sums out at exit
+__device__ unsigned long long lab_out[256 * 4];
+#define V7_LAB_DECLS unsigned lab_acc1 = 0, lab_acc2 = 0, lab_steps = 0; const int lab_v0 = (threadIdx.x & 63) * 16; (void)lab_v0; (void)lab_steps;
+#define V7_LAB_EXIT if (LAB_STAMP && tid == 0) { lab_out[b * 4] = lab_acc1; lab_out[b * 4 + 1] = lab_acc2; lab_out[b * 4 + 2] = lab_steps; }
+
+#include "../../visitron_amd/csrc/gemm_v7_kernels.hpp"
+
+// fill with a cheap hash: random-looking bf16 in (-1, 1) (random data: the clock the chip holds depends on it)
+__global__ void lab_fill(bf16_t* p, long n, unsigned seed) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 0x9E3779B1u + seed;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    p[i] = f32_to_bf16(((int)(x >> 8) - (1 << 23)) * (1.0f / (1 << 23)));
+  }
+}
+
+static float bf(bf16_t v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 58368, N = argc > 2 ? atoi(argv[2]) : 2304, K = argc > 3 ? atoi(argv[3]) : 768;
+  const int reps = 5;
+  bf16_t *A, *W, *C;
+  unsigned long long* trace;
+  (void)hipMalloc(&A, (size_t)M * K * 2); (void)hipMalloc(&W, (size_t)N * K * 2); (void)hipMalloc(&C, (size_t)M * N * 2);
+  (void)hipMalloc(&trace, (256 * 64 + 8) * 8);
+  (void)hipMemset(trace, 0, (256 * 64 + 8) * 8);
+  lab_fill<<<1024, 256>>>(A, (long)M * K, 1u);
+  lab_fill<<<1024, 256>>>(W, (long)N * K, 2u);
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.W = W; g.C = C; g.lda = K; g.ldw = K; g.ldc = N; g.M = M; g.N = N; g.K = K;
+  g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
+  auto kern = gemm_nt_bf16_v8<ACT_NONE, false, true, false, 8, 0>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES);
+  const int tiles = g.tiles_m * g.tiles_n, grid = tiles < 256 ? tiles : 256;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), V7_LDS_BYTES, 0, g);
+  double us = 0, us_min = 1e30;
+  for (int round = 0; round < 8; ++round) {   // 8 rounds of `reps` launches: mean and best round
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), V7_LDS_BYTES, 0, g);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    us += ms * 1e3 / reps / 8;
+    us_min = ms * 1e3 / reps < us_min ? ms * 1e3 / reps : us_min;
+  }
+  // one traced launch: K loop time per tile from the kernel's own realtime stamps (100 MHz)
+  g.trace = trace;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), V7_LDS_BYTES, 0, g);
+  (void)hipDeviceSynchronize();
+  std::vector<unsigned long long> t(256 * 64 + 8);
+  (void)hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost);
+  double loop_sum = 0, epi_sum = 0, clk_sum = 0;
+  long loops = 0;
+  for (int b = 0; b < grid; ++b) {
+    const unsigned long long* r = &t[b * 64];
+    clk_sum += (double)(r[63] - r[1]) / ((double)(r[62] - r[0]) / 100.0);
+    for (int i = 2; i + 2 < 40 && r[i + 2]; i += 3) { loop_sum += (r[i + 1] - r[i]) / 100.0; epi_sum += (r[i + 2] - r[i + 1]) / 100.0; ++loops; }
+  }
+  const int nk = K / 64;
+  printf("%-24s M=%d N=%d K=%d  kernel %7.1f us (min %7.1f) %7.1f TF/s | traced launch: K-step %.3f us = %4.0f cycles  epilogue %.2f us  clock %.0f MHz",
+         LAB_NAME, M, N, K, us, us_min, 2.0 * M * N * K / us * 1e-6, loop_sum / loops / nk, loop_sum / loops / nk * clk_sum / grid, epi_sum / loops,
+         clk_sum / grid);
+#if LAB_STAMP
+  {
+    unsigned long long h[256 * 4];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(lab_out), sizeof(h));
+    double a1 = 0, a2 = 0, st = 0;
+    for (int b = 0; b < grid; ++b) { a1 += h[b * 4]; a2 += h[b * 4 + 1]; st += h[b * 4 + 2]; }
+    printf("  stamp site %d: wait %.1f cycles, barrier %.1f cycles per K-step (wave 0 mean over %0.f steps)", LAB_STAMP, a1 / st, a2 / st, st / grid);
+  }
+#endif
+  printf("\n");
+#ifdef LAB_CHECK
+  {   // a few rows against a host product (only meaningful when nothing was removed)
+    std::vector<bf16_t> ha((size_t)4 * K), hw((size_t)N * K), hc((size_t)4 * N);
+    const int rows[4] = {0, 257, M / 2 + 3, M - 1};
+    (void)hipMemcpy(hw.data(), W, hw.size() * 2, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int q = 0; q < 4; ++q) {
+      (void)hipMemcpy(&ha[(size_t)q * K], A + (size_t)rows[q] * K, K * 2, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&hc[(size_t)q * N], C + (size_t)rows[q] * N, N * 2, hipMemcpyDeviceToHost);
+      for (int n = 0; n < N; n += 7) {
+        double s = 0;
+        for (int k = 0; k < K; ++k) s += (double)bf(ha[(size_t)q * K + k]) * bf(hw[(size_t)n * K + k]);
+        const double d = fabs(s - bf(hc[(size_t)q * N + n])) / (1.0 + fabs(s));
+        worst = d > worst ? d : worst;
+      }
+    }
+    printf("    check: worst relative error on 4 rows %.3e %s\n", worst, worst < 1e-2 ? "ok" : "MISMATCH");
+  }
+#endif
+  return 0;
+}

@@ -267,6 +267,8 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
 #define V7_STEP_FIRST_LN() const int stat_l16 = v7_lane_now() * 16;   /* no VALU inside the MFMA stream */ \
   V7_STEP_(17, V7_MFMA0, V7_STAT_HOOK)
 #define V7_STAT_HOOK(i) if ((i) >= 40 && (i) < 48 && !((i) & 1)) V7_DMA_STAT(((i) - 40) >> 1);
+/* (tools/experiments/kstep_lab.hip pre-defines V7_STEP_ with its timing-only ablations of this stream) */
+#ifndef V7_STEP_
 #define V7_STEP_(VMW, MFMA_A, HOOK)                                                                               \
   {                                                                                                        \
     const unsigned xn0 = xa0 ^ V7_STAGE, wn0 = wa0 ^ V7_STAGE; /* substep-0 addresses of the other stage */ \
@@ -308,7 +310,12 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
     xa0 ^= V7_STAGE; xa1 ^= V7_STAGE; wa0 ^= V7_STAGE; wa1 ^= V7_STAGE; dst ^= V7_STAGE;                   \
   }
+#endif
 
+#ifndef V7_LAB_DECLS
+#define V7_LAB_DECLS
+#define V7_LAB_EXIT
+#endif
 #define V7_TR nullptr
 #define V7_RING_PRE (LNM == 2)
 template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R, int MTN = 8, int LNM = 0>
@@ -384,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
 
   f32x4 acc[8][8];   // defined by the first K-step (C = 0)
   u32x4 xf[2][8], wf[2][8];
+  V7_LAB_DECLS
 
   auto rsrc_x = [&](int kt) {
     const unsigned kb = (unsigned)kt * 128u;
@@ -564,6 +572,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   f32x4 acc[8][8];
   u32x4 xf[2][8], wf[2][8];
   u32x4 ln_ring[V7_LN_RING][2];   // deferred-LayerNorm mode 2: filled inside the epilogue (tiles of a persistent workgroup drift apart)
+  V7_LAB_DECLS   // (empty in the product: tools/experiments/kstep_lab.hip declares its stamp accumulators here)
 
   if (first >= c1) return;   // uniform: more workgroups than tiles on this XCD
   // debug trace: slot 0 = realtime (100 MHz) at entry, 1 = shader clock at entry, then per tile (realtime): K loop
@@ -622,6 +631,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
     V8_TRACE_RT();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  V7_LAB_EXIT
   if (tr && tid == 0) { tr[62] = __builtin_amdgcn_s_memrealtime(); tr[63] = __builtin_amdgcn_s_memtime(); }
 }
 
