@@ -569,7 +569,8 @@ def _attn_keep(ops, B, nh, S, drop, dev):
 
 @pytest.mark.parametrize("B,S,nh,waves", [(2, 228, 3, 8), (1, 37, 2, 8), (2, 300, 2, 8), (1, 656, 1, 8), (2, 228, 2, 4),
                                           (1, 300, 1, 4), (2, 228, 3, 10), (1, 37, 2, 10), (2, 300, 2, 10),
-                                          (2, 228, 3, 16), (1, 37, 2, 16), (3, 193, 2, 16), (2, 256, 1, 16), (2, 64, 2, 16)])
+                                          (2, 228, 3, 16), (1, 37, 2, 16), (3, 193, 2, 16), (2, 256, 1, 16), (2, 64, 2, 16),
+                                          (2, 228, 3, 17), (1, 37, 2, 17), (3, 193, 2, 17), (2, 256, 1, 17), (2, 64, 2, 17), (5, 1, 2, 17)])
 def test_attention_dropout_fwd_bwd_match_autograd(dev, B, S, nh, waves):
     """attention_probs dropout (oscar/modeling_bert.py:62) with the kernel's own keep-mask fed to torch."""
     from visitron_amd import ops
@@ -589,15 +590,16 @@ def test_attention_dropout_fwd_bwd_match_autograd(dev, B, S, nh, waves):
     want = qkv.grad
     qd = qkv.detach().to(dev, BF16)
     lse = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
-    # waves == 16: the 16-wave kernel (the default where it serves: S <= 256, dropout through the forward's keep words)
-    words = torch.zeros(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev) if waves == 16 else None
+    # waves == 16 / 17: the 16-wave kernel, one pair per workgroup / persistent and pipelined (the default where it serves:
+    # S <= 256, dropout through the forward's keep words)
+    words = torch.zeros(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev) if waves >= 16 else None
     ctx = ops.attention_fwd(qd, B, S, nh, mask=mask.to(dev), lse=lse, drop=drop, keep_bits=words)
     ops.set_attn_bwd_waves(waves)
     try:
         got = ops.attention_bwd(qd, dctx.to(dev, BF16), ctx, lse, B, S, nh, mask=mask.to(dev), drop=drop, keep_bits=words)
         torch.cuda.synchronize()
     finally:
-        ops.set_attn_bwd_waves(16)
+        ops.set_attn_bwd_waves(0)       # back to the default (the persistent 16-wave kernel where it serves)
     assert maxabs(ctx, ctx_ref) < 4e-2
     got = got.float().cpu()
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
@@ -680,7 +682,8 @@ def test_transpose_batch(dev):
         ops.TransposeBatch([(pairs[0][0], pairs[1][1])])   # shape mismatch is refused on the host
 
 
-@pytest.mark.parametrize("B,S,nh,waves", [(5, 228, 3, 8), (3, 300, 2, 8), (4, 228, 2, 4), (2, 656, 1, 8), (5, 228, 3, 10), (3, 300, 2, 10), (5, 228, 3, 16), (4, 100, 2, 16)])
+@pytest.mark.parametrize("B,S,nh,waves", [(5, 228, 3, 8), (3, 300, 2, 8), (4, 228, 2, 4), (2, 656, 1, 8), (5, 228, 3, 10), (3, 300, 2, 10), (5, 228, 3, 16), (4, 100, 2, 16),
+                                          (5, 228, 3, 17), (4, 100, 2, 17)])
 def test_attention_on_compacted_rows_equals_masked_padded_run(dev, B, S, nh, waves):
     """The *_seq_* attention entry points (rows of padded keys dropped, per-sequence start / length) against the padded
     kernels with the same keys masked: context rows, log-sum-exp and the packed q|k|v gradient of the real rows agree."""
@@ -711,7 +714,7 @@ def test_attention_on_compacted_rows_equals_masked_padded_run(dev, B, S, nh, wav
         dq_c = ops.attention_bwd(qkv_c, dctx_c, ctx_c, lse_c, B, S, nh, seq=seq)
         torch.cuda.synchronize()
     finally:
-        ops.set_attn_bwd_waves(16)
+        ops.set_attn_bwd_waves(0)       # back to the default (the persistent 16-wave kernel where it serves)
     assert ctx_c.shape == (seq.rows, H) and dq_c.shape == (seq.rows, 3 * H)
     assert maxabs(ctx_c, ctx_p.index_select(0, seq.index)) < 1e-6
     kq = keep[:, None, :].expand(B, nh, S)

@@ -496,7 +496,7 @@ def test_attention_keep_words_are_the_hash_mask_and_drive_the_backward(dev, B, S
         d2 = ops.attention_bwd(qkv, dctx, ctx1, lse1, B, S, nh, mask=mask, drop=drop, keep_bits=words)
         torch.cuda.synchronize()
     finally:
-        ops.set_attn_bwd_waves(16)
+        ops.set_attn_bwd_waves(0)       # back to the default (the persistent 16-wave kernel where it serves)
     if S <= 256:
         assert torch.equal(d0, d2)
 
@@ -527,7 +527,7 @@ def test_attention_keep_words_on_compacted_rows(dev):
         d2 = ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, seq=seq, keep_bits=words)
         torch.cuda.synchronize()
     finally:
-        ops.set_attn_bwd_waves(16)
+        ops.set_attn_bwd_waves(0)       # back to the default (the persistent 16-wave kernel where it serves)
     assert torch.equal(d0, d2)                          # the same kernel, hash against words: bit for bit
     got = _unpack_keep_words(words, B, nh, S)
     for b in range(B):

@@ -1,0 +1,75 @@
+"""GPU, round 5: the persistent, software-pipelined attention backward (attention_bwd_d64_w16p: one workgroup per compute
+unit walks its (batch, head) pairs, the next slots / keys / V fragments land under the current arithmetic) against the
+one-pair-per-workgroup 16-wave kernel it restates -- same tiles, same order of the sums over keys and queries; delta (an fp32
+MFMA sum here) and the exponent's bias (one fma here) are rounded differently, so the packed bf16 dQ | dK | dV agree to a last
+bit of bf16 on a few elements, not bitwise -- on padded and compacted batches, with and without dropout keep words, fewer and more pairs than compute
+units, one-iteration and four-iteration sequences next to each other (oscar/modeling_bert.py:52-68 under loss.backward())."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def _same(a, b):
+    """bf16 outputs of the two kernels: equal up to one bf16 rounding step on isolated elements."""
+    a, b = a.float(), b.float()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    scale = float(a.abs().max()) + 1e-30
+    assert float((a - b).abs().max()) <= 1.0 / 64 * scale, float((a - b).abs().max()) / scale     # two bf16 steps at full scale
+    assert float((a - b).norm() / (a.norm() + 1e-30)) <= 2e-3, float((a - b).norm() / (a.norm() + 1e-30))
+
+
+def _run(ops, waves, fn):
+    ops.set_attn_bwd_waves(waves)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_attn_bwd_waves(0)
+    return out
+
+
+@pytest.mark.parametrize("B,S,nh,p", [(3, 228, 2, 0.1), (40, 228, 12, 0.1), (2, 256, 3, 0.0), (7, 64, 2, 0.3), (5, 65, 1, 0.1),
+                                      (9, 1, 2, 0.1), (4, 129, 3, 0.0), (64, 100, 12, 0.1)])
+def test_persistent_attention_backward_equals_the_16_wave_kernel_padded(dev, B, S, nh, p):
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(B * 131 + S)
+    H = nh * 64
+    qkv = (torch.randn(B * S, 3 * H, generator=g) * 0.8).to(dev, BF16)
+    dctx = torch.randn(B * S, H, generator=g).to(dev, BF16)
+    mask = (torch.rand(B, S, generator=g) > 0.2).float()
+    mask[:, 0] = 1.0
+    mask = mask.to(dev)
+    drop = (p, 77, 3) if p > 0 else ops.NO_DROP
+    words = torch.zeros(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev) if p > 0 else None
+    lse = torch.zeros(B, nh, S, device=dev)
+    ctx = ops.attention_fwd(qkv, B, S, nh, mask=mask, lse=lse, drop=drop, keep_bits=words)
+    a = _run(ops, 16, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=mask, drop=drop, keep_bits=words))
+    b = _run(ops, 17, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=mask, drop=drop, keep_bits=words))
+    _same(a, b)
+    c = _run(ops, 17, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, mask=mask, drop=drop, keep_bits=words))
+    assert torch.equal(b, c)                      # and reproducible from launch to launch
+
+
+@pytest.mark.parametrize("B,S,nh,p", [(6, 228, 2, 0.1), (48, 228, 12, 0.1), (5, 256, 2, 0.0), (33, 90, 12, 0.2)])
+def test_persistent_attention_backward_equals_the_16_wave_kernel_compacted(dev, B, S, nh, p):
+    """Per-sequence lengths from 1 to S: a workgroup's consecutive pairs have one to four iterations, odd lengths, single keys."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(B * 17 + S)
+    H = nh * 64
+    lens = torch.randint(1, S + 1, (B,), generator=g)
+    lens[0], lens[1], lens[-1] = S, 1, 63
+    keep = torch.arange(S)[None, :] < lens[:, None]
+    seq = ops.SeqLayout(keep.to(dev))
+    qkv = (torch.randn(seq.rows, 3 * H, generator=g) * 0.8).to(dev, BF16)
+    dctx = torch.randn(seq.rows, H, generator=g).to(dev, BF16)
+    drop = (p, 99, 5) if p > 0 else ops.NO_DROP
+    words = torch.zeros(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev) if p > 0 else None
+    lse = torch.zeros(B, nh, S, device=dev)
+    ctx = ops.attention_fwd(qkv, B, S, nh, lse=lse, drop=drop, seq=seq, keep_bits=words)
+    a = _run(ops, 16, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, seq=seq, keep_bits=words))
+    b = _run(ops, 17, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, seq=seq, keep_bits=words))
+    _same(a, b)

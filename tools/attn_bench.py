@@ -18,7 +18,7 @@ drop = (p, 1234, 0) if p > 0 else ops.NO_DROP
 delta = torch.empty(B, nh, S, device=dev)
 out = torch.empty(B * S, 3 * H, device=dev, dtype=torch.bfloat16)
 ctx = ops.attention_fwd(qkv, B, S, nh, mask=mask, lse=lse, drop=drop)
-ops.set_attn_bwd_waves(int(os.environ.get("ATTN_BWD_WAVES", "16")))   # 16 default, 8 eight waves, 10 separate delta pass, 4 four waves
+ops.set_attn_bwd_waves(int(os.environ.get("ATTN_BWD_WAVES", "17")))   # 17 default (persistent), 16 one pair per workgroup, 8 eight waves, 10 separate delta pass, 4 four waves
 
 
 def timeit(fn):

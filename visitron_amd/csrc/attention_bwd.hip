@@ -23,6 +23,7 @@
 // wave-instruction adds 256 contiguous bytes of one row (the full-rate atomic shape), then a small
 // kernel rounds the slab to bf16.
 #include "common.hpp"
+#include <type_traits>
 
 #define LOG2E 1.4426950408889634f
 
@@ -806,6 +807,12 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
 // Everything a (batch, head) needs is fetched ONCE, in the prologue, and stays in LDS (K, Q, dO: 3 x 32 KB at S <= 256): a
 // workgroup that owns a whole compute unit has nothing to hide a global load behind, and the slice-by-slice kernels above pay
 // one exposed load latency per slice (8 per (batch, head): 25 us per workgroup for ~5 us of MFMA and ~5 us of vector work).
+// AW_LAB (tools/experiments/Makefile builds libvisitron_hip_awlab<N>.so with -DAW_LAB=<bits>; 0 / undefined in the product):
+// timing-only removals -- 1 no iteration loop (prologue + epilogue), 2 no dQ phase, 4 trivial element-wise work, 8 no dV^T / dK^T
+// products (and their transposed reads), 16 no S / dP products (and their row reads), 32 no workgroup barriers in the loop
+#ifndef AW_LAB
+#define AW_LAB 0
+#endif
 template <bool BITS>
 __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -916,7 +923,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int it = 0; it < niter; ++it) {
+  for (int it = 0; it < ((AW_LAB & 1) ? 0 : niter); ++it) {
     const unsigned sQ = lds0 + AW_Q + it * 8192, sDO = lds0 + AW_DO + it * 8192;
     const float* rowv = rowc + 64 * it;
     char* sDS = smem + AW_DS;
@@ -941,6 +948,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
         const bf16x8 d0 = *(const bf16x8*)(smem + (db_ - lds0) + ro + (((0 + g) ^ sw) << 4));
         const bf16x8 d1 = *(const bf16x8*)(smem + (db_ - lds0) + ro + (((4 + g) ^ sw) << 4));
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (AW_LAB & 16) { sacc[t] = (f32x4){kb2, kb2, 0.f, 0.f}; dpacc[t] = sacc[t]; continue; }
         sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf[0], z, 0, 0, 0);
         sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf[1], sacc[t], 0, 0, 0);
         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf[0], z, 0, 0, 0);
@@ -955,6 +963,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
         const f32x4 e4 = *(const f32x4*)(rowv + 256 + 32 * ss + 16 * t + 4 * g);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+          if (AW_LAB & 4) { pm[4 * t + j] = sacc[t][j]; dsv[4 * t + j] = dpacc[t][j] + l4[j] + e4[j]; continue; }
           const float p = __builtin_amdgcn_exp2f(fmaf(sacc[t][j], scale2, kb2 - l4[j]));
           float dpv = dpacc[t][j], pv = p;
           if (BITS) {   // (launched only with dropout on)
@@ -975,7 +984,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
       const bf16x8 pb = __builtin_bit_cast(bf16x8, pw4), sb = __builtin_bit_cast(bf16x8, sw4);
       // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries, k-slot order = the tiles' own) ----
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < ((AW_LAB & 8) ? 0 : 4); ++dt) {
         const int cb = 32 * dt + 8 * pp;            // byte offset of head columns 16 dt + 4 pp inside the 128-byte row
         const int r0 = tr_row, r1 = tr_row + 16;
         const unsigned o0 = r0 * 128 + ((((cb >> 4) ^ ((r0 >> 1) & 7)) << 4) | (cb & 8));
@@ -996,10 +1005,10 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
       }
     }
 
-    __syncthreads();   // every wave's dS is in the image
+    if (!(AW_LAB & 32)) __syncthreads();   // every wave's dS is in the image
 
     // ---- dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: this wave's tile = head columns 16 dq_dt .., queries 16 dq_qt .. ----
-    if (it * 64 + 16 * dq_qt < S) {                    // uniform: the tile holds a query of this sequence
+    if (!(AW_LAB & 2) && it * 64 + 16 * dq_qt < S) {   // uniform: the tile holds a query of this sequence
       f32x4 dq = {0.f, 0.f, 0.f, 0.f};
       const unsigned kbase = lds0 + AW_K, dsb = lds0 + AW_DS;
       const int G = 4 * dq_qt + pp;
@@ -1022,7 +1031,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
         *(u32x2*)(dq8 + ((unsigned)q * lddq_b + 2u * (16 * dq_dt + 4 * g))) = w;
       }
     }
-    if (it + 1 < niter) __syncthreads();               // the (single) dS image is rewritten by the next iteration
+    if (!(AW_LAB & 32) && it + 1 < niter) __syncthreads();   // the (single) dS image is rewritten by the next iteration
   }
 
   // ---- dK, dV of this wave's keys: lane = key, register j of tile dt <-> head column 16 dt + 4 g + j ----
@@ -1038,6 +1047,368 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
       *(u32x2*)(orow + 2 * (H + 16 * dt)) = kq;
       *(u32x2*)(orow + 2 * (2 * H + 16 * dt)) = vq;
     }
+  }
+}
+
+// ================================================================================================
+// 16-wave form, PERSISTENT and software-pipelined (round 5).  profiles/r05/attention_bwd_ablation.txt: the kernel above with
+// its iteration loop removed -- prologue and epilogue alone -- takes 137 of its 329 us: a workgroup owns its compute unit, every
+// workgroup of the grid fetches its 175 KB (Q, K, V, dO, O) at the same time at HBM's full rate while no MFMA runs, then all of
+// them compute while HBM idles.  Here one workgroup per compute unit walks its share of the (batch, head) pairs and the loads of
+// what comes next run under the arithmetic of what is there:
+//   * Q, dO and O rows travel in 64-query slots (24 KB: two slots), fetched TWO iterations ahead by LDS-DMA across pair
+//     boundaries, the slot's lse as one 256-byte piece; dO goes through a buffer descriptor, so rows past the sequence read
+//     as ZERO -- their dP, delta, dS and dV terms vanish whatever P is -- while Q and lse repeat the last row (a finite P);
+//   * delta = rowsum(dO o O) of a landed slot is the DIAGONAL of dO O^T: four waves take two MFMAs each in the dQ phase of
+//     the iteration before the slot's use (an all-thread pass over the slot cost 28 us per launch, a pre-pass kernel 38);
+//   * the K image is double-buffered (the next pair's keys land during the current pair's first iteration); the next pair's V
+//     fragments, key bias and first keep words are fetched into registers during the pair's last dQ phase -- the only point
+//     where 16 registers are free in a 128-register kernel -- and its K fragments come from the landed image;
+//   * dK / dV leave at the pair switch, dQ per iteration as before.
+// The LDS-DMA instructions are issued from inline asm: hipcc orders every LDS access behind a pending LDS-DMA it knows of
+// (s_waitcnt vmcnt(0)), which would expose the latency this kernel exists to hide; the landing wait is the explicit
+// vmcnt(0) in front of the iteration's dS barrier, a full iteration after issue.  Arithmetic, tile shapes, LDS images and
+// the order of the sums over keys and queries are those of attention_bwd_d64_w16; delta and the exponent's bias are rounded
+// differently (fp32 MFMA sum; one fma), so results agree to rounding, not bitwise (tests/test_gpu_round5.py).
+#define AP_K 0                        // 2 x [256 keys][128 B]
+#define AP_RING 65536                 // 2 slots x (Q [64 q][128 B] | dO [64 q][128 B] | O [64 q][128 B])
+#define AP_SLOT 24576
+#define AP_DS (AP_RING + 2 * AP_SLOT) // [16 q-groups][256 keys][8 B]
+#define AP_ROW (AP_DS + 32768)        // 2 slots x (lse[64] | delta[64]) fp32
+#define AP_KEEP (AP_ROW + 1024)       // 2 slots x 2 sub-slices x [256 keys] keep words
+#define AP_META (AP_KEEP + 4096)      // [B <= 1024] x (sequence length, first row): scalar metadata the loop reads from LDS
+#define AP_MAX_B 1024
+#define AP_LDS_BYTES (AP_META + 8 * AP_MAX_B)
+
+// 16 bytes per lane global -> LDS (wave-uniform LDS byte address in M0), invisible to the compiler's waitcnt insertion
+__device__ __forceinline__ void ap_dma16(const void* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");   // (M0 is written: nothing else in this kernel uses it)
+}
+__device__ __forceinline__ void ap_dma4(const void* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+}
+// the same through a buffer descriptor: bytes at or past `bytes` read as ZERO (rows past the sequence)
+__device__ __forceinline__ u32x4 ap_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xffffu);
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void ap_bdma16(u32x4 rs, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void ap_bdma4(u32x4 rs, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+}
+
+// AP_LAB (tools/experiments, timing only; 0 / undefined in the product): 1 no LDS-DMA after the prologue (arithmetic on stale
+// slots), 4 no arithmetic (the transfer pipeline alone), 8 no dQ stores
+#ifndef AP_LAB
+#define AP_LAB 0
+#endif
+// 1: this wave's K fragments are re-read from the key image in every sub-slice instead of living in registers for the pair
+#ifndef AP_KF_LDS
+#define AP_KF_LDS 1
+#endif
+template <bool BITS>
+__global__ __launch_bounds__(1024) void attention_bwd_d64_w16p(AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kl = lane & 15, g = lane >> 4;
+  const int Smax = a.S, H = a.nh * 64;
+  const int npairs = a.B * a.nh, G = gridDim.x;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned ldq_b = (unsigned)a.ld_qkv * 2u, ldd_b = (unsigned)a.ld_d * 2u, ldo_b = (unsigned)a.ld_ctx * 2u, lddq_b = (unsigned)a.ld_dqkv * 2u;
+  const float drop_scale = a.drop.thresh ? a.drop.scale : 1.0f;
+  const float ds_scale = a.scale * drop_scale;
+  const float scale2 = a.scale * LOG2E;
+  const int key = 16 * wave + kl;
+  const unsigned keep_step = (unsigned)((Smax + 31) >> 5) << 5;
+  const long keep_pair = (long)((Smax + 31) >> 5) * (long)keep_step;   // keep words per (batch, head)
+
+  // Per-batch metadata -> LDS once.  Inside the loop NOTHING is loaded from global memory by compiler-visible instructions
+  // except at a pair's end: hipcc fetches even uniform values with vector loads once the kernel contains stores, and waits
+  // for each with vmcnt(0) -- which would also wait for every LDS-DMA piece in flight, the latency this kernel hides.
+  int* meta = (int*)(smem + AP_META);
+  if (tid < a.B) {
+    meta[2 * tid] = a.seq_len ? a.seq_len[tid] : a.S;
+    meta[2 * tid + 1] = a.seq_start ? a.seq_start[tid] : tid * a.S;
+  }
+  __syncthreads();
+  auto pair_S = [&](int p) -> int { return __builtin_amdgcn_readfirstlane(meta[2 * (p / a.nh)]); };
+  auto pair_rows = [&](int p) -> long { return (long)__builtin_amdgcn_readfirstlane(meta[2 * (p / a.nh) + 1]); };
+  // this workgroup's k-th pair, or npairs when its list has ended.  (A length-balanced order -- batches ranked by length in
+  // the kernel, dealt boustrophedon -- was built and measured: no gain, 272 -> 277 us on the compacted batch.  A pair's work
+  // is quantised in 64-query iterations, so sequences of 193 .. 256 rows all cost four of them.)
+  auto pair_at = [&](int k) -> int {
+    const int i = k * G + (int)blockIdx.x;
+    return i < npairs ? i : npairs;
+  };
+
+  // ---- the slot cursor: (pair, iteration) of the next 64-query slot to fetch; runs two iterations ahead of the arithmetic ----
+  int ck = 0, cp = pair_at(0), cit = 0, cS = pair_S(cp);
+  auto issue_slot = [&](int slot) {
+    if (cp >= npairs) return;                       // uniform: past this workgroup's last pair
+    const long r0 = pair_rows(cp);
+    const int head = cp % a.nh;
+    const unsigned sb = lds0 + AP_RING + slot * AP_SLOT;
+    const int pw = wave & 7;
+    const int row = 8 * pw + (lane >> 3);           // slot-relative query row of this lane's 16 bytes
+    const int qa = cit * 64 + row;
+    const unsigned q = qa < cS ? qa : cS - 1;       // Q rows past the sequence repeat its last row (dO reads zeros there)
+    const unsigned c16 = 16u * ((lane & 7) ^ ((row >> 1) & 7));
+    if (wave < 8) {
+      ap_dma16(a.qkv + r0 * a.ld_qkv + head * 64, q * ldq_b + c16, sb + pw * 1024);
+      ap_dma16(a.ctx + r0 * a.ld_ctx + head * 64, q * ldo_b + c16, sb + 16384 + pw * 1024);
+      if (wave == 0) {                              // the slot's 64 log-sum-exps (natural log, as the forward left them)
+        const int qi = cit * 64 + lane;
+        ap_dma4(a.lse + (long)cp * Smax, 4u * (unsigned)(qi < cS ? qi : cS - 1), lds0 + AP_ROW + slot * 512);
+      }
+    } else {
+      const void* db = a.dctx + r0 * a.ld_d + head * 64;
+      ap_bdma16(ap_rsrc(db, (unsigned)(cS - 1) * ldd_b + 128u), (unsigned)qa * ldd_b + c16, sb + 8192 + pw * 1024);
+    }
+    if (BITS && (pw >= 1 && pw <= 4)) {             // keep words of the slot's two 32-query sub-slices: 4 pieces of 64 keys each
+      const int ss = wave >> 3, j = pw - 1;
+      const int qb = 2 * cit + ss;
+      if (qb * 32 < cS && 64 * j < (int)keep_step)
+        ap_bdma4(ap_rsrc(a.keep_bits + (long)cp * keep_pair + (long)qb * keep_step, 4u * keep_step), 4u * (unsigned)(64 * j + lane),
+                 lds0 + AP_KEEP + slot * 2048 + ss * 1024 + j * 256);
+    }
+    if (++cit * 64 >= cS) { cit = 0; cp = pair_at(++ck); cS = cp < npairs ? pair_S(cp) : 0; }
+  };
+  // the key image of pair p -> K[par]: 8-row pieces of 1 KiB, rows past the sequence repeat its last row
+  auto issue_keys = [&](int p, int par) {
+    const int S = pair_S(p);
+    const bf16_t* kb = a.qkv + pair_rows(p) * a.ld_qkv + (p % a.nh) * 64 + H;
+    const int np = ((S + 31) >> 5) * 4;
+    for (int j = wave; j < np; j += 16) {
+      const int row = 8 * j + (lane >> 3);
+      const unsigned kr = row < S ? row : S - 1;
+      const int sw = (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
+      ap_dma16(kb, kr * ldq_b + 16u * ((lane & 7) ^ sw), lds0 + AP_K + par * 32768 + j * 1024);
+    }
+  };
+  // this lane's V fragments and raw mask value of pair p: plain loads into registers, issued BEFORE the step's LDS-DMA pieces
+  // (a compiler-placed wait for them then drains nothing younger) and consumed behind the pair's final drain
+  auto load_vm = [&](int p, bf16x8 (&vf)[2], float& mval) {
+    const int S = pair_S(p), b = p / a.nh;
+    const int kr = key < S ? key : S - 1;
+    const bf16_t* vp = a.qkv + (pair_rows(p) + kr) * a.ld_qkv + (p % a.nh) * 64 + 2 * H + 8 * g;
+    vf[0] = *(const bf16x8*)vp; vf[1] = *(const bf16x8*)(vp + 32);
+    mval = a.mask ? a.mask[(long)b * Smax + kr] : 1.0f;
+  };
+  auto key_bias = [&](int p, float mval) -> float {  // in the exp2 domain; -inf: a key past the sequence (p = 0)
+    if (key >= pair_S(p)) return -INFINITY;
+    const float add = !a.mask ? 0.f : a.mask_additive ? mval : (1.0f - mval) * -10000.0f;
+    return add * LOG2E;
+  };
+  // delta of a landed slot: waves 0 .. 3 take 16 queries each; D = dO_tile O_tile^T (16 x 16, two MFMAs over the 64 head
+  // columns), delta[q] = D[q][q] x (1 - p_drop): lane (kl, g) holds rows 4 g .. 4 g + 3 of column kl
+  auto slot_delta = [&](int slot) {
+    if (wave >= 4) return;
+    const int row = 16 * wave + kl;
+    const unsigned ro = row * 128, sw = (row >> 1) & 7;
+    const char* sd = smem + AP_RING + slot * AP_SLOT + 8192 + ro;
+    const char* so = smem + AP_RING + slot * AP_SLOT + 16384 + ro;
+    const bf16x8 d0 = *(const bf16x8*)(sd + (((0 + g) ^ sw) << 4)), d1 = *(const bf16x8*)(sd + (((4 + g) ^ sw) << 4));
+    const bf16x8 o0 = *(const bf16x8*)(so + (((0 + g) ^ sw) << 4)), o1 = *(const bf16x8*)(so + (((4 + g) ^ sw) << 4));
+    f32x4 dd = {0.f, 0.f, 0.f, 0.f};
+    dd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, o0, dd, 0, 0, 0);
+    dd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, o1, dd, 0, 0, 0);
+    const int r = kl & 3;
+    const float v = r == 0 ? dd[0] : r == 1 ? dd[1] : r == 2 ? dd[2] : dd[3];
+    if (g == (kl >> 2)) ((float*)(smem + AP_ROW + slot * 512))[64 + row] = v * a.delta_mul;
+  };
+  // K fragments of this wave's 16 keys from the landed image (B operands: lane = key, 8 head columns at 32 ks + 8 g)
+  auto read_kf = [&](int par, bf16x8 (&kf)[2]) {
+    const int sw = ((((key >> 1) & 1) | (((key >> 3) & 1) << 1)) << 1);
+    const char* kr = smem + AP_K + par * 32768 + key * 128;
+    kf[0] = *(const bf16x8*)(kr + (((0 + g) ^ sw) << 4));
+    kf[1] = *(const bf16x8*)(kr + (((4 + g) ^ sw) << 4));
+  };
+
+  // lane-constant addressing (see attention_bwd_d64_w16)
+  const int qp = kl >> 2, pp = kl & 3;
+  const int tr_row = 4 * g + qp;
+  const int dq_dt = wave >> 2, dq_qt = wave & 3;
+
+  // ---- prologue: the first pair's keys, slots 0 and 1, its V fragments / bias / keep words; then slot 0's row constants ----
+  int p = pair_at(0);
+  bf16x8 kf[2], vf[2];
+  float kb2, mv;
+  load_vm(p, vf, mv);
+  issue_keys(p, 0);
+  issue_slot(0);
+  issue_slot(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  slot_delta(0);
+  if (!AP_KF_LDS) read_kf(0, kf);
+  kb2 = key_bias(p, mv);
+  __syncthreads();
+
+  int par = 0, J = 0;                               // K buffer of the current pair; global iteration count (slot = J & 1)
+  for (int k = 0; p < npairs; ++k) {
+    const int S = pair_S(p);
+    const int pn = pair_at(k + 1);
+    const bool has_next = pn < npairs;
+    const int niter = (S + 63) >> 6, nkt = (S + 31) >> 5;
+    char* dq8 = (char*)(a.dqkv + pair_rows(p) * a.ld_dqkv + (p % a.nh) * 64);
+    f32x4 dv[4], dk[4];   // [d tile]: lane = key, register j <-> head column 16 dt + 4 g + j
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    bf16x8 vfn[2];
+    float mvn = 1.0f;
+
+    // one 64-query iteration; LAST (compile-time) = the pair's last: the next pair's V fragments, bias and keep words are
+    // fetched in its dQ phase (two instantiations, so that those registers are not live across the score phase)
+    auto iteration = [&](const int it, auto last_tag) {
+      constexpr bool last = decltype(last_tag)::value;
+      const int slot = J & 1;
+      const unsigned sQ = lds0 + AP_RING + slot * AP_SLOT, sDO = sQ + 8192;
+      const float* rowv = (const float*)(smem + AP_ROW + slot * 512);
+      char* sDS = smem + AP_DS;
+      const uint32_t* keepw = (const uint32_t*)(smem + AP_KEEP + slot * 2048);
+
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        if ((AP_LAB & 4) || it * 64 + ss * 32 >= S) break;   // uniform: the sub-slice holds no query of this sequence
+        const unsigned qb_ = sQ + ss * 4096, db_ = sDO + ss * 4096;
+        // ---- S = Q K^T and dP = dO V^T for this wave's 16 keys (lane = key; register j of tile t <-> query 16 t + 4 g + j) ----
+        f32x4 sacc[2], dpacc[2];
+        if (AP_KF_LDS) read_kf(par, kf);            // (re-read per sub-slice: eight registers the pair's end needs for the next V)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int row = 16 * t + kl;
+          const unsigned ro = row * 128, sw = (row >> 1) & 7;
+          const bf16x8 q0 = *(const bf16x8*)(smem + (qb_ - lds0) + ro + (((0 + g) ^ sw) << 4));
+          const bf16x8 q1 = *(const bf16x8*)(smem + (qb_ - lds0) + ro + (((4 + g) ^ sw) << 4));
+          const bf16x8 d0 = *(const bf16x8*)(smem + (db_ - lds0) + ro + (((0 + g) ^ sw) << 4));
+          const bf16x8 d1 = *(const bf16x8*)(smem + (db_ - lds0) + ro + (((4 + g) ^ sw) << 4));
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, kf[0], z, 0, 0, 0);
+          sacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, kf[1], sacc[t], 0, 0, 0);
+          dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, vf[0], z, 0, 0, 0);
+          dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, vf[1], dpacc[t], 0, 0, 0);
+        }
+        // ---- P = exp2(acc scale2 + key bias - lse2);  dS = P (keep dP - delta) ----
+        const uint32_t kw = BITS ? keepw[ss * 256 + key] >> (4 * g) : 0u;   // bit 16 t + j = the keep flag of query 16 t + 4 g + j
+        float pm[8], dsv[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 l4 = *(const f32x4*)(rowv + 32 * ss + 16 * t + 4 * g);
+          const f32x4 e4 = *(const f32x4*)(rowv + 64 + 32 * ss + 16 * t + 4 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float pr = __builtin_amdgcn_exp2f(fmaf(sacc[t][j], scale2, fmaf(l4[j], -LOG2E, kb2)));
+            float dpv = dpacc[t][j], pv = pr;
+            if (BITS) {   // (launched only with dropout on)
+              const int km = __builtin_amdgcn_sbfe((int)kw, 16 * t + j, 1);   // 0 / -1
+              dpv = __int_as_float(__float_as_int(dpv) & km);
+              pv = __int_as_float(__float_as_int(pr) & km);
+            }
+            pm[4 * t + j] = pv;
+            dsv[4 * t + j] = pr * (dpv - e4[j]);
+          }
+        }
+        u32x4 pw4, sw4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pw4[i] = pack_bf16x2(pm[2 * i], pm[2 * i + 1]);
+          sw4[i] = pack_bf16x2(dsv[2 * i], dsv[2 * i + 1]);
+        }
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, pw4), sb = __builtin_bit_cast(bf16x8, sw4);
+        // ---- dV^T += dO^T P ; dK^T += Q^T dS   (contraction over the 32 queries, k-slot order = the tiles' own) ----
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int cb = 32 * dt + 8 * pp;
+          const int r0 = tr_row, r1 = tr_row + 16;
+          const unsigned o0 = r0 * 128 + ((((cb >> 4) ^ ((r0 >> 1) & 7)) << 4) | (cb & 8));
+          const unsigned o1 = r1 * 128 + ((((cb >> 4) ^ ((r1 >> 1) & 7)) << 4) | (cb & 8));
+          const bf16x8 dot = tr_pair_b(db_ + o0, (int)(o1 - o0));
+          const bf16x8 qt = tr_pair_b(qb_ + o0, (int)(o1 - o0));
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pb, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, sb, dk[dt], 0, 0, 0);
+        }
+        // ---- dS -> LDS image [q-group G][key][4 q] (8 B per (G, key)), key index XOR-swizzled by G ----
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int Gq = 8 * ss + 4 * t + g;
+          const int kx = key ^ (((Gq >> 1) & 1) << 2) ^ ((Gq & 1) << 4);
+          u32x2 w;
+          w[0] = sw4[2 * t]; w[1] = sw4[2 * t + 1];
+          *(u32x2*)(sDS + (Gq * 256 + kx) * 8) = w;
+        }
+      }
+
+      // slot J + 1 (and, behind it, the next pair's keys) has had a whole iteration to land
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // every wave's dS is in the image; nobody reads slot J's rows any more; slot J + 1 is visible
+      if (last && has_next) load_vm(pn, vfn, mvn);
+      if (!(AP_LAB & 1)) issue_slot(slot);  // global iteration J + 2 -> the slot just freed
+      if (!(AP_LAB & 1) && it == 0 && has_next) issue_keys(pn, par ^ 1);
+
+      // ---- dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: this wave's tile = head columns 16 dq_dt .., queries 16 dq_qt .. ----
+      if (!(AP_LAB & 4) && it * 64 + 16 * dq_qt < S) {   // uniform: the tile holds a query of this sequence
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+        const unsigned kbase = lds0 + AP_K + par * 32768, dsb = lds0 + AP_DS;
+        const int Gq = 4 * dq_qt + pp;
+        const int gsw = (((Gq >> 1) & 1) << 2) ^ ((Gq & 1) << 4);
+        for (int ks = 0; ks < nkt; ++ks) {
+          const int krow = 32 * ks + 8 * g + qp;         // first block row; second block = +4
+          const int ksw = ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 5);
+          const int ksw2 = (((((krow + 4) >> 1) & 1) | ((((krow + 4) >> 3) & 1) << 1)) << 5);
+          const int kcol = 2 * (16 * dq_dt) + 8 * pp;
+          const bf16x8 ka = tr_pair_b(kbase + krow * 128 + (kcol ^ ksw), 4 * 128 + ((kcol ^ ksw2) - (kcol ^ ksw)));
+          const unsigned s0a = dsb + (Gq * 256 + (krow ^ gsw)) * 8, s1a = dsb + (Gq * 256 + ((krow + 4) ^ gsw)) * 8;
+          const bf16x8 sbq = tr_pair_b(s0a, (int)(s1a - s0a));
+          dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, sbq, dq, 0, 0, 0);
+        }
+        const int q = it * 64 + 16 * dq_qt + kl;         // lane (query kl of the tile, g): head columns 16 dq_dt + 4 g .. + 3
+        if (!(AP_LAB & 8) && q < S) {
+          u32x2 w;
+          w[0] = pack_bf16x2(dq[0] * ds_scale, dq[1] * ds_scale);
+          w[1] = pack_bf16x2(dq[2] * ds_scale, dq[3] * ds_scale);
+          *(u32x2*)(dq8 + ((unsigned)q * lddq_b + 2u * (16 * dq_dt + 4 * g))) = w;
+        }
+      }
+      // delta of global iteration J + 1's slot (landed and published by this iteration's dS barrier)
+      if (!last || has_next) slot_delta(slot ^ 1);
+      if (last) {
+        // the next pair's keys (when this pair had a single iteration), V fragments and bias must be there before the switch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- dK, dV of this wave's keys: lane = key, register j of tile dt <-> head column 16 dt + 4 g + j ----
+        if (key < S) {
+          char* orow = dq8 + ((unsigned)key * lddq_b + 8u * g);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            u32x2 kq, vq;
+            kq[0] = pack_bf16x2(dk[dt][0] * ds_scale, dk[dt][1] * ds_scale);
+            kq[1] = pack_bf16x2(dk[dt][2] * ds_scale, dk[dt][3] * ds_scale);
+            vq[0] = pack_bf16x2(dv[dt][0] * drop_scale, dv[dt][1] * drop_scale);
+            vq[1] = pack_bf16x2(dv[dt][2] * drop_scale, dv[dt][3] * drop_scale);
+            *(u32x2*)(orow + 2 * (H + 16 * dt)) = kq;
+            *(u32x2*)(orow + 2 * (2 * H + 16 * dt)) = vq;
+          }
+        }
+      }
+      __syncthreads();   // the (single) dS image and slot J + 1's row constants; at a pair's end also the next pair's keys
+      ++J;
+    };
+    for (int it = 0; it + 1 < niter; ++it) iteration(it, std::false_type{});
+    iteration(niter - 1, std::true_type{});
+    if (has_next) {
+      vf[0] = vfn[0]; vf[1] = vfn[1]; kb2 = key_bias(pn, mvn);
+      par ^= 1;
+      if (!AP_KF_LDS) read_kf(par, kf);
+    }
+    p = pn;
   }
 }
 
@@ -1085,8 +1456,9 @@ __global__ __launch_bounds__(256) void attn_dq_round(const float* __restrict__ d
 // 8 (default): the 8-wave kernel forming delta = rowsum(dO o O) itself; 10: the same kernel behind a separate
 // attn_delta_rows pass (the form before round 3's last change: 330-338 against 320 us per launch at B = 256); 4: the 4-wave kernel
 // 16 (default): the 16-wave kernel where it serves (one key block, no per-query bias, keep words or no dropout), else as 8
-static int g_attn_bwd_waves = 16;
-void vt_attn_bwd_set_waves(int w) { g_attn_bwd_waves = (w == 4 || w == 10 || w == 8) ? w : 16; }
+// 17 (default): the persistent, software-pipelined 16-wave kernel where the 16-wave kernel serves; 16: the one-pair-per-workgroup form
+static int g_attn_bwd_waves = 17;
+void vt_attn_bwd_set_waves(int w) { g_attn_bwd_waves = (w == 4 || w == 10 || w == 8 || w == 16) ? w : 17; }
 
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
@@ -1108,8 +1480,8 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   if (seq_start && (mask || rows_total <= 0)) return VT_ERR_UNSUPPORTED;   // compacted rows carry no masked keys
   const long rows = seq_start ? rows_total : (long)B * S;
   const float delta_mul = (drop && drop->thresh) ? 1.0f / drop->scale : 1.0f;
-  const bool w16 = g_attn_bwd_waves == 16 && nkb == 1 && mask_additive != 2 && (keep_bits || !(drop && drop->thresh));
-  if (g_attn_bwd_waves != 8 && g_attn_bwd_waves != 16)
+  const bool w16 = g_attn_bwd_waves >= 16 && nkb == 1 && mask_additive != 2 && (keep_bits || !(drop && drop->thresh));
+  if (g_attn_bwd_waves != 8 && g_attn_bwd_waves < 16)
     hipLaunchKernelGGL(attn_delta_rows, dim3((unsigned)((S + 3) / 4), B), dim3(256), 0, stream, (const bf16_t*)dctx, ld_d,
                        (const bf16_t*)ctx, ld_ctx, delta_ws, B, S, nh, seq_start, seq_len, delta_mul);
   AttnBwdArgs a;
@@ -1123,7 +1495,17 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
   if (drop) a.drop = *drop; else { a.drop.thresh = 0; a.drop.seed = 0; a.drop.scale = 1.0f; }
   a.keep_bits = a.drop.thresh ? keep_bits : nullptr;
   a.ctx = (const bf16_t*)ctx; a.ld_ctx = ld_ctx; a.delta_mul = delta_mul;
-  if (w16) {
+  if (w16 && g_attn_bwd_waves == 17 && (long)B * nh <= 65535 && B <= AP_MAX_B) {
+    static VtLdsAttrOnce attr17, attr17b;
+    if (!attr17.set((const void*)attention_bwd_d64_w16p<false>, AP_LDS_BYTES)) return VT_ERR_HIP;
+    if (!attr17b.set((const void*)attention_bwd_d64_w16p<true>, AP_LDS_BYTES)) return VT_ERR_HIP;
+    const int cus = vt_device_cus();
+    if (cus <= 0) return VT_ERR_HIP;
+    const long pairs = (long)B * nh;
+    const unsigned grid = (unsigned)(pairs < cus ? pairs : cus);
+    if (a.keep_bits) hipLaunchKernelGGL((attention_bwd_d64_w16p<true>), dim3(grid), dim3(1024), AP_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((attention_bwd_d64_w16p<false>), dim3(grid), dim3(1024), AP_LDS_BYTES, stream, a);
+  } else if (w16) {
     static VtLdsAttrOnce attr16, attr16b;
     if (!attr16.set((const void*)attention_bwd_d64_w16<false>, AW_LDS_BYTES)) return VT_ERR_HIP;
     if (!attr16b.set((const void*)attention_bwd_d64_w16<true>, AW_LDS_BYTES)) return VT_ERR_HIP;
@@ -1138,7 +1520,7 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
     if (!attr8d.set((const void*)attention_bwd_d64_w8<false, true>, AB_LDS_BYTES)) return VT_ERR_HIP;
     if (!attr8bd.set((const void*)attention_bwd_d64_w8<true, true>, AB_LDS_BYTES)) return VT_ERR_HIP;
     const dim3 grid(nh, B, nkb);
-    if (g_attn_bwd_waves == 8 || g_attn_bwd_waves == 16) {
+    if (g_attn_bwd_waves == 8 || g_attn_bwd_waves >= 16) {
       if (a.keep_bits) hipLaunchKernelGGL((attention_bwd_d64_w8<true, true>), grid, dim3(512), AB_LDS_BYTES, stream, a);
       else hipLaunchKernelGGL((attention_bwd_d64_w8<false, true>), grid, dim3(512), AB_LDS_BYTES, stream, a);
     } else {

@@ -866,9 +866,10 @@ def ce_double_softmax_rows(z, y, V, dz, scale):
 
 
 def set_attn_bwd_waves(waves):
-    """Tuning/test hook: 16 (default) = the 16-wave attention backward kernel where it serves (one key block, per-key masks,
-    dropout through the forward's keep words) and the 8-wave kernel elsewhere; 8 = always the 8-wave kernel (forms delta =
-    rowsum(dO o O) itself), 10 = the same behind a separate delta pass, 4 = the 4-wave kernel."""
+    """Tuning/test hook: 17 (default; any other value restores it) = the persistent, software-pipelined 16-wave attention
+    backward kernel where it serves (one key block, per-key masks, dropout through the forward's keep words) and the 8-wave
+    kernel elsewhere; 16 = the 16-wave kernel with one (batch, head) per workgroup; 8 = always the 8-wave kernel (forms
+    delta = rowsum(dO o O) itself), 10 = the same behind a separate delta pass, 4 = the 4-wave kernel."""
     _lib.load().vt_debug_set_attn_bwd_waves(int(waves))
 
 
