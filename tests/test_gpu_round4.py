@@ -17,7 +17,7 @@ def _rand(shape, g, std=1.0):
     return torch.randn(shape, generator=g) * std
 
 
-@pytest.mark.parametrize("variant", [1, 14, 11, 15, 16, 18, 19, 22, 23, 24, 9])
+@pytest.mark.parametrize("variant", [1, 14, 11, 15, 16, 18, 19, 22, 23, 9])
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (777, 768, 3072), (300, 200, 128)])
 def test_linear_fp16_residual_in_and_fp16_sum_out(dev, M, N, K, variant):
     """C (fp16, saturating) = A W^T + b + R with R fp16: every kernel variant's epilogue (variant 9's grouped epilogue is

@@ -695,9 +695,11 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_bf16_v6(GemmArgs g) {
 //          256-row tiling leaves the last round mostly empty).
 int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn);  // gemm_v7.hip (tile height 32 * mtn)
 int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn);  // gemm_v7.hip (persistent; tile height 32 * mtn)
+#ifdef VT_EXPERIMENTAL_GEMM   // tools/experiments (make gemmlab): the measured-negative redesigns of round 4, variants 24 .. 27; not in the product
 int vt_gemm_v10_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);           // gemm_v10.hip (two persistent 256x128-tile workgroups per CU)
 int vt_gemm_v11_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);           // gemm_v11.hip (eight waves on shared 256x256 stages)
 int vt_gemm_v12_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn);  // gemm_v12.hip (short tiles on three operand stages)
+#endif
 static void* g_gemm_trace = nullptr;
 void vt_gemm_set_trace(void* p) { g_gemm_trace = p; }
 static int g_gemm_variant = -1;  // -1: table / heuristic (tuning hook only; set through vt_debug_set_gemm_variant)
@@ -821,10 +823,12 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
     case 19: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 6);   // ... on 192-row tiles
     case 20: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 5);   // ... on 160-row tiles
     case 21: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 4);   // ... on 128-row tiles (small batches)
+#ifdef VT_EXPERIMENTAL_GEMM
     case 24: return vt_gemm_v10_launch(g, ACT, OUT_F32 ? 1 : 0, stream);     // two co-resident persistent workgroups per CU, 256x128 tiles
     case 25: return vt_gemm_v11_launch(g, ACT, OUT_F32 ? 1 : 0, stream);     // eight waves (two groups of four) on shared 256x256 stages
     case 26: return vt_gemm_v12_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 5);  // persistent, 160-row tiles on three operand stages
     case 27: return vt_gemm_v12_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 4);  // ... 128-row tiles
+#endif
     default: return VT_ERR_UNSUPPORTED;
   }
 }

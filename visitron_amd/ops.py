@@ -217,7 +217,7 @@ def encoder_forward_ln(layer_weights, stream_a, stream_b, qkv, ctx, mid, mask, m
 # 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring), 256x256 with 128x128 wave tiles
 # and AGPR accumulators (15: one tile per workgroup, 16: persistent; 18 .. 21: the persistent kernel on 224- / 192- / 160- / 128-row tiles; 22 / 23: the one-tile-per-workgroup kernel on 224- / 192-row tiles,
 # which balance the rounds over the 256 CUs when the 256-row tiling leaves the last round mostly empty).
-GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16, 18, 19, 20, 21, 22, 23)   # 24 (gemm_v10.hip), 25 (gemm_v11.hip), 26 / 27 (gemm_v12.hip) are tested, not candidates: profiles/r04/gemm_v10_two_workgroups.txt, gemm_v11_eight_waves.txt, gemm_v12_three_stages.txt
+GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16, 18, 19, 20, 21, 22, 23)   # (24 .. 27: the measured-negative redesigns of round 4 live in tools/experiments, outside the product library)
 
 
 # -1: shape table / heuristic; -2: the same plus the tail launch of the persistent kernel's last round (VT_GEMM_TAIL_SPLIT=1)
