@@ -19,6 +19,7 @@ Prints ONE JSON line (rank 0) with whole-job samples/s, the live per-kernel roof
 dominant kernel (the MFMA GEMM), and -- at N=1 -- the CPU oracle timed on the host cores.
 """
 import argparse
+import glob
 import json
 import os
 import socket
@@ -297,14 +298,16 @@ def main():
             default_shape = a.text == 128 and a.regions == 100 and a.batch == (256 if train else 64)
             rels = ()
             if default_shape:
-                rels = (("profiles/r04/train_b256_pmc_hbm_traffic.json", "profiles/r03/train_b256_pmc_hbm_traffic_v5.json") if train else
-                        ("profiles/r04/fwd_b64_pmc_hbm_traffic.json", "profiles/r03/fwd_b64_pmc_hbm_traffic_v3.json"))
+                rels = (("profiles/r05/train_b256_pmc_hbm_traffic.json",) if train else ("profiles/r05/fwd_b64_pmc_hbm_traffic.json",))
             elif train and a.text == 512 and a.regions == 144 and a.batch == 64:   # BASELINE configs[4]'s shape on one GPU
-                rels = ("profiles/r04/cfg5_pmc_hbm_traffic.json",)
+                rels = ("profiles/r05/cfg5_pmc_hbm_traffic.json",)
             for rel in rels:
                 tp = os.path.join(here, rel)
                 if os.path.exists(tp):
                     pmc = json.load(open(tp))
+                    if pmc.get("kernel_tree") != kernel_tree_stamp():
+                        traffic_src = rel + " (NOT reported: taken on another tree, kernel_tree %s)" % pmc.get("kernel_tree")
+                        continue
                     traffic, traffic_src = pmc["hbm_bytes_per_launch"], rel
                     hbm_step_bytes = pmc.get("all_kernels_hbm_bytes_per_step")
                     break
@@ -409,6 +412,22 @@ def main():
     if dist is not None:
         dist.barrier()   # rank 0's kernel-timing replay and print are done before any rank tears the group down
         dist.destroy_process_group()
+
+
+def kernel_tree_stamp():
+    """sha256 (16 hex) over the kernel sources and the Python that picks kernels: the identity of the tree a PMC profile was
+    taken on (there is no .git on the GPU box).  profiles/*/..._pmc_hbm_traffic.json carry it; a profile from another tree is
+    not reported as this run's traffic."""
+    import hashlib
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(here, "visitron_amd", "csrc", "*.h*")) + glob.glob(os.path.join(here, "visitron_amd", "csrc", "*.inc")))
+    files += [os.path.join(here, "visitron_amd", f) for f in ("ops.py", "training.py", "modeling.py", "gemm_defaults.json")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def hip_outputs_for_diff(full, trunk, batch):

@@ -73,3 +73,17 @@ def test_persistent_attention_backward_equals_the_16_wave_kernel_compacted(dev, 
     a = _run(ops, 16, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, seq=seq, keep_bits=words))
     b = _run(ops, 17, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, seq=seq, keep_bits=words))
     _same(a, b)
+
+
+def test_attention_dropout_probabilities_the_quantisation_cannot_serve(dev):
+    """p > 255.5 / 256 is refused by the library (VT_ERR_UNSUPPORTED) instead of returning 0 * inf; 0 < p < 1 / 512 drops one
+    key in 256 instead of none (oscar/modeling_bert.py:62 nn.Dropout(attention_probs_dropout_prob))."""
+    from visitron_amd import ops
+
+    B, S, nh = 1, 64, 1
+    qkv = torch.randn(B * S, 3 * 64, device=dev).to(BF16)
+    lse = torch.zeros(B, nh, S, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.attention_fwd(qkv, B, S, nh, lse=lse, drop=(0.999, 1, 0))
+    m = torch.stack([ops.attn_dropout_mask(256, (0.001, 7, 0), h, device=dev) for h in range(16)]).float()
+    assert 0.99 < float(m.mean()) < 0.9999          # ~ 255 / 256 kept: the dropout is on

@@ -4,23 +4,21 @@ import pytest
 import torch
 
 
-def test_multi_rank_gemm_policy_is_decided_from_the_environment_alone():
+def test_multi_rank_gemm_policy_is_opt_in():
     from visitron_amd.ops import multi_rank_gemm_policy
 
     k, text = multi_rank_gemm_policy({})
-    assert k == 0 and "off" in text and "NCCL_MAX_NCHANNELS unset" in text
-    k, text = multi_rank_gemm_policy({"NCCL_MAX_NCHANNELS": "16"})
-    assert k == 16 and "CUs - 16" in text
-    k, _ = multi_rank_gemm_policy({"NCCL_MAX_NCHANNELS": "8", "NCCL_MIN_NCHANNELS": "12"})
-    assert k == 12                       # RCCL raises the maximum to the minimum
-    k, _ = multi_rank_gemm_policy({"NCCL_MIN_NCHANNELS": "12"})
-    assert k == 0                        # a minimum alone bounds nothing
+    assert k == 0 and "off" in text
+    k, _ = multi_rank_gemm_policy({"NCCL_MAX_NCHANNELS": "16"})
+    assert k == 0                        # a pinned channel count no longer switches the reservation on by inference
     k, text = multi_rank_gemm_policy({"VT_GEMM_RESERVE_CUS": "0", "NCCL_MAX_NCHANNELS": "16"})
-    assert k == 0 and "VT_GEMM_RESERVE_CUS=0" in text   # the explicit setting wins
-    k, _ = multi_rank_gemm_policy({"VT_GEMM_RESERVE_CUS": "24"})
-    assert k == 24
-    k, _ = multi_rank_gemm_policy({"NCCL_MAX_NCHANNELS": "4096"})
-    assert k == 0                        # not a channel count: nothing is reserved on its word
+    assert k == 0 and "VT_GEMM_RESERVE_CUS=0" in text
+    k, text = multi_rank_gemm_policy({"VT_GEMM_RESERVE_CUS": "24"})
+    assert k == 24 and "CUs - 24" in text
+    k, _ = multi_rank_gemm_policy({"VT_GEMM_RESERVE_CUS": "4096"})
+    assert k == 0                        # not a plausible CU count: nothing is reserved on its word
+    k, _ = multi_rank_gemm_policy({"VT_GEMM_RESERVE_CUS": "many"})
+    assert k == 0
 
 
 @pytest.mark.parametrize("tied", [True, False])

@@ -21,9 +21,9 @@ python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 "${ARGS[@]}" > "$OUT/be
 echo "$NAME live done" >> "$OUT/progress.txt"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$NAME" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fwd-rate --no-kernel-timing "${ARGS[@]}" > "$OUT/${NAME}_trace.out" 2> "$OUT/${NAME}_trace.err"
 echo "$NAME trace done" >> "$OUT/progress.txt"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_$NAME" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-fwd-rate "${ARGS[@]}" > "$OUT/${NAME}_pmc_fetch.out" 2> "$OUT/${NAME}_pmc_fetch.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_$NAME" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-fwd-rate "${ARGS[@]}" > "$OUT/${NAME}_pmc_fetch.out" 2> "$OUT/${NAME}_pmc_fetch.err"
 echo "$NAME fetch done" >> "$OUT/progress.txt"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_$NAME" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-fwd-rate "${ARGS[@]}" > "$OUT/${NAME}_pmc_write.out" 2> "$OUT/${NAME}_pmc_write.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_$NAME" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-fwd-rate "${ARGS[@]}" > "$OUT/${NAME}_pmc_write.out" 2> "$OUT/${NAME}_pmc_write.err"
 echo "$NAME write done" >> "$OUT/progress.txt"
 F=$(find "$OUT/pmc_fetch_$NAME" -name "*counter_collection.csv" | head -1)
 W=$(find "$OUT/pmc_write_$NAME" -name "*counter_collection.csv" | head -1)
@@ -32,7 +32,7 @@ if [ -z "$F" ] || [ -z "$W" ] || [ -z "$S" ]; then
   echo "profile_round.sh: a profiler pass left no csv (fetch='$F' write='$W' stats='$S'); raw directories kept under $OUT" >&2
   exit 5
 fi
-python3 tools/summarize_pmc.py "$F" "$W" "$OUT/${NAME}_pmc_hbm_traffic"
+python3 tools/summarize_pmc.py "$F" "$W" "$OUT/${NAME}_pmc_hbm_traffic" 3 "$(python3 -c 'import bench; print(bench.kernel_tree_stamp())')"
 cp "$S" "$OUT/${NAME}_kernel_stats.csv"
 # the raw per-dispatch csv files are large: keep the summaries only (reached only when every summary exists)
 rm -rf "$OUT/pmc_fetch_$NAME" "$OUT/pmc_write_$NAME" "$OUT/trace_$NAME"

@@ -1,16 +1,29 @@
+#!/bin/bash
+# The round's bench lines and profile sets (run on the GPU box from the repo root):  bash tools/round_benches.sh r05
+# Profiles first (the bench lines read the HBM figures of THIS tree's passes: bench.kernel_tree_stamp), then the lines.
 set -o pipefail
-mkdir -p gpurun_out/r04i
-bash tools/profile_round.sh r04 > gpurun_out/r04i/profile_train.log 2>&1 && echo "profile train done" >> gpurun_out/r04i/progress.txt
-bash tools/profile_round.sh r04 fwd_b64 --mode fwd > gpurun_out/r04i/profile_fwd.log 2>&1 && echo "profile fwd done" >> gpurun_out/r04i/progress.txt
-bash tools/profile_round.sh r04 cfg5 --batch 64 --text 512 --regions 144 > gpurun_out/r04i/profile_cfg5.log 2>&1 && echo "profile cfg5 done" >> gpurun_out/r04i/progress.txt
-# the bench lines below read the HBM figures of THIS tree's passes
-cp gpurun_out/prof_r04/*_pmc_hbm_traffic.json gpurun_out/prof_r04/*_pmc_hbm_traffic.csv profiles/r04/ 2>/dev/null
-python bench.py --batch 36 --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/r04i/bench_b36.json 2> gpurun_out/r04i/bench_b36.err; echo b36 >> gpurun_out/r04i/progress.txt
-python bench.py --batch 288 --steps 30 --warmup 8 --no-cpu-baseline > gpurun_out/r04i/bench_b288.json 2> gpurun_out/r04i/bench_b288.err; echo b288 >> gpurun_out/r04i/progress.txt
-python bench.py --mode fwd --batch 256 --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/r04i/bench_fwd256.json 2> gpurun_out/r04i/bench_fwd256.err; echo fwd256 >> gpurun_out/r04i/progress.txt
-python bench.py --batch 64 --text 512 --regions 144 --steps 30 --warmup 8 --no-cpu-baseline > gpurun_out/r04i/bench_cfg5.json 2> gpurun_out/r04i/bench_cfg5.err; echo cfg5 >> gpurun_out/r04i/progress.txt
-python bench.py --mode fwd --batch 64 --text 512 --regions 144 --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/r04i/bench_cfg5f.json 2> gpurun_out/r04i/bench_cfg5f.err; echo cfg5f >> gpurun_out/r04i/progress.txt
-python bench.py --gpus 2 --share-gpu --backend gloo --batch 36 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r04i/bench_2rank.json 2> gpurun_out/r04i/bench_2rank.err; echo 2rank >> gpurun_out/r04i/progress.txt
-python bench.py --mode fwd > gpurun_out/r04i/bench_fwd_b64.json 2> gpurun_out/r04i/bench_fwd_b64.err; echo fwdb64 >> gpurun_out/r04i/progress.txt
-python bench.py > gpurun_out/r04i/bench_train_b256.json 2> gpurun_out/r04i/bench_train_b256.err; echo train >> gpurun_out/r04i/progress.txt
-tail -3 gpurun_out/r04i/progress.txt
+R=${1:-r05}
+O=gpurun_out/${R}_benches
+mkdir -p $O profiles/$R
+bash tools/profile_round.sh $R > $O/profile_train.log 2>&1 && echo "profile train done" >> $O/progress.txt
+bash tools/profile_round.sh $R fwd_b64 --mode fwd > $O/profile_fwd.log 2>&1 && echo "profile fwd done" >> $O/progress.txt
+bash tools/profile_round.sh $R cfg5 --batch 64 --text 512 --regions 144 > $O/profile_cfg5.log 2>&1 && echo "profile cfg5 done" >> $O/progress.txt
+cp gpurun_out/prof_$R/*_pmc_hbm_traffic.json gpurun_out/prof_$R/*_pmc_hbm_traffic.csv gpurun_out/prof_$R/*_kernel_stats.csv gpurun_out/prof_$R/tune_*.json gpurun_out/prof_$R/bench_*_live.json profiles/$R/ 2>/dev/null
+b() { name=$1; shift; python bench.py "$@" --no-cpu-baseline > $O/bench_$name.json 2> $O/bench_$name.err; echo $name >> $O/progress.txt; }
+b b36 --batch 36 --steps 50 --warmup 10
+# configs[3]'s per-GPU share under each multi-rank GEMM policy, on one rank (the kernel mix an 8-GPU run executes)
+VT_FORCE_MULTI_RANK_GEMM=1 b b36_policy_stood_down --batch 36 --steps 50 --warmup 10
+VT_FORCE_MULTI_RANK_GEMM=1 VT_GEMM_RESERVE_CUS=16 b b36_policy_reserved16 --batch 36 --steps 50 --warmup 10
+b b288 --batch 288 --steps 30 --warmup 8
+b fwd256 --mode fwd --batch 256 --steps 50 --warmup 10
+b cfg5 --batch 64 --text 512 --regions 144 --steps 30 --warmup 8
+b cfg5f --mode fwd --batch 64 --text 512 --regions 144 --steps 50 --warmup 10
+# the reference's shipped shapes: pretrain 511 + 256 at the shipped per-GPU batch x 4, rollout text-only T = 511
+b shipped_s767_b8 --text 511 --regions 256 --batch 8 --steps 30 --warmup 8
+b shipped_s767_b8_fwd --mode fwd --text 511 --regions 256 --batch 8 --steps 50 --warmup 10
+b text511_b8_fwd --mode fwd --text 511 --regions 0 --batch 8 --steps 50 --warmup 10
+b 2rank --gpus 2 --share-gpu --backend gloo --batch 36 --steps 20 --warmup 5
+python bench.py --mode fwd > $O/bench_fwd_b64.json 2> $O/bench_fwd_b64.err; echo fwdb64 >> $O/progress.txt
+python bench.py > $O/bench_train_b256.json 2> $O/bench_train_b256.err; echo train >> $O/progress.txt
+cp $O/bench_*.json profiles/$R/ 2>/dev/null
+tail -3 $O/progress.txt

@@ -270,7 +270,15 @@ __host__ __forceinline__ DropCfg vt_make_drop(float p, uint64_t step_seed, uint3
 __host__ __device__ __forceinline__ bool vt_keep_attn(const DropCfg& d, uint32_t idx) {
   return ((vt_hash32(d.seed, idx >> 2) >> (8u * (idx & 3u))) & 0xffu) >= d.thresh;
 }
-__host__ __forceinline__ float vt_attn_drop_p(float p) { return p > 0.f ? (float)(uint32_t)(p * 256.0f + 0.5f) / 256.0f : 0.f; }
+// p in (0, 1/512) runs as 1/256 (never silently as "no dropout"); p > 255.5/256 -- where the quantised value would be 1, the
+// scale 1 / (1 - p) infinite and every output 0 * inf -- is refused by the entry points (vt_attn_drop_ok): VT_ERR_UNSUPPORTED.
+__host__ __forceinline__ bool vt_attn_drop_ok(float p) { return p >= 0.f && p * 256.0f + 0.5f < 256.0f; }
+__host__ __forceinline__ float vt_attn_drop_p(float p) {
+  if (!(p > 0.f)) return 0.f;
+  uint32_t q = (uint32_t)(p * 256.0f + 0.5f);
+  q = q < 1u ? 1u : (q > 255u ? 255u : q);
+  return (float)q / 256.0f;
+}
 __host__ __forceinline__ DropCfg vt_make_drop_attn(float p, uint64_t step_seed, uint32_t site) {
   DropCfg d;
   const float pq = vt_attn_drop_p(p);

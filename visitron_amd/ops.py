@@ -232,32 +232,26 @@ def set_gemm_variant(v):
 # time.  Data-parallel training (gradient all-reduce overlapped with the backward) therefore tunes without it; the
 # one-tile-per-workgroup forms of the same kernel (15, 22, 23) are within 1 % over the step and simply queue their tiles.
 PERSISTENT_GEMM_OK = True
-PERSISTENT_VARIANTS = (16, 18, 19, 20, 21, 24, 25, 26, 27)
+PERSISTENT_VARIANTS = (16, 18, 19, 20, 21)
 
 
 def multi_rank_gemm_policy(environ=None):
-    """What the NT GEMM does under more than one rank, decided from the environment alone (no knob has to be set by hand):
-    -> (k, text).  k > 0: the persistent kernels stay in the candidate list and launch on CUs - k workgroups, leaving k
-    compute units to the collective's kernels; k == 0: they stand down and the one-tile-per-workgroup forms (15, 22, 23:
-    within 0-0.8 % over the step on one GPU) queue their tiles behind whatever RCCL occupies.
-      * VT_GEMM_RESERVE_CUS=k   explicit: k > 0 reserves, 0 turns the persistent kernels off;
-      * NCCL_MAX_NCHANNELS=c    RCCL runs one workgroup per channel, so a pinned channel count bounds the CUs it can hold:
-                                k = c (NCCL_MIN_NCHANNELS larger than that wins, as in RCCL);
-      * neither                 the channel count is RCCL's own choice per topology and message size (not knowable here
-                                before the first collective): persistent kernels off."""
+    """What the NT GEMM does under more than one rank -> (k, text).  k == 0 (the default): the persistent kernels stand down
+    and the one-tile-per-workgroup forms (15, 22, 23: within 0-0.8 % over the step on one GPU) queue their tiles behind
+    whatever RCCL occupies.  k > 0: they stay in the candidate list and launch on CUs - k workgroups, leaving k compute units
+    to the collective's kernels -- OPT-IN through VT_GEMM_RESERVE_CUS=k only: the reservation has never been measured beside a
+    real RCCL collective (no multi-GPU node in five rounds; the weight-gradient side stream competes for the same k CUs), so
+    nothing switches it on by inference.  (Round 4 derived k from NCCL_MAX_NCHANNELS; withdrawn: one RCCL workgroup per
+    channel is an assumption, not a measurement.)  Both policies have a profiled single-rank twin: profiles/r05/bench_b36_*.json."""
     env = os.environ if environ is None else environ
     v = env.get("VT_GEMM_RESERVE_CUS")
-    if v is not None and str(v).strip() != "":
+    if v is not None and str(v).strip().lstrip("-").isdigit():
         k = max(0, int(v))
-        return k, ("persistent GEMM on CUs - %d (VT_GEMM_RESERVE_CUS)" % k if k else
-                   "persistent GEMM off beside the collective (VT_GEMM_RESERVE_CUS=0): one-tile-per-workgroup kernels")
-    ch = [int(env[n]) for n in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS") if str(env.get(n, "")).strip().isdigit()]
-    if "NCCL_MAX_NCHANNELS" in env and ch:
-        k = max(ch)
         if 0 < k <= 64:
-            return k, "persistent GEMM on CUs - %d (one CU per RCCL channel: NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS)" % k
-    return 0, ("persistent GEMM off beside the collective (RCCL's channel count is not pinned: NCCL_MAX_NCHANNELS unset): "
-               "one-tile-per-workgroup kernels")
+            return k, "persistent GEMM on CUs - %d (VT_GEMM_RESERVE_CUS)" % k
+        return 0, "persistent GEMM off beside the collective (VT_GEMM_RESERVE_CUS=%s): one-tile-per-workgroup kernels" % str(v).strip()
+    return 0, ("persistent GEMM off beside the collective (default; VT_GEMM_RESERVE_CUS=k opts into the persistent kernels on "
+               "CUs - k): one-tile-per-workgroup kernels")
 _tuned = {}
 _forced_variant = None
 
@@ -324,7 +318,12 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
     if key in _tuned:
         return _tuned[key]
     lib = _lib.load()
-    usable = lambda v: v is not None and (v not in PERSISTENT_VARIANTS or PERSISTENT_GEMM_OK)
+    # The training layer's residual GEMMs (out-proj, FFN-down) read an fp16 residual and write the fp16 pre-LayerNorm sum
+    # (F16_STREAM); the grouped epilogue of variants 9 / 10 is bf16-only and the library would silently run variant 1 in their
+    # place -- a kernel never timed for the shape.  Such kinds are tuned with the dtypes they run with, without 9 / 10.
+    f16_io = F16_STREAM and residual and act == ACT_NONE and not out_f32 and not pre_act and not ln_mode
+    usable = lambda v: (v is not None and (v not in PERSISTENT_VARIANTS or PERSISTENT_GEMM_OK)
+                        and not (f16_io and v in (9, 10)))
     saved = _tune_file_table().get("%d,%d,%d,%d" % key)
     if usable(saved):   # VT_TUNE_FILE: a previous run's choices
         lib.vt_gemm_tune(M, N, K, kind, int(saved))
@@ -353,8 +352,8 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
         def run():
             linear_ln(a, w, b, colv, stats, 1e-12, ln_mode, act=act, out=out, rs=r16, out_s=o16, stats_out=so)
     else:
-        r = torch.randn(M, N, generator=g, device=device).to(BF16) if (residual or act == ACT_MUL) else None
-        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=device)
+        r = torch.randn(M, N, generator=g, device=device).to(F16 if f16_io else BF16) if (residual or act == ACT_MUL) else None
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else (F16 if f16_io else BF16), device=device)
         pre = torch.empty((M, N), dtype=BF16, device=device) if pre_act else None
 
         def run():
@@ -903,8 +902,13 @@ def attn_dropout_mask(n, drop, head_index, device="cuda"):
 
 def attn_drop_p(p):
     """The attention-probability dropout's effective probability: p quantised to 1/256 (0.1 -> 26/256 = 0.1016); kept
-    probabilities are scaled by 1 / (1 - attn_drop_p(p))."""
-    return float(int(p * 256.0 + 0.5)) / 256.0 if p > 0 else 0.0
+    probabilities are scaled by 1 / (1 - attn_drop_p(p)).  0 < p < 1/512 runs as 1/256 (never silently as no dropout);
+    p > 255.5/256 is refused (the library returns VT_ERR_UNSUPPORTED: the quantised value would be 1)."""
+    if not p > 0:
+        return 0.0
+    if p * 256.0 + 0.5 >= 256.0:
+        raise ValueError("attention_probs_dropout_prob %r is not served: the attention sites quantise p to n/256, n <= 255" % (p,))
+    return float(min(255, max(1, int(p * 256.0 + 0.5)))) / 256.0
 
 
 def transpose(src, out):

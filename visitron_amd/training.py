@@ -202,6 +202,9 @@ class PretrainEngine(object):
         for p_ in (cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob):
             if not 0.0 <= p_ < 1.0:
                 raise ValueError("dropout probability must be in [0, 1)")
+        # the attention sites run p quantised to n / 256 (ops.attn_drop_p raises where that is not served): the value the
+        # step actually uses is recorded in state_dict()["hyper"] and in bench.py's line, not only the configured one
+        self.attention_dropout_effective = ops.attn_drop_p(float(cfg.attention_probs_dropout_prob))
         self.model, self.cfg = model, cfg
         self.flat = FlatParams(model, attach_grads=attach_grads)
         self.lr, self.wd, self.eps, self.betas, self.correct_bias = lr, weight_decay, eps, betas, correct_bias
@@ -362,10 +365,11 @@ class PretrainEngine(object):
                 self._bufs.clear()
             b = _TrainBuffers(cfg.num_hidden_layers, B * S, B, S, cfg.hidden_size, cfg.intermediate_size,
                               cfg.num_attention_heads, self.flat.p.device)
-            if self.world > 1:
-                # collectives share the CUs with the backward: ops.multi_rank_gemm_policy decides once, from the
-                # environment RCCL itself reads, whether the persistent GEMM keeps running (on CUs - k workgroups, k = one
-                # CU per RCCL channel) or stands down for the one-tile-per-workgroup kernels; bench.py prints the choice
+            if self.world > 1 or os.environ.get("VT_FORCE_MULTI_RANK_GEMM") == "1":
+                # collectives share the CUs with the backward: ops.multi_rank_gemm_policy decides once whether the persistent
+                # GEMM keeps running (on CUs - k workgroups: opt-in, VT_GEMM_RESERVE_CUS=k) or stands down for the
+                # one-tile-per-workgroup kernels (default); bench.py prints the choice.  VT_FORCE_MULTI_RANK_GEMM=1 applies the
+                # policy on ONE rank: the profiled single-rank twin of each multi-GPU kernel mix (profiles/r05/bench_b36_*.json)
                 k, self.gemm_policy = ops.multi_rank_gemm_policy()
                 if k > 0:
                     _lib.load().vt_gemm_reserve_cus(k)
@@ -965,7 +969,10 @@ class PretrainEngine(object):
                                t_total=self.t_total,
                                # what travelled in the gradient all-reduce of the run that wrote this state (recorded, not
                                # restored: it is a property of the launch, and it changes the result at rounding level)
-                               grad_comm_dtype=self.grad_comm_dtype, world_size=self.world))
+                               grad_comm_dtype=self.grad_comm_dtype, world_size=self.world,
+                               hidden_dropout=float(self.cfg.hidden_dropout_prob),
+                               attention_dropout_configured=float(self.cfg.attention_probs_dropout_prob),
+                               attention_dropout_effective=self.attention_dropout_effective))
 
     def load_state_dict(self, sd, load_hyper=True):
         f = self.flat
