@@ -48,8 +48,9 @@ _REC = None
 def effective_bound(name, bound):
     import os
 
-    # VT_PARITY_RECORD=1: a re-measurement run after a kernel change -- stated bounds only, every check recorded
-    # (gpurun_out/parity_measured.txt), then tools/merge_parity.py folds the run into the committed record
+    # VT_PARITY_RECORD=1: the round's re-measurement run -- stated bounds only, every check recorded
+    # (gpurun_out/parity_measured.txt); tools/merge_parity.py then REPLACES the committed record with this run and lists
+    # every check that rose by more than 1.5 x (the list and its reason go into the commit message)
     rec = None if os.environ.get("VT_PARITY_RECORD") == "1" else _recorded().get(name)
     if rec is None:
         return bound
