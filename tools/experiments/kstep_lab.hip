@@ -262,6 +262,7 @@ static float bf(bf16_t v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, 
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 58368, N = argc > 2 ? atoi(argv[2]) : 2304, K = argc > 3 ? atoi(argv[3]) : 768;
+  const int grid_arg = argc > 4 ? atoi(argv[4]) : 256;   // workgroups of the persistent grid (fewer CUs: a higher clock?)
   const int reps = 5;
   bf16_t *A, *W, *C;
   unsigned long long* trace;
@@ -276,7 +277,7 @@ int main(int argc, char** argv) {
   g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
   auto kern = gemm_nt_bf16_v8<ACT_NONE, false, true, false, 8, 0>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES);
-  const int tiles = g.tiles_m * g.tiles_n, grid = tiles < 256 ? tiles : 256;
+  const int tiles = g.tiles_m * g.tiles_n, grid = tiles < grid_arg ? tiles : grid_arg;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), V7_LDS_BYTES, 0, g);
@@ -305,8 +306,8 @@ int main(int argc, char** argv) {
     for (int i = 2; i + 2 < 40 && r[i + 2]; i += 3) { loop_sum += (r[i + 1] - r[i]) / 100.0; epi_sum += (r[i + 2] - r[i + 1]) / 100.0; ++loops; }
   }
   const int nk = K / 64;
-  printf("%-24s M=%d N=%d K=%d  kernel %7.1f us (min %7.1f) %7.1f TF/s | traced launch: K-step %.3f us = %4.0f cycles  epilogue %.2f us  clock %.0f MHz",
-         LAB_NAME, M, N, K, us, us_min, 2.0 * M * N * K / us * 1e-6, loop_sum / loops / nk, loop_sum / loops / nk * clk_sum / grid, epi_sum / loops,
+  printf("%-14s grid %3d M=%d N=%d K=%d  kernel %7.1f us (min %7.1f) %7.1f TF/s | traced launch: K-step %.3f us = %4.0f cycles  epilogue %.2f us  clock %.0f MHz",
+         LAB_NAME, grid, M, N, K, us, us_min, 2.0 * M * N * K / us * 1e-6, loop_sum / loops / nk, loop_sum / loops / nk * clk_sum / grid, epi_sum / loops,
          clk_sum / grid);
 #if LAB_STAMP
   {

@@ -8,6 +8,7 @@ mkdir -p $O profiles/$R
 bash tools/profile_round.sh $R > $O/profile_train.log 2>&1 && echo "profile train done" >> $O/progress.txt
 bash tools/profile_round.sh $R fwd_b64 --mode fwd > $O/profile_fwd.log 2>&1 && echo "profile fwd done" >> $O/progress.txt
 bash tools/profile_round.sh $R cfg5 --batch 64 --text 512 --regions 144 > $O/profile_cfg5.log 2>&1 && echo "profile cfg5 done" >> $O/progress.txt
+# (profiles/ on the GPU box is not merged back: after the call, copy gpurun_out/prof_$R/* and $O/bench_*.json into profiles/$R/ in the build container)
 cp gpurun_out/prof_$R/*_pmc_hbm_traffic.json gpurun_out/prof_$R/*_pmc_hbm_traffic.csv gpurun_out/prof_$R/*_kernel_stats.csv gpurun_out/prof_$R/tune_*.json gpurun_out/prof_$R/bench_*_live.json profiles/$R/ 2>/dev/null
 b() { name=$1; shift; python bench.py "$@" --no-cpu-baseline > $O/bench_$name.json 2> $O/bench_$name.err; echo $name >> $O/progress.txt; }
 b b36 --batch 36 --steps 50 --warmup 10
