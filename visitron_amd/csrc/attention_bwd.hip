@@ -1071,8 +1071,13 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
 // the order of the sums over keys and queries are those of attention_bwd_d64_w16; delta and the exponent's bias are rounded
 // differently (fp32 MFMA sum; one fma), so results agree to rounding, not bitwise (tests/test_gpu_round5.py).
 #define AP_K 0                        // 2 x [256 keys][128 B]
-#define AP_RING 65536                 // 2 slots x (Q [64 q][128 B] | dO [64 q][128 B] | O [64 q][128 B])
+#define AP_RING 65536                 // 2 slots x (Q [64 q][128 B] | dO [64 q][128 B] | O [64 q][128 B]), 16-B chunk XOR AP_SWZ(row)
 #define AP_SLOT 24576
+// Chunk swizzle of the slot images.  The round-4 images used (row >> 1) & 7: conflict-free for the row reads (ds_read_b128) but
+// 2-way conflicting on EVERY transposed read of the dV^T / dK^T operands (rows 4 g + q' of a 32-lane group: rows 0 and 2 landed in
+// the same 32-byte bank group) -- SQ_LDS_BANK_CONFLICT 1.16e7 of 5.9e7 LDS cycles per launch.  row & 6 is conflict-free for both
+// patterns (exhaustive check over the xor-linear swizzles: profiles/r05/attention_bwd_persistent.txt).
+#define AP_SWZ(row) ((row) & 6)
 #define AP_DS (AP_RING + 2 * AP_SLOT) // [16 q-groups][256 keys][8 B]
 #define AP_ROW (AP_DS + 32768)        // 2 slots x (lse[64] | delta[64]) fp32
 #define AP_KEEP (AP_ROW + 1024)       // 2 slots x 2 sub-slices x [256 keys] keep words
@@ -1161,7 +1166,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16p(AttnBwdArgs a) {
     const int row = 8 * pw + (lane >> 3);           // slot-relative query row of this lane's 16 bytes
     const int qa = cit * 64 + row;
     const unsigned q = qa < cS ? qa : cS - 1;       // Q rows past the sequence repeat its last row (dO reads zeros there)
-    const unsigned c16 = 16u * ((lane & 7) ^ ((row >> 1) & 7));
+    const unsigned c16 = 16u * ((lane & 7) ^ AP_SWZ(row));
     if (wave < 8) {
       ap_dma16(a.qkv + r0 * a.ld_qkv + head * 64, q * ldq_b + c16, sb + pw * 1024);
       ap_dma16(a.ctx + r0 * a.ld_ctx + head * 64, q * ldo_b + c16, sb + 16384 + pw * 1024);
@@ -1213,7 +1218,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16p(AttnBwdArgs a) {
   auto slot_delta = [&](int slot) {
     if (wave >= 4) return;
     const int row = 16 * wave + kl;
-    const unsigned ro = row * 128, sw = (row >> 1) & 7;
+    const unsigned ro = row * 128, sw = AP_SWZ(row);
     const char* sd = smem + AP_RING + slot * AP_SLOT + 8192 + ro;
     const char* so = smem + AP_RING + slot * AP_SLOT + 16384 + ro;
     const bf16x8 d0 = *(const bf16x8*)(sd + (((0 + g) ^ sw) << 4)), d1 = *(const bf16x8*)(sd + (((4 + g) ^ sw) << 4));
@@ -1286,7 +1291,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16p(AttnBwdArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int row = 16 * t + kl;
-          const unsigned ro = row * 128, sw = (row >> 1) & 7;
+          const unsigned ro = row * 128, sw = AP_SWZ(row);
           const bf16x8 q0 = *(const bf16x8*)(smem + (qb_ - lds0) + ro + (((0 + g) ^ sw) << 4));
           const bf16x8 q1 = *(const bf16x8*)(smem + (qb_ - lds0) + ro + (((4 + g) ^ sw) << 4));
           const bf16x8 d0 = *(const bf16x8*)(smem + (db_ - lds0) + ro + (((0 + g) ^ sw) << 4));
@@ -1329,8 +1334,8 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16p(AttnBwdArgs a) {
         for (int dt = 0; dt < 4; ++dt) {
           const int cb = 32 * dt + 8 * pp;
           const int r0 = tr_row, r1 = tr_row + 16;
-          const unsigned o0 = r0 * 128 + ((((cb >> 4) ^ ((r0 >> 1) & 7)) << 4) | (cb & 8));
-          const unsigned o1 = r1 * 128 + ((((cb >> 4) ^ ((r1 >> 1) & 7)) << 4) | (cb & 8));
+          const unsigned o0 = r0 * 128 + ((((cb >> 4) ^ AP_SWZ(r0)) << 4) | (cb & 8));
+          const unsigned o1 = r1 * 128 + ((((cb >> 4) ^ AP_SWZ(r1)) << 4) | (cb & 8));
           const bf16x8 dot = tr_pair_b(db_ + o0, (int)(o1 - o0));
           const bf16x8 qt = tr_pair_b(qb_ + o0, (int)(o1 - o0));
           dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pb, dv[dt], 0, 0, 0);
