@@ -87,3 +87,55 @@ def test_attention_dropout_probabilities_the_quantisation_cannot_serve(dev):
         ops.attention_fwd(qkv, B, S, nh, lse=lse, drop=(0.999, 1, 0))
     m = torch.stack([ops.attn_dropout_mask(256, (0.001, 7, 0), h, device=dev) for h in range(16)]).float()
     assert 0.99 < float(m.mean()) < 0.9999          # ~ 255 / 256 kept: the dropout is on
+
+
+def test_persistent_attention_backward_on_twenty_random_geometries(dev):
+    """Random (batch, heads, padded length, per-sequence lengths, dropout on / off, mask density): workgroups with one pair
+    and with dozens, sequences of 1 .. 256 rows side by side, every iteration count from 1 to 4."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(2025)
+    for case in range(20):
+        B = int(torch.randint(1, 70, (1,), generator=g))
+        nh = int(torch.randint(1, 13, (1,), generator=g))
+        S = int(torch.randint(1, 257, (1,), generator=g))
+        p = 0.15 if case % 2 else 0.0
+        compact = case % 3 == 0
+        H = nh * 64
+        drop = (p, 1000 + case, case) if p > 0 else ops.NO_DROP
+        words = torch.zeros(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev) if p > 0 else None
+        lse = torch.zeros(B, nh, S, device=dev)
+        if compact:
+            lens = torch.randint(1, S + 1, (B,), generator=g)
+            keep = torch.arange(S)[None, :] < lens[:, None]
+            seq = ops.SeqLayout(keep.to(dev))
+            rows, kw = seq.rows, dict(seq=seq)
+        else:
+            mask = (torch.rand(B, S, generator=g) > float(torch.rand(1, generator=g)) * 0.6).float()
+            mask[:, 0] = 1.0
+            rows, kw = B * S, dict(mask=mask.to(dev))
+        qkv = (torch.randn(rows, 3 * H, generator=g) * 0.8).to(dev, BF16)
+        dctx = torch.randn(rows, H, generator=g).to(dev, BF16)
+        ctx = ops.attention_fwd(qkv, B, S, nh, lse=lse, drop=drop, keep_bits=words, **kw)
+        a = _run(ops, 16, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, keep_bits=words, **kw))
+        b = _run(ops, 17, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, keep_bits=words, **kw))
+        try:
+            _same(a, b)
+        except AssertionError as e:
+            raise AssertionError("case %d: B=%d nh=%d S=%d p=%.2f compact=%s: %s" % (case, B, nh, S, p, compact, e))
+
+
+def test_persistent_attention_backward_stands_down_for_more_batches_than_its_metadata_table(dev):
+    """B > 1 024 sequences (the per-batch metadata the kernel keeps in LDS): the dispatcher takes the one-pair-per-workgroup
+    kernel; same answer either way."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    B, S, nh = 1030, 9, 1
+    qkv = (torch.randn(B * S, 3 * 64, generator=g) * 0.8).to(dev, BF16)
+    dctx = torch.randn(B * S, 64, generator=g).to(dev, BF16)
+    lse = torch.zeros(B, nh, S, device=dev)
+    ctx = ops.attention_fwd(qkv, B, S, nh, lse=lse)
+    a = _run(ops, 16, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh))
+    b = _run(ops, 17, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh))
+    assert torch.equal(a, b)          # the same kernel ran
