@@ -139,3 +139,51 @@ def test_persistent_attention_backward_stands_down_for_more_batches_than_its_met
     a = _run(ops, 16, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh))
     b = _run(ops, 17, lambda: ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh))
     assert torch.equal(a, b)          # the same kernel ran
+
+
+@pytest.mark.parametrize("M,H", [(4099, 768), (9, 256), (130, 512), (8201, 1024), (1, 768)])
+@pytest.mark.parametrize("xdt", [torch.float16, torch.bfloat16])
+def test_full_width_layernorm_forward_and_backward_match_fp32(dev, M, H, xdt):
+    """layernorm_rows_full / layernorm_bwd_rows_full (H = 768, 512, 1 024, 256: every lane owns 8 C8 + 4 C4 columns, rows walked
+    over a fixed grid with the next row prefetched, reductions on the vector ALU): forward with both outputs and the row
+    statistics, backward with the dropout-masked second copy, against fp32 torch on the same rounded inputs; M covers one
+    row, a ragged tail and several trips of the grid-stride loop."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(M + H)
+    x = (torch.randn(M, H, generator=g) * 2.0 + 0.3).to(xdt)
+    dy = torch.randn(M, H, generator=g).to(BF16)
+    gamma = 1 + 0.1 * torch.randn(H, generator=g)
+    beta = 0.1 * torch.randn(H, generator=g)
+    xf = x.float().requires_grad_(True)
+    gf, bf = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    want = torch.nn.functional.layer_norm(xf, (H,), gf, bf, 1e-12)
+    want.backward(dy.float())
+    mean, rstd = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+    if xdt == torch.float16:
+        yh = torch.empty(M, H, dtype=torch.float16, device=dev)
+        y = ops.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-12, mean=mean, rstd=rstd, out_h=yh)
+        assert float((yh.float().cpu() - want.detach()).abs().max()) <= 2.0 ** -9 * (1 + float(want.abs().max()))
+        assert torch.equal(yh.float().to(BF16), y) or float((yh.float() - y.float()).abs().max()) <= 2.0 ** -7 * (1 + float(want.abs().max()))
+    else:
+        y = ops.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-12, mean=mean, rstd=rstd)
+    assert float((y.float().cpu() - want.detach()).abs().max()) <= 2.0 ** -7 * (1 + float(want.abs().max()))
+    u = x.float().mean(-1)
+    var = (x.float() - u[:, None]).pow(2).mean(-1)
+    assert float((mean.cpu() - u).abs().max()) < 1e-4
+    assert float((rstd.cpu() - 1 / torch.sqrt(var + 1e-12)).abs().max()) < 1e-3
+    drop = (0.1, 77, 5)
+    keep = ops.dropout_mask(M * H, drop, device=dev).view(M, H).cpu().float()
+    dgam, dbet = torch.full((H,), 3.0, device=dev), torch.full((H,), 3.0, device=dev)
+    dxd = torch.empty(M, H, dtype=BF16, device=dev)
+    dx = ops.layernorm_bwd(x.to(dev), dy.to(dev), gamma.to(dev), 1e-12, dgam, dbet, dx_dropped=dxd, drop=drop)
+    torch.cuda.synchronize()
+    scale = 1 + float(xf.grad.abs().max())
+    assert float((dx.float().cpu() - xf.grad).abs().max()) <= 2.0 ** -7 * scale
+    # the masked copy: exactly dx (before its bf16 rounding) * keep / (1 - p), so within one bf16 rounding of dx * keep / 0.9
+    assert float((dxd.float().cpu() - xf.grad * keep / 0.9).abs().max()) <= 2.0 ** -7 * scale / 0.9
+    assert bool(((dxd.float().cpu() == 0) | (keep > 0)).all())
+    assert float((dgam.cpu() - gf.grad).abs().max()) <= 1e-3 * (1 + float(gf.grad.abs().max())) * max(1.0, M / 1000)
+    assert float((dbet.cpu() - bf.grad).abs().max()) <= 1e-3 * (1 + float(bf.grad.abs().max())) * max(1.0, M / 1000)
+    ops.layernorm_bwd(x.to(dev), dy.to(dev), gamma.to(dev), 1e-12, dgam, dbet, accumulate=True)
+    assert float((dgam.cpu() - 2 * gf.grad).abs().max()) <= 2e-3 * (1 + float(gf.grad.abs().max())) * max(1.0, M / 1000)

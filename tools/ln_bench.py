@@ -1,4 +1,9 @@
-"""LayerNorm forward / backward at the bench shape: us per call and effective TB/s (HIP events)."""
+"""LayerNorm forward / backward kernels alone, on the training step's shapes (run on the GPU box):
+    python tools/ln_bench.py [M] [H] [sets]
+M rows (default 50 820: the real rows of BASELINE configs[2]'s batch), fp16 pre-LayerNorm sums, bf16 gradients, dropout-masked
+second copy of dx as in the step.  `sets` operand sets are rotated (default 6 = 1.9 GB: nothing is served from the 256 MB
+infinity cache, as in the step where 40 other kernels run between two LayerNorms); sets = 1 is the warm-cache figure.
+Prints microseconds per launch and the rate on the algorithmic bytes (forward 6 B, backward 8 B per element)."""
 import os
 import sys
 
@@ -7,37 +12,59 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visitron_amd import ops  # noqa: E402
 
-dev = "cuda:0"
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 58368
-H = 768
-x = torch.randn(M, H, device=dev).to(torch.bfloat16)
-dy = torch.randn(M, H, device=dev).to(torch.bfloat16)
-g, b = torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev)
-y = torch.empty_like(x)
-dx = torch.empty_like(x)
-dg, db = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
-ws = torch.empty(ops.LN_BWD_WS_ROWS * 2 * H, device=dev)
 
-
-def timeit(fn, n=30):
+def timed(fn, n):
     for _ in range(3):
-        fn()
+        fn(0)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(n):
+        fn(i)
+    b.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    return a.elapsed_time(b) * 1e3 / n
 
 
-t = timeit(lambda: ops.layernorm(x, g, b, 1e-12, out=y))
-print("layernorm fwd  M=%d: %6.1f us  %.2f TB/s" % (M, t, 4.0 * M * H / t / 1e6))
-t = timeit(lambda: ops.layernorm_bwd(x, dy, g, 1e-12, dg, db, dx=dx, ws=ws))
-print("layernorm bwd  M=%d: %6.1f us  %.2f TB/s" % (M, t, 6.0 * M * H / t / 1e6))
-# the training step's form: fp16 pre-LayerNorm sums in, dx written twice (plain + dropout-masked for the dense branch)
-xh = x.to(torch.float16)
-dxd = torch.empty_like(dx)
-t = timeit(lambda: ops.layernorm_bwd(xh, dy, g, 1e-12, dg, db, dx=dx, ws=ws, dx_dropped=dxd, drop=(0.1, 4242, ops.site_out(1))))
-print("layernorm bwd  M=%d, fp16 x, dx + dropped dx: %6.1f us  %.2f TB/s" % (M, t, 8.0 * M * H / t / 1e6))
+def main():
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 50820
+    H = int(sys.argv[2]) if len(sys.argv) > 2 else 768
+    sets = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    gamma = (1.0 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(H, generator=g)).to(dev)
+    xs = [(torch.randn(M, H, generator=g) * 2.0).to(dev, torch.float16) for _ in range(sets)]
+    dys = [torch.randn(M, H, generator=g).to(dev, torch.bfloat16) for _ in range(sets)]
+    ys = [torch.empty(M, H, dtype=torch.bfloat16, device=dev) for _ in range(sets)]
+    yhs = [torch.empty(M, H, dtype=torch.float16, device=dev) for _ in range(sets)]
+    dxs = [torch.empty(M, H, dtype=torch.bfloat16, device=dev) for _ in range(sets)]
+    dx2s = [torch.empty(M, H, dtype=torch.bfloat16, device=dev) for _ in range(sets)]
+    dgam, dbet = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    ws = torch.empty(ops.LN_BWD_WS_ROWS * 2 * H, dtype=torch.float32, device=dev)
+    n = 20 * sets
+
+    def fwd2(i):
+        k = i % sets
+        ops.layernorm(xs[k], gamma, beta, 1e-12, out=ys[k], out_h=yhs[k])
+
+    def fwd1(i):
+        k = i % sets
+        ops.layernorm(xs[k], gamma, beta, 1e-12, out=ys[k])
+
+    def bwd(i):
+        k = i % sets
+        ops.layernorm_bwd(xs[k], dys[k], gamma, 1e-12, dgam, dbet, dx=dxs[k], ws=ws, dx_dropped=dx2s[k], drop=(0.1, 1234, 7))
+
+    def bwd1(i):
+        k = i % sets
+        ops.layernorm_bwd(xs[k], dys[k], gamma, 1e-12, dgam, dbet, dx=dxs[k], ws=ws)
+
+    for name, fn, bytes_per in (("layernorm fwd, bf16 + fp16 out", fwd2, 6), ("layernorm fwd, bf16 out", fwd1, 4),
+                                ("layernorm bwd + reduce, dx + masked dx", bwd, 8), ("layernorm bwd + reduce, dx only", bwd1, 6)):
+        us = timed(fn, n)
+        print("%-42s M=%d H=%d sets=%d  %7.1f us  %5.2f TB/s" % (name, M, H, sets, us, bytes_per * M * H / us / 1e6))
+
+
+if __name__ == "__main__":
+    main()

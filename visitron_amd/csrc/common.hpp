@@ -176,6 +176,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// The same sum on the vector ALU alone (no LDS-crossbar shuffles, whose six dependent round trips per reduction were the
+// latency chain of the LayerNorm kernels): four DPP adds inside a 16-lane row (xor 1, xor 2, mirror within 8, mirror within
+// 16), then v_permlane16_swap / v_permlane32_swap pair the rows and the halves.  Every lane ends with the total; the order
+// of the additions differs from wave_sum's butterfly (last-bit differences).
+__device__ __forceinline__ float wave_sum_valu(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));
+  const auto p16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(p16[0]) + __uint_as_float(p16[1]);
+  const auto p32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(p32[0]) + __uint_as_float(p32[1]);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -123,6 +123,115 @@ __global__ __launch_bounds__(256) void layernorm_rows(LnArgs a) {
   }
 }
 
+// The same forward for H == 512 * C8 + 256 * C4 exactly and no row remap, laid out like layernorm_bwd_rows_full below: every
+// lane owns 8 * C8 + 4 * C4 columns (H = 768: 12 columns on all 64 lanes instead of 8 + 8 with half the wave idle in the second
+// chunk), a wave walks rows R at a time over a fixed grid with the next R rows' loads issued before the current rows'
+// arithmetic, and the two reductions per row run on the vector ALU (wave_sum_valu).
+template <int C8, int C4, int R, bool XF16>
+__global__ __launch_bounds__(256) void layernorm_rows_full(LnArgs a) {
+  constexpr int E = 8 * C8 + 4 * C4, H = 512 * C8 + 256 * C4, W = E / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col4 = 512 * C8 + lane * 4;
+  float gam[E], bet[E];
+#pragma unroll
+  for (int c = 0; c < C8; ++c) {
+    const int col = (lane + 64 * c) * 8;
+    const f32x4 g0 = *(const f32x4*)(a.gamma + col), g1 = *(const f32x4*)(a.gamma + col + 4);
+    const f32x4 b0 = *(const f32x4*)(a.beta + col), b1 = *(const f32x4*)(a.beta + col + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { gam[8 * c + i] = g0[i]; gam[8 * c + 4 + i] = g1[i]; bet[8 * c + i] = b0[i]; bet[8 * c + 4 + i] = b1[i]; }
+  }
+  if (C4) {
+    const f32x4 g0 = *(const f32x4*)(a.gamma + col4), b0 = *(const f32x4*)(a.beta + col4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { gam[8 * C8 + i] = g0[i]; bet[8 * C8 + i] = b0[i]; }
+  }
+  const float invH = 1.0f / (float)H;
+  const long ngroups = ((long)a.M + R - 1) / R, stride = (long)gridDim.x * 4;
+  uint32_t xw[R][W];
+  auto load_rows = [&](long g) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      long row = g * R + r;
+      row = row < a.M ? row : (long)a.M - 1;   // the tail repeats the last row (its stores are skipped)
+      const bf16_t* px = a.x + row * a.ldx;
+#pragma unroll
+      for (int c = 0; c < C8; ++c) {
+        const u32x4 vx = *(const u32x4*)(px + (lane + 64 * c) * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xw[r][4 * c + i] = vx[i];
+      }
+      if (C4) {
+        const u32x2 vx = *(const u32x2*)(px + col4);
+        xw[r][4 * C8] = vx[0]; xw[r][4 * C8 + 1] = vx[1];
+      }
+    }
+  };
+  long g = (long)blockIdx.x * 4 + wave;
+  if (g < ngroups) load_rows(g);
+  for (; g < ngroups; g += stride) {
+    float xv[R][E];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        xv[r][2 * k] = XF16 ? f16lo(xw[r][k]) : bf16lo(xw[r][k]);
+        xv[r][2 * k + 1] = XF16 ? f16hi(xw[r][k]) : bf16hi(xw[r][k]);
+      }
+    if (g + stride < ngroups) load_rows(g + stride);
+    float u[R], rs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s += xv[r][e];
+      u[r] = s;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[r] = wave_sum_valu(u[r]) * invH;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { const float d = xv[r][e] - u[r]; ss += d * d; }
+      rs[r] = ss;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) rs[r] = 1.0f / sqrtf(wave_sum_valu(rs[r]) * invH + a.eps);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long row = g * R + r;
+      if (row < a.M) {
+        if (lane == 0) {
+          if (a.mean) a.mean[row] = u[r];
+          if (a.rstd) a.rstd[row] = rs[r];
+        }
+        float o[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = (xv[r][e] - u[r]) * rs[r] * gam[e] + bet[e];
+        bf16_t* yp = a.y + row * a.ldy;
+        uint16_t* hp = a.yh ? a.yh + row * a.ldyh : nullptr;
+#pragma unroll
+        for (int c = 0; c < C8; ++c) {
+          const int col = (lane + 64 * c) * 8;
+          u32x4 o4, h4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o4[i] = pack_bf16x2(o[8 * c + 2 * i], o[8 * c + 2 * i + 1]);
+            h4[i] = pack_f16x2(o[8 * c + 2 * i], o[8 * c + 2 * i + 1]);
+          }
+          *(u32x4*)(yp + col) = o4;
+          if (hp) *(u32x4*)(hp + col) = h4;
+        }
+        if (C4) {
+          *(u32x2*)(yp + col4) = (u32x2){pack_bf16x2(o[8 * C8], o[8 * C8 + 1]), pack_bf16x2(o[8 * C8 + 2], o[8 * C8 + 3])};
+          if (hp) *(u32x2*)(hp + col4) = (u32x2){pack_f16x2(o[8 * C8], o[8 * C8 + 1]), pack_f16x2(o[8 * C8 + 2], o[8 * C8 + 3])};
+        }
+      }
+    }
+  }
+}
+
 int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
                           float* mean, float* rstd, int M, int H, float eps, int grp_rows, int grp_stride,
                           hipStream_t stream, int x_f16 = 0, void* y_f16 = nullptr, long ldyh = 0) {
@@ -134,6 +243,30 @@ int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const floa
   a.x = (const bf16_t*)x; a.ldx = ldx; a.y = (bf16_t*)y; a.ldy = ldy; a.gamma = gamma; a.beta = beta;
   a.yh = (uint16_t*)y_f16; a.ldyh = ldyh;
   a.mean = mean; a.rstd = rstd; a.M = M; a.H = H; a.grp_rows = grp_rows; a.grp_stride = grp_stride; a.eps = eps;
+  // VT_LN_FWD_ROWS: rows a wave holds at once (1 or 2; 0 = the chunked kernel above).  Measured at M = 50 820, H = 768, two
+  // outputs, cold operands (tools/ln_bench.py): chunked 49.0 us, 1 row 44.2, 2 rows 44.7; 1 024 / 2 048 / 4 096 workgroups
+  // within 2 us of each other.
+  static const int rows_per_wave = [] { const char* e = getenv("VT_LN_FWD_ROWS"); return e ? atoi(e) : 1; }();
+  if (rows_per_wave > 0 && grp_rows == 0 && (H == 768 || H == 512 || H == 1024 || H == 256)) {
+    const int R = rows_per_wave >= 2 ? 2 : 1;
+    long nb = (((long)M + R - 1) / R + 3) / 4;
+    static const int max_blocks = [] { const char* e = getenv("VT_LN_FWD_BLOCKS"); return e ? atoi(e) : 1024; }();
+    if (nb > max_blocks) nb = max_blocks;
+#define VT_LNF_LAUNCH(C8, C4, RR)                                                                                          \
+    do {                                                                                                                   \
+      if (x_f16) hipLaunchKernelGGL((layernorm_rows_full<C8, C4, RR, true>), dim3((unsigned)nb), dim3(256), 0, stream, a);  \
+      else hipLaunchKernelGGL((layernorm_rows_full<C8, C4, RR, false>), dim3((unsigned)nb), dim3(256), 0, stream, a);      \
+    } while (0)
+#define VT_LNF_SHAPE(RR)                                                                                                   \
+    do {                                                                                                                   \
+      if (H == 768) VT_LNF_LAUNCH(1, 1, RR); else if (H == 512) VT_LNF_LAUNCH(1, 0, RR);                                   \
+      else if (H == 1024) VT_LNF_LAUNCH(2, 0, RR); else VT_LNF_LAUNCH(0, 1, RR);                                           \
+    } while (0)
+    if (R == 2) VT_LNF_SHAPE(2); else VT_LNF_SHAPE(1);
+#undef VT_LNF_SHAPE
+#undef VT_LNF_LAUNCH
+    return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+  }
   const dim3 grid((M + 15) / 16), block(256);   // 4 waves x 4 rows per workgroup
   const int ch = (H + 511) / 512;
 #define VT_LN_LAUNCH(CH_)                                                                     \
@@ -436,6 +569,166 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows(LnBwdArgs a) {
   }
 }
 
+// The same backward for H == 512 * C8 + 256 * C4 exactly (768 = 512 + 256, 512, 1024, 256), built for the memory system
+// instead of around it:
+//  * every lane owns E = 8 * C8 + 4 * C4 columns of a row -- chunk c < C8: columns (lane + 64 c) * 8 .. + 8 (16-byte
+//    accesses), then 4 columns at 512 * C8 + lane * 4 (8-byte accesses): at H = 768 all 64 lanes carry 12 columns (the
+//    chunked form leaves half the wave idle in its second chunk and pays the full vector-issue time for it);
+//  * a wave works on R consecutive rows at once and loads the NEXT R rows (raw words) before it starts on the current ones:
+//    with one row per wave and four dependent reductions between its loads and the next row's, the kernel kept ~ 30 KB per CU
+//    in flight where 8 TB/s needs ~ 64 KB;
+//  * the four reductions per row run on the vector ALU (wave_sum_valu) instead of 24 LDS-crossbar shuffles.
+// Same arithmetic per element as layernorm_bwd_rows; the in-lane summation order differs (last-bit differences in dx).
+template <int C8, int C4, int R, bool XF16>
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_full(LnBwdArgs a) {
+  constexpr int E = 8 * C8 + 4 * C4, H = 512 * C8 + 256 * C4, W = E / 2;
+  __shared__ float red[4][2][H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col4 = 512 * C8 + lane * 4;
+  float gam[E], dg[E], db[E];
+#pragma unroll
+  for (int c = 0; c < C8; ++c) {
+    const int col = (lane + 64 * c) * 8;
+    const f32x4 g0 = *(const f32x4*)(a.gamma + col), g1 = *(const f32x4*)(a.gamma + col + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { gam[8 * c + i] = g0[i]; gam[8 * c + 4 + i] = g1[i]; }
+  }
+  if (C4) {
+    const f32x4 g0 = *(const f32x4*)(a.gamma + col4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gam[8 * C8 + i] = g0[i];
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+  const float invH = 1.0f / (float)H;
+  const long ngroups = ((long)a.M + R - 1) / R, stride = (long)gridDim.x * 4;
+  uint32_t xw[R][W], dw[R][W];
+  auto load_rows = [&](long g) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      long row = g * R + r;
+      row = row < a.M ? row : (long)a.M - 1;   // the tail repeats the last row: no contribution, no store (below)
+      const bf16_t* px = a.x + row * a.ldx;
+      const bf16_t* pd = a.dy + row * a.ldy;
+#pragma unroll
+      for (int c = 0; c < C8; ++c) {
+        const int col = (lane + 64 * c) * 8;
+        const u32x4 vx = *(const u32x4*)(px + col), vd = *(const u32x4*)(pd + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xw[r][4 * c + i] = vx[i]; dw[r][4 * c + i] = vd[i]; }
+      }
+      if (C4) {
+        const u32x2 vx = *(const u32x2*)(px + col4), vd = *(const u32x2*)(pd + col4);
+        xw[r][4 * C8] = vx[0]; xw[r][4 * C8 + 1] = vx[1]; dw[r][4 * C8] = vd[0]; dw[r][4 * C8 + 1] = vd[1];
+      }
+    }
+  };
+  long g = (long)blockIdx.x * 4 + wave;
+  if (g < ngroups) load_rows(g);
+  for (; g < ngroups; g += stride) {
+    float xv[R][E], gv[R][E];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool valid = g * R + r < a.M;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        xv[r][2 * k] = XF16 ? f16lo(xw[r][k]) : bf16lo(xw[r][k]);
+        xv[r][2 * k + 1] = XF16 ? f16hi(xw[r][k]) : bf16hi(xw[r][k]);
+        gv[r][2 * k] = valid ? bf16lo(dw[r][k]) : 0.f;
+        gv[r][2 * k + 1] = valid ? bf16hi(dw[r][k]) : 0.f;
+      }
+    }
+    if (g + stride < ngroups) load_rows(g + stride);
+    float u[R], rs[R], m1[R], m2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s += xv[r][e];
+      u[r] = s;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[r] = wave_sum_valu(u[r]) * invH;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { const float d = xv[r][e] - u[r]; ss += d * d; }
+      rs[r] = ss;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) rs[r] = 1.0f / sqrtf(wave_sum_valu(rs[r]) * invH + a.eps);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float xh = (xv[r][e] - u[r]) * rs[r];
+        const float dyv = gv[r][e];
+        dg[e] += dyv * xh;
+        db[e] += dyv;
+        const float gg = dyv * gam[e];
+        xv[r][e] = xh;
+        gv[r][e] = gg;
+        s1 += gg;
+        s2 += gg * xh;
+      }
+      m1[r] = s1; m2[r] = s2;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { m1[r] = wave_sum_valu(m1[r]) * invH; m2[r] = wave_sum_valu(m2[r]) * invH; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long row = g * R + r;
+      if (row < a.M) {
+        bf16_t* po = a.dx + row * a.lddx;
+        bf16_t* po2 = a.dx2 ? a.dx2 + row * a.lddx2 : nullptr;
+        const uint32_t erow = (uint32_t)row * (uint32_t)H;
+#pragma unroll
+        for (int c = 0; c < C8; ++c) {
+          const int col = (lane + 64 * c) * 8;
+          float o[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = rs[r] * (gv[r][8 * c + i] - m1[r] - xv[r][8 * c + i] * m2[r]);
+          u32x4 w;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
+          *(u32x4*)(po + col) = w;
+          if (po2) {
+            vt_drop_run<8>(a.drop, erow + (uint32_t)col, o);   // thresh 0: everything kept, scale 1
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
+            *(u32x4*)(po2 + col) = w;
+          }
+        }
+        if (C4) {
+          float o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = rs[r] * (gv[r][8 * C8 + i] - m1[r] - xv[r][8 * C8 + i] * m2[r]);
+          *(u32x2*)(po + col4) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+          if (po2) {
+            vt_drop_run<4>(a.drop, erow + (uint32_t)col4, o);
+            *(u32x2*)(po2 + col4) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+          }
+        }
+      }
+    }
+  }
+  // block combine: 4 waves -> one partial row
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int col = e < 8 * C8 ? (lane + 64 * (e >> 3)) * 8 + (e & 7) : col4 + (e - 8 * C8);
+    red[wave][0][col] = dg[e];
+    red[wave][1][col] = db[e];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * H; idx += 256) {
+    const int which = idx >= H ? 1 : 0, col = idx - which * H;
+    const float v = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+    a.partial[((long)blockIdx.x * 2 + which) * H + col] = v;
+  }
+}
+
 // out[j] (+)= sum_b partial[b][j], j < n  (n = 2H: dgamma | dbeta; n % 4 == 0).  A block owns 16 columns (4 lanes x
 // 16 bytes); its 64 row groups each sum every 64th partial row with independent 16-byte loads (1024 partial rows = 16
 // loads per thread, all in flight), then combine through LDS.  (The first form -- 32 columns x 8 row groups, 128
@@ -490,7 +783,28 @@ int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy,
   if (dx2 && ((lddx2 % 8) || ((uintptr_t)dx2 & 15))) return VT_ERR_BAD_ALIGN;
   int nblocks = (M + 3) / 4;
   if (nblocks > LN_BWD_MAX_BLOCKS) nblocks = LN_BWD_MAX_BLOCKS;
-  if (H <= 512) {
+  // VT_LN_BWD_ROWS: rows a wave holds at once (1, 2 or 4; 0 = the chunked kernel).  Measured at M = 50 820, H = 768 with the
+  // masked second copy, cold operands, reduce kernel included (tools/ln_bench.py): chunked 74.9 us, 1 row 66.6 (122 registers,
+  // four waves per SIMD), 2 rows 70.3 (182), 4 rows 78.3 (302); in the pretrain step 65.3 -> 51.5 us per launch.
+  static const int rows_per_wave = [] { const char* e = getenv("VT_LN_BWD_ROWS"); return e ? atoi(e) : 1; }();
+  if (rows_per_wave > 0 && (H == 768 || H == 512 || H == 1024 || H == 256) && (((uintptr_t)gamma) & 15) == 0) {
+    const int R = rows_per_wave >= 4 ? 4 : rows_per_wave >= 2 ? 2 : 1;
+    nblocks = (int)((((long)M + R - 1) / R + 3) / 4);
+    if (nblocks > LN_BWD_MAX_BLOCKS) nblocks = LN_BWD_MAX_BLOCKS;
+#define VT_LNB_LAUNCH(C8, C4, RR)                                                                                        \
+    do {                                                                                                                 \
+      if (x_f16) hipLaunchKernelGGL((layernorm_bwd_rows_full<C8, C4, RR, true>), dim3(nblocks), dim3(256), 0, stream, a);  \
+      else hipLaunchKernelGGL((layernorm_bwd_rows_full<C8, C4, RR, false>), dim3(nblocks), dim3(256), 0, stream, a);      \
+    } while (0)
+#define VT_LNB_SHAPE(RR)                                                                                                 \
+    do {                                                                                                                 \
+      if (H == 768) VT_LNB_LAUNCH(1, 1, RR); else if (H == 512) VT_LNB_LAUNCH(1, 0, RR);                                 \
+      else if (H == 1024) VT_LNB_LAUNCH(2, 0, RR); else VT_LNB_LAUNCH(0, 1, RR);                                         \
+    } while (0)
+    if (R == 4) VT_LNB_SHAPE(4); else if (R == 2) VT_LNB_SHAPE(2); else VT_LNB_SHAPE(1);
+#undef VT_LNB_SHAPE
+#undef VT_LNB_LAUNCH
+  } else if (H <= 512) {
     if (x_f16) hipLaunchKernelGGL((layernorm_bwd_rows<1, true>), dim3(nblocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((layernorm_bwd_rows<1, false>), dim3(nblocks), dim3(256), 0, stream, a);
   } else {
