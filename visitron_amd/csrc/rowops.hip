@@ -244,9 +244,9 @@ int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const floa
   a.yh = (uint16_t*)y_f16; a.ldyh = ldyh;
   a.mean = mean; a.rstd = rstd; a.M = M; a.H = H; a.grp_rows = grp_rows; a.grp_stride = grp_stride; a.eps = eps;
   // VT_LN_FWD_ROWS: rows a wave holds at once (1 or 2; 0 = the chunked kernel above).  Measured at M = 50 820, H = 768, two
-  // outputs, cold operands (tools/ln_bench.py): chunked 49.0 us, 1 row 44.2, 2 rows 44.7; 1 024 / 2 048 / 4 096 workgroups
-  // within 2 us of each other.
-  static const int rows_per_wave = [] { const char* e = getenv("VT_LN_FWD_ROWS"); return e ? atoi(e) : 1; }();
+  // outputs: cold operands (tools/ln_bench.py) chunked 49.0 us, 1 row 44.2, 2 rows 44.7 (1 024 / 2 048 / 4 096 workgroups
+  // within 2 us of each other); inside the pretrain step on one box (tools/experiments/ln_fwd_ab.sh) 41.8-42.1 / 39.4 / 38.1.
+  static const int rows_per_wave = [] { const char* e = getenv("VT_LN_FWD_ROWS"); return e ? atoi(e) : 2; }();
   if (rows_per_wave > 0 && grp_rows == 0 && (H == 768 || H == 512 || H == 1024 || H == 256)) {
     const int R = rows_per_wave >= 2 ? 2 : 1;
     long nb = (((long)M + R - 1) / R + 3) / 4;
