@@ -187,3 +187,42 @@ def test_full_width_layernorm_forward_and_backward_match_fp32(dev, M, H, xdt):
     assert float((dbet.cpu() - bf.grad).abs().max()) <= 1e-3 * (1 + float(bf.grad.abs().max())) * max(1.0, M / 1000)
     ops.layernorm_bwd(x.to(dev), dy.to(dev), gamma.to(dev), 1e-12, dgam, dbet, accumulate=True)
     assert float((dgam.cpu() - 2 * gf.grad).abs().max()) <= 2e-3 * (1 + float(gf.grad.abs().max())) * max(1.0, M / 1000)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_adamw_under_the_backward_gives_the_same_weights_bit_for_bit(dev, monkeypatch, compact):
+    """VT_OVERLAP_ADAMW=1 (one rank): the fused AdamW of a parameter range runs on a side stream as soon as that range's
+    gradients are final (heads before the encoder backward, encoder layers in chunks of three under the earlier layers'
+    backward, embeddings / region projection last).  Same kernels on the same numbers in another order of launches: after
+    three steps every parameter, both Adam moments and the bf16 mirror are identical to the plain step's, and so are the
+    returned losses."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import deterministic_state_dict, make_batch
+    from visitron_amd.training import PretrainEngine
+
+    cfg = mini_config()
+    cfg.num_hidden_layers = 5          # chunks of 3 + 2
+    b = make_batch(cfg, 6, text_len=24, region_len=10, seed=4)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    runs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VT_OVERLAP_ADAMW", flag)
+        m = PreTrainOscar(cfg)
+        m.load_state_dict(deterministic_state_dict(m, seed=3, weight_std=0.05))
+        m.tie_weights()
+        m = m.to(dev).train()
+        eng = PretrainEngine(m, lr=2e-3, weight_decay=0.05, schedule="constant", warmup_steps=0)
+        assert eng.overlap_adamw == (flag == "1")
+        if compact:
+            eng.compact_min_rows = 1          # the real-rows-only step of large batches, on this small one
+        losses = [[float(x) for x in eng.train_step(bd)[:4]] for _ in range(3)]
+        torch.cuda.synchronize()
+        f = eng.flat
+        runs.append((losses, f.p.clone(), f.m.clone(), f.v.clone(), f.mirror.clone(), eng.step_count, eng.sched_step))
+    a, c = runs
+    assert a[0] == c[0], (a[0], c[0])
+    for i in (1, 2, 3, 4):
+        assert torch.equal(a[i], c[i]), i
+    assert a[5:] == c[5:] == (3, 3)
+    assert not torch.equal(a[1], torch.zeros_like(a[1])) and float(a[3].abs().max()) > 0   # the steps did update

@@ -246,6 +246,9 @@ class PretrainEngine(object):
         # persistent kernel (its workgroups queue behind the wgrad's and still do a full share each); with a second
         # process on the same GPU it lost a lot, and beside RCCL's kernels it could not be measured here.
         self.overlap_wgrad = os.environ.get("VT_OVERLAP_WGRAD", "0") != "0"
+        # one rank: AdamW per parameter range on a side stream under the backward (_train_step_adamw_under_backward)
+        self.overlap_adamw = os.environ.get("VT_OVERLAP_ADAMW", "0") != "0"
+        self._adam_stream = None
         # the training step on the real rows only (no padding rows; vt_encoder_*_seq_bf16): same losses and gradients
         # as the padded run (tests/test_gpu_train.py); VT_COMPACT_ROWS=0 or the attribute turns it off
         self.compact_rows = os.environ.get("VT_COMPACT_ROWS", "1") != "0"
@@ -954,6 +957,40 @@ class PretrainEngine(object):
         self._adam_ranges(self._adam_begin(), [(0, self.flat.total)], grad_scale, grads)
         self._adam_end()
 
+    def _train_step_adamw_under_backward(self, batch, scale, layers_per_chunk):
+        """One rank: the fused AdamW of a parameter range runs on a side stream as soon as that range's gradients are final
+        -- the heads' before the encoder backward starts, a chunk of encoder layers' while the earlier layers' backward
+        runs (pretrain.py:191-193 has no gradient clipping between backward and step: a range's update needs nothing but
+        its own gradients).  The update is HBM-bound (30 bytes per parameter) and finds its CUs beside the kernels that do
+        not fill the chip (the grouped weight-gradient launch runs 216 of 256 workgroups; attention, LayerNorm and the
+        heads are not persistent).  A layer's weights are not read again once its backward is enqueued (dgrad reads the
+        transposed copies, rebuilt at the start of the next step); embeddings, region projection and everything else follow
+        on the main stream, which then waits for the side stream."""
+        from .distributed import complement_ranges
+
+        if self._adam_stream is None:
+            self._adam_stream = torch.cuda.Stream(device=self.flat.p.device)
+        side = self._adam_stream
+        consts = self._adam_begin()
+        try:
+            def launch(rng):
+                ev = torch.cuda.Event()
+                ev.record()
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self._adam_ranges(consts, rng, 1.0)
+
+            comm = dict(layers_per_chunk=layers_per_chunk, launch=launch, done=[])
+            out = self.forward_backward(batch, grad_scale=scale, comm=comm)
+        except BaseException:
+            self.step_count -= 1   # no update was completed on behalf of this step's counter
+            torch.cuda.current_stream().wait_stream(side)
+            raise
+        self._adam_ranges(consts, complement_ranges(self.flat.total, comm["done"]), 1.0)
+        torch.cuda.current_stream().wait_stream(side)
+        self._adam_end()
+        return out
+
     # ------------------------------------------------------------------------------ optimizer state (resume)
     def state_dict(self):
         """What a resumed run needs beside the model's own state_dict: AdamW's moments per parameter NAME (layout-
@@ -1009,6 +1046,8 @@ class PretrainEngine(object):
         encoder layers' gradients runs under the backward of the earlier layers."""
         ws = self.world
         scale = (1.0 / ws) if (ws > 1 and self.loss_scale_by_world) else 1.0
+        if ws == 1 and _force_comm is None and overlap and self.overlap_adamw:
+            return self._train_step_adamw_under_backward(batch, scale, layers_per_chunk)
         if (ws == 1 and _force_comm is None) or not overlap:
             out = self.forward_backward(batch, grad_scale=scale)
             self.all_reduce_grads()
