@@ -168,8 +168,13 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
   const int rows = g.M - m0 < 32 * MTN ? g.M - m0 : 32 * MTN;
   const int ldc_b = (int)g.ldc * 2, ldc2_b = (int)g.ldc2 * 2, ldr_b = (int)g.ldr * 2;
   // rows past M fall outside num_records: their loads read zeros, their stores are dropped
+#ifdef V7_LAB_DROP_STORES   // experiment builds only: zero-length descriptors, every C / C2 store is issued and dropped
+  const u32x4 rs_c = v7_rsrc((const bf16_t*)g.C + (long)m0 * g.ldc, 0u);
+  const u32x4 rs_c2 = v7_rsrc(g.C2 ? g.C2 + (long)m0 * g.ldc2 : nullptr, 0u);
+#else
   const u32x4 rs_c = v7_rsrc((const bf16_t*)g.C + (long)m0 * g.ldc, (unsigned)rows * ldc_b);
   const u32x4 rs_c2 = v7_rsrc(g.C2 ? g.C2 + (long)m0 * g.ldc2 : nullptr, g.C2 ? (unsigned)rows * ldc2_b : 0u);
+#endif
   const u32x4 rs_r = v7_rsrc(g.R ? g.R + (long)m0 * g.ldr : nullptr, g.R ? (unsigned)rows * ldr_b : 0u);
   const int gq = lane >> 4, j = lane & 15;
   const int vo_c = j * ldc_b + gq * 32, vo_c2 = j * ldc2_b + gq * 32, vo_r = j * ldr_b + gq * 32;
