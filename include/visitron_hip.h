@@ -85,6 +85,17 @@ int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, co
                       int K, int act, int out_f32, int grp_rows, int grp_stride, float drop_p, uint64_t drop_seed,
                       uint32_t drop_site, vt_stream_t stream);
 
+/* The dense + dropout + residual of BertSelfOutput / BertOutput (oscar/modeling_bert.py:94,120) with the residual given as
+ * a LayerNorm that was never written out (ABI 10; vt_layer_acts::ln_residual_mode):
+ *   C = dropout(A W^T + bias) + ((Rv - mean[row]) * rstd[row] * gamma[col] + beta[col])
+ * Rv: FP16 [M,N] (row stride ldr) = the previous sub-layer's pre-LayerNorm sum; mean / rstd fp32 [M] = what the LayerNorm
+ * kernel wrote for those rows (vt_layernorm_h_bf16); gamma / beta fp32 [N] = that LayerNorm's weight and bias (16-byte
+ * aligned).  C: bf16, or FP16 with out_f16 != 0.  N a multiple of 16; no row remap, no activation. */
+int vt_linear_lnres_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* Rv,
+                         int64_t ldr, const float* mean, const float* rstd, const float* gamma, const float* beta, void* C,
+                         int64_t ldc, int M, int N, int K, int out_f16, float drop_p, uint64_t drop_seed,
+                         uint32_t drop_site, vt_stream_t stream);
+
 /* ---- dropout (nn.Dropout of BertEmbeddings / BertSelfOutput / BertOutput / the image embedding,
  * tasks/viewpoint_select/encoder.py:284, and the attention-probability dropout oscar/modeling_bert.py:62).
  * Every kernel that applies dropout takes (p, step seed, site): keep(element) is a counter-based hash of
@@ -509,6 +520,13 @@ typedef struct vt_layer_acts {
    * add reads this copy).  Transient: every layer may point at the same two buffers (ln2_h of layer l is read by layer
    * l + 1's first residual add and overwritten after it).  The last layer's ln2_h is the encoder output at fp16 precision. */
   void* ln1_h; void* ln2_h;
+  /* ABI 10.  1: attn_pre / out_pre hold FP16 as above, but the LayerNorm outputs' fp16 copies are never written (ln1_h /
+   * ln2_h are ignored): each residual add reconstructs LayerNorm(v) from the fp16 sum v, the row statistics the LayerNorm
+   * kernel wrote (ln1_mean / ln1_rstd / ln2_mean / ln2_rstd: REQUIRED in this mode) and that LayerNorm's weight and bias
+   * -- (v - mean) * rstd * gamma + beta in the GEMM epilogue (BertSelfOutput / BertOutput.forward, oscar/modeling_bert.py:
+   * 94,120: LayerNorm(dense(h) + input), `input` being the previous LayerNorm's output).  The LayerNorm kernel then writes 4
+   * bytes per element instead of 6 and the residual branch is not rounded to fp16 a second time.  0: as described above. */
+  int32_t ln_residual_mode; int32_t reserved0;
 } vt_layer_acts;
 
 /* x: [B*S, H] bf16 embedding output (layer-0 input).  head_scale: [L, nh] fp32 or null.

@@ -37,10 +37,12 @@ def test_struct_layouts_match_the_header():
     from visitron_amd import _lib
 
     assert ctypes.sizeof(_lib.LayerWeights) == 12 * ctypes.sizeof(ctypes.c_void_p)
-    assert ctypes.sizeof(_lib.LayerActs) == len(_lib.LayerActs._fields_) * ctypes.sizeof(ctypes.c_void_p)
+    # vt_layer_acts: 16 pointers, then two int32 (ln_residual_mode, reserved0: ABI 10)
+    assert ctypes.sizeof(_lib.LayerActs) == 16 * ctypes.sizeof(ctypes.c_void_p) + 8
+    assert _lib.LayerActs.ln_residual_mode.offset == 16 * ctypes.sizeof(ctypes.c_void_p)
     src = open(os.path.join(ROOT, "include", "visitron_hip.h")).read()
     for struct, cls in (("vt_layer_weights", _lib.LayerWeights), ("vt_layer_acts", _lib.LayerActs)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-        fields = re.findall(r"\*\s*([a-z0-9_]+)\s*;", body)
+        fields = re.findall(r"(?:\*|int32_t)\s*([a-z0-9_]+)\s*;", body)
         assert fields == [f[0] for f in cls._fields_], struct

@@ -226,3 +226,91 @@ def test_adamw_under_the_backward_gives_the_same_weights_bit_for_bit(dev, monkey
         assert torch.equal(a[i], c[i]), i
     assert a[5:] == c[5:] == (3, 3)
     assert not torch.equal(a[1], torch.zeros_like(a[1])) and float(a[3].abs().max()) > 0   # the steps did update
+
+
+@pytest.mark.parametrize("variant", [-1, 1, 14, 11, 15, 16, 18, 19, 20, 21, 22, 23, 9])
+@pytest.mark.parametrize("M,N,K,p", [(1000, 768, 768, 0.1), (777, 768, 3072, 0.0), (300, 208, 128, 0.1), (4100, 768, 768, 0.0)])
+def test_linear_with_a_residual_that_is_a_layernorm_never_written(dev, M, N, K, p, variant):
+    """C = dropout(A W^T + b) + LayerNorm(v), LayerNorm(v) rebuilt in the epilogue from the fp16 sum v and the saved row
+    statistics (vt_linear_lnres_bf16, GemmArgs::r_mean): every kernel variant's epilogue (persistent and one-tile fast
+    epilogues with the vectors parked in LDS, the register epilogues, the scalar tail at N = 208; variant 9's bf16-only
+    grouped epilogue is substituted by the library), fp16 and bf16 outputs, against fp32 on the same operands."""
+    from visitron_amd import ops
+
+    F16 = torch.float16
+    g = torch.Generator().manual_seed(M + N + K + variant + 7)
+    a = (torch.randn(M, K, generator=g)).to(BF16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(BF16)
+    b = torch.randn(N, generator=g) * 0.1
+    v = (torch.randn(M, N, generator=g) * 2.0 + 0.5).to(F16)
+    gamma, beta = 1 + 0.2 * torch.randn(N, generator=g), 0.3 * torch.randn(N, generator=g)
+    mean = v.float().mean(-1)
+    rstd = 1.0 / torch.sqrt((v.float() - mean[:, None]).pow(2).mean(-1) + 1e-12)
+    ln = (v.float() - mean[:, None]) * rstd[:, None] * gamma + beta
+    drop = (p, 91, 3) if p > 0 else ops.NO_DROP
+    dense = a.float() @ w.float().t() + b
+    if p > 0:
+        keep = ops.dropout_mask(M * N, drop, device=dev).view(M, N).cpu().float()
+        dense = dense * keep / (1.0 - p)
+    want = dense + ln
+    ops.set_gemm_variant(variant)
+    try:
+        kw = dict(residual=v.to(dev), residual_ln=(mean.to(dev), rstd.to(dev), gamma.to(dev), beta.to(dev)), drop=drop)
+        out = torch.empty((M, N), dtype=F16, device=dev)
+        ops.linear(a.to(dev), w.to(dev), b.to(dev), out=out, **kw)
+        out2 = ops.linear(a.to(dev), w.to(dev), b.to(dev), **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_variant(-1)
+    scale = float(want.abs().max())
+    assert float((out.float().cpu() - want).abs().max()) <= scale * 2.0 ** -10
+    assert out2.dtype == BF16 and float((out2.float().cpu() - want).abs().max()) <= scale * 2.0 ** -7
+
+
+def test_layernorm_residual_mode_is_the_default_training_layer_and_matches_the_two_output_layer(dev, monkeypatch):
+    """ops.LN_RESIDUAL (vt_layer_acts::ln_residual_mode = 1): the engine's layers write no fp16 copy of a LayerNorm output.
+    Against the round-4 layer (VT_LN_RESIDUAL=0: two-output LayerNorm, fp16 copy read by the residual add) on the same
+    weights and batch: the hidden states agree to the fp16 rounding the old layer applies to the residual branch, the losses
+    to 2e-3, and the C loop equals the op-by-op sequence (ops.profiling) bit for bit in the new mode."""
+    import importlib
+
+    from visitron_amd import ops
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import deterministic_state_dict, make_batch
+    from visitron_amd.training import PretrainEngine
+
+    assert ops.LN_RESIDUAL and ops.F16_STREAM
+    cfg = mini_config()
+    cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob = 0.1, 0.1
+    b = make_batch(cfg, 5, text_len=20, region_len=9, seed=11)
+    bd = {k: v.to(dev) for k, v in b.items()}
+
+    def run(ln_residual, unrolled=False):
+        monkeypatch.setattr(ops, "LN_RESIDUAL", ln_residual)
+        m = PreTrainOscar(cfg)
+        m.load_state_dict(deterministic_state_dict(m, seed=5, weight_std=0.05))
+        m.tie_weights()
+        m = m.to(dev).train()
+        eng = PretrainEngine(m)
+        if unrolled:
+            monkeypatch.setattr(ops, "profiling", lambda: True)
+        out = eng.forward_backward(bd)
+        if unrolled:
+            monkeypatch.undo()
+            monkeypatch.setattr(ops, "LN_RESIDUAL", ln_residual)
+        torch.cuda.synchronize()
+        bufs = eng._buffers(5, 29)
+        assert bufs.ln_residual == ln_residual and (bufs.ln_h is None) == ln_residual
+        last = bufs.layers[-1]["out"].float().clone()
+        return [float(x) for x in out[:4]], last, eng.flat.g.clone()
+
+    l_new, h_new, g_new = run(True)
+    l_old, h_old, g_old = run(False)
+    l_unr, h_unr, g_unr = run(True, unrolled=True)
+    assert torch.equal(h_new, h_unr) and l_new == l_unr and torch.equal(g_new, g_unr)
+    assert float((h_new - h_old).abs().max()) <= 2.0 ** -6 * (1 + float(h_old.abs().max()))
+    for x, y in zip(l_new, l_old):
+        assert abs(x - y) <= 2e-3 * (1 + abs(y)), (l_new, l_old)
+    rel = float((g_new - g_old).norm() / g_old.norm())
+    assert rel <= 2e-2, rel

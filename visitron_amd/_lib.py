@@ -26,7 +26,8 @@ class LayerWeights(ctypes.Structure):  # vt_layer_weights
 class LayerActs(ctypes.Structure):  # vt_layer_acts
     _fields_ = [(n, c_void_p) for n in (
         "qkv", "ctx", "attn_pre", "attn_out", "mid_pre", "mid", "out_pre", "out", "lse",
-        "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd", "keep_bits", "ln1_h", "ln2_h")]
+        "ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd", "keep_bits", "ln1_h", "ln2_h")] + [
+        ("ln_residual_mode", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 class LayerWeightsLn(ctypes.Structure):  # vt_layer_weights_ln
@@ -77,6 +78,8 @@ SIGNATURES = {
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_linear_bf16_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int] + DROP + [c_void_p]),
+    "vt_linear_lnres_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int] + DROP + [c_void_p]),
     "vt_apply_dropout_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int] + DROP + [c_void_p]),
     "vt_debug_dropout_mask": (c_int, [c_void_p, c_int64] + DROP + [c_int, c_void_p]),
     "vt_attention_probs_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -5,7 +5,8 @@
 
 int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const void* R, long ldr,
                      void* C, long ldc, int M, int N, int K, int act, int out_f32, int grp_rows, int grp_stride,
-                     hipStream_t stream, void* C2 = nullptr, long ldc2 = 0, const DropCfg* drop = nullptr);
+                     hipStream_t stream, void* C2 = nullptr, long ldc2 = 0, const DropCfg* drop = nullptr,
+                     const VtLnResidual* rln = nullptr);
 int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, long ld_d, const void* ctx, long ld_ctx,
                               const float* mask, int mask_additive, const float* lse, float* delta_ws, void* dqkv,
                               long ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size, hipStream_t stream,
@@ -133,7 +134,7 @@ const char* vt_error_string(int code) {
   }
 }
 
-int vt_abi_version(void) { return 9; }
+int vt_abi_version(void) { return 10; }
 
 int vt_batch_row_counts(const int64_t* labels, const int64_t* token_labels, const float* mask, const int32_t* err_flag, int B,
                         int S, int64_t* counts, int32_t* tile_counts, vt_stream_t stream) {
@@ -194,6 +195,17 @@ int vt_linear_bf16_ex(const void* A, int64_t lda, const void* W, int64_t ldw, co
   const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
   return vt_gemm_dispatch(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, act, out_f32, grp_rows, grp_stride,
                           (hipStream_t)stream, C2, ldc2, &d);
+}
+
+int vt_linear_lnres_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* Rv,
+                         int64_t ldr, const float* mean, const float* rstd, const float* gamma, const float* beta, void* C,
+                         int64_t ldc, int M, int N, int K, int out_f16, float drop_p, uint64_t drop_seed,
+                         uint32_t drop_site, vt_stream_t stream) {
+  if (!Rv) return VT_ERR_NULL;
+  const DropCfg d = vt_make_drop(drop_p, drop_seed, drop_site);
+  const VtLnResidual rln = {mean, rstd, gamma, beta};
+  return vt_gemm_dispatch(A, lda, W, ldw, bias, Rv, ldr, C, ldc, M, N, K, VT_ACT_NONE, (out_f16 ? 2 : 0) | 4, 0, 0,
+                          (hipStream_t)stream, nullptr, 0, &d, &rln);
 }
 
 int vt_apply_dropout_bf16(void* x, int64_t ld, int64_t rows, int cols, float drop_p, uint64_t drop_seed, uint32_t drop_site,
@@ -695,7 +707,9 @@ static int encoder_forward_impl(const vt_layer_weights* layers, const vt_layer_a
   if (rows && (!seq_start || !seq_len || mask || rows < 0 || rows > (long)B * S)) return VT_ERR_BAD_SHAPE;
   const int M = rows ? (int)rows : B * S;
   const void* cur = x;
-  const void* cur_h = nullptr;   // fp16 copy of `cur` (the previous layer's output), when that layer kept one
+  const void* cur_h = nullptr;   // fp16 copy of `cur` (the previous layer's output), when that layer kept one -- or, with
+                                 // cur_ln set, the previous layer's fp16 pre-LayerNorm sum whose LayerNorm `cur` is
+  VtLnResidual cur_ln = {nullptr, nullptr, nullptr, nullptr};
   for (int l = 0; l < num_layers; ++l) {
     const vt_layer_weights& w = layers[l];
     const vt_layer_acts& a = acts[l];
@@ -716,25 +730,33 @@ static int encoder_forward_impl(const vt_layer_weights* layers, const vt_layer_a
     // output twice -- bf16 for the next GEMM's A operand (and the backward), fp16 for the next sub-layer's residual add --
     // so the stream itself is rounded to 11 significant bits instead of 8 (north_star's 5e-2 on the hidden states of the
     // path training runs: 5.8e-2 with the bf16 stream on the stress weights).
-    const bool h16 = a.ln1_h && a.ln2_h;
+    // ln_residual_mode 1: the fp16 copies are never written -- a residual add reads the previous sub-layer's fp16 SUM and
+    // reconstructs its LayerNorm from the row statistics that LayerNorm's kernel wrote (GemmArgs::r_mean); the LayerNorm
+    // kernel then has one output instead of two.
+    const bool rln = a.ln_residual_mode == 1;
+    if (rln && (!a.ln1_mean || !a.ln1_rstd || !a.ln2_mean || !a.ln2_rstd)) return VT_ERR_NULL;
+    if (a.ln_residual_mode != 0 && !rln) return VT_ERR_UNSUPPORTED;
+    const bool h16 = rln || (a.ln1_h && a.ln2_h);
     const void* res = cur_h ? cur_h : cur;
     rc = vt_gemm_dispatch(a.ctx, H, w.w_ao, H, w.b_ao, res, H, a.attn_pre, H, M, H, H, VT_ACT_NONE,
-                          (h16 ? 2 : 0) | (cur_h ? 4 : 0), 0, 0, stream, nullptr, 0, &d_so);
+                          (h16 ? 2 : 0) | (cur_h ? 4 : 0), 0, 0, stream, nullptr, 0, &d_so, cur_ln.mean ? &cur_ln : nullptr);
     if (rc) return rc;
     rc = vt_layernorm_dispatch(a.attn_pre, H, a.attn_out, H, w.ln1_g, w.ln1_b, a.ln1_mean, a.ln1_rstd, M, H, ln_eps, 0, 0, stream,
-                               h16 ? 1 : 0, h16 ? a.ln1_h : nullptr, H);
+                               h16 ? 1 : 0, (h16 && !rln) ? a.ln1_h : nullptr, H);
     if (rc) return rc;
     rc = vt_gemm_dispatch(a.attn_out, H, w.w_in, H, w.b_in, nullptr, 0, a.mid, I, M, I, H, VT_ACT_GELU, 0, 0, 0, stream,
                           a.mid_pre, I);
     if (rc) return rc;
-    rc = vt_gemm_dispatch(a.mid, I, w.w_out, I, w.b_out, h16 ? a.ln1_h : a.attn_out, H, a.out_pre, H, M, H, I, VT_ACT_NONE,
-                          h16 ? 6 : 0, 0, 0, stream, nullptr, 0, &d_out);
+    const VtLnResidual ln1 = {a.ln1_mean, a.ln1_rstd, w.ln1_g, w.ln1_b};
+    rc = vt_gemm_dispatch(a.mid, I, w.w_out, I, w.b_out, rln ? a.attn_pre : (h16 ? a.ln1_h : a.attn_out), H, a.out_pre, H, M, H, I,
+                          VT_ACT_NONE, h16 ? 6 : 0, 0, 0, stream, nullptr, 0, &d_out, rln ? &ln1 : nullptr);
     if (rc) return rc;
     rc = vt_layernorm_dispatch(a.out_pre, H, a.out, H, w.ln2_g, w.ln2_b, a.ln2_mean, a.ln2_rstd, M, H, ln_eps, 0, 0, stream,
-                               h16 ? 1 : 0, h16 ? a.ln2_h : nullptr, H);
+                               h16 ? 1 : 0, (h16 && !rln) ? a.ln2_h : nullptr, H);
     if (rc) return rc;
     cur = a.out;
-    cur_h = h16 ? a.ln2_h : nullptr;
+    cur_h = rln ? a.out_pre : (h16 ? a.ln2_h : nullptr);
+    cur_ln = rln ? VtLnResidual{a.ln2_mean, a.ln2_rstd, w.ln2_g, w.ln2_b} : VtLnResidual{nullptr, nullptr, nullptr, nullptr};
   }
   return VT_OK;
 }
@@ -827,7 +849,7 @@ static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_
     void* g_pre_dn = p_hidden > 0.f ? ws->g_pre_d : ws->g_pre;
     void* g_pre2_dn = p_hidden > 0.f ? ws->g_pre2_d : ws->g_pre2;
     // LayerNorm 2 backward: dL/d(out_pre)
-    const int h16 = (a.ln1_h && a.ln2_h) ? 1 : 0;   // the forward kept the pre-LayerNorm sums as fp16 (see encoder_forward_impl)
+    const int h16 = ((a.ln1_h && a.ln2_h) || a.ln_residual_mode == 1) ? 1 : 0;   // the forward kept the pre-LayerNorm sums as fp16 (see encoder_forward_impl)
     rc = vt_layernorm_bwd_dispatch(a.out_pre, H, g, H, w.ln2_g, ws->g_pre, H, d.d_ln2_g, d.d_ln2_b, ws->ln_partial, M, H,
                                    ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre_d : nullptr, H, &d_out, h16);
     if (rc) return rc;

@@ -171,6 +171,10 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// A residual operand that is a LayerNorm never written out (GemmArgs::r_mean, vt_layer_acts::ln_residual_mode): row
+// statistics [M] and the LayerNorm's weight / bias [N], all fp32
+struct VtLnResidual { const float* mean; const float* rstd; const float* gamma; const float* beta; };
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -836,7 +836,8 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
 // Host entry used by the C ABI (capi.hip).  Returns a VT_* code; never synchronises.
 int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const float* bias, const void* R, long ldr,
                      void* C, long ldc, int M, int N, int K, int act, int out_mode, int grp_rows, int grp_stride,
-                     hipStream_t stream, void* C2 = nullptr, long ldc2 = 0, const DropCfg* drop = nullptr) {
+                     hipStream_t stream, void* C2 = nullptr, long ldc2 = 0, const DropCfg* drop = nullptr,
+                     const VtLnResidual* rln = nullptr) {
   // out_mode: bit 0 fp32 output; bit 1 C written as fp16 (saturating) instead of bf16; bit 2 the residual R holds fp16
   // (GemmArgs::c_f16 / r_f16: the training layer's higher-precision residual stream)
   const int out_f32 = out_mode & 1, c_f16 = (out_mode >> 1) & 1, r_f16 = (out_mode >> 2) & 1;
@@ -857,6 +858,12 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   g.ln_mode = 0; g.ln_np = 0; g.ln_rows = 0; g.ln_inv_n = 0.f; g.ln_eps = 0.f; g.ln_stats = nullptr; g.colv = nullptr;
   g.Rs = nullptr; g.Cs = nullptr; g.stats_out = nullptr; g.ldrs = 0; g.ldcs = 0; g.ksplit = 0; g.c_plane = 0;
   g.r_f16 = r_f16; g.c_f16 = c_f16;
+  if (rln) {   // residual = LayerNorm(R) from saved row statistics (GemmArgs::r_mean)
+    if (!rln->mean || !rln->rstd || !rln->gamma || !rln->beta) return VT_ERR_NULL;
+    if (!r_f16 || act != ACT_NONE || grp_rows || (N % 16)) return VT_ERR_UNSUPPORTED;
+    if ((((uintptr_t)rln->gamma | (uintptr_t)rln->beta) & 15) || (((uintptr_t)rln->mean | (uintptr_t)rln->rstd) & 3)) return VT_ERR_BAD_ALIGN;
+    g.r_mean = rln->mean; g.r_rstd = rln->rstd; g.r_gamma = rln->gamma; g.r_beta = rln->beta;
+  }
   if (g.drop.thresh && (long)M * N >= (1L << 32)) return VT_ERR_UNSUPPORTED;
   g.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   g.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
@@ -895,6 +902,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
         g2.tiles_m = (g2.M + GEMM_BM - 1) / GEMM_BM;
         g2.A = g.A + M1 * lda;
         if (g.R) g2.R = g.R + M1 * ldr;
+        if (g.r_mean) { g2.r_mean = g.r_mean + M1; g2.r_rstd = g.r_rstd + M1; }
         g2.C = out_f32 ? (void*)((float*)C + M1 * ldc) : (void*)((bf16_t*)C + M1 * ldc);
         if (g.C2) g2.C2 = g.C2 + M1 * ldc2;
         g2.drop.seed = g.drop.seed + (uint32_t)((M1 * N) >> 1);

@@ -48,6 +48,15 @@ struct GemmArgs {
   // c_f16: C is written as fp16 (saturating): the pre-LayerNorm sum dense(h) + bias + residual.  Same bytes as bf16, three
   // more significant bits where the stream is rounded twice per sub-layer.
   int r_f16, c_f16;
+  // ---- the residual as a LayerNorm that was never written out (training layer, vt_layer_acts::ln_residual_mode) ------
+  // r_mean != null: R holds the fp16 PRE-LayerNorm sum v of the previous sub-layer (r_f16 is set) and the value added is
+  // LayerNorm(v) = (v - r_mean[row]) * r_rstd[row] * r_gamma[col] + r_beta[col], the statistics being the ones the
+  // LayerNorm kernel wrote beside its bf16 output -- so that kernel writes ONE output instead of two (the fp16 copy of its
+  // output was 2 of its 6 bytes per element) and the stream is not rounded to fp16 a second time.
+  const float* r_mean = nullptr;
+  const float* r_rstd = nullptr;
+  const float* r_gamma = nullptr;
+  const float* r_beta = nullptr;
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_MUL = 3 };  // MUL: out = acc * R (R = saved gelu'(pre-activation))
@@ -131,6 +140,15 @@ __device__ __forceinline__ void epi_row_values(const GemmArgs& g, const f32x4 (&
       rv[8 + 2 * i] = g.r_f16 ? f16lo(r1[i]) : bf16lo(r1[i]);
       rv[8 + 2 * i + 1] = g.r_f16 ? f16hi(r1[i]) : bf16hi(r1[i]);
     }
+    if (g.r_mean) {   // the residual is LayerNorm(v), v = the fp16 row just read (GemmArgs::r_mean)
+      const float mu = g.r_mean[orow], rs = g.r_rstd[orow];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 gm = *(const f32x4*)(g.r_gamma + nb + 4 * i), bt = *(const f32x4*)(g.r_beta + nb + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv[4 * i + e] = (rv[4 * i + e] - mu) * rs * gm[e] + bt[e];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = (ACT == ACT_MUL) ? v[i] * rv[i] : v[i] + rv[i];
   }
@@ -182,7 +200,8 @@ __device__ __forceinline__ void epi_row_direct(const GemmArgs& g, const f32x4 (&
         if (g.drop.thresh) x = vt_keep(g.drop, (uint32_t)m * (uint32_t)g.N + (uint32_t)(nb + i)) ? x * g.drop.scale : 0.f;
         if (g.R) {
           const uint16_t rb = g.R[orow * g.ldr + nb + i];
-          const float rr = g.r_f16 ? f16bits_to_f32(rb) : bf16_to_f32(rb);
+          float rr = g.r_f16 ? f16bits_to_f32(rb) : bf16_to_f32(rb);
+          if (g.r_mean) rr = (rr - g.r_mean[orow]) * g.r_rstd[orow] * g.r_gamma[nb + i] + g.r_beta[nb + i];
           x = (ACT == ACT_MUL) ? x * rr : x + rr;
         }
         if (OUT_F32) ((float*)g.C)[orow * g.ldc + nb + i] = x;

@@ -28,6 +28,7 @@ static int launch_v8(const GemmArgs& g, hipStream_t stream, int mtn) {
   const bool fast = !OUT_F32 && (g.N & 63) == 0 && g.grp_rows == 0;
   if (ACT == ACT_MUL && !g.R) return VT_ERR_NULL;
   if (!fast || OUT_F32 || ACT == ACT_TANH) mtn = 8;   // the shorter tiles exist for the encoder's own (bf16, fast-epilogue) shapes
+  else if (g.r_mean && mtn == 8) mtn = 7;             // a rebuilt LayerNorm residual: not in the 256-row instantiation (v7_epilogue_fast)
   const int th = 32 * mtn;
   g8.tiles_m = (g.M + th - 1) / th;
   const int grid = v8_grid(g8.tiles_m * g8.tiles_n);

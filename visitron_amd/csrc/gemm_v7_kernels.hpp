@@ -23,7 +23,13 @@
 // swizzle depends on the piece parity only); rows past M / N and tiles past K read as zeros through
 // num_records, so no clamping and no tail code.
 #define V7_STAGE 65536
-#define V7_LDS_BYTES (2 * V7_STAGE + 4096)   // two operand stages + 1 KiB per wave: the tile's bias values
+// two operand stages + 1 KiB per wave: the tile's bias values; + four more such slots for a residual that is a LayerNorm
+// never written out (GemmArgs::r_mean): gamma and beta of the tile's 256 columns, mean and rstd of the wave's 16 MTN rows
+#define V7_RLN_GAMMA (2 * V7_STAGE + 4096)
+#define V7_RLN_BETA (2 * V7_STAGE + 8192)
+#define V7_RLN_MEAN (2 * V7_STAGE + 12288)
+#define V7_RLN_RSTD (2 * V7_STAGE + 16384)
+#define V7_LDS_BYTES (2 * V7_STAGE + 4096 + 16384)
 #define V7_WOFF 32768
 // deferred-LayerNorm modes (GemmArgs::ln_mode): + 1 KiB per wave for the second per-column vector, + 8 KiB per wave-row
 // half for the row statistics (8 slices x 128 rows x 8 B; shared by the two column waves of a row half)
@@ -125,6 +131,22 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
       vt_drop_run<16>(g.drop, e0, v);                                                                     \
     }                                                                                                     \
     if (HAS_R) {                                                                                          \
+      /* residual = LayerNorm(R): this slab's gamma / beta (16 columns) and the row's mean / rstd come out of the wave's  \
+         LDS slots (V7_DMA_BIAS parked them), issued here -- in front of the ring's wait, which hides their round trip --   \
+         and awaited where they are used (held across slabs they cost 48 registers: the 256-row kernel spilled; issued  \
+         at the slab's top they overlapped the dropout hash's temporaries: it spilled again) */                            \
+      u32x4 lg_[4], lb_[4];                                                                               \
+      u32x2 ls_;                                                                                          \
+      if (ACT != ACT_MUL && r_ln) {                                                                       \
+        const unsigned co_ = lds0 + wave * 1024 + 4 * (128 * wn + 64 * (NH) + 16 * gq);                   \
+        const unsigned ro_ = lds0 + wave * 1024 + 4 * (16 * (MT) + j);                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+          asm volatile("ds_read_b128 %0, %1" : "=v"(lg_[i]) : "v"(co_ + V7_RLN_GAMMA + 16 * i));          \
+          asm volatile("ds_read_b128 %0, %1" : "=v"(lb_[i]) : "v"(co_ + V7_RLN_BETA + 16 * i));           \
+        }                                                                                                 \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(ls_[0]) : "v"(ro_ + V7_RLN_MEAN));                       \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(ls_[1]) : "v"(ro_ + V7_RLN_RSTD));                       \
+      }                                                                                                   \
       /* slab s = 8*NH + MT; its residual was issued 8 slabs ago (the first eight before slab 0: a 4-deep ring left \
          each slab waiting ~0.45 us on HBM latency).  Behind it in the queue: the younger residual loads and the    \
          stores issued since -> counted wait (VMEM retires in order).  With C2 stores in the stream as well (not a  \
@@ -132,12 +154,27 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
       if (has_c2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NH) == 0 ? 2 * (MTN - 1) + 2 * (MT) : 4 * MTN - 2 - 2 * (MT)) : "memory"); \
       asm volatile("" : "+v"(rq[MT][0]), "+v"(rq[MT][1]));                                                \
+      if (ACT != ACT_MUL && r_ln) {   /* the residual is LayerNorm(row of fp16 sums): (x - mean) rstd gamma + beta */ \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+        asm volatile("" : "+v"(lg_[0]), "+v"(lg_[1]), "+v"(lg_[2]), "+v"(lg_[3]));                        \
+        asm volatile("" : "+v"(lb_[0]), "+v"(lb_[1]), "+v"(lb_[2]), "+v"(lb_[3]), "+v"(ls_));             \
+        const float mu_ = __uint_as_float(ls_[0]), rs_ = __uint_as_float(ls_[1]);                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+          const u32x4 q0 = rq[MT][0], q1 = rq[MT][1];                                                     \
+          /* v[k] <-> column k of the lane's 16: gamma / beta word k = lg_[k >> 2][k & 3] */               \
+          v[2 * i] += fmaf((f16lo(q0[i]) - mu_) * rs_, __uint_as_float(lg_[i >> 1][(2 * i) & 3]), __uint_as_float(lb_[i >> 1][(2 * i) & 3])); \
+          v[2 * i + 1] += fmaf((f16hi(q0[i]) - mu_) * rs_, __uint_as_float(lg_[i >> 1][(2 * i + 1) & 3]), __uint_as_float(lb_[i >> 1][(2 * i + 1) & 3])); \
+          v[8 + 2 * i] += fmaf((f16lo(q1[i]) - mu_) * rs_, __uint_as_float(lg_[2 + (i >> 1)][(2 * i) & 3]), __uint_as_float(lb_[2 + (i >> 1)][(2 * i) & 3])); \
+          v[8 + 2 * i + 1] += fmaf((f16hi(q1[i]) - mu_) * rs_, __uint_as_float(lg_[2 + (i >> 1)][(2 * i + 1) & 3]), __uint_as_float(lb_[2 + (i >> 1)][(2 * i + 1) & 3])); \
+        }                                                                                                 \
+      } else {                                                                                            \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
         const u32x4 q0 = rq[MT][0], q1 = rq[MT][1];                                                       \
         const float r0 = r_f16 ? f16lo(q0[i]) : bf16lo(q0[i]), r1 = r_f16 ? f16hi(q0[i]) : bf16hi(q0[i]); \
         const float r2 = r_f16 ? f16lo(q1[i]) : bf16lo(q1[i]), r3 = r_f16 ? f16hi(q1[i]) : bf16hi(q1[i]); \
         if (ACT == ACT_MUL) { v[2 * i] *= r0; v[2 * i + 1] *= r1; v[8 + 2 * i] *= r2; v[8 + 2 * i + 1] *= r3; } \
         else { v[2 * i] += r0; v[2 * i + 1] += r1; v[8 + 2 * i] += r2; v[8 + 2 * i + 1] += r3; }          \
+      }                                                                                                   \
       }                                                                                                   \
       if ((NH) == 0) {   /* same rows of the other column half; issued unconditionally: the counts above rely on it \
                             (columns past N are never used, rows past M read zeros) */                              \
@@ -161,7 +198,10 @@ __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, 
     v7_buf_store16_o16(o1, rs_c, vo_c, so_row * ldc_b + ec * 2);                                          \
   }
 
-template <int ACT, bool HAS_R, int MTN>
+// RLN: the instantiation can rebuild a LayerNorm residual (GemmArgs::r_mean).  Not the persistent kernel's 256-row tile: it
+// carries the next tile's 64 fragment registers through its epilogue and the 34 transient registers of the rebuilt residual
+// spilled there (tests/test_build_isa.py) -- the host gives such a GEMM the 224-row tile instead (launch_v8).
+template <int ACT, bool HAS_R, int MTN, bool RLN = true>
 __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)[8][8], int lane, int wave, int m0, int n0, unsigned lds0) {
   const int wm = wave >> 1, wn = wave & 1;
   const unsigned bias_slot = lds0 + 2 * V7_STAGE + wave * 1024;   // this wave's copy of the tile's 256 bias values
@@ -180,6 +220,7 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
   const int vo_c = j * ldc_b + gq * 32, vo_c2 = j * ldc2_b + gq * 32, vo_r = j * ldr_b + gq * 32;
   const bool has_c2 = g.C2 != nullptr;
   const bool r_f16 = g.r_f16 != 0, c_f16 = g.c_f16 != 0;
+  const bool r_ln = RLN && HAS_R && g.r_mean != nullptr;   // residual = LayerNorm(R) (GemmArgs::r_mean); vectors parked in LDS by V7_DMA_BIAS
   u32x4 rq[8][2];   // residual ring: the next eight slabs (one column half), two 8-column halves each
   // the two 64-column halves spelled out: a rolled (or not fully unrolled) loop would index the accumulators
   // dynamically and demote them to scratch
@@ -245,6 +286,18 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
     if (LNM) {   /* the second per-column vector of the deferred-LayerNorm modes (g / gamma) */                 \
       __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(g.colv ? g.colv + n0 : nullptr), 0, g.colv ? bn_ * 4 : 0, 0x00020000); \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, LDS_PTR(smem + V7_LN_COLV + wave * 1024), 16, l16_, 0, 0, 0); \
+    }                                                                                                     \
+    if (LNM == 0 && HAS_R && V7_RLN_OK && g.r_mean) {   /* residual = LayerNorm(R): its per-column and per-row vectors (wave-uniform) */ \
+      const int r0_ = m0 + 16 * MTN * wm;                                                                 \
+      const int nr_ = g.M - r0_ < 16 * MTN ? (g.M - r0_ < 0 ? 0 : g.M - r0_) : 16 * MTN;                  \
+      __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void*)(g.r_gamma + n0), 0, bn_ * 4, 0x00020000);   \
+      __amdgpu_buffer_rsrc_t rbt_ = __builtin_amdgcn_make_buffer_rsrc((void*)(g.r_beta + n0), 0, bn_ * 4, 0x00020000);   \
+      __amdgpu_buffer_rsrc_t rm_ = __builtin_amdgcn_make_buffer_rsrc((void*)(g.r_mean + r0_), 0, nr_ * 4, 0x00020000);   \
+      __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc((void*)(g.r_rstd + r0_), 0, nr_ * 4, 0x00020000);   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg_, LDS_PTR(smem + V7_RLN_GAMMA + wave * 1024), 16, l16_, 0, 0, 0);      \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbt_, LDS_PTR(smem + V7_RLN_BETA + wave * 1024), 16, l16_, 0, 0, 0);      \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rm_, LDS_PTR(smem + V7_RLN_MEAN + wave * 1024), 16, l16_, 0, 0, 0);       \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rr_, LDS_PTR(smem + V7_RLN_RSTD + wave * 1024), 16, l16_, 0, 0, 0);       \
     }                                                                                                     \
   }
 // slice p = 2 i + (column wave) of the row statistics of this wave's row half -> the half's LDS slot (i = 0 .. 3; slices
@@ -325,6 +378,7 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
 #define V7_RING_PRE (LNM == 2)
 template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R, int MTN = 8, int LNM = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
+  constexpr bool V7_RLN_OK = true;
   constexpr int TH = 32 * MTN;   // tile height (see gemm_nt_bf16_v8): 256, or 224 / 192 to fill one round better
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -458,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
   if constexpr (LNM != 0) {                                                                               \
     v7_epilogue_ln<ACT, LNM, MTN, V7_RING_PRE>(g, acc, lane, wave, m0, n0, lds0, ln_ring);                \
   } else if (EPI_LDS) {                                                                                   \
-    v7_epilogue_fast<ACT, HAS_R, MTN>(g, acc, lane, wave, m0, n0, lds0);                                  \
+    v7_epilogue_fast<ACT, HAS_R, MTN, V7_RLN_OK>(g, acc, lane, wave, m0, n0, lds0);                       \
   } else {                                                                                                \
     _Pragma("unroll 1") for (int h = 0; h < 16; ++h) {                                                    \
       f32x4 a[4];                                                                                         \
@@ -501,6 +555,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
 // 2.66 rounds of tiles that are 7/8 the work -- the same 3 rounds, 12.5 % fewer MFMAs.  The host picks per shape.
 template <int ACT, bool OUT_F32, bool EPI_LDS, bool HAS_R, int MTN = 8, int LNM = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
+  constexpr bool V7_RLN_OK = MTN < 8;   // see v7_epilogue_fast
   constexpr int TH = 32 * MTN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;

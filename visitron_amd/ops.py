@@ -101,13 +101,19 @@ F16 = torch.float16
 # pre-LayerNorm sums are written as fp16 and every LayerNorm output also as an fp16 copy that the next residual add reads
 # (include/visitron_hip.h, vt_layer_acts::ln1_h).  VT_F16_STREAM=0: every tensor bf16, as through round 3 (A/B switch).
 F16_STREAM = os.environ.get("VT_F16_STREAM", "1") != "0"
+# With the fp16 stream, the TRAINING layer does not write the LayerNorm outputs' fp16 copies at all: a residual add reads the
+# previous sub-layer's fp16 sum and reconstructs its LayerNorm from the row statistics the LayerNorm kernel wrote
+# (vt_layer_acts::ln_residual_mode = 1; linear(..., residual_ln=...)).  VT_LN_RESIDUAL=0: the two-output LayerNorm of round 4.
+LN_RESIDUAL = F16_STREAM and os.environ.get("VT_LN_RESIDUAL", "1") != "0"
 
 
 def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False, grp_rows=0, grp_stride=0,
-           M=None, lda=None, ldc=None, pre_act_out=None, drop=NO_DROP):
+           M=None, lda=None, ldc=None, pre_act_out=None, drop=NO_DROP, residual_ln=None):
     """out = act(a @ w.T + bias) (+ residual).  a [M,K] bf16 (row stride lda), w [N,K] bf16.
     pre_act_out: optional bf16 [M,N] buffer saved for backward: gelu'(a @ w.T + bias) when act == ACT_GELU,
-    else a @ w.T + bias.  act == ACT_MUL: out = (a @ w.T) * residual."""
+    else a @ w.T + bias.  act == ACT_MUL: out = (a @ w.T) * residual.
+    residual_ln = (mean [M], rstd [M], gamma [N], beta [N]), all fp32: `residual` is an FP16 pre-LayerNorm sum v and what is
+    added is LayerNorm(v) = (v - mean) * rstd * gamma + beta (vt_linear_lnres_bf16)."""
     _require_hip(a, w, bias, residual, out, pre_act_out)
     assert a.dtype == BF16 and w.dtype == BF16
     N, K = w.shape
@@ -121,6 +127,20 @@ def linear(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_f32=False
     if ldc is None:
         ldc = out.stride(0)
     ldr = residual.stride(0) if residual is not None else 0
+    if residual_ln is not None:
+        mean, rstd, gamma, beta = residual_ln
+        _require_hip(mean, rstd, gamma, beta)
+        assert residual is not None and residual.dtype == F16 and act == ACT_NONE and not out_f32 and pre_act_out is None
+        assert grp_rows == 0 and out.dtype in (BF16, F16)
+        assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (mean, rstd, gamma, beta))
+        assert mean.numel() >= M and rstd.numel() >= M and gamma.numel() == N and beta.numel() == N
+        with _timed("gemm_nt_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N)):
+            rc = _lib.load().vt_linear_lnres_bf16(
+                _ptr(a), lda, _ptr(w), w.stride(0), _ptr(bias), _ptr(residual), ldr, _ptr(mean), _ptr(rstd), _ptr(gamma),
+                _ptr(beta), _ptr(out), ldc, M, N, K, 1 if out.dtype == F16 else 0, float(drop[0]), int(drop[1]),
+                int(drop[2]), _stream())
+        _lib.check(rc, "vt_linear_lnres_bf16")
+        return out
     # an fp16 `out` / `residual` (the training layer's higher-precision residual stream) is told to the library by bits 1 / 2
     # of its output-mode argument
     assert out.dtype == (torch.float32 if out_f32 else out.dtype) and out.dtype in (BF16, F16, torch.float32)

@@ -122,7 +122,10 @@ class _TrainBuffers(object):
         # backward reads them) and every LayerNorm output has a second, fp16 copy that the next residual add reads -- those
         # copies are transient: ONE pair of buffers serves all layers (include/visitron_hip.h, vt_layer_acts::ln1_h)
         mkpre = (lambda: torch.empty((M, H), dtype=ops.F16, device=dev)) if ops.F16_STREAM else (lambda: mk(H))
-        self.ln_h = (mkpre(), mkpre()) if ops.F16_STREAM else None
+        # ops.LN_RESIDUAL: no fp16 copies at all -- the residual adds rebuild each LayerNorm from its fp16 input and the row
+        # statistics its kernel wrote (4 x [M] fp32 per layer; vt_layer_acts::ln_residual_mode)
+        self.ln_residual = bool(ops.LN_RESIDUAL)
+        self.ln_h = (mkpre(), mkpre()) if (ops.F16_STREAM and not self.ln_residual) else None
         self.layers = []
         self.acts = (_lib.LayerActs * L)()
         for i in range(L):
@@ -130,6 +133,10 @@ class _TrainBuffers(object):
                      out_pre=mkpre(), out=mk(H), lse=torch.empty((B, nh, S), dtype=torch.float32, device=dev))
             if self.ln_h is not None:
                 d["ln1_h"], d["ln2_h"] = self.ln_h
+            if self.ln_residual:
+                for k in ("ln1_mean", "ln1_rstd", "ln2_mean", "ln2_rstd"):
+                    d[k] = torch.empty(M, dtype=torch.float32, device=dev)
+                self.acts[i].ln_residual_mode = 1
             if KEEP_BITS:   # the attention dropout's keep decisions, forward -> backward (25 MB per layer at B = 256)
                 d["keep_bits"] = torch.empty(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev)
             self.layers.append(d)
@@ -839,7 +846,7 @@ class PretrainEngine(object):
                                   hs=None):
         cfg = self.cfg
         nh, eps = cfg.num_attention_heads, cfg.layer_norm_eps
-        cur, cur_h = x0, None
+        cur, cur_h, cur_ln = x0, None, None
         n = x0.shape[0]
         for l, ((t, _), a) in enumerate(zip(self._keep, bufs.layers)):
             a = {k: (v if k in ("lse", "keep_bits") else v[:n]) for k, v in a.items()}   # the rows in use (all, or the compacted ones)
@@ -857,6 +864,18 @@ class PretrainEngine(object):
                 ops.scale_heads(raw, hs[l].contiguous(), out=a["ctx"])
             # (fp16 copies of the stream, ops.F16_STREAM: attn_pre / out_pre are fp16 tensors, the residual adds read the
             # LayerNorm outputs' fp16 copies ln1_h / ln2_h -- the library learns all of it from the dtypes)
+            if bufs.ln_residual:
+                # (ops.LN_RESIDUAL: no fp16 copies -- each residual add rebuilds the previous LayerNorm from its fp16 input
+                # and the statistics its kernel wrote; the same arithmetic as the C loop's ln_residual_mode 1)
+                ops.linear(a["ctx"], t["w_ao"], t["b_ao"], residual=cur if cur_h is None else cur_h, out=a["attn_pre"],
+                           drop=(p_h, seed, ops.site_selfout(l)), residual_ln=cur_ln)
+                ops.layernorm(a["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=a["attn_out"], mean=a["ln1_mean"], rstd=a["ln1_rstd"])
+                ops.linear(a["attn_out"], t["w_in"], t["b_in"], act=ACT_GELU, out=a["mid"], pre_act_out=a["mid_pre"])
+                ops.linear(a["mid"], t["w_out"], t["b_out"], residual=a["attn_pre"], out=a["out_pre"],
+                           drop=(p_h, seed, ops.site_out(l)), residual_ln=(a["ln1_mean"], a["ln1_rstd"], t["ln1_g"], t["ln1_b"]))
+                ops.layernorm(a["out_pre"], t["ln2_g"], t["ln2_b"], eps, out=a["out"], mean=a["ln2_mean"], rstd=a["ln2_rstd"])
+                cur, cur_h, cur_ln = a["out"], a["out_pre"], (a["ln2_mean"], a["ln2_rstd"], t["ln2_g"], t["ln2_b"])
+                continue
             ops.linear(a["ctx"], t["w_ao"], t["b_ao"], residual=cur if cur_h is None else cur_h, out=a["attn_pre"],
                        drop=(p_h, seed, ops.site_selfout(l)))
             ops.layernorm(a["attn_pre"], t["ln1_g"], t["ln1_b"], eps, out=a["attn_out"], out_h=a.get("ln1_h"))
