@@ -82,11 +82,15 @@ __device__ __forceinline__ void v7_buf_load16(u32x4& d, u32x4 rs, int voff, int 
 __device__ __forceinline__ void v7_buf_load16_o16(u32x4& d, u32x4 rs, int voff, int soff) {
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(d) : "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
+// V7_STORE_CC: cache-control suffix of the C stores (experiment builds: " nt", " sc1", ...; empty in the product)
+#ifndef V7_STORE_CC
+#define V7_STORE_CC ""
+#endif
 __device__ __forceinline__ void v7_buf_store16(u32x4 d, u32x4 rs, int voff, int soff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(d), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" V7_STORE_CC ::"v"(d), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void v7_buf_store16_o16(u32x4 d, u32x4 rs, int voff, int soff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:16" ::"v"(d), "v"(voff), "s"(rs), "s"(soff) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:16" V7_STORE_CC ::"v"(d), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 // slab = 16 rows x 64 columns of the 128x128 wave tile: accumulator row block MT, column half NH.  Spelled out 16
 // times (about 50 instructions each): one wave per SIMD has nothing to hide a taken branch or an LDS round trip
