@@ -229,7 +229,8 @@ def test_adamw_under_the_backward_gives_the_same_weights_bit_for_bit(dev, monkey
 
 
 @pytest.mark.parametrize("variant", [-1, 1, 14, 11, 15, 16, 18, 19, 20, 21, 22, 23, 9])
-@pytest.mark.parametrize("M,N,K,p", [(1000, 768, 768, 0.1), (777, 768, 3072, 0.0), (300, 208, 128, 0.1), (4100, 768, 768, 0.0)])
+@pytest.mark.parametrize("M,N,K,p", [(1000, 768, 768, 0.1), (777, 768, 3072, 0.0), (300, 208, 128, 0.1), (4100, 768, 768, 0.0),
+                                     (600, 832, 128, 0.1)])
 def test_linear_with_a_residual_that_is_a_layernorm_never_written(dev, M, N, K, p, variant):
     """C = dropout(A W^T + b) + LayerNorm(v), LayerNorm(v) rebuilt in the epilogue from the fp16 sum v and the saved row
     statistics (vt_linear_lnres_bf16, GemmArgs::r_mean): every kernel variant's epilogue (persistent and one-tile fast
