@@ -371,7 +371,9 @@ def main():
                 # between sub-layers in fp16 (+ a bf16 copy for the next GEMM) and defers every LayerNorm into the GEMM
                 # epilogues that consume it; training keeps bf16 activations and LayerNorm passes (its backward reads them) with
                 # the pre-LayerNorm sums and the residual operands as fp16 (VT_F16_STREAM=0: all bf16)
-                "residual_stream": (("fp16 copies beside the bf16 GEMM operands (seven-launch layer, LayerNorm passes)" if ops.F16_STREAM
+                "residual_stream": (((("fp16 pre-LayerNorm sums; each residual add rebuilds the previous LayerNorm from them and its saved "
+                                       "row statistics (seven-launch layer, one-output LayerNorm passes)") if ops.LN_RESIDUAL else
+                                      "fp16 copies beside the bf16 GEMM operands (seven-launch layer, LayerNorm passes)") if ops.F16_STREAM
                                      else "bf16 (seven-launch layer, LayerNorm passes)") if train else
                                     ("fp16, LayerNorms deferred into the GEMM epilogues" if trunk.encoder.serves_deferred_ln()
                                      else "bf16 (seven-launch layer, LayerNorm passes)")),
