@@ -45,7 +45,10 @@ def _recorded():
 _REC = None
 
 
-def effective_bound(name, bound):
+def effective_bound(name, bound, scalar=False):
+    """scalar: the checked quantity is a single number (a loss of a two-sequence batch): its error is one draw of the bf16
+    noise -- it moved 8e-4 -> 2.9e-3 -> 2.5e-4 between rebuilds that changed nothing but a summation order -- so the recorded
+    value says little about the next draw and the floor is half the stated bound instead of a tenth."""
     import os
 
     # VT_PARITY_RECORD=1: the round's re-measurement run -- stated bounds only, every check recorded
@@ -54,7 +57,7 @@ def effective_bound(name, bound):
     rec = None if os.environ.get("VT_PARITY_RECORD") == "1" else _recorded().get(name)
     if rec is None:
         return bound
-    return min(bound, max(2.0 * rec, 0.1 * bound))
+    return min(bound, max(2.0 * rec, (0.5 if scalar else 0.1) * bound))
 
 
 def check_close(name, got, want, bound, kind="maxabs"):
@@ -69,7 +72,7 @@ def check_close(name, got, want, bound, kind="maxabs"):
         err = float((g - w).norm() / (w.norm() + 1e-30))
     else:
         raise ValueError(kind)
-    stated, bound = float(bound), effective_bound(name, float(bound))
+    stated, bound = float(bound), effective_bound(name, float(bound), scalar=w.numel() <= 1)
     _MEASURED.append((name, kind, err, bound))
     print("PARITY %-58s %-7s measured %.3e  bound %.3e (stated %.1e: margin x%.1f)" % (
         name, kind, err, bound, stated, stated / err if err > 0 else float("inf")))

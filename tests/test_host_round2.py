@@ -55,6 +55,8 @@ def test_effective_parity_bound_rule(tmp_path, monkeypatch):
     assert helpers.effective_bound("b", 5e-2) == pytest.approx(5e-2)      # never above the stated bound
     assert helpers.effective_bound("c", 1e-3) == pytest.approx(1e-4)
     assert helpers.effective_bound("unknown", 5e-2) == 5e-2
+    assert helpers.effective_bound("a", 5e-2, scalar=True) == pytest.approx(2.5e-2)   # single numbers (losses): floor at half
+    assert helpers.effective_bound("b", 5e-2, scalar=True) == pytest.approx(5e-2)
     rec = json.load(open(os.path.join(ROOT, "tests", "golden", "parity_measured.json")))
     assert len(rec) > 200 and all(v >= 0 for v in rec.values())
     # the committed table is the one profiles/r02 was written from
