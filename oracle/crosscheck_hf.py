@@ -114,8 +114,81 @@ def run(dtype=torch.float64, seed=0):
             tsd[k] = sd["predictions.bias"]
     th.load_state_dict(tsd)
     res["mlmhead_maxabs"] = _maxdiff(mh(x), th(x))
+    res.update(run_optim(dtype, seed))
     res["transformers_version"] = __import__("transformers").__version__
     res["torch_version"] = torch.__version__
+    return res
+
+
+def run_optim(dtype=torch.float64, seed=0):
+    """AdamW and the linear schedule of oracle/optim.py against two implementations by other hands.
+
+    * ``torch.optim.AdamW(eps=0, weight_decay=0)``: at eps = 0 the pytorch-transformers rule (eps on the UN-corrected sqrt(v),
+      corrections folded into the step size) and torch's (eps on the corrected one) are the same function -- ten steps pin
+      the two moments and both bias corrections.  eps > 0 and the decay placement differ BY DESIGN (oracle/optim.py header)
+      and stay with the hand KAT (tests/test_oracle_kat.py); here their difference from torch's rule is recorded with its
+      closed form: one step from zero moments moves p by lr * g / (|g| + eps_pt) against lr * g / (|g| + eps_torch), and a
+      decayed step differs by lr * wd * (p_moved - p_before).
+    * ``transformers.get_linear_schedule_with_warmup`` / ``get_constant_schedule_with_warmup``: the published successors of
+      WarmupLinearSchedule / WarmupConstantSchedule, same lambda by definition."""
+    from .optim import AdamW, WarmupConstantSchedule, WarmupLinearSchedule
+
+    res = {}
+    gen = torch.Generator().manual_seed(seed + 17)
+    shapes = [(7, 5), (11,), (3, 4, 2)]
+    p0 = [torch.randn(s, generator=gen, dtype=dtype) for s in shapes]
+    grads = [[torch.randn(s, generator=gen, dtype=dtype) * (0.1 + 0.3 * t) for s in shapes] for t in range(10)]
+    mine = [p.clone().requires_grad_(True) for p in p0]
+    theirs = [p.clone().requires_grad_(True) for p in p0]
+    om = AdamW(mine, lr=3e-3, betas=(0.9, 0.999), eps=0.0, weight_decay=0.0)
+    ot = torch.optim.AdamW(theirs, lr=3e-3, betas=(0.9, 0.999), eps=0.0, weight_decay=0.0)
+    worst = 0.0
+    for t in range(10):
+        for a_, b_, g_ in zip(mine, theirs, grads[t]):
+            a_.grad = g_.clone()
+            b_.grad = g_.clone()
+        om.step()
+        ot.step()
+        worst = max(worst, max(_maxdiff(a_.detach(), b_.detach()) for a_, b_ in zip(mine, theirs)))
+    res["adamw_eps0_10steps_vs_torch_maxabs"] = worst
+    res["adamw_eps0_moments_vs_torch_maxabs"] = max(
+        max(_maxdiff(om.state[a_]["exp_avg"], ot.state[b_]["exp_avg"]),
+            _maxdiff(om.state[a_]["exp_avg_sq"], ot.state[b_]["exp_avg_sq"])) for a_, b_ in zip(mine, theirs))
+    # eps placement: first step from zero moments, closed form of the pytorch-transformers rule
+    eps, lr = 1e-3, 1e-2
+    q = p0[0].clone().requires_grad_(True)
+    q.grad = grads[0][0].clone()
+    AdamW([q], lr=lr, eps=eps, weight_decay=0.0).step()
+    g0 = grads[0][0]
+    b1, b2 = 0.9, 0.999
+    want = p0[0] - lr * (1 - b2) ** 0.5 / (1 - b1) * ((1 - b1) * g0) / (((1 - b2) * g0 * g0).sqrt() + eps)
+    res["adamw_eps_on_uncorrected_sqrt_closed_form_maxabs"] = _maxdiff(q.detach(), want)
+    # decay placement: after the move, on the moved parameter
+    q2 = p0[0].clone().requires_grad_(True)
+    q2.grad = grads[0][0].clone()
+    AdamW([q2], lr=lr, eps=eps, weight_decay=0.05).step()
+    res["adamw_decay_after_move_closed_form_maxabs"] = _maxdiff(q2.detach(), want * (1.0 - lr * 0.05))
+    # schedules
+    from transformers.optimization import get_constant_schedule_with_warmup, get_linear_schedule_with_warmup
+
+    def lrs(make, n=60):
+        w = torch.zeros(1, requires_grad=True)
+        opt = torch.optim.SGD([w], lr=5e-5)
+        sch = make(opt)
+        out = []
+        for _ in range(n):
+            out.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        return torch.tensor(out, dtype=torch.float64)
+
+    for name, ws, tt in (("w0", 0, 50), ("w7", 7, 50), ("w10_short", 10, 30)):
+        a_ = lrs(lambda o: WarmupLinearSchedule(o, warmup_steps=ws, t_total=tt))
+        b_ = lrs(lambda o: get_linear_schedule_with_warmup(o, num_warmup_steps=ws, num_training_steps=tt))
+        res["linear_schedule_%s_vs_hf_maxabs" % name] = _maxdiff(a_, b_)
+    a_ = lrs(lambda o: WarmupConstantSchedule(o, warmup_steps=7))
+    b_ = lrs(lambda o: get_constant_schedule_with_warmup(o, num_warmup_steps=7))
+    res["constant_schedule_w7_vs_hf_maxabs"] = _maxdiff(a_, b_)
     return res
 
 

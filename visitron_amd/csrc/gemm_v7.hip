@@ -24,11 +24,11 @@ static int launch_v8(const GemmArgs& g, hipStream_t stream, int mtn) {
   GemmArgs g8 = g;
   g8.tiles_n = (g.N + 255) / 256;
   if ((g.K & 63) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31)) return VT_ERR_UNSUPPORTED;
-  // bf16 output in whole 64-column slabs without row remap: the straight-line epilogue, specialised on the residual.  With a
-  // residual operand only for N % 128 == 0: the epilogue's first column half issues the second half's ring loads
-  // unconditionally, and a wave whose second half lies past N would never wait for them (registers still being written by
-  // loads while the next tile's K loop reuses them).
-  const bool fast = !OUT_F32 && (g.N & 63) == 0 && g.grp_rows == 0 && (!(g.R || ACT == ACT_MUL) || (g.N & 127) == 0);
+  // bf16 output in whole 64-column slabs without row remap: the straight-line epilogue, specialised on the residual.
+  // (Round 5 kept residual GEMMs with N % 128 != 0 away from it: a wave whose second column half lies past N never waited
+  // for that half's ring loads.  Round 6 drains the ring in the kernel -- V7_HALF's else branch -- and the guard is gone;
+  // tests/test_gpu_round5.py runs N = 832 / 384 / 640 with a residual and with ACT_MUL on every 256x256-tile variant.)
+  const bool fast = !OUT_F32 && (g.N & 63) == 0 && g.grp_rows == 0;
   if (ACT == ACT_MUL && !g.R) return VT_ERR_NULL;
   if (!fast || OUT_F32 || ACT == ACT_TANH) mtn = 8;   // the shorter tiles exist for the encoder's own (bf16, fast-epilogue) shapes
   else if (g.r_mean && mtn == 8) mtn = 7;             // a rebuilt LayerNorm residual: not in the 256-row instantiation (v7_epilogue_fast)
@@ -57,7 +57,7 @@ static int launch_v7(const GemmArgs& g, hipStream_t stream, int mtn) {
   g7.tiles_n = (g.N + 255) / 256;
   // operand panels are addressed with 32-bit byte offsets inside a tile's row panel
   if ((g.K & 63) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31)) return VT_ERR_UNSUPPORTED;
-  const bool fast = !OUT_F32 && (g.N & 63) == 0 && g.grp_rows == 0 && (!(g.R || ACT == ACT_MUL) || (g.N & 127) == 0);   // as in launch_v8
+  const bool fast = !OUT_F32 && (g.N & 63) == 0 && g.grp_rows == 0;   // as in launch_v8
   if (ACT == ACT_MUL && !g.R) return VT_ERR_NULL;
   if (!fast || OUT_F32 || ACT == ACT_TANH) mtn = 8;
   g7.tiles_m = (g.M + 32 * mtn - 1) / (32 * mtn);

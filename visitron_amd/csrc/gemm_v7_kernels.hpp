@@ -255,6 +255,15 @@ __device__ __forceinline__ void v7_epilogue_fast(const GemmArgs& g, f32x4 (&acc)
       if (MTN > 5) V7_SLAB(5, NH)                                                                         \
       if (MTN > 6) V7_SLAB(6, NH)                                                                         \
       if (MTN > 7) V7_SLAB(7, NH)                                                                         \
+    } else if (HAS_R && (NH) == 1) {                                                                      \
+      /* This half lies past N but half 0 issued its ring loads all the same (the counted waits rely on it): they must  \
+         land before the ring's registers mean anything else.  Unwaited, the youngest one (rq[MTN-1][1] = v[62:65] in  \
+         the 224-row kernel) was still in flight when the next tile's cursor_tile() used v62 as the scratch register of \
+         its uniform division (v_cvt / v_rcp / v_readfirstlane): a garbage quotient = a garbage tile origin = an operand \
+         descriptor based outside the allocation -> memory fault, process abort (round 5's test2.log; K = 128 puts the  \
+         division right behind the epilogue).  The pins keep the registers allocated to the ring up to the wait. */     \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+      _Pragma("unroll") for (int q = 0; q < MTN; ++q) asm volatile("" : "+v"(rq[q][0]), "+v"(rq[q][1]));  \
     }                                                                                                     \
   }
   V7_HALF(0)
@@ -571,8 +580,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   const int nwg = gridDim.x, b = blockIdx.x;
   const int xcd = b & 7;
   const int nx = (nwg - xcd + 7) >> 3;                 // workgroups on this XCD
-  const int ng = nwg < 8 ? nwg : 8;                    // XCD groups that have a workgroup
-  const int c0 = (int)((long)T * xcd / ng), c1 = (int)((long)T * (xcd + 1) / ng);
+  // The XCD's chunk of the tile order is sized by its SHARE OF THE WORKGROUPS (w0 = workgroups on the XCDs before this
+  // one), not as T / 8: with nwg = T = 195 (M = 8 208 on 128-row tiles) equal chunks of 24 / 25 tiles met 25 / 24
+  // workgroups in the other order on three XCDs, and one workgroup there walked two tiles -- the whole launch took two
+  // rounds (round 6: 79 -> 45 us at [8 208, 768] x 3 072).
+  const int wq = nwg >> 3, wr = nwg & 7;
+  const int w0 = xcd * wq + (xcd < wr ? xcd : wr);
+  const int c0 = (int)((long)T * w0 / nwg), c1 = (int)((long)T * (w0 + nx) / nwg);
   const int first = c0 + (b >> 3);
   const int band_tiles = 8 * g.tiles_n;
   const int nk = g.K >> 6;

@@ -264,7 +264,7 @@ class PretrainEngine(object):
         self._tuned_rows = set()
         # below this many (padded) token rows the layout's own launches and host sync cost more than the rows saved
         # (B=36: 3 036 against 3 352 samples/s; B=64 x 656 and B=256 x 228: +6 %)
-        self.compact_min_rows = 16384
+        self.compact_min_rows = int(os.environ.get("VT_COMPACT_MIN_ROWS", "16384"))
         self._side_stream = None
         self._fwd_serial = 0      # forwards issued: a backward must belong to the latest one (the buffers are shared)
         self._build_tables()
