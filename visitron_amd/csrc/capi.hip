@@ -83,6 +83,9 @@ void vt_gemm_set_trace(void* p);
 void vt_wgrad_set_tile(int tn);
 void vt_wgrad_v8_enable(int on);
 int vt_wgrad_v8_timeouts(unsigned* out);
+int vt_gemm_set_workspace_impl(void* base, long bytes);        // gemm_v7.hip
+int vt_gemm_shared_tile_timeouts_impl(unsigned* out);
+long vt_gemm_workspace_region_bytes_impl();
 int vt_gemm_f32_dispatch(const float* A, long lda, long sA_b, long sA_h, const float* W, long ldw, long sW_b, long sW_h,
                          int w_is_kn, const float* bias, const float* R, long ldr, float* C, long ldc, long sC_b, long sC_h,
                          int M, int N, int K, int act, float alpha, int batch, int heads, int grp_rows, int grp_stride,
@@ -134,7 +137,7 @@ const char* vt_error_string(int code) {
   }
 }
 
-int vt_abi_version(void) { return 10; }
+int vt_abi_version(void) { return 11; }
 
 int vt_batch_row_counts(const int64_t* labels, const int64_t* token_labels, const float* mask, const int32_t* err_flag, int B,
                         int S, int64_t* counts, int32_t* tile_counts, vt_stream_t stream) {
@@ -180,6 +183,12 @@ void vt_debug_set_wgrad_kernel(int mode) {
 void vt_gemm_tune(int M, int N, int K, int kind, int variant) { vt_gemm_tune_set(M, N, K, kind, variant); }
 void vt_debug_set_attn_bwd_waves(int waves) { vt_attn_bwd_set_waves(waves); }
 void vt_gemm_reserve_cus(int k) { vt_gemm_set_reserved_cus(k); }
+int vt_gemm_set_workspace(void* base, int64_t bytes) { return vt_gemm_set_workspace_impl(base, (long)bytes); }
+int64_t vt_gemm_workspace_region_bytes(void) { return (int64_t)vt_gemm_workspace_region_bytes_impl(); }
+int vt_gemm_shared_tile_timeouts(unsigned* host_count) {
+  if (!host_count) return VT_ERR_NULL;
+  return vt_gemm_shared_tile_timeouts_impl(host_count);
+}
 
 int vt_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* R,
                    int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int act, int out_f32, int grp_rows,

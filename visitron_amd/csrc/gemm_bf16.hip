@@ -694,7 +694,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_bf16_v6(GemmArgs g) {
 //          (gemm_v7.hip); 18 .. 21 = the persistent kernel on 224- / 192- / 160- / 128-row tiles (fewer, better balanced rounds when the
 //          256-row tiling leaves the last round mostly empty).
 int vt_gemm_v7_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn);  // gemm_v7.hip (tile height 32 * mtn)
-int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn);  // gemm_v7.hip (persistent; tile height 32 * mtn)
+int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn, bool shared_tiles = false);  // gemm_v7.hip (persistent; tile height 32 * mtn)
 #ifdef VT_EXPERIMENTAL_GEMM   // tools/experiments (make gemmlab): the measured-negative redesigns of round 4, variants 24 .. 27; not in the product
 int vt_gemm_v10_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);           // gemm_v10.hip (two persistent 256x128-tile workgroups per CU)
 int vt_gemm_v11_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream);           // gemm_v11.hip (eight waves on shared 256x256 stages)
@@ -823,6 +823,13 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
     case 19: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 6);   // ... on 192-row tiles
     case 20: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 5);   // ... on 160-row tiles
     case 21: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 4);   // ... on 128-row tiles (small batches)
+    // 28 .. 32: the persistent kernel (256 .. 128-row tiles) with its left-over tiles SHARED along K among the workgroups a
+    // last round would leave idle (GemmArgs::sk_parts; needs vt_gemm_set_workspace)
+    case 28: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 8, true);
+    case 29: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 7, true);
+    case 30: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 6, true);
+    case 31: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 5, true);
+    case 32: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 4, true);
 #ifdef VT_EXPERIMENTAL_GEMM
     case 24: return vt_gemm_v10_launch(g, ACT, OUT_F32 ? 1 : 0, stream);     // two co-resident persistent workgroups per CU, 256x128 tiles
     case 25: return vt_gemm_v11_launch(g, ACT, OUT_F32 ? 1 : 0, stream);     // eight waves (two groups of four) on shared 256x256 stages
@@ -943,7 +950,7 @@ int vt_gemm_ln_dispatch(const void* A, long lda, const void* W, long ldw, const 
   g.ln_stats = stats_in; g.colv = colv; g.Rs = (const uint16_t*)Rs; g.Cs = (uint16_t*)Cs; g.stats_out = stats_out; g.ldrs = ldrs; g.ldcs = ldcs;
   g.ksplit = 0; g.c_plane = 0; g.r_f16 = 0; g.c_f16 = 0;
   int variant = g_gemm_variant >= 0 ? g_gemm_variant : vt_gemm_pick_variant(M, N, K, VT_TUNE_KIND(act, 0, 0, 0, ln_mode));
-  if (variant != 15 && variant != 16 && (variant < 18 || variant > 23)) variant = 16;   // only the 256x256-tile kernels
+  if (variant != 15 && variant != 16 && (variant < 18 || variant > 23) && (variant < 28 || variant > 32)) variant = 16;   // only the 256x256-tile kernels
   return vt_gemm_ln_launch(g, act, variant, stream);
 }
 

@@ -57,7 +57,20 @@ struct GemmArgs {
   const float* r_rstd = nullptr;
   const float* r_gamma = nullptr;
   const float* r_beta = nullptr;
+  // ---- stream-K region of the persistent kernel (gemm_nt_bf16_v8, round 6; kernel variants 28 .. 32) --------------------
+  // sk_parts > 1: the tiles an XCD's workgroups cannot take in whole rounds are worked as ONE sequence of K-steps cut into
+  // equal contiguous shares (see the kernel).  A share that starts inside a tile leaves that tile's partial accumulators
+  // (fp32, raw register layout, 256 KiB) in slot [xcd][workgroup] of sk_ws; the workgroup holding the tile's first K-steps
+  // adds the parts to its own in workgroup order (deterministic) and runs the ordinary epilogue.  sk_sem[xcd][workgroup]:
+  // arrival counter of the tile that workgroup finishes, left at zero by it.  (vt_gemm_set_workspace)
+  float* sk_ws = nullptr;
+  int* sk_sem = nullptr;
+  unsigned* sk_err = nullptr;   // bounded waits that ran out (host: vt_gemm_shared_tile_timeouts)
+  int sk_parts = 0;
 };
+#define V8_SK_WGS_PER_XCD 32                   // workgroups per XCD the region is laid out for (a 256-CU grid)
+#define V8_SK_PART_BYTES (256 * 64 * 16)       // one part's accumulators: 256 lanes x 64 registers of 16 B
+#define V8_SK_REGION_BYTES ((long)8 * V8_SK_WGS_PER_XCD * V8_SK_PART_BYTES + 4096)   // + the counters and the error word
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_MUL = 3 };  // MUL: out = acc * R (R = saved gelu'(pre-activation))
 

@@ -1,5 +1,7 @@
 // NT GEMM, 256x256 tile with 128x128 wave tiles and AGPR accumulators (variants 15, 16, 18 .. 23 of vt_gemm_dispatch):
 // launchers of the kernels in gemm_v7_kernels.hpp with the plain epilogues.
+#include <atomic>
+#include <cstdlib>
 #include "gemm_v7_kernels.hpp"
 
 // Compute units the persistent grid leaves free (vt_gemm_reserve_cus): with a collective running beside the backward (one
@@ -13,6 +15,58 @@ int vt_gemm_persistent_cus() {
   const int k = g_reserved_cus.load(std::memory_order_relaxed);
   return cus - k >= 8 ? cus - k : cus;
 }
+// ---- workspace of the stream-K region (GemmArgs::sk_parts) ------------------------------------------------------------
+// Caller-owned device memory, registered per device (vt_gemm_set_workspace): `regions` regions of V8_SK_REGION_BYTES, each
+// = 8 x 32 workgroup slots x 256 KiB of fp32 accumulators, then 256 arrival counters and one error counter (the
+// caller hands the memory over ZEROED; the kernels leave the counters at zero).  Launches take the regions round-robin, so
+// that many launches may be in flight on different streams of one device; launches of one stream never overlap.
+struct SkWorkspace { char* base; int regions; };
+static SkWorkspace g_sk_ws[VT_MAX_DEVICES];
+static std::atomic<unsigned> g_sk_ctr{0};
+int vt_gemm_set_workspace_impl(void* base, long bytes) {
+  const int dev = vt_current_device();
+  if (dev < 0 || dev >= VT_MAX_DEVICES) return VT_ERR_HIP;
+  if (base && (((uintptr_t)base & 255) || bytes < V8_SK_REGION_BYTES)) return VT_ERR_BAD_ALIGN;
+  g_sk_ws[dev].base = (char*)base;
+  g_sk_ws[dev].regions = base ? (int)(bytes / V8_SK_REGION_BYTES) : 0;
+  return VT_OK;
+}
+long vt_gemm_workspace_region_bytes_impl() { return V8_SK_REGION_BYTES; }
+int vt_gemm_has_workspace() {
+  const int dev = vt_current_device();
+  return dev >= 0 && dev < VT_MAX_DEVICES && g_sk_ws[dev].regions > 0;
+}
+// Sum of the regions' error counters (bounded waits of a finishing workgroup that ran out), cleared on read.  Blocking.
+int vt_gemm_shared_tile_timeouts_impl(unsigned* out) {
+  *out = 0;
+  const int dev = vt_current_device();
+  if (dev < 0 || dev >= VT_MAX_DEVICES || g_sk_ws[dev].regions <= 0) return VT_OK;
+  for (int r = 0; r < g_sk_ws[dev].regions; ++r) {
+    unsigned v = 0;
+    char* p = g_sk_ws[dev].base + (long)(r + 1) * V8_SK_REGION_BYTES - 4096 + 2048;
+    if (hipMemcpy(&v, p, 4, hipMemcpyDeviceToHost) != hipSuccess) return VT_ERR_HIP;
+    if (v) {
+      const unsigned zero = 0;
+      if (hipMemcpy(p, &zero, 4, hipMemcpyHostToDevice) != hipSuccess) return VT_ERR_HIP;
+      *out += v;
+    }
+  }
+  return VT_OK;
+}
+// fills the shared-tile fields of a launch's arguments; false: no workspace on this device
+static bool v8_take_region(GemmArgs& g) {
+  const int dev = vt_current_device();
+  if (dev < 0 || dev >= VT_MAX_DEVICES || g_sk_ws[dev].regions <= 0) return false;
+  static const int parts_env = [] { const char* e = getenv("VT_GEMM_SK"); return e ? atoi(e) : 2; }();   // 0 / 1: the region off
+  char* reg = g_sk_ws[dev].base + (long)(g_sk_ctr.fetch_add(1) % (unsigned)g_sk_ws[dev].regions) * V8_SK_REGION_BYTES;
+  g.sk_ws = (float*)reg;
+  g.sk_sem = (int*)(reg + V8_SK_REGION_BYTES - 4096);
+  g.sk_err = (unsigned*)(reg + V8_SK_REGION_BYTES - 4096 + 2048);
+  g.sk_parts = parts_env;
+  return true;
+}
+int vt_gemm_v8_take_region(GemmArgs& g) { return v8_take_region(g) ? 1 : 0; }   // gemm_v7_ln.hip
+
 static int v8_grid(int tiles) {
   const int cus = vt_gemm_persistent_cus();
   if (cus <= 0) return -1;
@@ -20,7 +74,7 @@ static int v8_grid(int tiles) {
 }
 
 template <int ACT, bool OUT_F32>
-static int launch_v8(const GemmArgs& g, hipStream_t stream, int mtn) {
+static int launch_v8(const GemmArgs& g, hipStream_t stream, int mtn, bool shared_tiles) {
   GemmArgs g8 = g;
   g8.tiles_n = (g.N + 255) / 256;
   if ((g.K & 63) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31)) return VT_ERR_UNSUPPORTED;
@@ -30,12 +84,24 @@ static int launch_v8(const GemmArgs& g, hipStream_t stream, int mtn) {
   // tests/test_gpu_round5.py runs N = 832 / 384 / 640 with a residual and with ACT_MUL on every 256x256-tile variant.)
   const bool fast = !OUT_F32 && (g.N & 63) == 0 && g.grp_rows == 0;
   if (ACT == ACT_MUL && !g.R) return VT_ERR_NULL;
+  // variants 28 .. 32 need vt_gemm_set_workspace; the register-epilogue kernels do not share tiles (they run as 16 .. 21)
+  if (shared_tiles && !vt_gemm_has_workspace()) return VT_ERR_UNSUPPORTED;
   if (!fast || OUT_F32 || ACT == ACT_TANH) mtn = 8;   // the shorter tiles exist for the encoder's own (bf16, fast-epilogue) shapes
   else if (g.r_mean && mtn == 8) mtn = 7;             // a rebuilt LayerNorm residual: not in the 256-row instantiation (v7_epilogue_fast)
+  // the stream-K region exists in the fast-epilogue kernels on 160- and 128-row tiles (gemm_nt_bf16_v8: SK_OK); the other
+  // variants of 28 .. 32 run as their plain twins
+  if (shared_tiles && fast && mtn <= 5 && !v8_take_region(g8)) return VT_ERR_UNSUPPORTED;
   const int th = 32 * mtn;
   g8.tiles_m = (g.M + th - 1) / th;
-  const int grid = v8_grid(g8.tiles_m * g8.tiles_n);
+  int grid = v8_grid(g8.tiles_m * g8.tiles_n);
   if (grid <= 0) return VT_ERR_HIP;
+  // the stream-K region spreads a chunk's tiles over every workgroup of the XCD: launch the whole grid even for fewer
+  // tiles than CUs (the region's slots are laid out for 32 workgroups per XCD)
+  if (g8.sk_parts > 1) {
+    const int cus = vt_gemm_persistent_cus();
+    if (cus > 8 * V8_SK_WGS_PER_XCD) g8.sk_parts = 0;
+    else grid = cus;
+  }
   const bool has_r = g.R || ACT == ACT_MUL;
   void (*kern)(GemmArgs) = nullptr;
   if (!fast) kern = gemm_nt_bf16_v8<ACT, OUT_F32, false, false>;
@@ -76,19 +142,19 @@ static int launch_v7(const GemmArgs& g, hipStream_t stream, int mtn) {
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
-int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn) {
+int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn, bool sk) {
 #ifdef V7_ONE
-  return launch_v8<ACT_NONE, false>(g, stream, mtn);
+  return launch_v8<ACT_NONE, false>(g, stream, mtn, sk);
 #else
   switch (act * 2 + (out_f32 ? 1 : 0)) {
-    case 0: return launch_v8<ACT_NONE, false>(g, stream, mtn);
-    case 1: return launch_v8<ACT_NONE, true>(g, stream, mtn);
-    case 2: return launch_v8<ACT_GELU, false>(g, stream, mtn);
-    case 3: return launch_v8<ACT_GELU, true>(g, stream, mtn);
-    case 4: return launch_v8<ACT_TANH, false>(g, stream, mtn);
-    case 5: return launch_v8<ACT_TANH, true>(g, stream, mtn);
-    case 6: return launch_v8<ACT_MUL, false>(g, stream, mtn);
-    case 7: return launch_v8<ACT_MUL, true>(g, stream, mtn);
+    case 0: return launch_v8<ACT_NONE, false>(g, stream, mtn, sk);
+    case 1: return launch_v8<ACT_NONE, true>(g, stream, mtn, sk);
+    case 2: return launch_v8<ACT_GELU, false>(g, stream, mtn, sk);
+    case 3: return launch_v8<ACT_GELU, true>(g, stream, mtn, sk);
+    case 4: return launch_v8<ACT_TANH, false>(g, stream, mtn, sk);
+    case 5: return launch_v8<ACT_TANH, true>(g, stream, mtn, sk);
+    case 6: return launch_v8<ACT_MUL, false>(g, stream, mtn, sk);
+    case 7: return launch_v8<ACT_MUL, true>(g, stream, mtn, sk);
     default: return VT_ERR_UNSUPPORTED;
   }
 #endif

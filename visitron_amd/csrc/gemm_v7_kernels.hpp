@@ -587,9 +587,59 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   const int wq = nwg >> 3, wr = nwg & 7;
   const int w0 = xcd * wq + (xcd < wr ? xcd : wr);
   const int c0 = (int)((long)T * w0 / nwg), c1 = (int)((long)T * (w0 + nx) / nwg);
-  const int first = c0 + (b >> 3);
+  const int iw = b >> 3;                               // this workgroup's index on its XCD
   const int band_tiles = 8 * g.tiles_n;
   const int nk = g.K >> 6;
+
+  // ---- work units.  The XCD's chunk holds rounds * nx + Rx tiles.  Plain: unit j of workgroup iw is the whole tile
+  // c0 + iw + j * nx (the Rx left-over tiles cost a last round with nx - Rx workgroups idle).  STREAM-K REGION
+  // (GemmArgs::sk_parts > 1, round 6): with Rx > 0 the last rounds' tiles -- nx + Rx of them, or all Rx when the chunk is
+  // shorter than one round -- are laid end to end as one sequence of Tsk * nk K-steps and cut into nx contiguous shares
+  // [skb(i), skb(i + 1)); a workgroup's share starts inside a tile (a TAIL part: computed first, its fp32 accumulators go
+  // to the workspace), runs over whole tiles, and ends inside a tile (a HEAD part, k = 0 ..: computed last; it adds the
+  // tile's other parts -- stored long before, or at this very moment by workgroups whose whole share lies inside the tile
+  // -- in workgroup order and runs the ordinary epilogue).  Every workgroup works skb(iw+1) - skb(iw) K-steps whatever
+  // T mod grid is, stores at most one partial tile and finishes at most one.  Cut points closer than three K-steps to a
+  // tile boundary snap to it.
+  const int Tx = c1 - c0;
+  const int rounds = Tx / nx, Rx = Tx - rounds * nx;
+  // (not in the register-epilogue instantiations -- fp32 output, N % 64 != 0, row remap: the extra code sent their
+  // accumulators to scratch; the host leaves sk_parts at 0 for them)
+  // Nor on the 192- .. 256-row tiles: with 192 .. 256 accumulator registers and every VGPR spoken for, hipcc's allocator
+  // gives the accumulators OTHER AGPR tuples inside the fix-up region than in the K loop (a live-range split around the
+  // region) and moves all of them through VGPRs and scratch at its borders -- measured in the ISA, whatever the form of the
+  // fix-up (tied operands, one statement per tile, do-while, break after the head).  160- and 128-row tiles compile clean,
+  // and they are the tiles small batches use.
+  constexpr bool SK_OK = (EPI_LDS || LNM != 0) && MTN <= 5;
+  // (32-bit arithmetic throughout: Tsk <= 2 nx tiles; every share at least six K-steps, so that the snapped cut points
+  // leave no share empty)
+  const int rounds_sk = rounds > 0 ? rounds - 1 : 0;
+  const int Wsk0 = (Tx - rounds_sk * nx) * nk;
+  const bool sk = SK_OK && g.sk_parts > 1 && Rx > 0 && nx <= V8_SK_WGS_PER_XCD && Wsk0 >= 6 * nx && Wsk0 < (1 << 24);
+  const int rounds_dp = sk ? rounds_sk : rounds;
+  const int Tsk = sk ? Tx - rounds_dp * nx : 0;          // tiles of the stream-K region
+  const int Wsk = Tsk * nk;                              // ... and its K-steps
+  auto skb = [&](int i) {                                // first K-step of workgroup i's share (i = nx: the end)
+    int p = (int)((unsigned)(Wsk * i) / (unsigned)nx);
+    const int k = (int)((unsigned)p % (unsigned)nk);
+    if (k < 3) p -= k;
+    else if (nk - k < 3) p += nk - k;
+    return p;
+  };
+  const int sk_lo = sk ? skb(iw) : 0, sk_hi = sk ? skb(iw + 1) : 0;
+  const int sk_t0 = sk_lo / nk;                          // first region tile of the share
+  const int n_sk = sk_hi > sk_lo ? (sk_hi - 1) / nk - sk_t0 + 1 : 0;
+  const int n_units = rounds_dp + (sk ? n_sk : (iw < Rx ? 1 : 0));
+  // unit j -> tile, first K-step, K-steps; role: 0 whole tile, 1 producer (the tile's head lies in another share), 2 head
+  auto unit = [&](int j, int& t, int& k0, int& nku, int& role) {
+    if (j < rounds_dp || !sk) { t = c0 + iw + j * nx; k0 = 0; nku = nk; role = 0; return; }
+    const int ts = sk_t0 + (j - rounds_dp);
+    k0 = j == rounds_dp ? sk_lo - sk_t0 * nk : 0;
+    const int kend = sk_hi - ts * nk < nk ? sk_hi - ts * nk : nk;
+    nku = kend - k0;
+    t = c0 + rounds_dp * nx + ts;
+    role = k0 > 0 ? 1 : (kend < nk ? 2 : 0);
+  };
 
   auto tile_origin = [&](int t, int& m0, int& n0) {   // grouped order: bands of 8 row-tiles, column-tile major inside
     const int band = t / band_tiles;
@@ -620,29 +670,32 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   unsigned wa0 = lds0 + V7_WOFF + wn * 16384 + fr, wa1 = wa0 ^ 64;
   unsigned dst = wave * 8192;
 
-  // ---- DMA cursor: the K-tile the next 16 pieces fetch (runs two K-tiles ahead of the MFMAs, across tiles)
-  int cur_t = first, cur_kt = 0;
+  // ---- DMA cursor: the K-tile the next 16 pieces fetch (runs two K-tiles ahead of the MFMAs, across units)
+  int cur_j = 0, cur_kt = 0, cur_nk = nk;
   const char* cur_x = nullptr;
   const char* cur_w = nullptr;
   unsigned cur_xb = 0, cur_wb = 0;
   const int dbg_same = g.trace ? (int)g.trace[256 * 64 + 1] : 0;   // experiment: every tile fetches tile (0,0)'s operands
-  auto cursor_tile = [&]() {
-    if (cur_t < c1) {
-      int m0, n0;
-      tile_origin(cur_t, m0, n0);
+  auto cursor_unit = [&]() {
+    if (cur_j < n_units) {
+      int t, k0, nku, role_, m0, n0;
+      unit(cur_j, t, k0, nku, role_);
+      tile_origin(t, m0, n0);
       if (dbg_same) { m0 = 0; n0 = 0; }
       const int rows_x = g.M - m0 < TH ? g.M - m0 : TH;
       const int rows_w = g.N - n0 < 256 ? g.N - n0 : 256;
-      cur_x = (const char*)(g.A + (long)m0 * g.lda);
-      cur_w = (const char*)(g.W + (long)n0 * g.ldw);
-      cur_xb = (unsigned)(((long)(rows_x - 1) * g.lda + g.K) * 2);
-      cur_wb = (unsigned)(((long)(rows_w - 1) * g.ldw + g.K) * 2);
+      cur_x = (const char*)(g.A + (long)m0 * g.lda) + k0 * 128;
+      cur_w = (const char*)(g.W + (long)n0 * g.ldw) + k0 * 128;
+      cur_xb = (unsigned)(((long)(rows_x - 1) * g.lda + g.K - 64 * k0) * 2);
+      cur_wb = (unsigned)(((long)(rows_w - 1) * g.ldw + g.K - 64 * k0) * 2);
+      cur_nk = nku;
     } else {
-      cur_xb = 0; cur_wb = 0;   // past the last tile: null descriptors, the pieces read nothing
+      cur_xb = 0; cur_wb = 0;   // past the last unit: null descriptors, the pieces read nothing
+      cur_nk = 1 << 30;
     }
   };
   auto cursor_next = [&]() {
-    if (++cur_kt == nk) { cur_kt = 0; cur_t += nx; cursor_tile(); }
+    if (++cur_kt == cur_nk) { cur_kt = 0; ++cur_j; cursor_unit(); }
   };
 #define V8_RSRC_X() __builtin_amdgcn_make_buffer_rsrc((void*)(cur_x + cur_kt * 128), 0, cur_xb ? (int)(cur_xb - cur_kt * 128) : 0, 0x00020000)
 #define V8_RSRC_W() __builtin_amdgcn_make_buffer_rsrc((void*)(cur_w + cur_kt * 128), 0, cur_wb ? (int)(cur_wb - cur_kt * 128) : 0, 0x00020000)
@@ -652,7 +705,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   u32x4 ln_ring[V7_LN_RING][2];   // deferred-LayerNorm mode 2: filled inside the epilogue (tiles of a persistent workgroup drift apart)
   V7_LAB_DECLS   // (empty in the product: tools/experiments/kstep_lab.hip declares its stamp accumulators here)
 
-  if (first >= c1) return;   // uniform: more workgroups than tiles on this XCD
+  if (n_units == 0) return;   // uniform: more workgroups than work on this XCD
   // debug trace: slot 0 = realtime (100 MHz) at entry, 1 = shader clock at entry, then per tile (realtime): K loop
   // start, K loop end, epilogue end; last two slots repeat (realtime, shader clock) at exit
   unsigned long long* tr = g.trace ? g.trace + (long)b * 64 : nullptr;
@@ -664,7 +717,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
     const unsigned long long d = (unsigned long long)((b * 37) & 63) * g.trace[256 * 64] / 64;
     while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
   }
-  cursor_tile();
+  cursor_unit();
   {
     __amdgpu_buffer_rsrc_t rx0 = V8_RSRC_X(), rw0 = V8_RSRC_W();
     cursor_next();
@@ -688,25 +741,126 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
-  for (int t = first; t < c1; t += nx) {
-    int m0, n0;
+  for (int j = 0; j < n_units; ++j) {
+    int t, k0, nku, role, m0, n0;
+    unit(j, t, k0, nku, role);
     tile_origin(t, m0, n0);
     V8_TRACE_RT();
-    {  // first K-step of the tile; the bias piece goes first, so the step's landing wait covers it too
+    {  // first K-step of the unit; the bias piece goes first, so the step's landing wait covers it too
       __amdgpu_buffer_rsrc_t rx = V8_RSRC_X(), rw = V8_RSRC_W();
       cursor_next();
       V7_DMA_BIAS()
       if constexpr (LNM != 0) { V7_STEP_FIRST_LN() } else { V7_STEP_FIRST(13) }
     }
-    for (int kt = 1; kt < nk; ++kt) {
+    for (int kt = 1; kt < nku; ++kt) {
       __amdgpu_buffer_rsrc_t rx = V8_RSRC_X(), rw = V8_RSRC_W();
       cursor_next();
       V7_STEP(13)
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     V8_TRACE_RT();
+    if constexpr (SK_OK) if (role != 0) {
+      // ---- a tile of the stream-K region that this workgroup holds a part of.  Partials travel as agent-scope accesses
+      // (sc1 on the stores and loads themselves: written through / fetched past whatever the L2 of another XCD holds), so
+      // no cache-wide write-back or invalidate is needed around the counter; the parts of a tile sit on one XCD anyway when
+      // workgroups are dealt to XCDs round-robin, but nothing here relies on it.  The head's wait for the other parts is
+      // bounded (a wave must reach the end of the grid); running out of it is recorded for the host
+      // (vt_gemm_shared_tile_timeouts), as in the weight-gradient kernel.
+      // Every touch of the accumulators below is an asm statement with the tuple as a TIED operand (or a read-only one): a
+      // C++ expression that redefines acc[..][..] lets the register allocator give the new value another AGPR tuple, and
+      // with all 256 in use that means shuffles through scratch (the first build: 120 .. 424 B of it, and scratch holding
+      // accumulators of asynchronous MFMAs is wrong, not just slow).
+      const int vo = tid * 16;
+      const int ts = t - c0 - rounds_dp * nx;            // the tile's index in the region
+      int head = iw;                                      // the workgroup whose share holds the tile's first K-step
+      if (role == 1)
+        for (head = iw - 1; head > 0 && skb(head) > ts * nk; --head) {}
+      int* sem = g.sk_sem + xcd * V8_SK_WGS_PER_XCD + head;
+      if (role == 1) {
+        const u32x4 rs = v7_rsrc((const char*)g.sk_ws + (long)(xcd * V8_SK_WGS_PER_XCD + iw) * V8_SK_PART_BYTES, (unsigned)V8_SK_PART_BYTES);
+#pragma unroll
+        for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt)   // (gfx90a and later: a VMEM store takes its data from AGPRs directly)
+            // (the tuple as a TIED operand although it is only read: as a plain input the allocator may stage it through
+            // another register, and there is none free)
+#ifndef SK_NO_STORE
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1" : "+a"(acc[mt][nt]) : "v"(vo), "s"(rs), "s"((8 * mt + nt) * 4096) : "memory");
+#else
+            asm volatile("s_nop 0" :: "s"(rs));
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(sem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SK_TRACE
+        V8_TRACE_RT();
+#endif
+        continue;
+      }
+      // head: the other parts are the non-empty shares after this one up to the share holding the tile's last K-step
+      int last = iw;                                      // ... and the one holding its last K-step
+      while (last + 1 < nx && skb(last + 1) < (ts + 1) * nk) ++last;
+      const int expect = last - iw;
+      if (tid == 0) {
+        int it = 0;
+        for (; it < (1 << 22) && __hip_atomic_load(sem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != expect; ++it)
+          __builtin_amdgcn_s_sleep(2);
+        if (it == (1 << 22)) __hip_atomic_fetch_add(g.sk_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sem, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch finds the counter at zero
+      }
+      __syncthreads();
+#ifdef SK_TRACE
+      V8_TRACE_RT();   // (debug trace of a head: K loop end, parts arrived, parts added, epilogue end)
+#endif
+      // acc += part, exactly and without the vector ALU (which cannot address AGPRs): the loaded tuple q of a lane is the
+      // part's 16x16 tile in the accumulator layout (lane (g, j): rows 4g + r of column j), and
+      //   v_mfma_f32_16x16x4_f32  D += A_r B_r,   B_r = q[r] (lane (k, j): P[4k + r][j]),   A_r[i][k] = (i == 4k + r)
+      // adds row 4k + r of the part to row 4k + r of D and zero to the others: four of them (r = 0 .. 3) add the whole tile,
+      // every element receiving ONE product 1.0 * p beside zeros -- the fp32 sum, rounded once.  Four tiles round-robin, so
+      // that an MFMA never follows the one whose result it accumulates onto.
+      float ar[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ar[r] = ((lane & 15) == 4 * (lane >> 4) + r) ? 1.0f : 0.0f;
+#ifndef SK_NO_ADD
+      int pw = iw + 1;   // (a head's tile has at least one other part: do-while -- no zero-trip path around the tied operands)
+      do {
+        const u32x4 rs = v7_rsrc((const char*)g.sk_ws + (long)(xcd * V8_SK_WGS_PER_XCD + pw) * V8_SK_PART_BYTES, (unsigned)V8_SK_PART_BYTES);
+        f32x4 q[8];
+#define V8_SK_LOAD(i) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "=v"(q[(i) & 7]) : "v"(vo), "s"(rs), "s"((i) * 4096) : "memory")
+#pragma unroll
+        for (int i = 0; i < 8; ++i) V8_SK_LOAD(i);
+#pragma unroll
+        for (int gi = 0; gi < 2 * MTN; ++gi) {   // groups of four tiles: loads 4 gi .. 4 gi + 3 have landed
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * MTN - 4 * gi - 4 < 4 ? 8 * MTN - 4 * gi - 4 : 4) : "memory");
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) asm volatile("" : "+v"(q[(4 * gi + tt) & 7]));
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) {
+            const int i = 4 * gi + tt;
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %5, %0\n\ts_nop 1\n\t"
+                         "v_mfma_f32_16x16x4_f32 %0, %2, %6, %0\n\ts_nop 1\n\t"
+                         "v_mfma_f32_16x16x4_f32 %0, %3, %7, %0\n\ts_nop 1\n\t"
+                         "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0"
+                         : "+a"(acc[i >> 3][i & 7])
+                         : "v"(ar[0]), "v"(ar[1]), "v"(ar[2]), "v"(ar[3]), "v"(q[i & 7][0]), "v"(q[i & 7][1]), "v"(q[i & 7][2]), "v"(q[i & 7][3]));
+          }
+          // the next loads into these four slots: behind the MFMAs that read them (sources are read at issue; the data
+          // returns hundreds of cycles later)
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)
+            if (4 * gi + tt + 8 < 8 * MTN) V8_SK_LOAD(4 * gi + tt + 8);
+        }
+#undef V8_SK_LOAD
+      } while (++pw <= last);
+#endif
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results, before the epilogue reads them
+#ifdef SK_TRACE
+      V8_TRACE_RT();
+#endif
+    }
     V7_EPILOGUE()
     V8_TRACE_RT();
+    if constexpr (SK_OK) if (role == 2) break;   // a head is its share's last unit: said aloud, the next unit's fragment registers are free in its fix-up
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   V7_LAB_EXIT

@@ -4,10 +4,13 @@
 #include "gemm_v7_kernels.hpp"
 
 int vt_gemm_persistent_cus();   // gemm_v7.hip: the device's CU count less the reserved ones
+int vt_gemm_v8_take_region(GemmArgs& g);   // gemm_v7.hip: shared-tile workspace of this launch (0: none registered)
 
 template <int ACT, int LNM>
-static int launch_ln(const GemmArgs& g, int persistent, int mtn, hipStream_t stream) {
+static int launch_ln(const GemmArgs& g, int persistent, int mtn, hipStream_t stream, bool shared_tiles) {
   GemmArgs ga = g;
+  if (shared_tiles && !persistent) return VT_ERR_UNSUPPORTED;
+  if (shared_tiles && mtn <= 5 && !vt_gemm_v8_take_region(ga)) return VT_ERR_UNSUPPORTED;   // (the region: 160- / 128-row tiles only)
   ga.tiles_n = (g.N + 255) / 256;
   ga.tiles_m = (g.M + 32 * mtn - 1) / (32 * mtn);
   const int tiles = ga.tiles_m * ga.tiles_n;
@@ -17,6 +20,10 @@ static int launch_ln(const GemmArgs& g, int persistent, int mtn, hipStream_t str
     const int cus = vt_gemm_persistent_cus();
     if (cus <= 0) return VT_ERR_HIP;
     grid = tiles < cus ? tiles : cus;
+    if (ga.sk_parts > 1) {   // the stream-K region: the whole grid (launch_v8 in gemm_v7.hip)
+      if (cus > 8 * V8_SK_WGS_PER_XCD) ga.sk_parts = 0;
+      else grid = cus;
+    }
     switch (mtn) {
       case 8: kern = gemm_nt_bf16_v8<ACT, false, true, false, 8, LNM>; break;
       case 7: kern = gemm_nt_bf16_v8<ACT, false, true, false, 7, LNM>; break;
@@ -42,6 +49,8 @@ static int launch_ln(const GemmArgs& g, int persistent, int mtn, hipStream_t str
 // persistent on 256- .. 128-row tiles)
 int vt_gemm_ln_launch(const GemmArgs& g, int act, int variant, hipStream_t stream) {
   int persistent, mtn;
+  const bool sk = variant >= 28 && variant <= 32;   // the persistent kernel sharing its left-over tiles (gemm_v7.hip)
+  if (sk) variant = variant == 28 ? 16 : variant - 11;   // 29 .. 32 -> 18 .. 21
   switch (variant) {
     case 15: persistent = 0; mtn = 8; break;
     case 22: persistent = 0; mtn = 7; break;
@@ -56,10 +65,10 @@ int vt_gemm_ln_launch(const GemmArgs& g, int act, int variant, hipStream_t strea
   if ((g.K & 63) || g.K < 128 || (g.N & 127) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31))
     return VT_ERR_UNSUPPORTED;
   if (g.ln_mode == 1) {
-    if (act == ACT_NONE) return launch_ln<ACT_NONE, 1>(g, persistent, mtn, stream);
-    if (act == ACT_GELU) return launch_ln<ACT_GELU, 1>(g, persistent, mtn, stream);
+    if (act == ACT_NONE) return launch_ln<ACT_NONE, 1>(g, persistent, mtn, stream, sk);
+    if (act == ACT_GELU) return launch_ln<ACT_GELU, 1>(g, persistent, mtn, stream, sk);
     return VT_ERR_UNSUPPORTED;
   }
-  if (g.ln_mode == 2 && act == ACT_NONE) return launch_ln<ACT_NONE, 2>(g, persistent, mtn, stream);
+  if (g.ln_mode == 2 && act == ACT_NONE) return launch_ln<ACT_NONE, 2>(g, persistent, mtn, stream, sk);
   return VT_ERR_UNSUPPORTED;
 }

@@ -237,7 +237,11 @@ def encoder_forward_ln(layer_weights, stream_a, stream_b, qkv, ctx, mid, mask, m
 # 128x128 (4 / 8 waves), 256x192, 256x256, 256x256 phased (BK32, 4-stage ring), 256x256 with 128x128 wave tiles
 # and AGPR accumulators (15: one tile per workgroup, 16: persistent; 18 .. 21: the persistent kernel on 224- / 192- / 160- / 128-row tiles; 22 / 23: the one-tile-per-workgroup kernel on 224- / 192-row tiles,
 # which balance the rounds over the 256 CUs when the 256-row tiling leaves the last round mostly empty).
-GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16, 18, 19, 20, 21, 22, 23)   # (24 .. 27: the measured-negative redesigns of round 4 live in tools/experiments, outside the product library)
+# 31 / 32: the persistent kernel on 160- / 128-row tiles with a STREAM-K region (round 6; 28 .. 30 exist as numbers and run as
+# their plain twins 16 / 18 / 19).  Measured negative on MI355X at every row count tried (profiles/r06/streamk_ab.txt: +10 .. +47 %
+# against the best plain variant, parity at best): opt-in candidates (VT_GEMM_STREAMK=1), never timed by default.
+STREAMK = os.environ.get("VT_GEMM_STREAMK", "0") == "1"
+GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16, 18, 19, 20, 21, 22, 23) + ((31, 32) if STREAMK else ())   # (24 .. 27: the measured-negative redesigns of round 4 live in tools/experiments, outside the product library)
 
 
 # -1: shape table / heuristic; -2: the same plus the tail launch of the persistent kernel's last round (VT_GEMM_TAIL_SPLIT=1)
@@ -246,13 +250,16 @@ AUTO_VARIANT = -2 if os.environ.get("VT_GEMM_TAIL_SPLIT") == "1" else -1
 
 def set_gemm_variant(v):
     """Tuning/test hook: force one GEMM kernel variant (-1: shape table / heuristic)."""
+    if int(v) in (28, 29, 30, 31, 32):
+        ensure_gemm_workspace()
     _lib.load().vt_debug_set_gemm_variant(int(AUTO_VARIANT if v == -1 else v))
 # The persistent kernel (16) launches one workgroup per CU and needs every CU to itself (512 registers per wave, 132 KiB
 # of LDS): a collective running beside it on a few CUs makes the workgroups mapped to those CUs wait for a whole kernel
 # time.  Data-parallel training (gradient all-reduce overlapped with the backward) therefore tunes without it; the
 # one-tile-per-workgroup forms of the same kernel (15, 22, 23) are within 1 % over the step and simply queue their tiles.
 PERSISTENT_GEMM_OK = True
-PERSISTENT_VARIANTS = (16, 18, 19, 20, 21)
+PERSISTENT_VARIANTS = (16, 18, 19, 20, 21, 28, 29, 30, 31, 32)
+SHARED_TILE_VARIANTS = (28, 29, 30, 31, 32)   # the persistent kernel sharing its left-over tiles along K (needs the workspace below)
 
 
 def multi_rank_gemm_policy(environ=None):
@@ -281,6 +288,8 @@ def force_gemm_variant(v):
     With one variant everywhere two processes run the same summation order, so their results can be compared exactly."""
     global _forced_variant
     _forced_variant = None if v is None else int(v)
+    if v is not None and int(v) in (28, 29, 30, 31, 32):
+        ensure_gemm_workspace()
     _lib.load().vt_debug_set_gemm_variant(AUTO_VARIANT if v is None else int(v))
 
 
@@ -290,7 +299,7 @@ def tune_kind(act, residual=False, pre_act=False, out_f32=False, ln_mode=0):
     return int(act) | (16 if (residual or act == ACT_MUL) else 0) | (32 if pre_act else 0) | (64 if out_f32 else 0) | (int(ln_mode) << 8)
 
 
-LN_GEMM_CANDIDATES = (15, 16, 18, 19, 20, 21, 22, 23)   # the deferred-LayerNorm epilogues exist on the 256x256-tile kernels
+LN_GEMM_CANDIDATES = (15, 16, 18, 19, 20, 21, 22, 23) + ((31, 32) if STREAMK else ())   # the deferred-LayerNorm epilogues exist on the 256x256-tile kernels
 TUNE_ROUNDS = 3          # interleaved timing rounds per candidate; a candidate's time is the MEDIAN of its rounds
 TUNE_KEEP_DEFAULT = 0.03   # the committed default stays unless a candidate beats it by more than this fraction
 _defaults = None
@@ -338,12 +347,13 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
     if key in _tuned:
         return _tuned[key]
     lib = _lib.load()
+    have_ws = STREAMK and ensure_gemm_workspace(device)   # (before any variant is registered: 28 .. 32 need it at launch time)
     # The training layer's residual GEMMs (out-proj, FFN-down) read an fp16 residual and write the fp16 pre-LayerNorm sum
     # (F16_STREAM); the grouped epilogue of variants 9 / 10 is bf16-only and the library would silently run variant 1 in their
     # place -- a kernel never timed for the shape.  Such kinds are tuned with the dtypes they run with, without 9 / 10.
     f16_io = F16_STREAM and residual and act == ACT_NONE and not out_f32 and not pre_act and not ln_mode
     usable = lambda v: (v is not None and (v not in PERSISTENT_VARIANTS or PERSISTENT_GEMM_OK)
-                        and not (f16_io and v in (9, 10)))
+                        and not (f16_io and v in (9, 10)) and (have_ws or v not in SHARED_TILE_VARIANTS))
     saved = _tune_file_table().get("%d,%d,%d,%d" % key)
     if usable(saved):   # VT_TUNE_FILE: a previous run's choices
         lib.vt_gemm_tune(M, N, K, kind, int(saved))
@@ -1031,6 +1041,43 @@ def wgrad(problems, M):
     with _timed("gemm_wgrad_tn_bf16", flops, 0.0):
         rc = _lib.load().vt_wgrad_bf16(arr, len(problems), M, _stream())
     _lib.check(rc, "vt_wgrad_bf16")
+
+
+_gemm_ws = {}
+
+
+def ensure_gemm_workspace(device=None):
+    """Register the shared-tile workspace of the persistent GEMM (vt_gemm_set_workspace) on `device`, once: VT_GEMM_WS_REGIONS
+    regions (default 2; 0: none -- kernel variants 28 .. 32 are then refused and the autotuner leaves them out) of ~96 MiB,
+    zeroed, owned by this module for the life of the process."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if dev.index in _gemm_ws:
+        return _gemm_ws[dev.index] is not None
+    regions = int(os.environ.get("VT_GEMM_WS_REGIONS", "2"))
+    lib = _lib.load()
+    if regions <= 0:
+        _gemm_ws[dev.index] = None
+        return False
+    n = int(lib.vt_gemm_workspace_region_bytes()) * regions
+    with torch.cuda.device(dev):
+        ws = torch.zeros(n + 256, dtype=torch.uint8, device=dev)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        torch.cuda.synchronize(dev)
+        _lib.check(lib.vt_gemm_set_workspace(ctypes.c_void_p(base), n), "vt_gemm_set_workspace")
+    _gemm_ws[dev.index] = ws
+    return True
+
+
+def gemm_shared_tile_timeouts():
+    """Finishing workgroups of shared GEMM tiles that ran out of their bounded wait since the last call (0 in a healthy run).
+    Blocking read-back: call it where the host synchronises anyway."""
+    if not any(v is not None for v in _gemm_ws.values()):
+        return 0
+    n = ctypes.c_uint(0)
+    _lib.check(_lib.load().vt_gemm_shared_tile_timeouts(ctypes.byref(n)), "vt_gemm_shared_tile_timeouts")
+    return int(n.value)
 
 
 def wgrad_turn_timeouts():

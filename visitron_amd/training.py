@@ -262,9 +262,11 @@ class PretrainEngine(object):
         self.last_rows = None
         self.last_layout = None
         self._tuned_rows = set()
-        # below this many (padded) token rows the layout's own launches and host sync cost more than the rows saved
-        # (B=36: 3 036 against 3 352 samples/s; B=64 x 656 and B=256 x 228: +6 %)
-        self.compact_min_rows = int(os.environ.get("VT_COMPACT_MIN_ROWS", "16384"))
+        # (padded) token rows below which the step stays on the padded layout.  Rounds 2 - 5: 16 384 -- the layout then cost
+        # two launches and a host synchronisation of its own.  Since the row counts and lists ride on the step's one
+        # synchronisation it wins at every batch measured (round 6, profiles/r06/compaction_by_batch.txt: B = 4 ... 36 x 228
+        # +0.2 ... +3.6 %, 8 x 767 +3.2 %), so the default is 0; VT_COMPACT_MIN_ROWS restores a threshold
+        self.compact_min_rows = int(os.environ.get("VT_COMPACT_MIN_ROWS", "0"))
         self._side_stream = None
         self._fwd_serial = 0      # forwards issued: a backward must belong to the latest one (the buffers are shared)
         self._build_tables()
@@ -473,6 +475,10 @@ class PretrainEngine(object):
         if late:
             raise RuntimeError("vt_wgrad_bf16: %d workgroup(s) ran out of their turn wait in an earlier launch; the weight "
                                "gradients of that step are unreliable" % late)
+        late = ops.gemm_shared_tile_timeouts()   # the same for the persistent GEMM's shared tiles (kernel variants 28 .. 32)
+        if late:
+            raise RuntimeError("vt_linear: %d finishing workgroup(s) of shared GEMM tiles ran out of their wait in an earlier "
+                               "launch; that step's activations / gradients are unreliable" % late)
         Ml, Mt = (int(vals[1]), int(vals[2])) if labels is not None else (0, 0)
         compact = try_compact and int(vals[3]) < M and not vals[4]
         lay = None
