@@ -658,7 +658,9 @@ int vt_encoder_backward_overlap_bf16(const vt_layer_weights* layers, const vt_la
  * mask 0, data_loader_pretrain.py:666-690).  Nothing in a training step reads those rows: as keys they get probability
  * exactly 0 (encoder.py:238-241: -10000 underflows in the softmax), their labels are -1, their gradient is exactly 0.
  * The *_seq_* entry points run the same kernels on the `rows` real rows only: sequence b occupies rows seq_start[b] ..
- * seq_start[b] + seq_len[b] of every activation (seq_len[b] <= S), all of its keys are attended (no mask argument);
+ * seq_start[b] + seq_len[b] of every activation, all of its keys are attended (no mask argument).  CONTRACT:
+ * 1 <= seq_len[b] <= S (position 0, [CLS], is always kept) -- device data the host side cannot check without a
+ * synchronisation: the kernels clamp a length outside that range into it (meaningless rows, never an out-of-bounds access);
  * lse / delta keep their [B, nh, S] layout.  Losses and gradients equal the padded run's; outputs AT padding positions
  * do not exist, so inference keeps the padded entry points. */
 int vt_attention_fwd_seq_bf16(const void* qkv, int64_t ld_qkv, const float* head_scale, void* ctx, int64_t ld_ctx,

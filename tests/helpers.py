@@ -45,6 +45,10 @@ def _recorded():
 _REC = None
 
 
+# RULE for the regression guard below (round 6, after two rounds in which it moved in the loosening direction at the end of a
+# round): the guard's floor (the 0.1 / 0.5 factors of effective_bound) may only be RAISED in a commit of its own that quotes
+# the measured series justifying it (as c912670 did), never in a commit that also changes a kernel; the STATED bounds in
+# the tests are the contract and do not move with it.
 def effective_bound(name, bound, scalar=False):
     """scalar: the checked quantity is a single number (a loss of a two-sequence batch): its error is one draw of the bf16
     noise -- it moved 8e-4 -> 2.9e-3 -> 2.5e-4 between rebuilds that changed nothing but a summation order -- so the recorded

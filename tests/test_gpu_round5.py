@@ -303,7 +303,8 @@ def test_layernorm_residual_mode_is_the_default_training_layer_and_matches_the_t
         torch.cuda.synchronize()
         bufs = eng._buffers(5, 29)
         assert bufs.ln_residual == ln_residual and (bufs.ln_h is None) == ln_residual
-        last = bufs.layers[-1]["out"].float().clone()
+        # (the rows the step computed: since round 6 small batches run on the real rows only, and the buffer's tail is not written)
+        last = bufs.layers[-1]["out"][:eng.last_rows].float().clone()
         return [float(x) for x in out[:4]], last, eng.flat.g.clone()
 
     l_new, h_new, g_new = run(True)

@@ -27,6 +27,12 @@
 
 #define LOG2E 1.4426950408889634f
 
+// A sequence's row count as the kernels use it: 1 .. S.  The engine always keeps the [CLS] row (seq_len >= 1) and never
+// exceeds the padded length; a C-ABI caller that hands 0 or more than S would otherwise turn the unsigned "last row" clamps
+// below (S - 1) into ~4 G rows of offset in LDS-DMA loads that are not range-checked.  Out-of-contract lengths therefore
+// compute (meaningless but in-bounds) rows instead of faulting; include/visitron_hip.h states the contract.
+__device__ __forceinline__ int vt_clamp_len(int len, int S) { return len < 1 ? 1 : (len > S ? S : len); }
+
 struct AttnBwdArgs {
   const bf16_t* qkv;    // [B*S, ld_qkv]
   const bf16_t* dctx;   // [B*S, ld_d]   gradient of the context
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_d64(AttnBwdArgs a) {
   const int b = blockIdx.y, head = blockIdx.x;
   const int kb0 = blockIdx.z * 256;   // first key of this workgroup's key block
   const int Smax = a.S, H = a.nh * 64;
-  const int S = a.seq_len ? a.seq_len[b] : a.S;                       // this sequence's rows
+  const int S = a.seq_len ? vt_clamp_len(a.seq_len[b], a.S) : a.S;                       // this sequence's rows
   const long row0 = a.seq_start ? (long)a.seq_start[b] : (long)b * a.S;
   if (kb0 >= S) return;                                               // uniform: a key block past a short sequence
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
   const int b = blockIdx.y, head = blockIdx.x;
   const int kb0 = blockIdx.z * 256;   // first key of this workgroup's key block
   const int Smax = a.S, H = a.nh * 64;
-  const int S = a.seq_len ? a.seq_len[b] : a.S;                       // this sequence's rows
+  const int S = a.seq_len ? vt_clamp_len(a.seq_len[b], a.S) : a.S;                       // this sequence's rows
   const long row0 = a.seq_start ? (long)a.seq_start[b] : (long)b * a.S;
   if (kb0 >= S) return;                                               // uniform: a key block past a short sequence
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
   const int kl = lane & 15, g = lane >> 4;          // this lane's key inside the wave's 16; k-slot group
   const int b = blockIdx.y, head = blockIdx.x;
   const int Smax = a.S, H = a.nh * 64;
-  const int S = a.seq_len ? a.seq_len[b] : a.S;
+  const int S = a.seq_len ? vt_clamp_len(a.seq_len[b], a.S) : a.S;
   const long row0 = a.seq_start ? (long)a.seq_start[b] : (long)b * a.S;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -1087,10 +1093,10 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16(AttnBwdArgs a) {
 
 // 16 bytes per lane global -> LDS (wave-uniform LDS byte address in M0), invisible to the compiler's waitcnt insertion
 __device__ __forceinline__ void ap_dma16(const void* base, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");   // (M0 is written: nothing else in this kernel uses it)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
 }
 __device__ __forceinline__ void ap_dma4(const void* base, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
 }
 // the same through a buffer descriptor: bytes at or past `bytes` read as ZERO (rows past the sequence)
 __device__ __forceinline__ u32x4 ap_rsrc(const void* base, unsigned bytes) {
@@ -1103,10 +1109,10 @@ __device__ __forceinline__ u32x4 ap_rsrc(const void* base, unsigned bytes) {
   return r;
 }
 __device__ __forceinline__ void ap_bdma16(u32x4 rs, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", "m0");
 }
 __device__ __forceinline__ void ap_bdma4(u32x4 rs, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", "m0");
 }
 
 // AP_LAB (tools/experiments, timing only; 0 / undefined in the product): 1 no LDS-DMA after the prologue (arithmetic on stale
@@ -1141,7 +1147,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_d64_w16p(AttnBwdArgs a) {
   // for each with vmcnt(0) -- which would also wait for every LDS-DMA piece in flight, the latency this kernel hides.
   int* meta = (int*)(smem + AP_META);
   if (tid < a.B) {
-    meta[2 * tid] = a.seq_len ? a.seq_len[tid] : a.S;
+    meta[2 * tid] = a.seq_len ? vt_clamp_len(a.seq_len[tid], a.S) : a.S;
     meta[2 * tid + 1] = a.seq_start ? a.seq_start[tid] : tid * a.S;
   }
   __syncthreads();

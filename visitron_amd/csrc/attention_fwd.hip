@@ -105,7 +105,8 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
   const int r = lane & 31, h2 = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int Smax = a.S, H = a.nh * 64;
-  const int S = a.seq_len ? a.seq_len[b] : a.S;                       // this sequence's rows
+  // (1 .. a.S: the contract of include/visitron_hip.h; a length outside it is clamped into it rather than indexed with)
+  const int S = a.seq_len ? (a.seq_len[b] < 1 ? 1 : (a.seq_len[b] > a.S ? a.S : a.seq_len[b])) : a.S;   // this sequence's rows
   const long row0 = a.seq_start ? (long)a.seq_start[b] : (long)b * a.S;
   if ((int)blockIdx.x * 256 >= S) return;                             // uniform: a query block past a short sequence
   const int q0 = blockIdx.x * 256 + wave * 32;

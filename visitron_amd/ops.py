@@ -385,10 +385,18 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
         r = torch.randn(M, N, generator=g, device=device).to(F16 if f16_io else BF16) if (residual or act == ACT_MUL) else None
         out = torch.empty((M, N), dtype=torch.float32 if out_f32 else (F16 if f16_io else BF16), device=device)
         pre = torch.empty((M, N), dtype=BF16, device=device) if pre_act else None
+        # LN_RESIDUAL (the training layer's default): those two GEMMs run the rebuilt-LayerNorm epilogue (vt_linear_lnres_bf16:
+        # four more LDS-DMA pieces and the vectors' ds_reads per slab) -- time THAT epilogue, with its operands
+        rln = None
+        if f16_io and LN_RESIDUAL:
+            rln = (torch.randn(M, generator=g, device=device), torch.rand(M, generator=g, device=device) + 0.5,
+                   torch.ones(N, device=device), torch.zeros(N, device=device))
 
         def run():
-            linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre, out_f32=out_f32)
+            linear(a, w, b, residual=r, act=act, out=out, pre_act_out=pre, out_f32=out_f32, residual_ln=rln)
     cands = [v for v in (LN_GEMM_CANDIDATES if ln_mode else GEMM_CANDIDATES) if usable(v)]
+    if not ln_mode and f16_io and LN_RESIDUAL:
+        cands = [v for v in cands if v != 16]   # (the library gives such a GEMM the 224-row tile: 16 would time variant 18 twice)
     times = {v: [] for v in cands}
     for rnd in range(TUNE_ROUNDS):
         for v in list(cands):

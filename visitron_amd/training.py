@@ -807,12 +807,24 @@ class PretrainEngine(object):
         st = self._trunk_fwd(batch, head_mask, None, None, bool(training), bool(unmasked_only))
         # the caller's hidden states come from the fp16 copy of the last LayerNorm's output where the layer keeps one (the
         # bf16 copy is the heads' / pooler's GEMM operand)
-        last = st.seq if st.bufs.ln_h is None else st.bufs.ln_h[1][:st.seq.shape[0]]
+        n = st.seq.shape[0]
+        if st.bufs.ln_h is not None:
+            last = st.bufs.ln_h[1][:n].float()
+        elif st.bufs.ln_residual:
+            # LN_RESIDUAL (the default): no fp16 copy of a LayerNorm output exists -- the last layer's is rebuilt at fp32 from
+            # its fp16 input and the row statistics its kernel wrote, as the residual adds do (one elementwise pass; the bf16
+            # output stays the heads' / pooler's GEMM operand).  8 more significant bits than the bf16 rows.
+            d = st.bufs.layers[-1]
+            ln = self.model.bert.encoder.layer[-1].output.LayerNorm
+            last = ((d["out_pre"][:n].float() - d["ln2_mean"][:n, None]) * d["ln2_rstd"][:n, None] * ln.weight.detach().float()
+                    + ln.bias.detach().float())
+        else:
+            last = st.seq.float()
         if st.lay is None:
-            seq = last.float().view(st.B, st.S, st.H)
+            seq = last.view(st.B, st.S, st.H)
         else:
             seq = torch.zeros((st.M, st.H), dtype=torch.float32, device=st.dev)
-            seq.index_copy_(0, st.lay.index, last.float())
+            seq.index_copy_(0, st.lay.index, last)
             seq = seq.view(st.B, st.S, st.H)
         return seq, st.pooled.clone(), st
 
