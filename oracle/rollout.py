@@ -84,8 +84,12 @@ class OscarEncoder(nn.Module):
         att_mask = ~mask                                                  # :267 bitwise NOT (uint8 masks give 254/255)
         outputs = self.bert(inputs, token_type_ids=token_type_ids, attention_mask=att_mask, position_ids=position_ids)
         output = outputs[0]
-        if self.reverse_input:
-            raise NotImplementedError("reverse_input is constructed False by every reference caller (agent.py:110-117)")
+        if self.reverse_input:                                            # :277-282, op for op
+            seq_max_len = mask.size(1)
+            reversed_output = torch.zeros(output.size()).to(output.device)
+            reverse_idx = torch.arange(seq_max_len - 1, -1, -1)
+            reversed_output[att_mask] = output[:, reverse_idx][att_mask[:, reverse_idx]]
+            output = reversed_output
         B = inputs.size(0)
         h0 = torch.zeros(self.num_layers * self.num_directions, B, self.hidden_size)   # :238-254
         c0 = torch.zeros_like(h0)

@@ -399,8 +399,40 @@ def case_rollout(R, O):
         REPORT["rollout"]["oscar_encoder_grad_max_rel"] = max(float((gr[n] - go[n]).norm() / (gr[n].norm() + 1e-30)) for n in gr)
         out["enc_in_ids"], out["enc_in_lengths"] = _np(ids), np.array(lengths)
         out.update({"enc_" + k: v for k, v in _grad_slices(gr).items()})
+        # round 6: the constructor arguments no reference caller sets (agent.py:110-117 leaves the defaults) -- reverse_input
+        # (agent_models.py:277-282; with a uint8 mask the byte index marks EVERY position) and stacked / bidirectional
+        # encoder LSTMs (num_layers = 2).  A separate file: ref_rollout.npz stays what round 5 wrote.
+        out2 = dict(enc_in_ids=_np(ids), enc_in_lengths=np.array(lengths))
+        for name, kw in (("rev", dict(reverse_input=True)), ("l2", dict(num_layers=2)),
+                         ("l2bi_rev", dict(num_layers=2, bidirectional=True, reverse_input=True))):
+            rx = R.agent_models.OscarEncoder(_Args(), rb, 128, 96, 0.5, **kw).eval()
+            ox = orollout.OscarEncoder(_Args(), ob, 128, 96, 0.5, **kw).eval()
+            sdx = deterministic_state_dict(rx, seed=12, weight_std=0.03)
+            sdx.update({k: v for k, v in rx.state_dict().items() if k.startswith("bert.")})
+            rx.load_state_dict(sdx)
+            ox.load_state_dict(sdx)
+            for tag, m in (("bool", pad), ("u8", pad.byte())):
+                with torch.no_grad():
+                    a = rx(ids, lengths, m)
+                    o = ox(ids, lengths, m)
+                for i, n in enumerate(("ctx", "decoder_init", "c_t")):
+                    _diff("rollout", "oscar_encoder_%s_%s.%s" % (name, tag, n), a[i], o[i])
+                    out2["enc_%s_%s_%s" % (name, tag, n)] = _np(a[i])
+            # gradients through the reversed / stacked encoder (bool mask; eval mode: no dropout draws)
+            a = rx(ids, lengths, pad)
+            o = ox(ids, lengths, pad)
+            rx.zero_grad(); ox.zero_grad()
+            (a[0].sum() + a[1].sum() + a[2].sum()).backward()
+            (o[0].sum() + o[1].sum() + o[2].sum()).backward()
+            grx = {n: p.grad for n, p in rx.named_parameters() if p.grad is not None}
+            gox = {n: p.grad for n, p in ox.named_parameters() if p.grad is not None}
+            assert sorted(grx) == sorted(gox)
+            REPORT["rollout"]["oscar_encoder_%s_grad_max_rel" % name] = max(
+                float((grx[n] - gox[n]).norm() / (grx[n].norm() + 1e-30)) for n in grx)
+            out2.update({"enc_%s_%s" % (name, k): v for k, v in _grad_slices(grx).items()})
     np.savez_compressed(os.path.join(HERE, "ref_rollout.npz"), **out)
-    print("ref_rollout written")
+    np.savez_compressed(os.path.join(HERE, "ref_rollout2.npz"), **out2)
+    print("ref_rollout, ref_rollout2 written")
 
 
 def case_text511(R, O):

@@ -215,3 +215,50 @@ def test_rollout_modules_against_the_reference_outputs(dev):
             out = enc(ids, lengths, mk.to(dev))
             for i, n in enumerate(("ctx", "decoder_init", "c_t")):
                 check_close("ref rollout OscarEncoder %s %s" % (tag, n), out[i], g["enc_%s_%s" % (tag, n)], TOL)
+
+
+@pytest.mark.parametrize("name,kw", [("rev", dict(reverse_input=True)), ("l2", dict(num_layers=2)),
+                                     ("l2bi_rev", dict(num_layers=2, bidirectional=True, reverse_input=True))])
+def test_oscar_encoder_reverse_input_and_stacked_lstm_against_the_reference(dev, name, kw):
+    """Round 6: OscarEncoder(reverse_input=True) (agent_models.py:277-282) and stacked / bidirectional encoder LSTMs
+    (num_layers = 2, :223-230) -- constructor arguments the earlier rounds refused -- against outputs and gradients of the
+    reference's own class run with them (ref_rollout2.npz): inference forward with bool and uint8 padding masks (the uint8
+    `~mask` indexes every position: a whole-row reversal, padding included), then the training path's autograd nodes."""
+    from visitron_amd.config import BertConfig
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.rollout import OscarEncoder
+    from visitron_amd.synth import deterministic_state_dict
+
+    g = np.load(os.path.join(GOLD, "ref_rollout2.npz"))
+    cfg = BertConfig(num_hidden_layers=2, vocab_size=600, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0, detector_classes=40)
+    bert = BertImgModelwithLocationEmbeds(cfg).eval()
+    bert.load_state_dict(deterministic_state_dict(bert, seed=9, weight_std=0.03))
+    enc = OscarEncoder(None, bert, 128, 96, 0.5, **kw).eval()
+    sd = deterministic_state_dict(enc, seed=12, weight_std=0.03)
+    sd.update({k: v for k, v in enc.state_dict().items() if k.startswith("bert.")})
+    enc.load_state_dict(sd)
+    enc = enc.to(dev)
+    ids, lengths = _d(g["enc_in_ids"], dev), torch.tensor([int(x) for x in g["enc_in_lengths"]])
+    pad = torch.zeros(ids.shape, dtype=torch.bool)
+    for i, n in enumerate(lengths.tolist()):
+        pad[i, n:] = True
+    with torch.no_grad():
+        for tag, mk in (("bool", pad), ("u8", pad.byte())):
+            out = enc(ids, lengths, mk.to(dev))
+            for i, n in enumerate(("ctx", "decoder_init", "c_t")):
+                check_close("ref rollout OscarEncoder(%s) %s %s" % (name, tag, n), out[i], g["enc_%s_%s_%s" % (name, tag, n)], TOL)
+    # the training path (autograd nodes, the trunk node on the pretrain engine): train() with every dropout probability at
+    # zero is the fixture's eval() arithmetic with a graph -- outputs and gradients
+    enc.drop.p = 0.0
+    enc.lstm.dropout = 0.0
+    enc.train()
+    with torch.enable_grad():
+        out = enc(ids, lengths, pad.to(dev))
+        for i, n in enumerate(("ctx", "decoder_init", "c_t")):
+            check_close("ref rollout OscarEncoder(%s) autograd %s" % (name, n), out[i], g["enc_%s_bool_%s" % (name, n)], TOL)
+        (out[0].sum() + out[1].sum() + out[2].sum()).backward()
+    # (attention key biases: their true gradient is exactly zero -- the softmax does not see a per-query shift -- and under
+    # this sum-of-outputs loss the rounding noise left on both sides is above the absolute floor sized for the pretrain loss)
+    _check_grad_slices("ref rollout OscarEncoder(%s)" % name, enc, g, bound=0.04, prefix="enc_%s_" % name,
+                       skip=("attention.self.key.bias",))

@@ -310,3 +310,46 @@ def test_pretrain_input_preparation_items():
         assert abs(float(out["img_feats"].double().sum()) - c[0]) <= 1e-9 * abs(c[0])
         n += 1
     assert n == 12
+
+
+def test_oscar_encoder_reverse_input_and_stacked_lstm():
+    """Round 6: the constructor arguments no reference caller sets -- reverse_input (agent_models.py:277-282; a uint8 mask
+    indexes as 'every position') and num_layers = 2 / bidirectional -- against the reference's own outputs and gradients
+    (ref_rollout2.npz, written by running agent_models.OscarEncoder with those arguments)."""
+    from oracle import rollout as orollout
+    from oracle.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.config import BertConfig
+    from visitron_amd.synth import deterministic_state_dict
+
+    g = _load("ref_rollout2.npz")
+    cfg = BertConfig(num_hidden_layers=2, vocab_size=600, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0, detector_classes=40)
+    bert = _oracle(BertImgModelwithLocationEmbeds, cfg, 9, 0.03)
+    ids, lengths = torch.from_numpy(g["enc_in_ids"]), [int(x) for x in g["enc_in_lengths"]]
+    pad = torch.zeros(ids.shape, dtype=torch.bool)
+    for i, n in enumerate(lengths):
+        pad[i, n:] = True
+    for name, kw in (("rev", dict(reverse_input=True)), ("l2", dict(num_layers=2)),
+                     ("l2bi_rev", dict(num_layers=2, bidirectional=True, reverse_input=True))):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            enc = orollout.OscarEncoder(_Args(), bert, 128, 96, 0.5, **kw).eval()
+            sd = deterministic_state_dict(enc, seed=12, weight_std=0.03)
+            sd.update({k: v for k, v in enc.state_dict().items() if k.startswith("bert.")})
+            enc.load_state_dict(sd)
+            for tag, m in (("bool", pad), ("u8", pad.byte())):
+                with torch.no_grad():
+                    out = enc(ids, lengths, m)
+                for i, n in enumerate(("ctx", "decoder_init", "c_t")):
+                    _close(out[i], g["enc_%s_%s_%s" % (name, tag, n)], 2e-4 if tag == "u8" else 2e-5, "%s %s %s" % (name, tag, n))
+            enc.zero_grad()
+            out = enc(ids, lengths, pad)
+        (out[0].sum() + out[1].sum() + out[2].sum()).backward()
+        gr = {n: p.grad for n, p in enc.named_parameters() if p.grad is not None}
+        names = list(g["enc_%s_grad_names" % name])
+        assert names == sorted(gr)
+        off = g["enc_%s_grad_slice_offsets" % name]
+        for i, n in enumerate(names):
+            want = g["enc_%s_grad_slices" % name][off[i]:off[i + 1]]
+            scale = max(float(np.abs(want).max()), 1e-6)
+            np.testing.assert_allclose(grad_slice(gr[n]).numpy(), want, atol=5e-4 * scale, rtol=1e-3, err_msg=name + " " + n)

@@ -274,21 +274,43 @@ class OscarEncoder(nn.Module):
 
     def _weights(self):
         L = self.lstm
-        names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
-        if self.num_directions == 2:
-            names += [n + "_reverse" for n in names]
-        ps = [getattr(L, n) for n in names] + [self.encoder_lstm2decoder_ht.weight, self.encoder_lstm2decoder_ct.weight]
+        sfxs = ["", "_reverse"][: self.num_directions]
+        ps = [getattr(L, "%s_l%d%s" % (n, l, sfx)) for l in range(self.num_layers) for sfx in sfxs
+              for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        ps += [self.encoder_lstm2decoder_ht.weight, self.encoder_lstm2decoder_ct.weight]
 
         def build():
-            dirs = []
-            for sfx in ["", "_reverse"][: self.num_directions]:
-                wih, whh = getattr(L, "weight_ih_l0" + sfx), getattr(L, "weight_hh_l0" + sfx)
-                b = getattr(L, "bias_ih_l0" + sfx).detach().float() + getattr(L, "bias_hh_l0" + sfx).detach().float()
-                dirs.append((_pad_weight(wih), b.contiguous(), whh.detach().to(BF16).contiguous()))
-            return dict(dirs=dirs, w_ht=_pad_weight(self.encoder_lstm2decoder_ht.weight),
+            layers = []
+            for l in range(self.num_layers):   # nn.LSTM's stacked layers (agent_models.py:223-230): layer l > 0 reads layer l - 1's outputs
+                dirs = []
+                for sfx in sfxs:
+                    wih, whh = getattr(L, "weight_ih_l%d%s" % (l, sfx)), getattr(L, "weight_hh_l%d%s" % (l, sfx))
+                    b = (getattr(L, "bias_ih_l%d%s" % (l, sfx)).detach().float()
+                         + getattr(L, "bias_hh_l%d%s" % (l, sfx)).detach().float())
+                    dirs.append((_pad_weight(wih), b.contiguous(), whh.detach().to(BF16).contiguous()))
+                layers.append(dirs)
+            return dict(layers=layers, dirs=layers[0], w_ht=_pad_weight(self.encoder_lstm2decoder_ht.weight),
                         w_ct=_pad_weight(self.encoder_lstm2decoder_ct.weight))
 
         return self._pk.get(ps, build)
+
+    @staticmethod
+    def _reverse_index(att_mask):
+        """reverse_input (agent_models.py:278-282): `reversed_output[att_mask] = output[:, reverse_idx][att_mask[:, reverse_idx]]`
+        -- a boolean-mask assignment (a uint8 mask indexes as its non-zero pattern): the k-th marked position of a sequence
+        receives the k-th marked position counted from the END, the unmarked ones stay zero.  -> (marked bool [B, S], source
+        position int64 [B, S])."""
+        M = att_mask != 0
+        B, S = M.shape
+        rank = M.long().cumsum(1) - 1                                   # rank of a marked position among its row's marked ones
+        cnt = M.long().sum(1, keepdim=True)
+        pos = torch.arange(S, device=M.device)[None, :].expand(B, S)
+        inv = torch.zeros((B, S), dtype=torch.int64, device=M.device)   # inv[b, r] = the position of rank r
+        inv.scatter_(1, torch.where(M, rank, torch.full_like(rank, S - 1)), torch.where(M, pos, inv))
+        # (unmarked positions scatter their own slot's old value into rank S - 1: harmless unless the row is all marked, and
+        # then nothing is unmarked)
+        src = inv.gather(1, (cnt - 1 - rank).clamp_(0, S - 1))
+        return M, torch.where(M, src, torch.zeros_like(src))
 
     def _forward_autograd(self, inputs, lens, lens_dev, T, mask, att_mask, position_ids, token_type_ids):
         """agent_models.py:256-310 as autograd nodes (training): the trunk node (the pretrain engine's forward / backward),
@@ -311,22 +333,32 @@ class OscarEncoder(nn.Module):
         if output is None:
             output = self.bert(inputs, token_type_ids=token_type_ids, attention_mask=att_mask,
                                position_ids=position_ids)[0].float()
+        if self.reverse_input:                                         # :277-282 (differentiable: a gather and a mask)
+            M, src = self._reverse_index(att_mask)
+            output = torch.where(M[:, :, None], output.gather(1, src[:, :, None].expand(-1, -1, output.shape[2])),
+                                 torch.zeros((), dtype=output.dtype, device=output.device))
         names = [""] + (["_reverse"] if D == 2 else [])
-        ps = [getattr(L, n + sfx) for sfx in names for n in ("weight_ih_l0", "weight_hh_l0")]
+        NL = self.num_layers
+        ps = [getattr(L, "%s_l%d%s" % (n, l, sfx)) for l in range(NL) for sfx in names for n in ("weight_ih", "weight_hh")]
         packs = self._pk_t.get(ps + [self.encoder_lstm2decoder_ht.weight, self.encoder_lstm2decoder_ct.weight], lambda: dict(
-            dirs=[ra.packed_lstm(getattr(L, "weight_ih_l0" + sfx), getattr(L, "weight_hh_l0" + sfx)) for sfx in names],
+            layers=[[ra.packed_lstm(getattr(L, "weight_ih_l%d%s" % (l, sfx)), getattr(L, "weight_hh_l%d%s" % (l, sfx)))
+                     for sfx in names] for l in range(NL)],
             ht=ra.packed_linear(self.encoder_lstm2decoder_ht.weight), ct=ra.packed_linear(self.encoder_lstm2decoder_ct.weight)))
-        outs = []
-        for d, sfx in enumerate(names):
-            outs.append(ra.lstm_sequence(output, getattr(L, "weight_ih_l0" + sfx), getattr(L, "weight_hh_l0" + sfx),
-                                         getattr(L, "bias_ih_l0" + sfx), getattr(L, "bias_hh_l0" + sfx), lens_dev, T,
-                                         d == 1, packs["dirs"][d]))
+        x_l = output
+        for l in range(NL):
+            outs = []
+            for d, sfx in enumerate(names):
+                outs.append(ra.lstm_sequence(x_l, getattr(L, "weight_ih_l%d%s" % (l, sfx)), getattr(L, "weight_hh_l%d%s" % (l, sfx)),
+                                             getattr(L, "bias_ih_l%d%s" % (l, sfx)), getattr(L, "bias_hh_l%d%s" % (l, sfx)),
+                                             lens_dev, T, d == 1, packs["layers"][l][d]))
+            ctx = torch.cat((outs[0][0], outs[1][0]), 2) if D == 2 else outs[0][0]
+            if l + 1 < NL:   # nn.LSTM(dropout=p): on the outputs of every layer but the last, in training mode
+                x_l = torch.nn.functional.dropout(ctx, p=float(L.dropout), training=self.training)
         if D == 2:                                                     # :289-297: (reverse, forward) order for the states
-            ctx = torch.cat((outs[0][0], outs[1][0]), 2)
             h_t = torch.cat((outs[1][1], outs[0][1]), 1)
             c_t = torch.cat((outs[1][2], outs[0][2]), 1)
         else:
-            ctx, h_t, c_t = outs[0]
+            _, h_t, c_t = outs[0]
         decoder_init = ra.dense(h_t, self.encoder_lstm2decoder_ht.weight, self.encoder_lstm2decoder_ht.bias, ACT_TANH,
                                 packs["ht"])                                                            # :299
         if hs * D != self.dec_hidden_size:
@@ -336,12 +368,6 @@ class OscarEncoder(nn.Module):
 
     def forward(self, inputs, lengths, mask, position_ids=None, token_type_ids=None):
         ops._require_hip(inputs)
-        if self.num_layers != 1:
-            raise NotImplementedError("stacked encoder LSTMs (num_layers > 1, agent_models.py:204,221) are not served: the "
-                                      "reference's only caller, agent.py:110-117, leaves the default 1")
-        if self.reverse_input:
-            raise NotImplementedError("reverse_input (agent_models.py:205,210) is not served: the reference's only caller, "
-                                      "agent.py:110-117, leaves it False")
         att_mask = ~mask                                               # :267 (uint8 masks: 254/255, the trunk keeps that)
         B, S = inputs.shape
         H = self.transformer_hidden_size
@@ -359,7 +385,8 @@ class OscarEncoder(nn.Module):
         # exactly the unmasked ones (mask = 1 on padding, agent.py:181) the trunk runs on them alone: compacted rows,
         # no masked keys -- the same values at the positions that are read.
         lay = None
-        if self.compact_rows and hasattr(self.bert, "run_trunk") and mask.shape == (B, S) and not ops.profiling():
+        if (self.compact_rows and hasattr(self.bert, "run_trunk") and mask.shape == (B, S) and not ops.profiling()
+                and not self.reverse_input):   # (reverse_input re-orders the padded positions: the padded layout)
             keep = torch.arange(S, device=dev)[None, :] < lens_dev[:, None]
             if bool(((mask != 0) == ~keep).all()):
                 outs, _, _, _, _ = self.bert.run_trunk(inputs, token_type_ids, None, position_ids, keep=keep)
@@ -373,22 +400,33 @@ class OscarEncoder(nn.Module):
         else:
             seq = self.bert(inputs, token_type_ids=token_type_ids, attention_mask=att_mask,
                             position_ids=position_ids)[0].detach().reshape(B * S, H).to(BF16).contiguous()
+        if self.reverse_input:                                         # :277-282, on the padded bf16 rows
+            M, src = self._reverse_index(att_mask)
+            rows = (torch.arange(B, device=dev)[:, None] * S + src).reshape(-1)
+            seq = seq.index_select(0, rows) * M.reshape(-1, 1).to(seq.dtype)
         w = self._weights()
         hs, D = self.hidden_size, self.num_directions
-        ctx = torch.empty((B, T, D * hs), dtype=torch.float32, device=dev)
-        finals = []
-        for d, (w_ih, b, w_hh) in enumerate(w["dirs"]):
-            xproj = torch.empty((seq.shape[0], 4 * hs), dtype=torch.float32, device=dev)
-            ops.linear(seq, w_ih, b, out=xproj, out_f32=True)
-            h2 = (torch.zeros((B, hs), dtype=torch.float32, device=dev), torch.empty((B, hs), dtype=torch.float32, device=dev))
-            c = torch.zeros((B, hs), dtype=torch.float32, device=dev)                      # init_state :238-254
-            if lay is None:
-                ops.lstm_sequence(xproj.view(B, S, 4 * hs), h2, c, w_hh, T, lens_dev, ctx[:, :, d * hs:(d + 1) * hs],
-                                  reverse=(d == 1))
-            else:
-                ops.lstm_sequence_rows(xproj, lay.start, h2, c, w_hh, T, lens_dev, ctx[:, :, d * hs:(d + 1) * hs],
-                                       reverse=(d == 1))
-            finals.append((h2[0], c))
+        S_l = S
+        for l, dirs in enumerate(w["layers"]):
+            ctx = torch.empty((B, T, D * hs), dtype=torch.float32, device=dev)
+            finals = []
+            for d, (w_ih, b, w_hh) in enumerate(dirs):
+                xproj = torch.empty((seq.shape[0], 4 * hs), dtype=torch.float32, device=dev)
+                ops.linear(seq, w_ih, b, out=xproj, out_f32=True)
+                h2 = (torch.zeros((B, hs), dtype=torch.float32, device=dev), torch.empty((B, hs), dtype=torch.float32, device=dev))
+                c = torch.zeros((B, hs), dtype=torch.float32, device=dev)                      # init_state :238-254
+                if lay is None:
+                    ops.lstm_sequence(xproj.view(B, S_l, 4 * hs), h2, c, w_hh, T, lens_dev, ctx[:, :, d * hs:(d + 1) * hs],
+                                      reverse=(d == 1))
+                else:
+                    ops.lstm_sequence_rows(xproj, lay.start, h2, c, w_hh, T, lens_dev, ctx[:, :, d * hs:(d + 1) * hs],
+                                           reverse=(d == 1))
+                finals.append((h2[0], c))
+            if l + 1 < len(w["layers"]):   # the next stacked layer reads this one's (padded, zero beyond the lengths) outputs
+                Kp = round_up(D * hs, 64)
+                nxt = torch.zeros((B * T, Kp), dtype=BF16, device=dev)
+                nxt[:, :D * hs] = ctx.reshape(B * T, D * hs)
+                seq, lay, S_l = nxt, None, T
         if D == 2:                                                     # :289-294: (reverse, forward) order
             h_t = torch.cat((finals[1][0], finals[0][0]), 1)
             c_t = torch.cat((finals[1][1], finals[0][1]), 1)
