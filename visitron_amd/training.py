@@ -488,11 +488,13 @@ class PretrainEngine(object):
         self.last_rows = Mr
         self.last_layout = lay
         if lay is not None:
-            # the tile quantisation changes with the row count: tune once per bucket of 2048 rows -- 512 below 16 384 rows,
-            # where a bucket's upper edge is otherwise another tile count altogether (7 091 real rows of a B = 36 batch are 28
-            # row tiles of 256, the 8 192 of a 2048-row bucket 32: QKV's 252 tiles are one round, 288 two) -- (the library
-            # then takes the nearest tuned M); a bucket is tuned at its upper edge
-            bucket = round_up(Mr, 2048 if Mr >= 16384 else int(os.environ.get("VT_TUNE_BUCKET_SMALL", "512")))
+            # the tile quantisation changes with the row count: tune once per bucket of 256 rows (512 below 16 384 rows), at
+            # the bucket's upper edge; the library then takes the nearest tuned M.  Rounds 2 - 5 used 2048-row buckets, whose
+            # upper edge is another tile count altogether: 7 091 real rows of a B = 36 batch are 28 row tiles of 256, 8 192 are
+            # 32 (QKV: 252 tiles = one round against 288 = two); 50 845 rows of the B = 256 batch are 199, 51 200 are 200 (QKV:
+            # 1 791 tiles = 7.00 rounds against 1 800 = 7.03, i.e. eight).  profiles/r06/tune_bucket_ab.txt: +1.9 % / +0.6 %.
+            bucket = round_up(Mr, int(os.environ.get("VT_TUNE_BUCKET_LARGE", "256")) if Mr >= 16384
+                              else int(os.environ.get("VT_TUNE_BUCKET_SMALL", "512")))
             if bucket not in self._tuned_rows and bucket < M:
                 ops.autotune_encoder_shapes(bucket, H, I, training=True, device=dev)
                 self._tuned_rows.add(bucket)
