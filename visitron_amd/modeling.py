@@ -1091,9 +1091,10 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
             lay = ops.SeqLayout(keep.to(device=dev, dtype=torch.bool))
             self._last_layout = lay
             xc = x.index_select(0, lay.index)
-            # the row count decides the tile quantisation: tune once per 2048-row bucket (nearest tuned M is used)
-            ops.autotune_encoder_shapes(round_up(lay.rows, 2048), H, self.config.intermediate_size, training=False,
-                                        device=dev)
+            # the row count decides the tile quantisation: tune once per 256-row bucket (512 below 16 384 rows; nearest tuned
+            # M is used) -- the engine's rule, training.py
+            ops.autotune_encoder_shapes(round_up(lay.rows, 256 if lay.rows >= 16384 else 512), H, self.config.intermediate_size,
+                                        training=False, device=dev)
             outs = self.encoder.run(xc, B, S, None, False, hs, seq=lay)
             cls = outs[-1][:lay.rows].index_select(0, lay.start.to(torch.int64))
             pooled = self.pooler.pooled(cls, B, 1)
