@@ -376,9 +376,10 @@ def main():
             default_shape = a.text == 128 and a.regions == 100 and a.batch == (256 if train else 64)
             rels = ()
             if default_shape:
-                rels = (("profiles/r05/train_b256_pmc_hbm_traffic.json",) if train else ("profiles/r05/fwd_b64_pmc_hbm_traffic.json",))
+                name = "train_b256_pmc_hbm_traffic.json" if train else "fwd_b64_pmc_hbm_traffic.json"
+                rels = ("profiles/r06/" + name, "profiles/r05/" + name)
             elif train and a.text == 512 and a.regions == 144 and a.batch == 64:   # BASELINE configs[4]'s shape on one GPU
-                rels = ("profiles/r05/cfg5_pmc_hbm_traffic.json",)
+                rels = ("profiles/r06/cfg5_pmc_hbm_traffic.json", "profiles/r05/cfg5_pmc_hbm_traffic.json")
             for rel in rels:
                 tp = os.path.join(here, rel)
                 if os.path.exists(tp):
