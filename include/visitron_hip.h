@@ -58,9 +58,9 @@ void vt_gemm_tune(int M, int N, int K, int kind, int variant);
 /* The persistent GEMM kernels launch one workgroup per compute unit; with k > 0 they leave k compute units free (for the
  * collective kernels of a data-parallel step that run beside the backward).  Process-global, 0 by default. */
 void vt_gemm_reserve_cus(int k);
-/* Workspace of the persistent GEMM's SHARED TILES (kernel variants 28 .. 32, round 6): the output tiles a launch's workgroups
- * cannot take in whole rounds are cut along K among the workgroups a last round would leave idle; the parts exchange fp32
- * accumulators through this memory (stream-K for the left-over tiles only; the sum is taken in part order: deterministic).
+/* Workspace of the persistent GEMM's STREAM-K REGION (kernel variants 31 / 32; 28 .. 30 run as their plain twins; round 6):
+ * the output tiles a launch's workgroups cannot take in whole rounds are worked as one sequence of K-steps in equal shares;
+ * a tile's parts exchange fp32 accumulators through this memory (the sum is taken in workgroup order: deterministic).
  * `base`: device memory of the calling thread's CURRENT DEVICE, 256-byte aligned, ZEROED by the caller, `bytes` >= one
  * region (vt_gemm_workspace_region_bytes()); every whole region in it serves one launch at a time, launches take the
  * regions round-robin -- so as many launches may be in flight on DIFFERENT streams as there are regions (one stream never
@@ -68,7 +68,7 @@ void vt_gemm_reserve_cus(int k);
  * variants 28 .. 32 return VT_ERR_UNSUPPORTED (the autotuner then leaves them out). */
 int vt_gemm_set_workspace(void* base, int64_t bytes);
 int64_t vt_gemm_workspace_region_bytes(void);
-/* Finishing workgroups of shared tiles wait for the other parts behind a BOUNDED wait (a grid must always drain).
+/* The workgroup finishing a tile of the stream-K region waits for the tile's other parts behind a BOUNDED wait (a grid must always drain).
  * *host_count = how many ran out of it on the current device since the last call (then cleared): non-zero = some GEMM
  * output of an earlier launch is unreliable.  Blocking (4-byte copies): call it where the host synchronises anyway. */
 int vt_gemm_shared_tile_timeouts(unsigned* host_count);

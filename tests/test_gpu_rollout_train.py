@@ -384,3 +384,53 @@ def test_rollout_training_at_the_reference_sizes(dev):
     gl.backward()
     _grads_close("rollout train base sizes encoder", p_enc, r_enc, 5e-2)
     _grads_close("rollout train base sizes decoder", p_dec, r_dec, 5e-2)
+
+
+@pytest.mark.parametrize("with_head_mask", [False, True])
+def test_trunk_level_training_with_output_hidden_states(dev, with_head_mask):
+    """output_hidden_states in trunk-level TRAINING (round 6; oscar/modeling_bert.py:146-158, encoder.py:300-303): the model
+    returns (sequence_output, pooled_output, all_hidden_states) and a loss on EVERY hidden state -- the embedding output and
+    each layer's output -- reaches every parameter: the engine adds the caller's gradient of layer l's output to the running
+    gradient in front of layer l's backward (the C loop one layer at a time; with a head_mask the op-by-op sequence)."""
+    from oracle.modeling import PreTrainOscar as OModel
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config(num_hidden_layers=3, output_hidden_states=True)
+    ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=47, device=dev)
+    rt, pt = ref.bert, prod.bert
+    rt.train()
+    pt.train()
+    B, T, R = 3, 20, 7
+    b = make_batch(cfg, B, text_len=T, region_len=R, seed=9, with_labels=False)
+    g = torch.Generator().manual_seed(3)
+    L = cfg.num_hidden_layers
+    ws = [torch.randn(B, T + R, cfg.hidden_size, generator=g) for _ in range(L + 2)]
+    wp = torch.randn(B, cfg.hidden_size, generator=g)
+    hm = None
+    if with_head_mask:
+        hm = torch.tensor([[1.0, 0.5], [0.0, 1.0], [0.7, 1.3]])
+
+    def loss_of(out, to):
+        seq, pooled, hidden = out
+        assert len(hidden) == L + 1
+        total = (seq * to(ws[L + 1])).sum() + (pooled * to(wp)).sum()
+        for l, h in enumerate(hidden):
+            total = total + (h * to(ws[l])).sum()
+        return total
+
+    want = rt(head_mask=hm, **b)
+    loss_of(want, lambda t: t).backward()
+    got = pt(head_mask=None if hm is None else hm.to(dev), **{k: v.to(dev) for k, v in b.items()})
+    assert len(got) == 3 and all(h.requires_grad for h in got[2])
+    tag = "trunk-level train hidden states%s" % (" head_mask" if with_head_mask else "")
+    check_close(tag + " sequence_output", got[0], want[0], 5e-2)
+    for l in range(L + 1):
+        check_close(tag + " hidden[%d]" % l, got[2][l], want[2][l], 5e-2)
+    loss_of(got, lambda t: t.to(dev)).backward()
+    _grads_close(tag, pt, rt, 2e-2)
+    # under torch.no_grad() (train mode, dropout off here): the same tuple without a graph
+    with torch.no_grad():
+        ng = pt(**{k: v.to(dev) for k, v in b.items()})
+    assert len(ng) == 3 and len(ng[2]) == L + 1 and not ng[2][0].requires_grad

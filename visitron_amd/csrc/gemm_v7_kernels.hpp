@@ -784,11 +784,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
           for (int nt = 0; nt < 8; ++nt)   // (gfx90a and later: a VMEM store takes its data from AGPRs directly)
             // (the tuple as a TIED operand although it is only read: as a plain input the allocator may stage it through
             // another register, and there is none free)
-#ifndef SK_NO_STORE
             asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1" : "+a"(acc[mt][nt]) : "v"(vo), "s"(rs), "s"((8 * mt + nt) * 4096) : "memory");
-#else
-            asm volatile("s_nop 0" :: "s"(rs));
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(sem, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -809,8 +805,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
         __hip_atomic_store(sem, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch finds the counter at zero
       }
       __syncthreads();
-#ifdef SK_TRACE
-      V8_TRACE_RT();   // (debug trace of a head: K loop end, parts arrived, parts added, epilogue end)
+#ifdef SK_TRACE   // (-DSK_TRACE: tools/sk_trace.py's stamps inside the fix-up -- a head: K loop end, parts arrived, parts added, epilogue end)
+      V8_TRACE_RT();
 #endif
       // acc += part, exactly and without the vector ALU (which cannot address AGPRs): the loaded tuple q of a lane is the
       // part's 16x16 tile in the accumulator layout (lane (g, j): rows 4g + r of column j), and
@@ -821,7 +817,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
       float ar[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) ar[r] = ((lane & 15) == 4 * (lane >> 4) + r) ? 1.0f : 0.0f;
-#ifndef SK_NO_ADD
       int pw = iw + 1;   // (a head's tile has at least one other part: do-while -- no zero-trip path around the tied operands)
       do {
         const u32x4 rs = v7_rsrc((const char*)g.sk_ws + (long)(xcd * V8_SK_WGS_PER_XCD + pw) * V8_SK_PART_BYTES, (unsigned)V8_SK_PART_BYTES);
@@ -852,7 +847,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
         }
 #undef V8_SK_LOAD
       } while (++pw <= last);
-#endif
       asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results, before the epilogue reads them
 #ifdef SK_TRACE
       V8_TRACE_RT();

@@ -703,7 +703,7 @@ class PretrainEngine(object):
                 out.append((s_, e_))
         return out
 
-    def _trunk_bwd(self, st, g32, acc, comm=None, word_grad_ready=False):
+    def _trunk_bwd(self, st, g32, acc, comm=None, word_grad_ready=False, d_hidden=None):
         """Back through the trunk: g32 fp32 [rows, H] = dL/d(sequence output) in the layout of the forward (st), or None
         when the caller has already put it (bf16) into bufs.g; the gradients of the encoder layers, the embeddings and the
         region projection land in the flat slab."""
@@ -721,8 +721,27 @@ class PretrainEngine(object):
         g = bufs.g[:Mr]
         if g32 is not None:
             g.copy_(g32)
+        if d_hidden is not None and comm is not None:
+            raise NotImplementedError("gradients of intermediate hidden states together with the chunked data-parallel backward")
         if ops.profiling() or hs is not None:
-            self._encoder_backward_unrolled(bufs, x_enc, enc_mask, g, B, S, acc, p_h, p_a, seed, lay, mask_additive, hs)
+            self._encoder_backward_unrolled(bufs, x_enc, enc_mask, g, B, S, acc, p_h, p_a, seed, lay, mask_additive, hs,
+                                            inject=d_hidden)
+        elif d_hidden is not None:
+            # a caller's gradients with respect to intermediate hidden states (output_hidden_states in trunk-level training,
+            # oscar/modeling_bert.py:146-158): the C loop one layer at a time, d_hidden[l + 1] (the output of layer l; bf16
+            # rows in the forward's layout) added to the running gradient in front of layer l's backward, d_hidden[0] (the
+            # embedding output) behind layer 0's.  (d_hidden[L] is part of g already.)
+            for lo in range(L - 1, -1, -1):
+                if lo + 1 < L and d_hidden[lo + 1] is not None:
+                    g.add_(d_hidden[lo + 1])
+                sub = lambda arr, typ: (typ * 1).from_address(ctypes.addressof(arr) + lo * ctypes.sizeof(typ))
+                x_in = x_enc if lo == 0 else bufs.layers[lo - 1]["out"]
+                ops.encoder_backward(sub(self.w_tab, _lib.LayerWeights), sub(self.wt_tab, _lib.LayerWeightsT),
+                                     sub(bufs.acts, _lib.LayerActs), sub(self.g_tab, _lib.LayerGrads), x_in, enc_mask, mask_additive,
+                                     g, bufs.ws, B, S, H, nh, I, cfg.layer_norm_eps, accumulate=acc, layer0=lo, seq=lay,
+                                     **dp_kw, **self._overlap_kw(bufs))
+            if d_hidden[0] is not None:
+                g.add_(d_hidden[0])
         elif comm is None:
             ops.encoder_backward(self.w_tab, self.wt_tab, bufs.acts, self.g_tab, x_enc, enc_mask, mask_additive, g, bufs.ws, B, S,
                                  H, nh, I, cfg.layer_norm_eps, accumulate=acc, seq=lay, **dp_kw, **self._overlap_kw(bufs))
@@ -800,7 +819,7 @@ class PretrainEngine(object):
                 gi.copy_(self.dw_img[:, :D]); gl.copy_(self.dw_img[:, D:D + 128]); gbi.copy_(self.db_img); gbl.copy_(self.db_img)
 
     # ------------------------------------------------------------------------------ trunk-level training
-    def trunk_forward(self, batch, head_mask=None, training=None, unmasked_only=False):
+    def trunk_forward(self, batch, head_mask=None, training=None, unmasked_only=False, want_hidden=False):
         """BertImgModelwithLocationEmbeds.forward for a caller that back-propagates through it (the rollout's
         OscarEncoder, agent.py:493-518): -> (sequence_output fp32 [B,S,H], pooled_output fp32 [B,H], state).
         unmasked_only: the caller vouches that it reads sequence_output only at positions whose attention mask is not
@@ -824,21 +843,45 @@ class PretrainEngine(object):
                     + ln.bias.detach().float())
         else:
             last = st.seq.float()
-        if st.lay is None:
-            seq = last.view(st.B, st.S, st.H)
-        else:
-            seq = torch.zeros((st.M, st.H), dtype=torch.float32, device=st.dev)
-            seq.index_copy_(0, st.lay.index, last)
-            seq = seq.view(st.B, st.S, st.H)
-        return seq, st.pooled.clone(), st
+        def padded(rows32):
+            if st.lay is None:
+                return rows32.view(st.B, st.S, st.H)
+            out = torch.zeros((st.M, st.H), dtype=torch.float32, device=st.dev)
+            out.index_copy_(0, st.lay.index, rows32)
+            return out.view(st.B, st.S, st.H)
 
-    def trunk_backward(self, st, d_seq, d_pooled=None, accumulate=False):
+        seq = padded(last)
+        if not want_hidden:
+            return seq, st.pooled.clone(), st
+        # all_hidden_states (oscar/modeling_bert.py:146-158): the embedding output, then every layer's output -- fp32, rebuilt
+        # from the fp16 sums and the row statistics where the layer keeps no higher-precision copy (as `last` above)
+        hidden = [padded(st.x_enc[:n].float())]
+        for l, d in enumerate(st.bufs.layers[:-1]):
+            if st.bufs.ln_residual:
+                ln = self.model.bert.encoder.layer[l].output.LayerNorm
+                hidden.append(padded((d["out_pre"][:n].float() - d["ln2_mean"][:n, None]) * d["ln2_rstd"][:n, None]
+                                     * ln.weight.detach().float() + ln.bias.detach().float()))
+            else:
+                hidden.append(padded(d["out"][:n].float()))
+        hidden.append(seq.clone())
+        return seq, st.pooled.clone(), st, hidden
+
+    def trunk_backward(self, st, d_seq, d_pooled=None, accumulate=False, d_hidden=None):
         """Gradients of the trunk's parameters into the flat slab, given dL/d(sequence_output) [B,S,H] and / or
         dL/d(pooled_output) [B,H] (either may be None).  The pooler's gradients are zeroed when d_pooled is None, the
         region projection's when the forward had no regions."""
         m, bufs, acc = self.model, st.bufs, bool(accumulate)
         B, S, H, M, Mr, lay = st.B, st.S, st.H, st.M, st.Mr, st.lay
         g32 = bufs.g_seq32[:Mr]
+        rows = lambda t: (t.detach().reshape(M, H).float() if lay is None
+                          else t.detach().reshape(M, H).float().index_select(0, lay.index))
+        extra = None
+        if d_hidden is not None and any(t is not None for t in d_hidden):
+            # d_hidden: L + 1 entries (None where the caller read nothing): the last one is dL/d(sequence_output) again
+            if d_hidden[-1] is not None:
+                d_seq = d_hidden[-1] if d_seq is None else d_seq + d_hidden[-1]
+            if any(t is not None for t in d_hidden[:-1]):
+                extra = [None if t is None else rows(t).to(BF16) for t in d_hidden[:-1]] + [None]
         if d_seq is None:
             g32.zero_()
         elif lay is None:
@@ -854,7 +897,7 @@ class PretrainEngine(object):
         elif not acc:
             self._grad(pw).zero_()
             self._grad(pb).zero_()
-        self._trunk_bwd(st, g32, acc)
+        self._trunk_bwd(st, g32, acc, d_hidden=extra)
         if st.img is None and not acc:
             for prm in (m.bert.img_embedding.weight, m.bert.img_embedding.bias, m.bert.location_embeds.weight,
                         m.bert.location_embeds.bias):
@@ -916,12 +959,14 @@ class PretrainEngine(object):
         return dict(ws_b=bufs.ws_b, side_stream=self._side_stream)
 
     def _encoder_backward_unrolled(self, bufs, x0, mask, g, B, S, acc, p_h=0.0, p_a=0.0, seed=0, lay=None,
-                                   mask_additive=False, hs=None):
+                                   mask_additive=False, hs=None, inject=None):
         cfg = self.cfg
         nh, eps, M = cfg.num_attention_heads, cfg.layer_norm_eps, x0.shape[0]
         rowed = ("g_pre", "g_pre2", "g_mid", "g_ctx", "g_qkv", "g_pre_d", "g_pre2_d", "dq32")
         w = {k: (v[:M] if k in rowed else v) for k, v in bufs.ws_t.items()}
         for l in range(cfg.num_hidden_layers - 1, -1, -1):
+            if inject is not None and l + 1 < cfg.num_hidden_layers and inject[l + 1] is not None:
+                g.add_(inject[l + 1])   # dL/d(output of layer l) from a caller that read the intermediate hidden states
             (t, gr), a, (_, wt) = self._keep[l], bufs.layers[l], self.wt[l]
             a = {k: (v if k in ("lse", "keep_bits") else v[:M]) for k, v in a.items()}
             x_in = x0 if l == 0 else bufs.layers[l - 1]["out"][:M]
@@ -948,6 +993,8 @@ class PretrainEngine(object):
                        dict(dy=g_pre_dn, x=a["mid"], dw=gr["d_w_out"], db=gr["d_b_out"], accumulate=acc),
                        dict(dy=w["g_qkv"], x=x_in, dw=gr["d_w_qkv"], db=gr["d_b_qkv"], accumulate=acc),
                        dict(dy=g_pre2_dn, x=a["ctx"], dw=gr["d_w_ao"], db=gr["d_b_ao"], accumulate=acc)], M)
+        if inject is not None and inject[0] is not None:
+            g.add_(inject[0])           # ... and with respect to the embedding output
 
     # ------------------------------------------------------------------------------ optimizer
     def _require_ownership(self):
@@ -1185,17 +1232,18 @@ class _TrunkWithGrads(torch.autograd.Function):
     parameter gradients to autograd."""
 
     @staticmethod
-    def forward(ctx, engine, batch, head_mask, unmasked_only, *params):
-        seq, pooled, st = engine.trunk_forward(batch, head_mask, unmasked_only=unmasked_only)
+    def forward(ctx, engine, batch, head_mask, unmasked_only, want_hidden, *params):
+        out = engine.trunk_forward(batch, head_mask, unmasked_only=unmasked_only, want_hidden=want_hidden)
+        seq, pooled, st = out[:3]
         ctx.engine, ctx.st = engine, st
         ctx.names = [engine._name_of(p) for p in params]
         ctx.set_materialize_grads(False)
-        return seq, pooled
+        return (seq, pooled) + (tuple(out[3]) if want_hidden else ())
 
     @staticmethod
-    def backward(ctx, d_seq, d_pooled):
+    def backward(ctx, d_seq, d_pooled, *d_hidden):
         eng, st = ctx.engine, ctx.st
-        eng.trunk_backward(st, d_seq, d_pooled)
+        eng.trunk_backward(st, d_seq, d_pooled, d_hidden=list(d_hidden) if d_hidden else None)
         f = eng.flat
         unused = set()
         if st.img is None:
@@ -1203,7 +1251,7 @@ class _TrunkWithGrads(torch.autograd.Function):
         if d_pooled is None:
             unused.add("bert.pooler.")
         grads = [None if n.startswith(tuple(unused)) else f.view(f.g, n).clone() for n in ctx.names]
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class _TrunkLazyGrads(torch.autograd.Function):
@@ -1239,16 +1287,18 @@ def lazy_autograd_trunk(trunk, batch, head_mask, seq, pooled):
     return _TrunkLazyGrads.apply(trunk, batch, head_mask, seq, pooled, *params)
 
 
-def autograd_trunk_forward(trunk, batch, head_mask=None, unmasked_only=False):
+def autograd_trunk_forward(trunk, batch, head_mask=None, unmasked_only=False, want_hidden=False):
     """BertImgModelwithLocationEmbeds.forward in training mode: (sequence_output, pooled_output) that back-propagate into the
     trunk's parameters through the HIP backward; under torch.no_grad() the same forward (dropout included) without a graph.
-    unmasked_only: see PretrainEngine.trunk_forward."""
+    unmasked_only: see PretrainEngine.trunk_forward.  want_hidden: a third element, the tuple of all_hidden_states
+    (embedding output + every layer's output, oscar/modeling_bert.py:146-158), each differentiable like sequence_output."""
     eng = _bridge_engine(trunk)
     if not torch.is_grad_enabled():
-        seq, pooled, _ = eng.trunk_forward(batch, head_mask, unmasked_only=unmasked_only)
-        return seq, pooled
+        out = eng.trunk_forward(batch, head_mask, unmasked_only=unmasked_only, want_hidden=want_hidden)
+        return (out[0], out[1]) + ((tuple(out[3]),) if want_hidden else ())
     params = [p for p in trunk.parameters() if p.requires_grad]
-    return _TrunkWithGrads.apply(eng, batch, head_mask, bool(unmasked_only), *params)
+    out = _TrunkWithGrads.apply(eng, batch, head_mask, bool(unmasked_only), bool(want_hidden), *params)
+    return (out[0], out[1]) + ((tuple(out[2:]),) if want_hidden else ())
 
 
 def _bridge_engine(model):
