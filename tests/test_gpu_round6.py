@@ -311,3 +311,81 @@ def test_shared_tiles_in_the_deferred_layernorm_gemms(dev, variant):
         x, y = res[variant][i], res[plain][i]
         assert float((x - y).abs().max()) <= float(y.abs().max()) * tol, i
     assert float((res[variant][3] - res[plain][3]).abs().max()) <= 1e-2 * float(res[plain][3].abs().max())
+
+
+# ------------------------------------------------------------------------------------------------
+# Variant 33: split-K of the one-tile kernel, the whole epilogue behind the ordered plane sum
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(912, 768, 3072), (1534, 768, 2304), (4088, 768, 3072), (300, 200, 1024), (1000, 2304, 768),
+                                   (640, 768, 768)])
+def test_splitk_with_the_whole_epilogue_equals_the_fp32_product(dev, M, N, K):
+    """Small M, long K (the reference's own per-GPU batches: 2 x 767, 8 x 511 rows): ksplit copies of the tile list write fp32
+    planes into the GEMM workspace, one elementwise kernel sums them in order and runs the register epilogue.  Every epilogue
+    kind the training layer uses -- bias, dropout, fp16 / bf16 residual, rebuilt-LayerNorm residual, ACT_MUL, GELU with its
+    derivative output, fp32 output, a ragged N -- against fp32 on the same operands; two launches agree bitwise."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _rand((M, K), g).to(BF16).to(dev)
+    w = _rand((N, K), g, 0.05).to(BF16).to(dev)
+    b = _rand((N,), g, 0.1).to(dev)
+    r = (_rand((M, N), g) * 3.0).to(F16).to(dev)
+    f = _rand((M, N), g).to(BF16).to(dev)
+    gamma, beta = (1 + 0.2 * _rand((N,), g)).to(dev), (0.3 * _rand((N,), g)).to(dev)
+    mean = r.float().mean(-1)
+    rstd = 1.0 / torch.sqrt((r.float() - mean[:, None]).pow(2).mean(-1) + 1e-12)
+    prod = a.float() @ w.float().t()
+    drop = (0.1, 77, 5)
+    ops.set_gemm_variant(33)
+    try:
+        out = torch.full((M, N), float("nan"), dtype=BF16, device=dev)
+        ops.linear(a, w, b, out=out)
+        out_b = ops.linear(a, w, b)
+        o32 = ops.linear(a, w, b, out_f32=True)
+        o_sum = torch.empty((M, N), dtype=F16, device=dev)
+        ops.linear(a, w, b, residual=r, out=o_sum, drop=drop)
+        o_mul = ops.linear(a, w, None, residual=f, act=ops.ACT_MUL)
+        pre = torch.empty((M, N), dtype=BF16, device=dev)
+        o_gelu = ops.linear(a, w, b, act=ops.ACT_GELU, pre_act_out=pre)
+        o_ln = None
+        if N % 16 == 0:
+            o_ln = torch.empty((M, N), dtype=F16, device=dev)
+            ops.linear(a, w, b, out=o_ln, residual=r, residual_ln=(mean, rstd, gamma, beta))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_variant(-1)
+    want = prod + b
+    scale = float(want.abs().max())
+    assert not bool(torch.isnan(out).any()) and torch.equal(out, out_b)
+    assert float((out.float() - want).abs().max()) <= scale * 2.0 ** -7
+    assert float((o32 - want).abs().max()) <= scale * 2.0 ** -15 * (K / 64) ** 0.5 + 1e-4
+    keep = ops.dropout_mask(M * N, drop, device=dev).view(M, N).float()
+    ws = want * keep / 0.9 + r.float()
+    assert float((o_sum.float() - ws).abs().max()) <= float(ws.abs().max()) * 2.0 ** -10
+    wm = prod * f.float()
+    assert float((o_mul.float() - wm).abs().max()) <= float(wm.abs().max()) * 2.0 ** -7
+    wg = torch.nn.functional.gelu(want)
+    assert float((o_gelu.float() - wg).abs().max()) <= max(1.0, float(wg.abs().max())) * 2.0 ** -7
+    x = want.double()
+    dg = (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5).float()
+    assert float((pre.float() - dg).abs().max()) <= 2.0 ** -6
+    if o_ln is not None:
+        wl = want + (r.float() - mean[:, None]) * rstd[:, None] * gamma + beta
+        assert float((o_ln.float() - wl).abs().max()) <= float(wl.abs().max()) * 2.0 ** -10
+
+
+def test_splitk_variant_in_a_tune_table_falls_back_where_nothing_can_be_split(dev):
+    """A table entry naming variant 33 that the library applies to a neighbouring row count with too many tiles to split:
+    the default kernel runs instead of an error."""
+    from visitron_amd import _lib, ops
+
+    ops.ensure_gemm_workspace()
+    M, N, K = 40000, 768, 768
+    _lib.load().vt_gemm_tune(M, N, K, ops.tune_kind(ops.ACT_NONE), 33)
+    g = torch.Generator().manual_seed(1)
+    a = _rand((M, K), g).to(BF16).to(dev)
+    w = _rand((N, K), g, 0.05).to(BF16).to(dev)
+    out = ops.linear(a, w)
+    want = a.float() @ w.float().t()
+    assert float((out.float() - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -7
+    _lib.load().vt_gemm_tune(M, N, K, ops.tune_kind(ops.ACT_NONE), 16)

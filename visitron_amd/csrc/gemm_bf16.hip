@@ -795,6 +795,32 @@ static int launch_kernel(K kern, const GemmArgs& g, int lds_bytes, hipStream_t s
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
+// ---- variant 33: split-K with the WHOLE epilogue behind the reduction (round 6) ----------------------------------------
+// Small batches leave a long-K product a handful of 256x256 tiles, each a chain of K / 64 dependent K-steps of ~0.8 us whatever
+// M is (the reference's own batch sizes: 2 x 767 or 8 x 511 rows per GPU; [912, 768] x 3 072 takes 38 us for 3.6 GFLOP).
+// ksplit copies of the tile list of the one-tile-per-workgroup kernel each take a share of the K-steps and leave their
+// accumulators RAW in the caller's GEMM workspace (vt_gemm_set_workspace; AGPR-sourced stores, no epilogue); one further
+// kernel sums a tile's copies IN ORDER (deterministic) and runs the ordinary register epilogue -- bias, activation, dropout,
+// residual / rebuilt-LayerNorm residual, second output, fp16 / bf16 / fp32 store, row remap -- on the sums (epi_row_direct, the
+// code the register-epilogue kernels run: every epilogue kind is served).  The autotuner decides per (M, N, K, kind).
+int vt_gemm_splitk_tiles_launch(const GemmArgs& g, int act, int out_f32, int ks, hipStream_t stream);   // gemm_v7.hip
+template <int ACT, bool OUT_F32>
+static int launch_splitk_epi(const GemmArgs& g, hipStream_t stream) {
+  const int cus = vt_device_cus();
+  if (cus <= 0) return VT_ERR_HIP;
+  const long tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+  const int nk = g.K >> 6;
+  // copies of the tile list: a copy's chain is nk / ks K-steps of ~0.8 us, the epilogue kernel reads ks x tiles x 256 KiB at
+  // ~5 TB/s (0.05 us per copy and tile): the sum is smallest near ks = sqrt(16 nk / tiles) -- within one round of workgroups,
+  // at least three K-steps per copy
+  long ks = (long)(sqrtf(16.0f * (float)nk / (float)tiles) + 0.5f);
+  if (ks > cus / tiles) ks = cus / tiles;
+  if (ks > nk / 3) ks = nk / 3;
+  if (ks > 16) ks = 16;
+  if (ks < 2 || (g.K & 63)) return VT_ERR_UNSUPPORTED;
+  return vt_gemm_splitk_tiles_launch(g, ACT, OUT_F32 ? 1 : 0, (int)ks, stream);
+}
+
 template <int ACT, bool OUT_F32>
 static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
   switch (variant) {
@@ -825,6 +851,7 @@ static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
     case 21: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 4);   // ... on 128-row tiles (small batches)
     // 28 .. 32: the persistent kernel (256 .. 128-row tiles) with its left-over tiles SHARED along K among the workgroups a
     // last round would leave idle (GemmArgs::sk_parts; needs vt_gemm_set_workspace)
+    case 33: return launch_splitk_epi<ACT, OUT_F32>(g, stream);
     case 28: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 8, true);
     case 29: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 7, true);
     case 30: return vt_gemm_v8_launch(g, ACT, OUT_F32 ? 1 : 0, stream, 6, true);
@@ -919,7 +946,11 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
       }
     }
   }
-  return launch(g, variant);
+  const int rc = launch(g, variant);
+  // a table entry tuned at a neighbouring row count may name the split-K variant where this M leaves it nothing to split
+  // (or no workspace is registered on this device): the default kernel instead -- never when the variant was forced
+  if (rc == VT_ERR_UNSUPPORTED && variant == 33 && g_gemm_variant < 0) return launch(g, GEMM_DEFAULT_VARIANT);
+  return rc;
 }
 
 // ---- deferred-LayerNorm GEMMs (GemmArgs::ln_mode; gemm_v7_ln.hip) --------------------------------------------------

@@ -66,6 +66,12 @@ static bool v8_take_region(GemmArgs& g) {
   return true;
 }
 int vt_gemm_v8_take_region(GemmArgs& g) { return v8_take_region(g) ? 1 : 0; }   // gemm_v7_ln.hip
+// one region of the workspace as plain scratch (the split-K planes of variant 33, gemm_bf16.hip); null: none / too small
+void* vt_gemm_take_scratch(long bytes) {
+  const int dev = vt_current_device();
+  if (dev < 0 || dev >= VT_MAX_DEVICES || g_sk_ws[dev].regions <= 0 || bytes > V8_SK_REGION_BYTES - 4096) return nullptr;
+  return g_sk_ws[dev].base + (long)(g_sk_ctr.fetch_add(1) % (unsigned)g_sk_ws[dev].regions) * V8_SK_REGION_BYTES;
+}
 
 static int v8_grid(int tiles) {
   const int cus = vt_gemm_persistent_cus();
@@ -140,6 +146,85 @@ static int launch_v7(const GemmArgs& g, hipStream_t stream, int mtn) {
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES) != hipSuccess) return VT_ERR_HIP;
   hipLaunchKernelGGL(kern, dim3(g7.tiles_m * g7.tiles_n * (g7.ksplit > 1 ? g7.ksplit : 1)), dim3(256), V7_LDS_BYTES, stream, g7);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// ---- variant 33: split-K over raw partial tiles + one epilogue kernel (see gemm_bf16.hip, launch_splitk_epi) -------------
+// Workgroup (tile, mt, nh) of splitk_tiles_epilogue: the 16 mt-rows of each wave of the 256x256 tile, one 64-column half;
+// thread tid reads, per copy, the 16-byte groups the GEMM's lane tid stored (coalesced), adds the copies in order and hands
+// the 16 sums of a row to the register epilogue.
+template <int ACT, bool OUT_F32>
+__global__ __launch_bounds__(256) void splitk_tiles_epilogue(GemmArgs g, int ksplit) {
+  const int tile = blockIdx.x >> 4, mt = (blockIdx.x >> 1) & 7, nh = blockIdx.x & 1;
+  const int bm = tile / g.tiles_n, bn = tile - bm * g.tiles_n;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, gq = lane >> 4, j = lane & 15;
+  const int row = bm * 256 + 128 * wm + 16 * mt + j;
+  const int nb = bn * 256 + 128 * wn + 64 * nh + 16 * gq;
+  if (row >= g.M || nb >= g.N) return;
+  const long stride = (long)g.tiles_m * g.tiles_n * (V8_SK_PART_BYTES / 4);   // floats between two copies of a tile
+  const float* base = g.sk_ws + (long)tile * (V8_SK_PART_BYTES / 4) + (long)(8 * mt + 4 * nh) * 1024 + (long)tid * 4;
+  f32x4 a[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a[t] = *(const f32x4*)(base + t * 1024);
+  int s = 1;
+  for (; s + 1 < ksplit; s += 2) {   // two copies' loads in flight; the sum stays in copy order
+    f32x4 u[4], v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      u[t] = *(const f32x4*)(base + s * stride + t * 1024);
+      v[t] = *(const f32x4*)(base + (s + 1) * stride + t * 1024);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[t][e] = (a[t][e] + u[t][e]) + v[t][e];
+  }
+  if (s < ksplit) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 u = *(const f32x4*)(base + s * stride + t * 1024);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[t][e] += u[e];
+    }
+  }
+  const bool full = nb + 16 <= g.N;
+  float bv[16];
+  epi_load_bias(g, nb, full, bv);
+  epi_row_direct<ACT, OUT_F32>(g, a, bv, row, nb, full);
+}
+
+template <int ACT, bool OUT_F32>
+static int launch_splitk_tiles(const GemmArgs& g, int ks, hipStream_t stream) {
+  GemmArgs gs = g;
+  gs.tiles_m = (g.M + 255) / 256;
+  gs.tiles_n = (g.N + 255) / 256;
+  const int ntile = gs.tiles_m * gs.tiles_n;
+  if ((g.K & 63) || 256L * g.lda * 2 + 2L * g.K >= (1L << 31) || 256L * g.ldw * 2 + 2L * g.K >= (1L << 31)) return VT_ERR_UNSUPPORTED;
+  float* ws = (float*)vt_gemm_take_scratch((long)ks * ntile * V8_SK_PART_BYTES);
+  if (!ws) return VT_ERR_UNSUPPORTED;
+  gs.sk_ws = ws;
+  gs.ksplit = ks;
+  GemmArgs gk = gs;   // the K-step copies: no epilogue operands at all
+  gk.bias = nullptr; gk.R = nullptr; gk.C2 = nullptr; gk.drop.thresh = 0; gk.r_mean = nullptr; gk.grp_rows = 0;
+  auto kern = gemm_nt_bf16_v7<ACT_NONE, false, true, false, 8, 0>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS_BYTES) != hipSuccess) return VT_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(ntile * ks), dim3(256), V7_LDS_BYTES, stream, gk);
+  hipLaunchKernelGGL((splitk_tiles_epilogue<ACT, OUT_F32>), dim3(ntile * 16), dim3(256), 0, stream, gs, ks);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+int vt_gemm_splitk_tiles_launch(const GemmArgs& g, int act, int out_f32, int ks, hipStream_t stream) {
+  switch (act * 2 + (out_f32 ? 1 : 0)) {
+    case 0: return launch_splitk_tiles<ACT_NONE, false>(g, ks, stream);
+    case 1: return launch_splitk_tiles<ACT_NONE, true>(g, ks, stream);
+    case 2: return launch_splitk_tiles<ACT_GELU, false>(g, ks, stream);
+    case 3: return launch_splitk_tiles<ACT_GELU, true>(g, ks, stream);
+    case 4: return launch_splitk_tiles<ACT_TANH, false>(g, ks, stream);
+    case 5: return launch_splitk_tiles<ACT_TANH, true>(g, ks, stream);
+    case 6: return launch_splitk_tiles<ACT_MUL, false>(g, ks, stream);
+    case 7: return launch_splitk_tiles<ACT_MUL, true>(g, ks, stream);
+    default: return VT_ERR_UNSUPPORTED;
+  }
 }
 
 int vt_gemm_v8_launch(const GemmArgs& g, int act, int out_f32, hipStream_t stream, int mtn, bool sk) {

@@ -540,6 +540,25 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v7(GemmArgs g) {
       }                                                                                                   \
     }                                                                                                     \
   }
+  // split-K with raw partial tiles (variant 33, GemmArgs::sk_ws set): copy `split` of tile (bm, bn) leaves its accumulators
+  // as they sit in the registers -- AGPR-sourced 16-byte stores, 256 KiB per workgroup -- in slot split * tiles + bm * tiles_n +
+  // bn of the workspace; splitk_tiles_epilogue (gemm_v7.hip) sums the slots in order and runs the register epilogue.  Only
+  // the instantiation the launcher names carries the code.
+  if constexpr (EPI_LDS && LNM == 0 && MTN == 8 && !HAS_R && ACT == ACT_NONE && !OUT_F32) {
+    if (g.ksplit > 1 && g.sk_ws) {
+      const int ntile = g.tiles_m * g.tiles_n;
+      const int split = ks_k0 / (((g.K >> 6) + g.ksplit - 1) / g.ksplit);
+      const u32x4 rs = v7_rsrc((const char*)g.sk_ws + ((long)split * ntile + (long)bm * g.tiles_n + bn) * V8_SK_PART_BYTES,
+                               (unsigned)V8_SK_PART_BYTES);
+      const int vo = tid * 16;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+          asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"a"(acc[mt][nt]), "v"(vo), "s"(rs), "s"((8 * mt + nt) * 4096) : "memory");
+      return;
+    }
+  }
 #ifdef V7_DIAG
   {
     float t = 0.f;

@@ -241,7 +241,8 @@ def encoder_forward_ln(layer_weights, stream_a, stream_b, qkv, ctx, mid, mask, m
 # their plain twins 16 / 18 / 19).  Measured negative on MI355X at every row count tried (profiles/r06/streamk_ab.txt: +10 .. +47 %
 # against the best plain variant, parity at best): opt-in candidates (VT_GEMM_STREAMK=1), never timed by default.
 STREAMK = os.environ.get("VT_GEMM_STREAMK", "0") == "1"
-GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16, 18, 19, 20, 21, 22, 23) + ((31, 32) if STREAMK else ())   # (24 .. 27: the measured-negative redesigns of round 4 live in tools/experiments, outside the product library)
+# 33: split-K of the one-tile kernel with the whole epilogue behind the ordered plane sum (small M, long K; needs the workspace)
+GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16, 18, 19, 20, 21, 22, 23, 33) + ((31, 32) if STREAMK else ())   # (24 .. 27: the measured-negative redesigns of round 4 live in tools/experiments, outside the product library)
 
 
 # -1: shape table / heuristic; -2: the same plus the tail launch of the persistent kernel's last round (VT_GEMM_TAIL_SPLIT=1)
@@ -250,7 +251,7 @@ AUTO_VARIANT = -2 if os.environ.get("VT_GEMM_TAIL_SPLIT") == "1" else -1
 
 def set_gemm_variant(v):
     """Tuning/test hook: force one GEMM kernel variant (-1: shape table / heuristic)."""
-    if int(v) in (28, 29, 30, 31, 32):
+    if int(v) in SHARED_TILE_VARIANTS:
         ensure_gemm_workspace()
     _lib.load().vt_debug_set_gemm_variant(int(AUTO_VARIANT if v == -1 else v))
 # The persistent kernel (16) launches one workgroup per CU and needs every CU to itself (512 registers per wave, 132 KiB
@@ -259,7 +260,7 @@ def set_gemm_variant(v):
 # one-tile-per-workgroup forms of the same kernel (15, 22, 23) are within 1 % over the step and simply queue their tiles.
 PERSISTENT_GEMM_OK = True
 PERSISTENT_VARIANTS = (16, 18, 19, 20, 21, 28, 29, 30, 31, 32)
-SHARED_TILE_VARIANTS = (28, 29, 30, 31, 32)   # the persistent kernel sharing its left-over tiles along K (needs the workspace below)
+SHARED_TILE_VARIANTS = (28, 29, 30, 31, 32, 33)   # variants that need the GEMM workspace below (stream-K region; split-K planes)
 
 
 def multi_rank_gemm_policy(environ=None):
@@ -288,7 +289,7 @@ def force_gemm_variant(v):
     With one variant everywhere two processes run the same summation order, so their results can be compared exactly."""
     global _forced_variant
     _forced_variant = None if v is None else int(v)
-    if v is not None and int(v) in (28, 29, 30, 31, 32):
+    if v is not None and int(v) in SHARED_TILE_VARIANTS:
         ensure_gemm_workspace()
     _lib.load().vt_debug_set_gemm_variant(AUTO_VARIANT if v is None else int(v))
 
@@ -347,7 +348,7 @@ def autotune_linear(M, N, K, act=ACT_NONE, residual=False, pre_act=False, device
     if key in _tuned:
         return _tuned[key]
     lib = _lib.load()
-    have_ws = STREAMK and ensure_gemm_workspace(device)   # (before any variant is registered: 28 .. 32 need it at launch time)
+    have_ws = ensure_gemm_workspace(device)   # (before any variant is registered: 28 .. 33 need it at launch time)
     # The training layer's residual GEMMs (out-proj, FFN-down) read an fp16 residual and write the fp16 pre-LayerNorm sum
     # (F16_STREAM); the grouped epilogue of variants 9 / 10 is bf16-only and the library would silently run variant 1 in their
     # place -- a kernel never timed for the shape.  Such kinds are tuned with the dtypes they run with, without 9 / 10.
