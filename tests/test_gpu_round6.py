@@ -389,3 +389,34 @@ def test_splitk_variant_in_a_tune_table_falls_back_where_nothing_can_be_split(de
     want = a.float() @ w.float().t()
     assert float((out.float() - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -7
     _lib.load().vt_gemm_tune(M, N, K, ops.tune_kind(ops.ACT_NONE), 16)
+
+
+@pytest.mark.parametrize("M,N,K", [(912, 768, 3072), (4088, 768, 2304), (300, 200, 1024), (640, 768, 128)])
+def test_three_stage_ring_of_the_128_tile_kernel(dev, M, N, K):
+    """Variant 35 (gemm_nt_bf16_v2 on a ring of three stages; K of one, two and many K-steps): bias, fp16 residual with dropout,
+    fp32 output and GELU against fp32; bitwise equal to the two-stage kernel (the same sums in the same order)."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K + 35)
+    a = _rand((M, K), g).to(BF16).to(dev)
+    w = _rand((N, K), g, 0.05).to(BF16).to(dev)
+    b = _rand((N,), g, 0.1).to(dev)
+    r = (_rand((M, N), g) * 3.0).to(F16).to(dev)
+    drop = (0.1, 5, 2)
+    res = {}
+    for v in (1, 35):
+        ops.set_gemm_variant(v)
+        try:
+            o = ops.linear(a, w, b)
+            o32 = ops.linear(a, w, b, out_f32=True)
+            os_ = torch.empty((M, N), dtype=F16, device=dev)
+            ops.linear(a, w, b, residual=r, out=os_, drop=drop)
+            og = ops.linear(a, w, b, act=ops.ACT_GELU)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_gemm_variant(-1)
+        res[v] = (o, o32, os_, og)
+    for x, y in zip(res[1], res[35]):
+        assert torch.equal(x, y)
+    want = a.float() @ w.float().t() + b
+    assert float((res[35][1] - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -15 * (K / 64) ** 0.5 + 1e-4

@@ -29,7 +29,7 @@ for M in [int(x) for x in sys.argv[1:]]:
         b = torch.zeros(N, device=dev)
         y = torch.empty(M, N, device=dev, dtype=BF16)
         res = {}
-        for v in (1, 14, 15, 23, 20, 21, 31, 32, 33):
+        for v in (1, 35, 14, 15, 23, 20, 21, 31, 32, 33):
             ops.set_gemm_variant(v)
             try:
                 res[v] = timeit(lambda: ops.linear(x, w, b, out=y))
@@ -37,9 +37,10 @@ for M in [int(x) for x in sys.argv[1:]]:
                 pass
         ops.set_gemm_variant(-1)
         plain = min((t, v) for v, t in res.items() if v < 28)
+        deep = min((t, v) for v, t in res.items() if v in (35,))
         sk = min((t, v) for v, t in res.items() if 28 <= v <= 32)
         s33 = res.get(33)
         print("M=%6d N=%5d K=%5d  best plain v%-2d %6.1f us | best stream-K v%-2d %6.1f us (%+5.1f %%) | split-K v33 %s   %s" % (
             M, N, K, plain[1], plain[0], sk[1], sk[0], 100 * (sk[0] / plain[0] - 1),
             "   n/a" if s33 is None else "%6.1f us (%+5.1f %%)" % (s33, 100 * (s33 / plain[0] - 1)),
-            " ".join("%d:%.1f" % (v, t) for v, t in res.items())))
+            "deep v%d %.1f (%+.1f %%)" % (deep[1], deep[0], 100 * (deep[0] / plain[0] - 1))))

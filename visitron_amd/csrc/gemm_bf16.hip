@@ -825,6 +825,10 @@ template <int ACT, bool OUT_F32>
 static int launch_gemm(const GemmArgs& g, int variant, hipStream_t stream) {
   switch (variant) {
     case 1: return launch_kernel(gemm_nt_bf16_v2<64, 2, ACT, OUT_F32>, g, 2 * 32768, stream);
+    // 35: the same 128x128-tile kernel on a ring of THREE stages (96 KiB: one workgroup per CU).  For launches of fewer tiles
+    // than CUs, where a tile's K-steps are a chain paced by the load latency and two stages keep ONE K-tile in flight: the
+    // long-K products of small batches (round 6; four stages measured no better than three)
+    case 35: return launch_kernel(gemm_nt_bf16_v2<64, 3, ACT, OUT_F32>, g, 3 * 32768, stream);
     case 9: return launch_kernel_v4(gemm_nt_bf16_v4<192, ACT, OUT_F32>, g, 192, stream);
     case 10: return launch_kernel_v4(gemm_nt_bf16_v4<256, ACT, OUT_F32>, g, 256, stream);
     case 11: {

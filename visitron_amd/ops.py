@@ -242,7 +242,8 @@ def encoder_forward_ln(layer_weights, stream_a, stream_b, qkv, ctx, mid, mask, m
 # against the best plain variant, parity at best): opt-in candidates (VT_GEMM_STREAMK=1), never timed by default.
 STREAMK = os.environ.get("VT_GEMM_STREAMK", "0") == "1"
 # 33: split-K of the one-tile kernel with the whole epilogue behind the ordered plane sum (small M, long K; needs the workspace)
-GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16, 18, 19, 20, 21, 22, 23, 33) + ((31, 32) if STREAMK else ())   # (24 .. 27: the measured-negative redesigns of round 4 live in tools/experiments, outside the product library)
+# 35: the 128x128-tile kernel on a three-stage ring (long K, fewer tiles than CUs)
+GEMM_CANDIDATES = (1, 14, 9, 10, 11, 15, 16, 18, 19, 20, 21, 22, 23, 33, 35) + ((31, 32) if STREAMK else ())   # (24 .. 27: the measured-negative redesigns of round 4 live in tools/experiments, outside the product library)
 
 
 # -1: shape table / heuristic; -2: the same plus the tail launch of the persistent kernel's last round (VT_GEMM_TAIL_SPLIT=1)
