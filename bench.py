@@ -134,7 +134,7 @@ def main():
         engine = PretrainEngine(full, lr=5e-5, weight_decay=0.05, eps=1e-8, schedule="linear", warmup_steps=0,
                                 t_total=20000)
         batch = make_batch(cfg, a.batch, a.text, a.regions, seed=1234 + rank, device=dev, with_labels=True)
-        fwd_batch = {k: batch[k] for k in ("input_ids", "attention_mask", "img_feats", "img_location_embeddings")}
+        fwd_batch = {k: batch[k] for k in ("input_ids", "attention_mask", "img_feats", "img_location_embeddings") if k in batch}   # (--regions 0: text only)
 
         def step():
             return engine.train_step(batch)
