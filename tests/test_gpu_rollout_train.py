@@ -434,3 +434,51 @@ def test_trunk_level_training_with_output_hidden_states(dev, with_head_mask):
     with torch.no_grad():
         ng = pt(**{k: v.to(dev) for k, v in b.items()})
     assert len(ng) == 3 and len(ng[2]) == L + 1 and not ng[2][0].requires_grad
+
+
+def test_trunk_level_training_with_output_attentions(dev):
+    """output_attentions in trunk-level TRAINING (round 6; oscar/modeling_bert.py:62-79, 160-167): the fourth output is the
+    tuple of per-layer probabilities after dropout and head_mask.  Without dropout against the oracle's train-mode forward
+    (with a head_mask); with attention dropout the first layer's values are either zero or the eval-mode probability over
+    1 - p_eff, dropped at the rate p_eff (the keep words the forward wrote); a loss on the other outputs still trains."""
+    from oracle.modeling import PreTrainOscar as OModel
+    from visitron_amd import ops
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config(num_hidden_layers=2, output_hidden_states=True, output_attentions=True)
+    ref, prod = model_pair(OModel, PreTrainOscar, cfg, seed=49, device=dev)
+    rt, pt = ref.bert, prod.bert
+    rt.train()
+    pt.train()
+    B, T, R = 3, 20, 7
+    S = T + R
+    b = make_batch(cfg, B, text_len=T, region_len=R, seed=10, with_labels=False)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    hm = torch.tensor([[1.0, 0.5], [0.0, 1.3]])
+    want = rt(head_mask=hm, **b)
+    got = pt(head_mask=hm.to(dev), **bd)
+    assert len(got) == 4 and len(got[3]) == cfg.num_hidden_layers and not got[3][0].requires_grad
+    for l in range(cfg.num_hidden_layers):
+        assert tuple(got[3][l].shape) == (B, cfg.num_attention_heads, S, S)
+        check_close("trunk-level train attentions[%d]" % l, got[3][l], want[3][l], 5e-3)
+    (got[0].sum() + got[1].sum()).backward()          # the differentiable outputs still reach the parameters
+    assert pt.encoder.layer[0].attention.self.query.weight.grad is not None
+    # attention dropout: layer 0 of a model whose hidden dropout is off
+    cfg2 = mini_config(num_hidden_layers=2, output_attentions=True, attention_probs_dropout_prob=0.25)
+    _, prod2 = model_pair(OModel, PreTrainOscar, cfg2, seed=49, device=dev)
+    p2 = prod2.bert
+    p2.eval()
+    with torch.no_grad():
+        base = p2(**bd)[2][0]
+    p2.train()
+    with torch.no_grad():
+        dropped = p2(**bd)[2][0]
+    pe = ops.attn_drop_p(0.25)
+    real = bd["attention_mask"].bool()[:, None, None, :].expand_as(base) & (base > 1e-6)
+    kept = dropped != 0
+    frac = 1.0 - float(kept[real].float().mean())
+    assert abs(frac - pe) < 0.03, (frac, pe)
+    err = (dropped - base / (1.0 - pe))[kept & real].abs().max()
+    assert float(err) <= 5e-3, float(err)

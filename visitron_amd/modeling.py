@@ -1146,9 +1146,9 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
             # a caller that trains THROUGH the trunk (the rollout's OscarEncoder, agent.py:493-518): one autograd node
             # backed by the engine's forward / backward kernels.  Also train() under torch.no_grad() with dropout on
             # (agent.py:476-489, test(use_dropout=True)): the same forward with its dropout, no graph.
-            if encoder_history_states or self.encoder.output_attentions:
-                raise NotImplementedError("trunk-level training serves the forward without encoder_history_states and "
-                                          "output_attentions (output_hidden_states is served)")
+            if encoder_history_states:
+                raise NotImplementedError("trunk-level training serves the forward without encoder_history_states "
+                                          "(output_hidden_states and output_attentions are served)")
             ops._require_hip(input_ids)
             from .training import autograd_trunk_forward
 
@@ -1159,10 +1159,11 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
             if img_feats is not None:
                 batch.update(img_feats=img_feats, img_location_embeddings=img_location_embeddings)
             dt = next(self.parameters()).dtype
-            out = autograd_trunk_forward(self, batch, head_mask, want_hidden=self.encoder.output_hidden_states)
+            out = autograd_trunk_forward(self, batch, head_mask, want_hidden=self.encoder.output_hidden_states,
+                                         want_attn=self.encoder.output_attentions)
             res = (out[0].to(dt), out[1].to(dt))
-            if self.encoder.output_hidden_states:   # (sequence_output, pooled_output) + encoder_outputs[1:], encoder.py:300-303
-                res = res + (tuple(h.to(dt) for h in out[2]),)
+            for extra in out[2:]:   # (sequence_output, pooled_output) + encoder_outputs[1:] = hidden states, then attentions (encoder.py:300-303)
+                res = res + (tuple(h.to(dt) for h in extra),)
             return res
         outs, pooled, x, B, S = self.run_trunk(input_ids, token_type_ids, attention_mask, position_ids, head_mask,
                                                img_feats, img_location_embeddings, encoder_history_states)

@@ -548,6 +548,17 @@ def keep_words(B, nh, S):
     return B * nh * nqb * nqb * 32
 
 
+def unpack_keep_bits(keep_bits, B, nh, S):
+    """bool [B, nh, S, S] (query, key) from the keep words attention_fwd wrote (word ((b nh + h) nqb + qb) kpitch + key, bit j =
+    query 32 qb + j): torch ops, for the rarely used output_attentions of a training-mode forward."""
+    nqb = (S + 31) // 32
+    kp = nqb * 32
+    w = keep_bits[:B * nh * nqb * kp].view(B, nh, nqb, 1, kp)
+    j = torch.arange(32, device=keep_bits.device, dtype=torch.int32).view(1, 1, 1, 32, 1)
+    bits = torch.bitwise_and(torch.bitwise_right_shift(w, j), 1)
+    return bits.reshape(B, nh, nqb * 32, kp)[:, :, :S, :S].bool()
+
+
 def attention_fwd(qkv, B, S, nh, mask=None, mask_additive=False, head_scale=None, out=None, lse=None, drop=NO_DROP,
                   seq=None, keep_bits=None):
     """qkv [B*S, 3*nh*64] bf16, mask fp32 [B,S] -> context [B*S, nh*64] bf16.  seq (SeqLayout): compacted rows, no

@@ -819,7 +819,7 @@ class PretrainEngine(object):
                 gi.copy_(self.dw_img[:, :D]); gl.copy_(self.dw_img[:, D:D + 128]); gbi.copy_(self.db_img); gbl.copy_(self.db_img)
 
     # ------------------------------------------------------------------------------ trunk-level training
-    def trunk_forward(self, batch, head_mask=None, training=None, unmasked_only=False, want_hidden=False):
+    def trunk_forward(self, batch, head_mask=None, training=None, unmasked_only=False, want_hidden=False, want_attn=False):
         """BertImgModelwithLocationEmbeds.forward for a caller that back-propagates through it (the rollout's
         OscarEncoder, agent.py:493-518): -> (sequence_output fp32 [B,S,H], pooled_output fp32 [B,H], state).
         unmasked_only: the caller vouches that it reads sequence_output only at positions whose attention mask is not
@@ -851,8 +851,28 @@ class PretrainEngine(object):
             return out.view(st.B, st.S, st.H)
 
         seq = padded(last)
+        attn = None
+        if want_attn:
+            # all_attentions (oscar/modeling_bert.py:62-79, 160-167): per layer the probabilities AFTER dropout and head_mask,
+            # fp32 [B, heads, S, S] -- recomputed from the layer's saved projection and log-sum-exp, the dropout decisions read
+            # back from the keep words the forward wrote.  Values only: no gradient flows into them (autograd_trunk_forward
+            # marks them non-differentiable).
+            if st.lay is not None:
+                raise NotImplementedError("output_attentions on compacted rows")
+            nh_, pa = st.nh, st.p_a
+            attn = []
+            for l, d in enumerate(st.bufs.layers):
+                pr = ops.attention_probs(d["qkv"][:n], d["lse"], st.B, st.S, nh_, mask=st.enc_mask, mask_additive=st.mask_additive,
+                                         head_scale=None if st.hs is None else st.hs[l].contiguous())
+                if pa > 0.0:
+                    if "keep_bits" not in d:
+                        raise NotImplementedError("output_attentions in training with attention dropout needs the keep words "
+                                                  "(VT_ATTN_KEEP_BITS=1, the default)")
+                    keep = ops.unpack_keep_bits(d["keep_bits"], st.B, nh_, st.S)
+                    pr = pr * keep / (1.0 - ops.attn_drop_p(pa))
+                attn.append(pr)
         if not want_hidden:
-            return seq, st.pooled.clone(), st
+            return (seq, st.pooled.clone(), st) + ((None, attn) if want_attn else ())
         # all_hidden_states (oscar/modeling_bert.py:146-158): the embedding output, then every layer's output -- fp32, rebuilt
         # from the fp16 sums and the row statistics where the layer keeps no higher-precision copy (as `last` above)
         hidden = [padded(st.x_enc[:n].float())]
@@ -864,7 +884,7 @@ class PretrainEngine(object):
             else:
                 hidden.append(padded(d["out"][:n].float()))
         hidden.append(seq.clone())
-        return seq, st.pooled.clone(), st, hidden
+        return (seq, st.pooled.clone(), st, hidden) + ((attn,) if want_attn else ())
 
     def trunk_backward(self, st, d_seq, d_pooled=None, accumulate=False, d_hidden=None):
         """Gradients of the trunk's parameters into the flat slab, given dL/d(sequence_output) [B,S,H] and / or
@@ -1232,17 +1252,21 @@ class _TrunkWithGrads(torch.autograd.Function):
     parameter gradients to autograd."""
 
     @staticmethod
-    def forward(ctx, engine, batch, head_mask, unmasked_only, want_hidden, *params):
-        out = engine.trunk_forward(batch, head_mask, unmasked_only=unmasked_only, want_hidden=want_hidden)
+    def forward(ctx, engine, batch, head_mask, unmasked_only, want_hidden, want_attn, *params):
+        out = engine.trunk_forward(batch, head_mask, unmasked_only=unmasked_only, want_hidden=want_hidden, want_attn=want_attn)
         seq, pooled, st = out[:3]
         ctx.engine, ctx.st = engine, st
         ctx.names = [engine._name_of(p) for p in params]
+        ctx.n_hidden = len(out[3]) if want_hidden else 0
         ctx.set_materialize_grads(False)
-        return (seq, pooled) + (tuple(out[3]) if want_hidden else ())
+        attn = tuple(out[4]) if want_attn else ()
+        ctx.mark_non_differentiable(*attn)
+        return (seq, pooled) + (tuple(out[3]) if want_hidden else ()) + attn
 
     @staticmethod
-    def backward(ctx, d_seq, d_pooled, *d_hidden):
+    def backward(ctx, d_seq, d_pooled, *d_rest):
         eng, st = ctx.engine, ctx.st
+        d_hidden = d_rest[:ctx.n_hidden]
         eng.trunk_backward(st, d_seq, d_pooled, d_hidden=list(d_hidden) if d_hidden else None)
         f = eng.flat
         unused = set()
@@ -1251,7 +1275,7 @@ class _TrunkWithGrads(torch.autograd.Function):
         if d_pooled is None:
             unused.add("bert.pooler.")
         grads = [None if n.startswith(tuple(unused)) else f.view(f.g, n).clone() for n in ctx.names]
-        return (None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
 class _TrunkLazyGrads(torch.autograd.Function):
@@ -1287,18 +1311,27 @@ def lazy_autograd_trunk(trunk, batch, head_mask, seq, pooled):
     return _TrunkLazyGrads.apply(trunk, batch, head_mask, seq, pooled, *params)
 
 
-def autograd_trunk_forward(trunk, batch, head_mask=None, unmasked_only=False, want_hidden=False):
+def autograd_trunk_forward(trunk, batch, head_mask=None, unmasked_only=False, want_hidden=False, want_attn=False):
     """BertImgModelwithLocationEmbeds.forward in training mode: (sequence_output, pooled_output) that back-propagate into the
     trunk's parameters through the HIP backward; under torch.no_grad() the same forward (dropout included) without a graph.
-    unmasked_only: see PretrainEngine.trunk_forward.  want_hidden: a third element, the tuple of all_hidden_states
-    (embedding output + every layer's output, oscar/modeling_bert.py:146-158), each differentiable like sequence_output."""
+    unmasked_only: see PretrainEngine.trunk_forward.  want_hidden: one more element, the tuple of all_hidden_states
+    (embedding output + every layer's output, oscar/modeling_bert.py:146-158), each differentiable like sequence_output.
+    want_attn: one more, the tuple of all_attentions (per layer, after dropout and head_mask) -- values only."""
     eng = _bridge_engine(trunk)
     if not torch.is_grad_enabled():
-        out = eng.trunk_forward(batch, head_mask, unmasked_only=unmasked_only, want_hidden=want_hidden)
-        return (out[0], out[1]) + ((tuple(out[3]),) if want_hidden else ())
+        out = eng.trunk_forward(batch, head_mask, unmasked_only=unmasked_only, want_hidden=want_hidden, want_attn=want_attn)
+        return (out[0], out[1]) + ((tuple(out[3]),) if want_hidden else ()) + ((tuple(out[4]),) if want_attn else ())
     params = [p for p in trunk.parameters() if p.requires_grad]
-    out = _TrunkWithGrads.apply(eng, batch, head_mask, bool(unmasked_only), bool(want_hidden), *params)
-    return (out[0], out[1]) + ((tuple(out[2:]),) if want_hidden else ())
+    out = _TrunkWithGrads.apply(eng, batch, head_mask, bool(unmasked_only), bool(want_hidden), bool(want_attn), *params)
+    L1 = trunk.config.num_hidden_layers + 1
+    res = (out[0], out[1])
+    k = 2
+    if want_hidden:
+        res = res + (tuple(out[k:k + L1]),)
+        k += L1
+    if want_attn:
+        res = res + (tuple(out[k:]),)
+    return res
 
 
 def _bridge_engine(model):
