@@ -72,6 +72,17 @@ int64_t vt_gemm_workspace_region_bytes(void);
  * *host_count = how many ran out of it on the current device since the last call (then cleared): non-zero = some GEMM
  * output of an earlier launch is unreliable.  Blocking (4-byte copies): call it where the host synchronises anyway. */
 int vt_gemm_shared_tile_timeouts(unsigned* host_count);
+/* Attention-probability dropout (oscar/modeling_bert.py:62, nn.Dropout(attention_probs_dropout_prob)): how finely the drop
+ * probability is resolved.  16 (default since ABI 12): steps of 1/65536 -- two neighbouring keys share one hash word, a 16-bit
+ * field each -- so the reference's 0.1 runs as 6554/65536 = 0.100006.  8 (the form of ABI 8 .. 11): steps of 1/256 -- four
+ * keys per hash word, a byte each -- so 0.1 runs as 26/256 = 0.1016 (kept probabilities scaled by 1 / (1 - 0.1016):
+ * unbiased either way); the forward's dropout arithmetic halves (that kernel ~5 % faster, the B = 256 step 0.15 %).
+ * Process-wide, read when a call builds its dropout state: set it before a step, never between a forward and its
+ * backward.  Also VT_ATTN_DROPOUT_BITS=8 in the environment.  vt_attn_dropout_effective(p) = the probability p runs as under
+ * the current setting (-1 where it is refused: p < 0 or rounding to 1). */
+int vt_set_attn_dropout_bits(int bits);
+int vt_get_attn_dropout_bits(void);
+float vt_attn_dropout_effective(float p);
 /* Tuning hook: 4 or 8 waves per workgroup in the attention backward (default 8). Process-global. */
 void vt_debug_set_attn_bwd_waves(int waves);
 
@@ -121,7 +132,8 @@ int vt_apply_dropout_bf16(void* x, int64_t ld, int64_t rows, int cols, float dro
                           uint32_t drop_site, vt_stream_t stream);
 /* Test hook: out[i] = 1 if element i of the site is kept (head_index = b*nh + h for attention sites where
  * element i = q * S' + key, S' = the sequence's length rounded up to a multiple of 4, and the keep decision is byte
- * (i & 3) of the hash word of i >> 2 against p quantised to 1/256 -- the attention sites' form, ABI 8 --, else -1). */
+ * (i & 3) of the hash word of i >> 2 against p quantised to 1/256 -- the attention sites' form, ABI 8; in exact-p mode
+ * (vt_set_attn_dropout_bits(16)) field (i & 1) of the hash word of i >> 1 against p quantised to 1/65536 --, else -1). */
 int vt_debug_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, uint32_t drop_site,
                           int head_index, vt_stream_t stream);
 

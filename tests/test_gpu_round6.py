@@ -7,6 +7,8 @@
   oscar/modeling_bert.py:94,120.
 * The persistent kernel's XCD chunks sized by workgroups (tile counts that are not multiples of 8).
 """
+import os
+
 import pytest
 import torch
 
@@ -420,3 +422,155 @@ def test_three_stage_ring_of_the_128_tile_kernel(dev, M, N, K):
         assert torch.equal(x, y)
     want = a.float() @ w.float().t() + b
     assert float((res[35][1] - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -15 * (K / 64) ** 0.5 + 1e-4
+
+
+# ---- attention-probability dropout, both resolutions (vt_set_attn_dropout_bits): 16-bit fields = the default since round 6
+# (oscar/modeling_bert.py:62's nn.Dropout(0.1) runs as 0.100006), 8-bit fields = the faster form of rounds 4-5 (0.1016) ------
+@pytest.fixture(params=[16, 8])
+def attn_bits(request):
+    from visitron_amd import ops
+
+    before = ops.attn_dropout_bits()
+    ops.set_attn_dropout_bits(request.param)
+    try:
+        yield request.param
+    finally:
+        ops.set_attn_dropout_bits(before)
+
+
+def test_attention_dropout_resolution_default_and_keep_function(dev, attn_bits):
+    """The default is the exact-p form: p resolved to 1/65536 (0.1 -> 6554/65536); the 8-bit form resolves 1/256 (0.1 ->
+    26/256).  Either way: the keep rate of the masks the kernels derive, independence between heads and between neighbouring
+    keys (fields of one hash word), a p below half a step runs as one step, a p that rounds to 1 is refused."""
+    from visitron_amd import ops
+
+    n_steps = float(1 << attn_bits)
+    assert ops.attn_dropout_bits() == attn_bits
+    assert ops.attn_drop_p(0.1) == (6554.0 / 65536.0 if attn_bits == 16 else 26.0 / 256.0) and ops.attn_drop_p(0.0) == 0.0
+    assert ops.attn_drop_p(1e-6) == 1.0 / n_steps                  # below half a step: one step, never silently off
+    with pytest.raises(ValueError):
+        ops.attn_drop_p(1.0 - 0.25 / n_steps)
+    n = 512
+    for p in (0.1, 0.25, 0.003):
+        pe = ops.attn_drop_p(p)
+        m = ops.attn_dropout_mask(n, (p, 4321, ops.site_attn(3)), 5, device=dev).float().cpu()
+        sd = (pe * (1 - pe) / (n * n)) ** 0.5
+        assert abs(float(m.mean()) - (1 - pe)) < 5 * sd, (p, float(m.mean()))
+        m2 = ops.attn_dropout_mask(n, (p, 4321, ops.site_attn(3)), 6, device=dev).float().cpu()
+        agree = float((m == m2).float().mean())
+        want = pe * pe + (1 - pe) * (1 - pe)
+        assert abs(agree - want) < 6 * (want * (1 - want) / (n * n)) ** 0.5 + 1e-4, (p, agree, want)
+        a, b = m[:, 0::2].flatten(), m[:, 1::2].flatten()
+        cov = float(((a - a.mean()) * (b - b.mean())).mean()) / max(float(a.std() * b.std()), 1e-9)
+        assert abs(cov) < 6.0 / (a.numel() ** 0.5), (p, cov)
+    with pytest.raises(RuntimeError):
+        ops.set_attn_dropout_bits(12)
+
+
+def test_attention_dropout_default_is_the_exact_p_form(dev):
+    from visitron_amd import ops
+
+    if os.environ.get("VT_ATTN_DROPOUT_BITS") in (None, "", "16"):
+        assert ops.attn_dropout_bits() == 16 and abs(ops.attn_drop_p(0.1) - 0.1) < 1e-5
+
+
+@pytest.mark.parametrize("B,S,nh", [(2, 228, 3), (1, 37, 2), (2, 300, 2)])
+def test_attention_dropout_words_hash_backward_and_fp32_at_both_resolutions(dev, attn_bits, B, S, nh):
+    """The forward's keep words are the mask of the resolution in force (vt_debug_dropout_mask), the context does not depend on writing them, the
+    backward that re-derives the mask from the hash (8-wave and 4-wave kernels) equals the backward reading the words, and
+    context / gradient agree with fp32 autograd under the same mask and 1 / (1 - p_effective)."""
+    from test_gpu_round3 import _unpack_keep_words
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(11 * S + nh)
+    H = nh * 64
+    drop = (0.1, 4242, ops.site_attn(1))
+    qkv = (torch.randn(B * S, 3 * H, generator=g) * 0.9).to(BF16)
+    dctx = (torch.randn(B * S, H, generator=g) * 0.6).to(BF16)
+    mask = (torch.rand(B, S, generator=g) > 0.2).float()
+    mask[:, 0] = 1.0
+    lse0 = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
+    lse1 = torch.zeros_like(lse0)
+    words = torch.full((ops.keep_words(B, nh, S),), -1, dtype=torch.int32, device=dev)
+    q_d, d_d, m_d = qkv.to(dev), dctx.to(dev), mask.to(dev)
+    ctx0 = ops.attention_fwd(q_d, B, S, nh, mask=m_d, lse=lse0, drop=drop)
+    ctx1 = ops.attention_fwd(q_d, B, S, nh, mask=m_d, lse=lse1, drop=drop, keep_bits=words)
+    torch.cuda.synchronize()
+    assert torch.equal(ctx0, ctx1) and torch.equal(lse0, lse1)
+    got = _unpack_keep_words(words, B, nh, S)[:, :S, :S]
+    want = torch.stack([ops.attn_dropout_mask(S, drop, i, device=dev) for i in range(B * nh)]).bool().cpu()
+    assert torch.equal(got, want)
+    assert abs(float(want.float().mean()) - (1 - ops.attn_drop_p(0.1))) < 0.01
+    d_words = ops.attention_bwd(q_d, d_d, ctx1, lse1, B, S, nh, mask=m_d, drop=drop, keep_bits=words)
+    outs = {}
+    for waves in (8, 4):
+        ops.set_attn_bwd_waves(waves)
+        try:
+            outs[waves] = ops.attention_bwd(q_d, d_d, ctx0, lse0, B, S, nh, mask=m_d, drop=drop)      # hash path
+            if waves == 8:
+                outs["8w"] = ops.attention_bwd(q_d, d_d, ctx1, lse1, B, S, nh, mask=m_d, drop=drop, keep_bits=words)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_attn_bwd_waves(0)
+    if S <= 256:
+        assert torch.equal(outs[8], outs["8w"])             # the same kernel, hash against words: bit for bit
+    top = float(d_words.float().abs().max())
+    for k, v in outs.items():
+        assert float((v.float() - d_words.float()).abs().max()) <= 2.0 ** -6 * top, k
+    # fp32 autograd under the same mask
+    x = qkv.float().requires_grad_(True)
+    t = x.view(B, S, 3, nh, 64).permute(2, 0, 3, 1, 4)
+    bias = ((1.0 - mask) * -10000.0)[:, None, None, :]
+    p = torch.softmax(t[0] @ t[1].transpose(-1, -2) / 8.0 + bias, -1)
+    km = want.view(B, nh, S, S).float()
+    o = ((p * km / (1.0 - ops.attn_drop_p(0.1))) @ t[2]).permute(0, 2, 1, 3).reshape(B * S, H)
+    o.backward(dctx.float())
+    assert maxabs(ctx1, o.detach()) < 3e-2
+    assert maxabs(d_words, x.grad) < 3e-2 * (1 + float(x.grad.abs().max()))
+
+
+def test_attention_dropout_on_compacted_rows_at_both_resolutions(dev, attn_bits):
+    """The same on the training step's compacted layout: the hash index runs over each sequence's own length."""
+    from test_gpu_round3 import _unpack_keep_words
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    B, S, nh = 3, 96, 2
+    H = nh * 64
+    lens = torch.tensor([96, 50, 33])
+    seq = ops.SeqLayout((torch.arange(S)[None, :] < lens[:, None]).to(dev))
+    drop = (0.1, 77, ops.site_attn(0))
+    qkv = (torch.randn(seq.rows, 3 * H, generator=g) * 0.8).to(dev, BF16)
+    dctx = torch.randn(seq.rows, H, generator=g).to(dev, BF16)
+    lse = torch.zeros((B, nh, S), dtype=torch.float32, device=dev)
+    words = torch.zeros(ops.keep_words(B, nh, S), dtype=torch.int32, device=dev)
+    ctx = ops.attention_fwd(qkv, B, S, nh, lse=lse, drop=drop, seq=seq, keep_bits=words)
+    d1 = ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, seq=seq, keep_bits=words)
+    ops.set_attn_bwd_waves(8)
+    try:
+        d0 = ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, seq=seq)
+        d2 = ops.attention_bwd(qkv, dctx, ctx, lse, B, S, nh, drop=drop, seq=seq, keep_bits=words)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_attn_bwd_waves(0)
+    assert torch.equal(d0, d2)
+    assert float((d0.float() - d1.float()).abs().max()) <= 2.0 ** -7 * float(d0.float().abs().max())
+    got = _unpack_keep_words(words, B, nh, S)
+    for b in range(B):
+        n = int(lens[b])
+        for h in range(nh):
+            want = ops.attn_dropout_mask(n, drop, b * nh + h, device=dev).bool().cpu()
+            assert torch.equal(got[b * nh + h, :n, :n], want), (b, h)
+
+
+@pytest.mark.parametrize("compact", [True, False])
+def test_training_matches_oracle_with_same_masks_at_both_resolutions(dev, attn_bits, compact):
+    """A whole training step at either resolution against the oracle running under the masks the kernels derived (losses and
+    every gradient: tests/test_gpu_train.py's dropout test), and the engine reports the probability it ran."""
+    import test_gpu_train as t
+    from visitron_amd import ops
+
+    t.test_dropout_training_matches_oracle_with_same_masks(dev, 0.1, 0.1, compact)
+    cfg = t._dropout_cfg(0.1, 0.1)
+    _, _, eng = t._engine_pair(cfg, 5, dev)
+    assert eng.attention_dropout_effective == ops.attn_drop_p(0.1) == (6554.0 / 65536.0 if attn_bits == 16 else 26.0 / 256.0)

@@ -73,6 +73,9 @@ SIGNATURES = {
     "vt_debug_set_wgrad_kernel": (None, [c_int]),
     "vt_gemm_tune": (None, [c_int, c_int, c_int, c_int, c_int]),
     "vt_debug_set_attn_bwd_waves": (None, [c_int]),
+    "vt_set_attn_dropout_bits": (c_int, [c_int]),
+    "vt_get_attn_dropout_bits": (c_int, []),
+    "vt_attn_dropout_effective": (ctypes.c_float, [ctypes.c_float]),
     "vt_gemm_reserve_cus": (None, [c_int]),
     "vt_gemm_set_workspace": (c_int, [c_void_p, c_int64]),
     "vt_gemm_workspace_region_bytes": (c_int64, []),

@@ -85,14 +85,18 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
 // sites' function (common.hpp, vt_keep_attn): byte key & 3 of the hash word of (query, key >> 2), row pitch Sp = the
 // sequence's length rounded up to a multiple of 4.  The word index is linear in the query, so the hash's first multiply is
 // taken once and the other queries are reached by adding multiples of (Sp / 4) * C1.
+// Exact-p mode (vt_attn_wide: 16-bit fields, two keys per word): the same walk with key >> 1 / Sp >> 1 and field key & 1.
 __device__ __forceinline__ void attn_bwd_keep16(const DropCfg& dr, uint32_t qbase, uint32_t key, uint32_t Sp, bool (&keep)[16]) {
-  const uint32_t sh = 8u * (key & 3u);
-  const uint32_t qstep = (Sp >> 2) * VT_HASH_C1;
-  const uint32_t x0 = vt_hash_pre(dr.seed, qbase * (Sp >> 2) + (key >> 2));
+  const bool wide = vt_attn_wide(dr);
+  const uint32_t lg = wide ? 1u : 2u;
+  const uint32_t sh = wide ? 16u * (key & 1u) : 8u * (key & 3u);
+  const uint32_t fmask = wide ? 0xffffu : 0xffu, th = wide ? dr.thresh >> 16 : dr.thresh;
+  const uint32_t qstep = (Sp >> lg) * VT_HASH_C1;
+  const uint32_t x0 = vt_hash_pre(dr.seed, qbase * (Sp >> lg) + (key >> lg));
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const uint32_t h = vt_hash_fin(x0 + (uint32_t)((i & 3) + 8 * (i >> 2)) * qstep);
-    keep[i] = ((h >> sh) & 0xffu) >= dr.thresh;
+    keep[i] = ((h >> sh) & fmask) >= th;
   }
 }
 
@@ -628,12 +632,16 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
       f32x16 pacc;
       // hash path (no keep words): the flags of a group of four queries are derived right before their use -- sixteen flags
       // held across the tile cost three spilled registers at this kernel's 128-register budget
-      uint32_t hx0 = 0, hstep = 0, hsh = 0;
+      uint32_t hx0 = 0, hstep = 0, hsh = 0, hmask = 0xffu, hth = dr.thresh;
       if (!BITS && dr.thresh) {
-        const uint32_t Sp4 = ((uint32_t)(S + 3) & ~3u) >> 2, key = (uint32_t)(kb0 + 32 * wave + r);
-        hsh = 8u * (key & 3u);
+        const bool wide = vt_attn_wide(dr);   // exact-p mode: 16-bit fields, two keys per word
+        const uint32_t lg = wide ? 1u : 2u;
+        const uint32_t Sp4 = ((uint32_t)(S + 3) & ~3u) >> lg, key = (uint32_t)(kb0 + 32 * wave + r);
+        hsh = wide ? 16u * (key & 1u) : 8u * (key & 3u);
+        hmask = wide ? 0xffffu : 0xffu;
+        hth = wide ? dr.thresh >> 16 : dr.thresh;
         hstep = Sp4 * VT_HASH_C1;
-        hx0 = vt_hash_pre(dr.seed, (uint32_t)(sl * 32 + 4 * h2) * Sp4 + (key >> 2));
+        hx0 = vt_hash_pre(dr.seed, (uint32_t)(sl * 32 + 4 * h2) * Sp4 + (key >> lg));
       }
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -643,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_d64_w8(AttnBwdArgs a) {
         if (!BITS && dr.thresh) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            keep[4 * g4 + e] = ((vt_hash_fin(hx0 + (uint32_t)(e + 8 * g4) * hstep) >> hsh) & 0xffu) >= dr.thresh;
+            keep[4 * g4 + e] = ((vt_hash_fin(hx0 + (uint32_t)(e + 8 * g4) * hstep) >> hsh) & hmask) >= hth;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -96,7 +96,8 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p) {
 // the running maximum is taken over acc itself and p = exp2(fma(acc, scale2, -max * scale2)): one fma per element where
 // round 3 spent a fma (scale + bias) and a subtract.  (The reference rounds fma(q.k, 1/8, mask) once; here a masked key's
 // q.k is added to -80 000 in fp32 -- its probability is 0 either way -- and an unmasked key's bias is 0: same values.)
-template <bool KEEP, bool MASK3>
+// WIDE: the exact-p mode of the probability dropout (common.hpp: 16-bit fields, TWO hash words per four neighbouring keys)
+template <bool KEEP, bool MASK3, bool WIDE = false>
 __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
         // a lane's elements 4 g4 .. 4 g4 + 3 are the four neighbouring keys 8 g4 + 4 h2 .. + 3: ONE hash word each (q * S' and
         // the key offsets are multiples of 4); the words of a tile sit at fixed offsets from one word index, so the hash's
         // first multiply is paid once per tile
-        const uint32_t xb = dr.thresh ? vt_hash_pre(dr.seed, (q_elem + (uint32_t)(kc + kt * 32 + 4 * h2)) >> 2) : 0u;
+        const uint32_t xb = dr.thresh ? vt_hash_pre(dr.seed, (q_elem + (uint32_t)(kc + kt * 32 + 4 * h2)) >> (WIDE ? 1 : 2)) : 0u;
 
         // ---- O^T += V^T . P^T ----
 #pragma unroll
@@ -250,10 +251,14 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; j += 4) {   // elements i .. i + 3 are four neighbouring keys: one hash word, a byte each
               const int i = 8 * s2 + j;          // key offset of element i: 8 (i >> 2) + 4 h2, word index + 2 (i >> 2)
-              const uint32_t hw = vt_hash_fin(xb + (uint32_t)(2 * (i >> 2)) * VT_HASH_C1);
+              const uint32_t hw = vt_hash_fin(xb + (uint32_t)((WIDE ? 4 : 2) * (i >> 2)) * VT_HASH_C1);
+              // exact-p mode: the word of keys 0 / 1 of the four, and the next word for keys 2 / 3
+              const uint32_t hw1 = WIDE ? vt_hash_fin(xb + (uint32_t)(4 * (i >> 2) + 1) * VT_HASH_C1) : 0u;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const bool k = ((hw >> (8 * e)) & 0xffu) >= dr.thresh;   // (an SDWA byte compare: no shift, no mask)
+                const uint32_t hx = e < 2 ? hw : hw1;
+                const bool k = WIDE ? ((e & 1) ? hx : (hx << 16)) >= dr.thresh
+                                    : ((hw >> (8 * e)) & 0xffu) >= dr.thresh;   // (an SDWA byte compare: no shift, no mask)
                 pm[j + e] = k ? pm[j + e] : 0.f;     // the 1 / (1 - p) factor is uniform: applied once to O below
                 if (KEEP) {
                   const uint64_t m = __builtin_amdgcn_ballot_w64(k);
@@ -317,11 +322,15 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
   if ((ld_qkv % 8) || (ld_ctx % 8) || ld_qkv < 3L * nh * 64 || ld_ctx < (long)nh * 64) return VT_ERR_BAD_ALIGN;
   if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return VT_ERR_BAD_ALIGN;
-  static VtLdsAttrOnce attr, attr_keep, attr_m3, attr_keep_m3;
+  static VtLdsAttrOnce attr, attr_keep, attr_m3, attr_keep_m3, attr_w, attr_keep_w, attr_m3_w, attr_keep_m3_w;
   if (!attr.set((const void*)attention_fwd_d64<false, false>, ATT_LDS_BYTES)) return VT_ERR_HIP;
   if (!attr_keep.set((const void*)attention_fwd_d64<true, false>, ATT_LDS_BYTES)) return VT_ERR_HIP;
   if (!attr_m3.set((const void*)attention_fwd_d64<false, true>, ATT_LDS_BYTES)) return VT_ERR_HIP;
   if (!attr_keep_m3.set((const void*)attention_fwd_d64<true, true>, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  if (!attr_w.set((const void*)attention_fwd_d64<false, false, true>, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  if (!attr_keep_w.set((const void*)attention_fwd_d64<true, false, true>, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  if (!attr_m3_w.set((const void*)attention_fwd_d64<false, true, true>, ATT_LDS_BYTES)) return VT_ERR_HIP;
+  if (!attr_keep_m3_w.set((const void*)attention_fwd_d64<true, true, true>, ATT_LDS_BYTES)) return VT_ERR_HIP;
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.mask = mask; a.mask_additive = mask_additive; a.head_scale = head_scale; a.ctx = (bf16_t*)ctx; a.lse = lse;
   a.ld_qkv = ld_qkv; a.ld_ctx = ld_ctx; a.B = B; a.S = S; a.nh = nh;
@@ -333,10 +342,17 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   a.keep_bits = keep_bits;
   dim3 grid((S + 255) / 256, nh, B);
   const bool keep = keep_bits && a.drop.thresh, m3 = mask && mask_additive == 2;
-  if (keep && m3) hipLaunchKernelGGL((attention_fwd_d64<true, true>), grid, dim3(512), ATT_LDS_BYTES, stream, a);
-  else if (keep) hipLaunchKernelGGL((attention_fwd_d64<true, false>), grid, dim3(512), ATT_LDS_BYTES, stream, a);
-  else if (m3) hipLaunchKernelGGL((attention_fwd_d64<false, true>), grid, dim3(512), ATT_LDS_BYTES, stream, a);
-  else hipLaunchKernelGGL((attention_fwd_d64<false, false>), grid, dim3(512), ATT_LDS_BYTES, stream, a);
+  const bool wide = vt_attn_wide(a.drop);   // exact-p mode (common.hpp): 16-bit fields
+#define ATT_FWD_LAUNCH(K_, M_)                                                                                        \
+  do {                                                                                                                \
+    if (wide) hipLaunchKernelGGL((attention_fwd_d64<K_, M_, true>), grid, dim3(512), ATT_LDS_BYTES, stream, a);       \
+    else hipLaunchKernelGGL((attention_fwd_d64<K_, M_, false>), grid, dim3(512), ATT_LDS_BYTES, stream, a);           \
+  } while (0)
+  if (keep && m3) ATT_FWD_LAUNCH(true, true);
+  else if (keep) ATT_FWD_LAUNCH(true, false);
+  else if (m3) ATT_FWD_LAUNCH(false, true);
+  else ATT_FWD_LAUNCH(false, false);
+#undef ATT_FWD_LAUNCH
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 

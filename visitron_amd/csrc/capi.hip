@@ -137,7 +137,28 @@ const char* vt_error_string(int code) {
   }
 }
 
-int vt_abi_version(void) { return 11; }
+int vt_abi_version(void) { return 12; }
+
+// attention-probability dropout: 16-bit fields (default since ABI 12: p in steps of 1/65536, two keys per hash word -- the
+// reference's nn.Dropout(0.1) runs as 0.100006) or 8-bit fields (rounds 4-5's form: steps of 1/256, four keys per hash word,
+// 0.1 runs as 0.1016; the attention forward is ~5 % faster, the B = 256 step 0.15 %; common.hpp).  Process-wide; read when a
+// call builds its DropCfg, so forward and backward of one step must run under the same setting (set it before building the
+// engine; VT_ATTN_DROPOUT_BITS=8 in the environment selects the old form from the start).
+static int g_attn_drop_bits = 0;
+static int attn_drop_bits() {
+  if (g_attn_drop_bits == 0) {
+    const char* e = getenv("VT_ATTN_DROPOUT_BITS");
+    g_attn_drop_bits = (e && atoi(e) == 8) ? 8 : 16;
+  }
+  return g_attn_drop_bits;
+}
+int vt_set_attn_dropout_bits(int bits) {
+  if (bits != 8 && bits != 16) return VT_ERR_UNSUPPORTED;
+  g_attn_drop_bits = bits;
+  return VT_OK;
+}
+int vt_get_attn_dropout_bits(void) { return attn_drop_bits(); }
+float vt_attn_dropout_effective(float p) { return vt_attn_drop_ok(p, attn_drop_bits()) ? vt_attn_drop_p(p, attn_drop_bits()) : -1.0f; }
 
 int vt_batch_row_counts(const int64_t* labels, const int64_t* token_labels, const float* mask, const int32_t* err_flag, int B,
                         int S, int64_t* counts, int32_t* tile_counts, vt_stream_t stream) {
@@ -225,8 +246,8 @@ int vt_apply_dropout_bf16(void* x, int64_t ld, int64_t rows, int cols, float dro
 int vt_debug_dropout_mask(uint8_t* out, int64_t n, float drop_p, uint64_t drop_seed, uint32_t drop_site, int head_index,
                           vt_stream_t stream) {
   if (head_index >= 0) {   // attention sites: one stream per (b, h), a hash word per four keys, 8-bit thresholds (common.hpp)
-    if (!vt_attn_drop_ok(drop_p)) return VT_ERR_UNSUPPORTED;
-    DropCfg d = vt_make_drop_attn(drop_p, drop_seed, drop_site);
+    if (!vt_attn_drop_ok(drop_p, attn_drop_bits())) return VT_ERR_UNSUPPORTED;
+    DropCfg d = vt_make_drop_attn(drop_p, drop_seed, drop_site, attn_drop_bits());
     d.seed = vt_hash32(d.seed, (uint32_t)head_index);
     return vt_dropout_mask_dispatch(out, n, d, (hipStream_t)stream, 1);
   }
@@ -238,8 +259,8 @@ int vt_attention_bwd_bf16(const void* qkv, int64_t ld_qkv, const void* dctx, int
                           void* dqkv, int64_t ld_dqkv, float* dq32_ws, int B, int S, int nh, int head_size,
                           float drop_p, uint64_t drop_seed, uint32_t drop_site, const uint32_t* keep_bits,
                           vt_stream_t stream) {
-  if (!vt_attn_drop_ok(drop_p)) return VT_ERR_UNSUPPORTED;
-  const DropCfg d = vt_make_drop_attn(drop_p, drop_seed, drop_site);
+  if (!vt_attn_drop_ok(drop_p, attn_drop_bits())) return VT_ERR_UNSUPPORTED;
+  const DropCfg d = vt_make_drop_attn(drop_p, drop_seed, drop_site, attn_drop_bits());
   return vt_attention_bwd_dispatch(qkv, ld_qkv, dctx, ld_d, ctx, ld_ctx, mask, mask_additive, lse, delta_ws, dqkv,
                                    ld_dqkv, dq32_ws, B, S, nh, head_size, (hipStream_t)stream, &d, nullptr, nullptr, 0,
                                    keep_bits);
@@ -251,8 +272,8 @@ int vt_attention_bwd_seq_bf16(const void* qkv, int64_t ld_qkv, const void* dctx,
                               uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, int64_t rows,
                               const uint32_t* keep_bits, vt_stream_t stream) {
   if (!seq_start || !seq_len) return VT_ERR_NULL;
-  if (!vt_attn_drop_ok(drop_p)) return VT_ERR_UNSUPPORTED;
-  const DropCfg d = vt_make_drop_attn(drop_p, drop_seed, drop_site);
+  if (!vt_attn_drop_ok(drop_p, attn_drop_bits())) return VT_ERR_UNSUPPORTED;
+  const DropCfg d = vt_make_drop_attn(drop_p, drop_seed, drop_site, attn_drop_bits());
   return vt_attention_bwd_dispatch(qkv, ld_qkv, dctx, ld_d, ctx, ld_ctx, nullptr, 0, lse, delta_ws, dqkv, ld_dqkv, dq32_ws,
                                    B, S, nh, head_size, (hipStream_t)stream, &d, seq_start, seq_len, rows, keep_bits);
 }
@@ -509,8 +530,8 @@ int vt_dgelu_mul_bf16(const void* g, const void* h, void* out, int64_t n, vt_str
 int vt_attention_fwd_bf16(const void* qkv, int64_t ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                           int64_t ld_ctx, float* lse, int B, int S, int nh, int head_size, float drop_p, uint64_t drop_seed,
                           uint32_t drop_site, uint32_t* keep_bits, vt_stream_t stream) {
-  if (!vt_attn_drop_ok(drop_p)) return VT_ERR_UNSUPPORTED;
-  const DropCfg d = vt_make_drop_attn(drop_p, drop_seed, drop_site);
+  if (!vt_attn_drop_ok(drop_p, attn_drop_bits())) return VT_ERR_UNSUPPORTED;
+  const DropCfg d = vt_make_drop_attn(drop_p, drop_seed, drop_site, attn_drop_bits());
   return vt_attention_fwd_dispatch(qkv, ld_qkv, mask, mask_additive, head_scale, ctx, ld_ctx, lse, B, S, nh, head_size,
                                    (hipStream_t)stream, &d, nullptr, nullptr, keep_bits);
 }
@@ -520,8 +541,8 @@ int vt_attention_fwd_seq_bf16(const void* qkv, int64_t ld_qkv, const float* head
                               uint32_t drop_site, const int32_t* seq_start, const int32_t* seq_len, uint32_t* keep_bits,
                               vt_stream_t stream) {
   if (!seq_start || !seq_len) return VT_ERR_NULL;
-  if (!vt_attn_drop_ok(drop_p)) return VT_ERR_UNSUPPORTED;
-  const DropCfg d = vt_make_drop_attn(drop_p, drop_seed, drop_site);
+  if (!vt_attn_drop_ok(drop_p, attn_drop_bits())) return VT_ERR_UNSUPPORTED;
+  const DropCfg d = vt_make_drop_attn(drop_p, drop_seed, drop_site, attn_drop_bits());
   return vt_attention_fwd_dispatch(qkv, ld_qkv, nullptr, 0, head_scale, ctx, ld_ctx, lse, B, S, nh, head_size,
                                    (hipStream_t)stream, &d, seq_start, seq_len, keep_bits);
 }
@@ -726,8 +747,8 @@ static int encoder_forward_impl(const vt_layer_weights* layers, const vt_layer_a
     int rc;
     rc = vt_gemm_dispatch(cur, H, w.w_qkv, H, w.b_qkv, nullptr, 0, a.qkv, 3L * H, M, 3 * H, H, VT_ACT_NONE, 0, 0, 0, stream);
     if (rc) return rc;
-    if (!vt_attn_drop_ok(p_attn)) return VT_ERR_UNSUPPORTED;
-    const DropCfg d_att = vt_make_drop_attn(p_attn, drop_seed, VT_SITE_ATTN(l));
+    if (!vt_attn_drop_ok(p_attn, attn_drop_bits())) return VT_ERR_UNSUPPORTED;
+    const DropCfg d_att = vt_make_drop_attn(p_attn, drop_seed, VT_SITE_ATTN(l), attn_drop_bits());
     const DropCfg d_so = vt_make_drop(p_hidden, drop_seed, VT_SITE_SELFOUT(l));
     const DropCfg d_out = vt_make_drop(p_hidden, drop_seed, VT_SITE_OUT(l));
     rc = vt_attention_fwd_dispatch(a.qkv, 3L * H, mask, mask_additive, head_scale ? head_scale + (long)l * nh : nullptr, a.ctx, H,
@@ -850,8 +871,8 @@ static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_
     if (overlap && l + 2 < num_layers && hipStreamWaitEvent(stream, ev_done[l + 2], 0) != hipSuccess) return VT_ERR_HIP;
     int rc;
     // dropout sites of this layer (the forward used layer index layer0 + l)
-    if (!vt_attn_drop_ok(p_attn)) return VT_ERR_UNSUPPORTED;
-    const DropCfg d_att = vt_make_drop_attn(p_attn, drop_seed, VT_SITE_ATTN(layer0 + l));
+    if (!vt_attn_drop_ok(p_attn, attn_drop_bits())) return VT_ERR_UNSUPPORTED;
+    const DropCfg d_att = vt_make_drop_attn(p_attn, drop_seed, VT_SITE_ATTN(layer0 + l), attn_drop_bits());
     const DropCfg d_so = vt_make_drop(p_hidden, drop_seed, VT_SITE_SELFOUT(layer0 + l));
     const DropCfg d_out = vt_make_drop(p_hidden, drop_seed, VT_SITE_OUT(layer0 + l));
     // with hidden dropout the gradient of a dense output is the pre-LayerNorm gradient times the mask

@@ -285,22 +285,42 @@ __host__ __forceinline__ DropCfg vt_make_drop(float p, uint64_t step_seed, uint3
 // and quantises the drop probability to 1/256: p = 0.1 runs as 26/256 = 0.1016, and the scale 1/(1-p) uses the quantised
 // value (unbiased).  DropCfg::thresh then holds p * 2^8.  Everything else (hidden-state dropout in the GEMM epilogues, the
 // embeddings) keeps the 16-bit pairs above.
+//
+// EXACT-p FORM (round 6; the DEFAULT since ABI 12, vt_set_attn_dropout_bits(8) / VT_ATTN_DROPOUT_BITS=8 selects the form
+// above): the attention sites take the 16-bit pairs as well -- element idx = q * pitch + key reads field idx & 1 of
+// hash32(seed, idx >> 1), the function vt_keep of every other site -- so p = 0.1 runs as 6 554 / 65 536 = 0.100006 at twice
+// the hash words per score tile (measured: attention forward 107 -> 112 us per layer at B = 256, the step +0.15 %).
+// DropCfg::thresh then holds (p * 2^16) << 16, i.e. any value above 255 says "wide" to the kernels (vt_attn_wide) and both
+// fields compare against it without extraction (vt_keep_hi / vt_keep_lo's form).
+__host__ __device__ __forceinline__ bool vt_attn_wide(const DropCfg& d) { return d.thresh > 255u; }
 __host__ __device__ __forceinline__ bool vt_keep_attn(const DropCfg& d, uint32_t idx) {
+  if (vt_attn_wide(d)) {
+    const uint32_t h = vt_hash32(d.seed, idx >> 1);
+    return ((idx & 1u) ? h : (h << 16)) >= d.thresh;
+  }
   return ((vt_hash32(d.seed, idx >> 2) >> (8u * (idx & 3u))) & 0xffu) >= d.thresh;
 }
 // p in (0, 1/512) runs as 1/256 (never silently as "no dropout"); p > 255.5/256 -- where the quantised value would be 1, the
 // scale 1 / (1 - p) infinite and every output 0 * inf -- is refused by the entry points (vt_attn_drop_ok): VT_ERR_UNSUPPORTED.
-__host__ __forceinline__ bool vt_attn_drop_ok(float p) { return p >= 0.f && p * 256.0f + 0.5f < 256.0f; }
-__host__ __forceinline__ float vt_attn_drop_p(float p) {
-  if (!(p > 0.f)) return 0.f;
-  uint32_t q = (uint32_t)(p * 256.0f + 0.5f);
-  q = q < 1u ? 1u : (q > 255u ? 255u : q);
-  return (float)q / 256.0f;
+// bits = 8 (default) or 16 (exact-p mode: steps of 1/65536, the same rules at that step).
+__host__ __forceinline__ bool vt_attn_drop_ok(float p, int bits = 8) {
+  const float n = bits == 16 ? 65536.0f : 256.0f;
+  return p >= 0.f && p * n + 0.5f < n;
 }
-__host__ __forceinline__ DropCfg vt_make_drop_attn(float p, uint64_t step_seed, uint32_t site) {
+__host__ __forceinline__ uint32_t vt_attn_drop_steps(float p, int bits) {   // p in steps of 2^-bits, 1 .. 2^bits - 1
+  const float n = bits == 16 ? 65536.0f : 256.0f;
+  const uint32_t top = bits == 16 ? 65535u : 255u;
+  uint32_t q = (uint32_t)(p * n + 0.5f);
+  return q < 1u ? 1u : (q > top ? top : q);
+}
+__host__ __forceinline__ float vt_attn_drop_p(float p, int bits = 8) {
+  if (!(p > 0.f)) return 0.f;
+  return (float)vt_attn_drop_steps(p, bits) / (bits == 16 ? 65536.0f : 256.0f);
+}
+__host__ __forceinline__ DropCfg vt_make_drop_attn(float p, uint64_t step_seed, uint32_t site, int bits = 8) {
   DropCfg d;
-  const float pq = vt_attn_drop_p(p);
-  d.thresh = (uint32_t)(pq * 256.0f + 0.5f);
+  const float pq = vt_attn_drop_p(p, bits);
+  d.thresh = pq > 0.f ? (bits == 16 ? vt_attn_drop_steps(p, 16) << 16 : vt_attn_drop_steps(p, 8)) : 0u;
   d.seed = vt_site_seed(step_seed, site);
   d.scale = pq > 0.f ? 1.0f / (1.0f - pq) : 1.0f;
   return d;

@@ -952,14 +952,33 @@ def attn_dropout_mask(n, drop, head_index, device="cuda"):
 
 
 def attn_drop_p(p):
-    """The attention-probability dropout's effective probability: p quantised to 1/256 (0.1 -> 26/256 = 0.1016); kept
-    probabilities are scaled by 1 / (1 - attn_drop_p(p)).  0 < p < 1/512 runs as 1/256 (never silently as no dropout);
-    p > 255.5/256 is refused (the library returns VT_ERR_UNSUPPORTED: the quantised value would be 1)."""
+    """The attention-probability dropout's effective probability under the current setting (set_attn_dropout_bits): by
+    default p resolved to 1/65536 (0.1 -> 0.100006), with 8-bit fields to 1/256 (0.1 -> 26/256 = 0.1016); kept
+    probabilities are scaled by 1 / (1 - attn_drop_p(p)).  A p below half a step runs as one step (never silently as no
+    dropout); a p that rounds to 1 is refused (the library returns VT_ERR_UNSUPPORTED: the scale would be infinite)."""
     if not p > 0:
         return 0.0
-    if p * 256.0 + 0.5 >= 256.0:
-        raise ValueError("attention_probs_dropout_prob %r is not served: the attention sites quantise p to n/256, n <= 255" % (p,))
-    return float(min(255, max(1, int(p * 256.0 + 0.5)))) / 256.0
+    n = float(1 << attn_dropout_bits())
+    if p * n + 0.5 >= n:
+        raise ValueError("attention_probs_dropout_prob %r is not served: the attention sites quantise p to n/%d, n <= %d"
+                         % (p, int(n), int(n) - 1))
+    return float(min(int(n) - 1, max(1, int(p * n + 0.5)))) / n
+
+
+def attn_dropout_bits():
+    """16 (default: exact p) or 8 (rounds 4-5's faster form): the width of the attention-probability dropout's hash fields."""
+    try:
+        return int(_lib.load().vt_get_attn_dropout_bits())
+    except Exception:   # noqa: BLE001 -- no HIP library on this host: the product path refuses elsewhere, loudly
+        return 8 if os.environ.get("VT_ATTN_DROPOUT_BITS") == "8" else 16
+
+
+def set_attn_dropout_bits(bits):
+    """Process-wide: 16 (default) = exact-p attention dropout (the reference's nn.Dropout(0.1) runs as 0.100006), 8 = p in
+    steps of 1/256 (0.1 runs as 0.1016; half the hash words in the attention forward: that kernel ~5 % faster, the B = 256
+    step 0.15 %).  Set it before building an engine / model: forward
+    and backward of a step must see the same setting (include/visitron_hip.h, vt_set_attn_dropout_bits)."""
+    _lib.check(_lib.load().vt_set_attn_dropout_bits(int(bits)), "vt_set_attn_dropout_bits")
 
 
 def transpose(src, out):

@@ -209,7 +209,8 @@ class PretrainEngine(object):
         for p_ in (cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob):
             if not 0.0 <= p_ < 1.0:
                 raise ValueError("dropout probability must be in [0, 1)")
-        # the attention sites run p quantised to n / 256 (ops.attn_drop_p raises where that is not served): the value the
+        # the attention sites run p in steps of 1 / 65536 (1 / 256 under VT_ATTN_DROPOUT_BITS=8; ops.attn_drop_p raises where a
+        # p is not served): the value the
         # step actually uses is recorded in state_dict()["hyper"] and in bench.py's line, not only the configured one
         self.attention_dropout_effective = ops.attn_drop_p(float(cfg.attention_probs_dropout_prob))
         self.model, self.cfg = model, cfg
