@@ -75,18 +75,29 @@ def test_persistent_attention_backward_equals_the_16_wave_kernel_compacted(dev, 
     _same(a, b)
 
 
-def test_attention_dropout_probabilities_the_quantisation_cannot_serve(dev):
-    """p > 255.5 / 256 is refused by the library (VT_ERR_UNSUPPORTED) instead of returning 0 * inf; 0 < p < 1 / 512 drops one
-    key in 256 instead of none (oscar/modeling_bert.py:62 nn.Dropout(attention_probs_dropout_prob))."""
+@pytest.mark.parametrize("bits", [16, 8])
+def test_attention_dropout_probabilities_the_quantisation_cannot_serve(dev, bits):
+    """A p that rounds to 1 at the resolution in force (steps of 2^-bits: 16 by default since round 6, 8 before) is refused by
+    the library (VT_ERR_UNSUPPORTED) instead of returning 0 * inf; a p below half a step drops one key per 2^bits instead of
+    none (oscar/modeling_bert.py:62 nn.Dropout(attention_probs_dropout_prob))."""
     from visitron_amd import ops
 
-    B, S, nh = 1, 64, 1
-    qkv = torch.randn(B * S, 3 * 64, device=dev).to(BF16)
-    lse = torch.zeros(B, nh, S, device=dev)
-    with pytest.raises(RuntimeError):
-        ops.attention_fwd(qkv, B, S, nh, lse=lse, drop=(0.999, 1, 0))
-    m = torch.stack([ops.attn_dropout_mask(256, (0.001, 7, 0), h, device=dev) for h in range(16)]).float()
-    assert 0.99 < float(m.mean()) < 0.9999          # ~ 255 / 256 kept: the dropout is on
+    before = ops.attn_dropout_bits()
+    ops.set_attn_dropout_bits(bits)
+    try:
+        steps = float(1 << bits)
+        B, S, nh = 1, 64, 1
+        qkv = torch.randn(B * S, 3 * 64, device=dev).to(BF16)
+        lse = torch.zeros(B, nh, S, device=dev)
+        with pytest.raises(RuntimeError):
+            ops.attention_fwd(qkv, B, S, nh, lse=lse, drop=(1.0 - 0.25 / steps, 1, 0))
+        ops.attention_fwd(qkv, B, S, nh, lse=lse, drop=(1.0 - 1.0 / steps, 1, 0))           # the last step below 1 is served
+        torch.cuda.synchronize()
+        m = torch.stack([ops.attn_dropout_mask(256, (0.1 / steps, 7, 0), h, device=dev) for h in range(64)]).float()
+        kept = float(m.mean())
+        assert 1.0 - 3.0 / steps < kept < 1.0 - 0.3 / steps, kept          # ~ one key in 2^bits dropped: the dropout is on
+    finally:
+        ops.set_attn_dropout_bits(before)
 
 
 def test_persistent_attention_backward_on_twenty_random_geometries(dev):

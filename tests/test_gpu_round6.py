@@ -574,3 +574,145 @@ def test_training_matches_oracle_with_same_masks_at_both_resolutions(dev, attn_b
     cfg = t._dropout_cfg(0.1, 0.1)
     _, _, eng = t._engine_pair(cfg, 5, dev)
     assert eng.attention_dropout_effective == ops.attn_drop_p(0.1) == (6554.0 / 65536.0 if attn_bits == 16 else 26.0 / 256.0)
+
+
+# ---- visitron_amd.parallel.DataParallel: the reference's multi-gpu-dp mode (pretrain.py:93-94), rehearsed on one GPU ----------
+def _dp_models(dev, cfg=None, seed=3):
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.parallel import DataParallel
+
+    cfg = cfg or mini_config()
+    cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.0
+    torch.manual_seed(seed)
+    master = PreTrainOscar(cfg).to(dev)
+    single = PreTrainOscar(cfg).to(dev)
+    single.load_state_dict(master.state_dict())
+    return cfg, master, single, DataParallel(master, device_ids=[0, 0])
+
+
+def _halves(batch, n=2):
+    parts = [dict() for _ in range(n)]
+    for k, v in batch.items():
+        for i, c in enumerate(v.chunk(n, 0)):
+            parts[i][k] = c
+    return parts
+
+
+@pytest.mark.parametrize("B", [6, 5])
+def test_data_parallel_training_step_equals_the_per_replica_steps(dev, B):
+    """`model = DataParallel(model)`; `loss = model(**batch)[0].mean()`; `loss.backward()` (pretrain.py:93-94,169-193): every
+    entry of the 7-tuple is the vector of the replicas' values, and the wrapped module's gradients are those of the mean of
+    the per-chunk losses computed by ONE module on the chunks (torch.chunk: 3 + 3 and 3 + 2 sequences) -- the replicas'
+    own gradients are gone afterwards, parameters() and state_dict() show the wrapped module only."""
+    from visitron_amd.synth import make_batch
+
+    cfg, master, single, dp = _dp_models(dev)
+    dp.train(); single.train()
+    batch = {k: v.to(dev) for k, v in make_batch(cfg, B, text_len=24, region_len=12, seed=9).items()}
+    out = dp(**batch)
+    assert len(out) == 7 and all(o.shape == (2,) for o in out)
+    out[0].mean().backward()
+    ref = []
+    for p in _halves(batch):                      # (one forward / backward pair at a time: the HIP step keeps one gradient set)
+        ref.append(single(**p))
+        (ref[-1][0] / 2).backward()
+    torch.cuda.synchronize()
+    for i in range(7):
+        want = torch.stack([torch.as_tensor(r[i], dtype=torch.float32, device=dev) for r in ref])
+        assert torch.allclose(out[i].float(), want, rtol=1e-4, atol=1e-5, equal_nan=True), (i, out[i], want)
+    worst = 0.0
+    for (n, pm), (_, ps) in zip(master.named_parameters(), single.named_parameters()):
+        assert (pm.grad is None) == (ps.grad is None), n
+        if ps.grad is not None:
+            err = float((pm.grad - ps.grad).norm() / (ps.grad.norm() + 1e-6 * ps.grad.numel() ** 0.5))
+            worst = max(worst, err)
+            assert err < 2e-3, (n, err)
+    assert all(p.grad is None for r in dp.replicas()[1:] for p in r.parameters())
+    assert len(list(dp.parameters())) == len(list(master.parameters()))
+    assert all(k.startswith("module.") for k in dp.state_dict()) and len(dp.state_dict()) == len(master.state_dict())
+    assert dp.module is master
+
+
+def test_data_parallel_replicas_follow_the_optimizer(dev):
+    """Two steps of the reference's loop with a torch optimizer on `model.parameters()`: the second forward must see the
+    updated weights on every replica (they are refreshed from the wrapped module before each forward), i.e. equal the
+    single module stepping on the same chunks' mean loss."""
+    from visitron_amd.synth import make_batch
+
+    cfg, master, single, dp = _dp_models(dev, seed=5)
+    dp.train(); single.train()
+    opt_dp = torch.optim.SGD(dp.parameters(), lr=0.05)
+    opt_s = torch.optim.SGD(single.parameters(), lr=0.05)
+    losses = []
+    for step in range(3):
+        batch = {k: v.to(dev) for k, v in make_batch(cfg, 4, text_len=20, region_len=8, seed=30 + step).items()}
+        opt_dp.zero_grad(); opt_s.zero_grad()
+        l_dp = dp(**batch)[0].mean()
+        l_dp.backward()
+        opt_dp.step()
+        l_s = 0.0
+        for p in _halves(batch):
+            l = single(**p)[0] / 2
+            l.backward()
+            l_s += float(l)
+        opt_s.step()
+        losses.append((float(l_dp), l_s))
+    torch.cuda.synchronize()
+    for a, b in losses:
+        assert abs(a - b) < 2e-3 * max(1.0, abs(b)), losses
+    assert losses[0][0] != losses[2][0]
+    for (n, pm), (_, ps) in zip(master.named_parameters(), single.named_parameters()):
+        assert float((pm - ps).abs().max()) < 2e-3 * (1.0 + float(ps.abs().max())), n
+
+
+def test_data_parallel_inference_gathers_along_the_batch(dev):
+    """eval mode, torch.no_grad(): the trunk's outputs of a scattered batch are the per-chunk outputs concatenated; one
+    device id is the wrapped module itself; a module on another device than device_ids[0] and torch.nn.DataParallel's own
+    replicas are refused with the way out."""
+    from visitron_amd.config import mini_config
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.parallel import DataParallel
+    from visitron_amd.synth import make_batch
+
+    cfg = mini_config()
+    torch.manual_seed(1)
+    trunk = BertImgModelwithLocationEmbeds(cfg).to(dev).eval()
+    dp = DataParallel(trunk, device_ids=[0, 0]).eval()
+    b = make_batch(cfg, 5, text_len=16, region_len=8, seed=2, with_labels=False)
+    kw = {k: b[k].to(dev) for k in ("input_ids", "token_type_ids", "attention_mask", "img_feats", "img_location_embeddings")
+          if k in b}
+    with torch.no_grad():
+        seq, pooled = dp(**kw)[:2]
+        parts = [trunk(**p)[:2] for p in _halves(kw)]
+    torch.cuda.synchronize()
+    assert seq.shape[0] == 5 and pooled.shape[0] == 5
+    assert torch.equal(seq, torch.cat([p[0] for p in parts])) and torch.equal(pooled, torch.cat([p[1] for p in parts]))
+    one = DataParallel(trunk, device_ids=[0])
+    with torch.no_grad():
+        s1 = one(**kw)[0]
+        s0 = trunk(**kw)[0]
+    assert torch.equal(s1, s0)
+    with pytest.raises(RuntimeError, match="device_ids"):
+        DataParallel(BertImgModelwithLocationEmbeds(cfg), device_ids=[0, 0])(**kw)      # parameters still on the CPU
+    replica = trunk._replicate_for_data_parallel()
+    replica._former_parameters = {}
+    with pytest.raises(NotImplementedError, match="visitron_amd.parallel.DataParallel"):
+        replica(**kw)
+
+
+def test_backward_after_a_later_forward_of_the_same_module_is_refused(dev):
+    """The fused step computes the gradients together with the forward and keeps one set per module: `l1 = model(a)[0];
+    l2 = model(b)[0]; l1.backward()` cannot be served and must say so instead of handing l2's gradients to l1."""
+    from visitron_amd.synth import make_batch
+
+    cfg, master, single, _ = _dp_models(dev)
+    single.train()
+    a = {k: v.to(dev) for k, v in make_batch(cfg, 2, text_len=16, region_len=8, seed=1).items()}
+    b = {k: v.to(dev) for k, v in make_batch(cfg, 2, text_len=16, region_len=8, seed=2).items()}
+    l1 = single(**a)[0]
+    l2 = single(**b)[0]
+    with pytest.raises(RuntimeError, match="before the next forward"):
+        l1.backward()
+    l2.backward()                                   # the latest pair is served
+    assert all(p.grad is not None for p in single.parameters() if p.requires_grad)

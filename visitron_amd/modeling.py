@@ -351,11 +351,14 @@ def _dense_residual_ln(mod, hidden_states, input_tensor):
 def _refuse_data_parallel_replica(module):
     """torch.nn.DataParallel (the reference's `multi-gpu-dp` mode, pretrain.py:93-94) re-creates the module per forward as
     replicas whose weights are plain broadcast tensors (no Parameters): the flat slabs, the packed bf16 copies and the saved
-    activations here belong to ONE device and one module object.  Refused with the way out instead of failing somewhere
-    inside: one process per GPU (the reference's `multi-gpu-ddp` mode, pretrain.py:96-102; PretrainEngine / bench.py --gpus N)."""
+    activations here belong to ONE device and one module object.  Refused with the ways out instead of failing somewhere
+    inside: visitron_amd.parallel.DataParallel (the same one line, replicas that persist), or one process per GPU (the
+    reference's `multi-gpu-ddp` mode, pretrain.py:96-102; PretrainEngine / bench.py --gpus N)."""
     if hasattr(module, "_former_parameters"):
-        raise NotImplementedError("torch.nn.DataParallel replicas are not served by the HIP path; run one process per GPU "
-                                  "(DistributedDataParallel, or PretrainEngine with torch.distributed)")
+        raise NotImplementedError("torch.nn.DataParallel replicas are not served by the HIP path; wrap the model in "
+                                  "visitron_amd.parallel.DataParallel (same constructor, persistent per-device replicas) or "
+                                  "run one process per GPU (DistributedDataParallel, or PretrainEngine with "
+                                  "torch.distributed)")
 
 
 def _centered_mask(mask_f32):   # (any dtype ops.center_mask takes; fp32 out)

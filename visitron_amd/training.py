@@ -1208,10 +1208,16 @@ class _LossWithGrads(torch.autograd.Function):
     def forward(ctx, engine, loss, *params):
         ctx.engine = engine
         ctx.names = [engine._name_of(p) for p in params]
+        ctx.fb_count = engine.fb_count      # which forward / backward pair of the engine these gradients belong to
         return loss.detach().clone()
 
     @staticmethod
     def backward(ctx, grad_out):
+        if ctx.engine.fb_count != ctx.fb_count:
+            # the gradients live in the engine's slab and the next training forward on this module has overwritten them
+            raise RuntimeError("backward() of a PreTrainOscar loss after a later training forward of the same module: the HIP "
+                               "step computes the gradients with the forward and keeps ONE set per module -- call "
+                               "loss.backward() before the next forward (the reference's loop does: pretrain.py:169-191)")
         f = ctx.engine.flat
         grads = []
         for n in ctx.names:
