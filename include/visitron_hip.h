@@ -83,6 +83,17 @@ int vt_gemm_shared_tile_timeouts(unsigned* host_count);
 int vt_set_attn_dropout_bits(int bits);
 int vt_get_attn_dropout_bits(void);
 float vt_attn_dropout_effective(float p);
+/* Weight prefetch in the encoder layer loops (ABI 12).  At a small batch a layer's GEMMs are one round of tiles whose K loop
+ * fetches two K-steps ahead, and a weight matrix last read a step (or a forward) ago comes from HBM rather than the Infinity
+ * Cache: FFN-down at 7 091 rows runs 45 us on warm weights and 67 us in the training step.  The loops therefore read the
+ * next GEMMs' weights ahead of time and drop them -- in spare workgroups of kernels that are launched anyway (training: the
+ * LayerNorm forward / the LayerNorm backward's reduction; inference: the attention kernel), so without a launch of their own.
+ * training_mode: 0 off, 1 one launch per layer, 2 two launches per layer, 3 on a side stream beside the attention kernels
+ * (measured slower), 4 (default) riding in the LayerNorm kernels, applied below 16 384 token rows (VT_PREFETCH_MAX_ROWS);
+ * inference_mode: 0 off, 1 / 2 launches, 3 (default) riding in the attention kernel.  -1 keeps a setting.  Also
+ * VT_PREFETCH_WEIGHTS / VT_PREFETCH_INFER in the environment.  Results do not depend on it (reads only). */
+int vt_set_weight_prefetch(int training_mode, int inference_mode);
+int vt_get_weight_prefetch(int inference);
 /* Tuning hook: 4 or 8 waves per workgroup in the attention backward (default 8). Process-global. */
 void vt_debug_set_attn_bwd_waves(int waves);
 

@@ -716,3 +716,71 @@ def test_backward_after_a_later_forward_of_the_same_module_is_refused(dev):
         l1.backward()
     l2.backward()                                   # the latest pair is served
     assert all(p.grad is not None for p in single.parameters() if p.requires_grad)
+
+
+# ---- weight prefetch in the layer loops (vt_set_weight_prefetch): reads only, so every mode must return the same bits -------------
+def test_weight_prefetch_modes_do_not_change_a_training_step(dev):
+    """PretrainEngine.forward_backward on the base hidden size with each training prefetch mode (off, per-layer launch, per-GEMM
+    launches, side stream, riding in the LayerNorm kernels): losses and the whole gradient slab bit for bit the same (the prefetch
+    reads weights and drops them; the spare workgroups of the LayerNorm forward / the LayerNorm backward's reduction must not
+    change what the row workgroups compute -- including the grid-stride of the rows)."""
+    from visitron_amd import ops
+    from visitron_amd.config import BertConfig
+    from visitron_amd.modeling import PreTrainOscar
+    from visitron_amd.synth import make_batch
+    from visitron_amd.training import PretrainEngine
+
+    cfg = BertConfig(num_hidden_layers=3, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    torch.manual_seed(0)
+    model = PreTrainOscar(cfg).to(dev).train()
+    eng = PretrainEngine(model)
+    batch = {k: v.to(dev) for k, v in make_batch(cfg, 5, text_len=40, region_len=23, seed=3).items()}
+    before = ops.weight_prefetch()
+    outs = {}
+    try:
+        for mode in (0, 1, 2, 3, 4):
+            ops.set_weight_prefetch(training=mode)
+            assert ops.weight_prefetch()[0] == mode
+            eng.fb_count = 7                       # the same dropout masks every time
+            t = eng.forward_backward(batch)
+            torch.cuda.synchronize()
+            outs[mode] = ([float(x) for x in t], eng.flat.g.clone())
+    finally:
+        ops.set_weight_prefetch(*before)
+    for mode in (1, 2, 3, 4):
+        assert outs[mode][0] == outs[0][0], (mode, outs[mode][0], outs[0][0])
+        assert torch.equal(outs[mode][1], outs[0][1]), mode
+    with pytest.raises(RuntimeError):
+        ops.set_weight_prefetch(training=9)
+
+
+@pytest.mark.parametrize("B,T,R", [(3, 40, 23), (2, 511, 0)])
+def test_weight_prefetch_modes_do_not_change_an_inference_forward(dev, B, T, R):
+    """BertImgModelwithLocationEmbeds in eval mode (the deferred-LayerNorm layer loop) under each inference prefetch mode: the
+    attention kernel's spare z-slices read the next GEMMs' weights, everything it returns stays bit for bit what it was."""
+    from visitron_amd import ops
+    from visitron_amd.config import BertConfig
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.synth import make_batch
+
+    cfg = BertConfig(num_hidden_layers=2)
+    torch.manual_seed(1)
+    trunk = BertImgModelwithLocationEmbeds(cfg).to(dev).eval()
+    b = make_batch(cfg, B, text_len=T, region_len=max(R, 1), seed=4, with_labels=False)
+    keys = ("input_ids", "token_type_ids", "attention_mask") + (("img_feats", "img_location_embeddings") if R else ())
+    kw = {k: b[k].to(dev) for k in keys if k in b}
+    if not R:
+        kw["attention_mask"] = kw["attention_mask"][:, :T]
+    before = ops.weight_prefetch()
+    outs = {}
+    try:
+        for mode in (0, 1, 2, 3):
+            ops.set_weight_prefetch(inference=mode)
+            with torch.no_grad():
+                seq, pooled = trunk(**kw)[:2]
+            torch.cuda.synchronize()
+            outs[mode] = (seq.clone(), pooled.clone())
+    finally:
+        ops.set_weight_prefetch(*before)
+    for mode in (1, 2, 3):
+        assert torch.equal(outs[mode][0], outs[0][0]) and torch.equal(outs[mode][1], outs[0][1]), mode

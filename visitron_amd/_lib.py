@@ -73,6 +73,8 @@ SIGNATURES = {
     "vt_debug_set_wgrad_kernel": (None, [c_int]),
     "vt_gemm_tune": (None, [c_int, c_int, c_int, c_int, c_int]),
     "vt_debug_set_attn_bwd_waves": (None, [c_int]),
+    "vt_set_weight_prefetch": (c_int, [c_int, c_int]),
+    "vt_get_weight_prefetch": (c_int, [c_int]),
     "vt_set_attn_dropout_bits": (c_int, [c_int]),
     "vt_get_attn_dropout_bits": (c_int, []),
     "vt_attn_dropout_effective": (ctypes.c_float, [ctypes.c_float]),

@@ -47,6 +47,10 @@ struct AttnArgs {
   // third of its vector instructions re-deriving them from the hash).  keep_bits[((b*nh + h) * nqb + qb) * kpitch + key]:
   // bit j = keep(query 32 qb + j, key), nqb = ceil(S / 32), kpitch = S rounded up to 32.  Null: nothing written.
   uint32_t* keep_bits;
+  // Weight prefetch riding along (round 6, common.hpp vt_prefetch_role; rowops.hip has the why): the workgroups of the grid's
+  // z-slices B .. gridDim.z - 1 compute no attention but read `pf`'s byte ranges -- the weights of the GEMMs that follow --
+  // and drop them, which leaves the lines in the Infinity Cache.  pf.n == 0 / gridDim.z == B: none.
+  PrefetchArgs pf;
 };
 
 #define LOG2E 1.4426950408889634f
@@ -105,6 +109,12 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h2 = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
+  if (b >= a.B) {   // a spare workgroup (uniform): two 256-lane halves, each one prefetch workgroup
+    const int nwg = (int)((gridDim.z - a.B) * gridDim.y * gridDim.x) * 2;
+    const int wg = (int)(((b - a.B) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2 + (tid >> 8);
+    vt_prefetch_role(a.pf, wg, nwg);
+    return;
+  }
   const int Smax = a.S, H = a.nh * 64;
   // (1 .. a.S: the contract of include/visitron_hip.h; a length outside it is clamped into it rather than indexed with)
   const int S = a.seq_len ? (a.seq_len[b] < 1 ? 1 : (a.seq_len[b] > a.S ? a.S : a.seq_len[b])) : a.S;   // this sequence's rows
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_d64(AttnArgs a) {
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                               long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream,
                               const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr,
-                              uint32_t* keep_bits = nullptr) {
+                              uint32_t* keep_bits = nullptr, const PrefetchArgs* pf = nullptr) {
   if (!qkv || !ctx) return VT_ERR_NULL;
   if (head_size != 64) return VT_ERR_UNSUPPORTED;
   if (B <= 0 || S <= 0 || nh <= 0 || B > 65535 || nh > 65535) return VT_ERR_BAD_SHAPE;
@@ -341,6 +351,17 @@ int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, i
   a.seq_start = seq_start; a.seq_len = seq_len;
   a.keep_bits = keep_bits;
   dim3 grid((S + 255) / 256, nh, B);
+  a.pf.n = 0;
+  for (int i = 0; i < 4; ++i) { a.pf.p[i] = nullptr; a.pf.bytes[i] = 0; }
+  if (pf && pf->n > 0 && B < 65535 - 8) {   // spare z-slices: about one prefetch workgroup (half a block) per 16 KiB, at most 8 slices
+    long blocks16k = 0;
+    for (int i = 0; i < pf->n; ++i) blocks16k += (pf->bytes[i] + 16383) >> 14;
+    const long per_slice = 2L * grid.x * grid.y;
+    long z = (blocks16k + per_slice - 1) / per_slice;
+    z = z < 1 ? 1 : (z > 8 ? 8 : z);
+    a.pf = *pf;
+    grid.z += (unsigned)z;
+  }
   const bool keep = keep_bits && a.drop.thresh, m3 = mask && mask_additive == 2;
   const bool wide = vt_attn_wide(a.drop);   // exact-p mode (common.hpp): 16-bit fields
 #define ATT_FWD_LAUNCH(K_, M_)                                                                                        \

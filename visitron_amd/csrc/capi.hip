@@ -15,7 +15,7 @@ int vt_attention_bwd_dispatch(const void* qkv, long ld_qkv, const void* dctx, lo
 int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
                               hipStream_t stream, void* dx2 = nullptr, long lddx2 = 0, const DropCfg* drop = nullptr,
-                              int x_f16 = 0);
+                              int x_f16 = 0, const PrefetchArgs* pf = nullptr);
 int vt_apply_dropout_dispatch(void* x, long ld, long rows, int cols, const DropCfg& d, hipStream_t stream);
 int vt_dropout_mask_dispatch(uint8_t* out, long n, const DropCfg& d, hipStream_t stream, int attn);
 int vt_dgelu_mul_dispatch(const void* g, const void* h, void* out, long n, hipStream_t stream);
@@ -65,10 +65,11 @@ int vt_attention_probs_dispatch(const void* qkv, long ld_qkv, const float* mask,
 int vt_attention_fwd_dispatch(const void* qkv, long ld_qkv, const float* mask, int mask_additive, const float* head_scale, void* ctx,
                               long ld_ctx, float* lse, int B, int S, int nh, int head_size, hipStream_t stream,
                               const DropCfg* drop = nullptr, const int* seq_start = nullptr, const int* seq_len = nullptr,
-                              uint32_t* keep_bits = nullptr);
+                              uint32_t* keep_bits = nullptr, const PrefetchArgs* pf = nullptr);
 int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
                           float* mean, float* rstd, int M, int H, float eps, int grp_rows, int grp_stride,
-                          hipStream_t stream, int x_f16 = 0, void* y_f16 = nullptr, long ldyh = 0);
+                          hipStream_t stream, int x_f16 = 0, void* y_f16 = nullptr, long ldyh = 0,
+                          const PrefetchArgs* pf = nullptr);
 int vt_embed_layernorm_dispatch(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                                 const float* pos, const float* type, const float* gamma, const float* beta, void* y,
                                 long ldy, int B, int T, int S, int H, int n_word, int n_pos, int n_type, float eps,
@@ -83,6 +84,7 @@ void vt_gemm_set_trace(void* p);
 void vt_wgrad_set_tile(int tn);
 void vt_wgrad_v8_enable(int on);
 int vt_wgrad_v8_timeouts(unsigned* out);
+int vt_prefetch_dispatch(const void* const* ptrs, const long* bytes, int n, hipStream_t stream);   // rowops.hip
 int vt_gemm_set_workspace_impl(void* base, long bytes);        // gemm_v7.hip
 int vt_gemm_shared_tile_timeouts_impl(unsigned* out);
 long vt_gemm_workspace_region_bytes_impl();
@@ -669,6 +671,31 @@ int vt_ln_stream_init(const float* x, int64_t ldx, void* x_f16, int64_t lds, voi
 // sequence attended (no mask) -- the layout of vt_encoder_forward_seq_bf16.
 }  // extern "C"
 
+static int prefetch4(const void* p0, long b0, const void* p1, long b1, const void* p2, long b2, const void* p3, long b3,
+                     hipStream_t stream);
+static PrefetchArgs prefetch_args(const void* p0, long b0, const void* p1, long b1, const void* p2 = nullptr, long b2 = 0,
+                                  const void* p3 = nullptr, long b3 = 0) {
+  PrefetchArgs a;
+  a.n = 0;
+  const void* p[4] = {p0, p1, p2, p3};
+  const long b[4] = {b0, b1, b2, b3};
+  for (int i = 0; i < 4; ++i)
+    if (p[i] && b[i] > 0 && !((uintptr_t)p[i] & 15)) { a.p[a.n] = p[i]; a.bytes[a.n] = b[i]; ++a.n; }
+  for (int i = a.n; i < 4; ++i) { a.p[i] = nullptr; a.bytes[i] = 0; }
+  return a;
+}
+// The inference layer loop (buffers shared by all layers; the twelve layers' weights do not survive a forward's traffic in the
+// Infinity Cache at small batch either): VT_PREFETCH_INFER = 0 off / 1 one launch per layer / 2 two launches per layer /
+// 3 (default) riding in the attention kernel's spare workgroups: no launch, measured -6 ... -9 % at B <= 16
+static int g_prefetch_infer = -2;
+static int prefetch_infer_mode() {
+  if (g_prefetch_infer == -2) {
+    const char* e = getenv("VT_PREFETCH_INFER");
+    g_prefetch_infer = e ? atoi(e) : 3;
+  }
+  return g_prefetch_infer;
+}
+
 static int encoder_forward_ln_impl(const vt_layer_weights_ln* layers, int num_layers, void* s16_a, void* sf_a, float* stats_a,
                                    void* s16_b, void* sf_b, float* stats_b, void* qkv, void* ctx, void* mid, const float* mask,
                                    int mask_additive, const float* head_scale, int B, int S, int H, int nh, int I, float ln_eps,
@@ -681,13 +708,29 @@ static int encoder_forward_ln_impl(const vt_layer_weights_ln* layers, int num_la
   for (int l = 0; l < num_layers; ++l) {
     const vt_layer_weights_ln& w = layers[l];
     int rc;
+    const int pfi = prefetch_infer_mode();
+    const long b_qkv = 6L * H * H, b_ao = 2L * H * H, b_ffn = 2L * H * I;
+    if (pfi == 1) {
+      rc = prefetch4(w.w_ao, b_ao, w.w_in, b_ffn, w.w_out, b_ffn, l + 1 < num_layers ? layers[l + 1].w_qkv : nullptr, b_qkv, stream);
+      if (rc) return rc;
+    } else if (pfi == 2) {
+      rc = prefetch4(w.w_ao, b_ao, w.w_in, b_ffn, nullptr, 0, nullptr, 0, stream);
+      if (rc) return rc;
+    }
     rc = vt_gemm_ln_dispatch(s16_a, H, w.w_qkv, H, w.h_qkv, w.g_qkv, stats_a, np, stat_rows, ln_eps, 1, nullptr, 0, qkv, 3L * H,
                              nullptr, 0, nullptr, M, 3 * H, H, VT_ACT_NONE, stream);
     if (rc) return rc;
     const DropCfg nodrop = vt_make_drop(0.f, 0, 0);
+    const PrefetchArgs pf_att = prefetch_args(w.w_ao, b_ao, w.w_in, b_ffn, w.w_out, b_ffn,
+                                              l + 1 < num_layers ? layers[l + 1].w_qkv : nullptr, b_qkv);
     rc = vt_attention_fwd_dispatch(qkv, 3L * H, mask, mask_additive, head_scale ? head_scale + (long)l * nh : nullptr, ctx, H,
-                                   nullptr, B, S, nh, 64, stream, &nodrop, rows ? seq_start : nullptr, rows ? seq_len : nullptr);
+                                   nullptr, B, S, nh, 64, stream, &nodrop, rows ? seq_start : nullptr, rows ? seq_len : nullptr,
+                                   nullptr, pfi == 3 ? &pf_att : nullptr);
     if (rc) return rc;
+    if (pfi == 2) {
+      rc = prefetch4(w.w_out, b_ffn, l + 1 < num_layers ? layers[l + 1].w_qkv : nullptr, b_qkv, nullptr, 0, nullptr, 0, stream);
+      if (rc) return rc;
+    }
     rc = vt_gemm_ln_dispatch(ctx, H, w.w_ao, H, w.cb_ao, w.gamma_in, stats_a, np, stat_rows, ln_eps, 2, sf_a, H, s16_b, H, sf_b,
                              H, stats_b, M, H, H, VT_ACT_NONE, stream);
     if (rc) return rc;
@@ -728,6 +771,59 @@ int vt_encoder_forward_ln_seq_bf16(const vt_layer_weights_ln* layers, int num_la
 
 // rows != 0: the activations hold `rows` compacted token rows (no padding rows), sequence b = rows seq_start[b] ..
 // seq_start[b] + seq_len[b]; every key of a sequence is attended (no mask).  rows == 0: B * S rows, sequence b at b * S.
+// Weight prefetch in the training layer loops (rowops.hip, prefetch_ranges): 0 off, 1 one launch per layer, 2 one launch in
+// front of every kernel that precedes a GEMM (the weights of that GEMM), -1 automatic = mode VT_PREFETCH_MODE (default 1)
+// below VT_PREFETCH_MAX_ROWS rows (default 16 384: at B = 256 the K loops run three rounds per CU at the chip's power-limited
+// rate and hide the first touch; measured level there).
+static int g_prefetch_mode = -2;
+static long g_prefetch_max_rows = 16384;
+static int prefetch_mode(long rows) {
+  if (g_prefetch_mode == -2) {
+    const char* e = getenv("VT_PREFETCH_WEIGHTS");
+    g_prefetch_mode = e ? atoi(e) : 4;
+    const char* r = getenv("VT_PREFETCH_MAX_ROWS");
+    if (r) g_prefetch_max_rows = atol(r);
+  }
+  return rows <= g_prefetch_max_rows ? g_prefetch_mode : 0;
+}
+static int prefetch4(const void* p0, long b0, const void* p1, long b1, const void* p2, long b2, const void* p3, long b3,
+                     hipStream_t stream) {
+  const void* p[4] = {p0, p1, p2, p3};
+  const long b[4] = {b0, b1, b2, b3};
+  return vt_prefetch_dispatch(p, b, 4, stream);
+}
+// Mode 3: the same reads on a SIDE stream of the library's own, started behind an event on the caller's stream and never
+// waited for (nothing depends on them): issued in front of the attention kernels, whose waves leave registers and memory
+// bandwidth free -- the persistent GEMMs hold every register of a CU they run on, so beside them a prefetch would only queue.
+struct PrefetchSide {
+  hipStream_t stream;
+  hipEvent_t ev[64];
+  unsigned next;
+  bool ok;
+};
+static PrefetchSide* prefetch_side() {
+  static PrefetchSide side[16];
+  static bool made[16] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!made[dev]) {
+    made[dev] = true;
+    PrefetchSide& s = side[dev];
+    s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; s.ok && i < 64; ++i) s.ok = hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) == hipSuccess;
+    s.next = 0;
+  }
+  return side[dev].ok ? &side[dev] : nullptr;
+}
+static int prefetch4_side(const void* p0, long b0, const void* p1, long b1, const void* p2, long b2, const void* p3, long b3,
+                          hipStream_t stream) {
+  PrefetchSide* s = prefetch_side();
+  if (!s) return prefetch4(p0, b0, p1, b1, p2, b2, p3, b3, stream);
+  hipEvent_t e = s->ev[s->next++ & 63];
+  if (hipEventRecord(e, stream) != hipSuccess || hipStreamWaitEvent(s->stream, e, 0) != hipSuccess) return VT_ERR_HIP;
+  return prefetch4(p0, b0, p1, b1, p2, b2, p3, b3, s->stream);
+}
+
 static int encoder_forward_impl(const vt_layer_weights* layers, const vt_layer_acts* acts, int num_layers, const void* x,
                                 const float* mask, int mask_additive, const float* head_scale, int B, int S, int H, int nh,
                                 int I, float ln_eps, float p_hidden, float p_attn, uint64_t drop_seed, hipStream_t stream,
@@ -745,12 +841,25 @@ static int encoder_forward_impl(const vt_layer_weights* layers, const vt_layer_a
     const vt_layer_acts& a = acts[l];
     if (!a.qkv || !a.ctx || !a.attn_pre || !a.attn_out || !a.mid || !a.out_pre || !a.out) return VT_ERR_NULL;
     int rc;
+    const int pf = prefetch_mode(M);
+    const long b_qkv = 6L * H * H, b_ao = 2L * H * H, b_ffn = 2L * H * I;   // bytes of the layer's four bf16 weight matrices
+    if (pf == 1) {   // this layer's later weights and the next layer's first one, in one launch
+      rc = prefetch4(w.w_ao, b_ao, w.w_in, b_ffn, w.w_out, b_ffn, l + 1 < num_layers ? layers[l + 1].w_qkv : nullptr, b_qkv, stream);
+      if (rc) return rc;
+    } else if (pf == 2) {
+      rc = prefetch4(w.w_ao, b_ao, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+      if (rc) return rc;
+    }
     rc = vt_gemm_dispatch(cur, H, w.w_qkv, H, w.b_qkv, nullptr, 0, a.qkv, 3L * H, M, 3 * H, H, VT_ACT_NONE, 0, 0, 0, stream);
     if (rc) return rc;
     if (!vt_attn_drop_ok(p_attn, attn_drop_bits())) return VT_ERR_UNSUPPORTED;
     const DropCfg d_att = vt_make_drop_attn(p_attn, drop_seed, VT_SITE_ATTN(l), attn_drop_bits());
     const DropCfg d_so = vt_make_drop(p_hidden, drop_seed, VT_SITE_SELFOUT(l));
     const DropCfg d_out = vt_make_drop(p_hidden, drop_seed, VT_SITE_OUT(l));
+    if (pf == 3) {   // beside the attention kernel: the three weights the rest of this layer reads, and the next layer's first
+      rc = prefetch4_side(w.w_ao, b_ao, w.w_in, b_ffn, w.w_out, b_ffn, l + 1 < num_layers ? layers[l + 1].w_qkv : nullptr, b_qkv, stream);
+      if (rc) return rc;
+    }
     rc = vt_attention_fwd_dispatch(a.qkv, 3L * H, mask, mask_additive, head_scale ? head_scale + (long)l * nh : nullptr, a.ctx, H,
                                    a.lse, B, S, nh, 64, stream, &d_att, rows ? seq_start : nullptr, rows ? seq_len : nullptr,
                                    a.keep_bits);
@@ -768,21 +877,34 @@ static int encoder_forward_impl(const vt_layer_weights* layers, const vt_layer_a
     if (a.ln_residual_mode != 0 && !rln) return VT_ERR_UNSUPPORTED;
     const bool h16 = rln || (a.ln1_h && a.ln2_h);
     const void* res = cur_h ? cur_h : cur;
+    if (pf == 2) {
+      rc = prefetch4(w.w_in, b_ffn, w.w_out, b_ffn, nullptr, 0, nullptr, 0, stream);
+      if (rc) return rc;
+    }
     rc = vt_gemm_dispatch(a.ctx, H, w.w_ao, H, w.b_ao, res, H, a.attn_pre, H, M, H, H, VT_ACT_NONE,
                           (h16 ? 2 : 0) | (cur_h ? 4 : 0), 0, 0, stream, nullptr, 0, &d_so, cur_ln.mean ? &cur_ln : nullptr);
     if (rc) return rc;
+    // mode 4: the LayerNorm kernels carry the prefetch in spare workgroups -- LayerNorm 1 the two FFN weights, LayerNorm 2 the
+    // next layer's attention weights (no launch of its own)
+    const PrefetchArgs pf_ln1 = prefetch_args(w.w_in, b_ffn, w.w_out, b_ffn);
+    const PrefetchArgs pf_ln2 = l + 1 < num_layers ? prefetch_args(layers[l + 1].w_qkv, b_qkv, layers[l + 1].w_ao, b_ao)
+                                                   : prefetch_args(nullptr, 0, nullptr, 0);
     rc = vt_layernorm_dispatch(a.attn_pre, H, a.attn_out, H, w.ln1_g, w.ln1_b, a.ln1_mean, a.ln1_rstd, M, H, ln_eps, 0, 0, stream,
-                               h16 ? 1 : 0, (h16 && !rln) ? a.ln1_h : nullptr, H);
+                               h16 ? 1 : 0, (h16 && !rln) ? a.ln1_h : nullptr, H, pf == 4 ? &pf_ln1 : nullptr);
     if (rc) return rc;
     rc = vt_gemm_dispatch(a.attn_out, H, w.w_in, H, w.b_in, nullptr, 0, a.mid, I, M, I, H, VT_ACT_GELU, 0, 0, 0, stream,
                           a.mid_pre, I);
     if (rc) return rc;
     const VtLnResidual ln1 = {a.ln1_mean, a.ln1_rstd, w.ln1_g, w.ln1_b};
+    if (pf == 2 && l + 1 < num_layers) {
+      rc = prefetch4(layers[l + 1].w_qkv, b_qkv, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+      if (rc) return rc;
+    }
     rc = vt_gemm_dispatch(a.mid, I, w.w_out, I, w.b_out, rln ? a.attn_pre : (h16 ? a.ln1_h : a.attn_out), H, a.out_pre, H, M, H, I,
                           VT_ACT_NONE, h16 ? 6 : 0, 0, 0, stream, nullptr, 0, &d_out, rln ? &ln1 : nullptr);
     if (rc) return rc;
     rc = vt_layernorm_dispatch(a.out_pre, H, a.out, H, w.ln2_g, w.ln2_b, a.ln2_mean, a.ln2_rstd, M, H, ln_eps, 0, 0, stream,
-                               h16 ? 1 : 0, (h16 && !rln) ? a.ln2_h : nullptr, H);
+                               h16 ? 1 : 0, (h16 && !rln) ? a.ln2_h : nullptr, H, pf == 4 ? &pf_ln2 : nullptr);
     if (rc) return rc;
     cur = a.out;
     cur_h = rln ? a.out_pre : (h16 ? a.ln2_h : nullptr);
@@ -807,6 +929,22 @@ int vt_encoder_forward_seq_bf16(const vt_layer_weights* layers, const vt_layer_a
   if (rows <= 0) return VT_ERR_BAD_SHAPE;
   return encoder_forward_impl(layers, acts, num_layers, x, nullptr, 0, head_scale, B, S, H, nh, I, ln_eps, p_hidden, p_attn,
                               drop_seed, (hipStream_t)stream, (long)rows, seq_start, seq_len);
+}
+
+// Weight prefetch of the layer loops (see prefetch_mode / prefetch_infer_mode above): training 0 off, 1 one launch per layer,
+// 2 a launch per GEMM pair, 3 side stream, 4 (default) in the LayerNorm kernels' spare workgroups; inference 0 off, 1 / 2
+// launches, 3 (default) in the attention kernel's spare workgroups.  -1 keeps a setting.  Values are never changed by it.
+int vt_set_weight_prefetch(int training_mode, int inference_mode) {
+  if (training_mode < -1 || training_mode > 4 || inference_mode < -1 || inference_mode > 3) return VT_ERR_UNSUPPORTED;
+  (void)prefetch_mode(0);
+  (void)prefetch_infer_mode();
+  if (training_mode >= 0) g_prefetch_mode = training_mode;
+  if (inference_mode >= 0) g_prefetch_infer = inference_mode;
+  return VT_OK;
+}
+int vt_get_weight_prefetch(int inference) {
+  (void)prefetch_mode(0);
+  return inference ? prefetch_infer_mode() : g_prefetch_mode;
 }
 
 // Backward of CaptionBertEncoder (oscar/modeling_bert.py:140-169) = the reverse layer loop; per layer
@@ -878,10 +1016,25 @@ static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_
     // with hidden dropout the gradient of a dense output is the pre-LayerNorm gradient times the mask
     void* g_pre_dn = p_hidden > 0.f ? ws->g_pre_d : ws->g_pre;
     void* g_pre2_dn = p_hidden > 0.f ? ws->g_pre2_d : ws->g_pre2;
+    const int pf = prefetch_mode(M);
+    const long b_qkv = 6L * H * H, b_ao = 2L * H * H, b_ffn = 2L * H * I;   // the transposed copies have the same sizes
+    if (pf == 1) {   // the four transposed weight copies this layer's dgrad GEMMs read
+      rc = prefetch4(wt.wt_out, b_ffn, wt.wt_in, b_ffn, wt.wt_ao, b_ao, wt.wt_qkv, b_qkv, stream);
+      if (rc) return rc;
+    } else if (pf == 2) {
+      rc = prefetch4(wt.wt_out, b_ffn, wt.wt_in, b_ffn, nullptr, 0, nullptr, 0, stream);
+      if (rc) return rc;
+    } else if (pf == 3 && l == num_layers - 1) {   // the call's first layer: beside its LayerNorm backward
+      rc = prefetch4_side(wt.wt_out, b_ffn, wt.wt_in, b_ffn, wt.wt_ao, b_ao, nullptr, 0, stream);
+      if (rc) return rc;
+    }
     // LayerNorm 2 backward: dL/d(out_pre)
     const int h16 = ((a.ln1_h && a.ln2_h) || a.ln_residual_mode == 1) ? 1 : 0;   // the forward kept the pre-LayerNorm sums as fp16 (see encoder_forward_impl)
+    const PrefetchArgs pf_ln2 = prefetch_args(wt.wt_out, b_ffn, wt.wt_in, b_ffn);   // mode 4: riding in the reduce kernels
+    const PrefetchArgs pf_ln1 = prefetch_args(wt.wt_ao, b_ao, wt.wt_qkv, b_qkv);
     rc = vt_layernorm_bwd_dispatch(a.out_pre, H, g, H, w.ln2_g, ws->g_pre, H, d.d_ln2_g, d.d_ln2_b, ws->ln_partial, M, H,
-                                   ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre_d : nullptr, H, &d_out, h16);
+                                   ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre_d : nullptr, H, &d_out, h16,
+                                   pf == 4 ? &pf_ln2 : nullptr);
     if (rc) return rc;
     // through output.dense and the GELU: g_mid = (g_pre . W_out) * gelu'(pre-activation) (saved in mid_pre)
     rc = vt_gemm_dispatch(g_pre_dn, H, wt.wt_out, H, nullptr, a.mid_pre, I, ws->g_mid, I, M, I, H, VT_ACT_MUL, 0, 0, 0, stream);
@@ -889,13 +1042,24 @@ static int encoder_backward_impl(const vt_layer_weights* layers, const vt_layer_
     // through intermediate.dense, plus the residual branch: dL/d(attn_out) -> g
     rc = vt_gemm_dispatch(ws->g_mid, I, wt.wt_in, I, nullptr, ws->g_pre, H, g, H, M, H, I, VT_ACT_NONE, 0, 0, 0, stream);
     if (rc) return rc;
+    if (pf == 2) {
+      rc = prefetch4(wt.wt_ao, b_ao, wt.wt_qkv, b_qkv, nullptr, 0, nullptr, 0, stream);
+      if (rc) return rc;
+    }
     // LayerNorm 1 backward: dL/d(attn_pre)
     rc = vt_layernorm_bwd_dispatch(a.attn_pre, H, g, H, w.ln1_g, ws->g_pre2, H, d.d_ln1_g, d.d_ln1_b, ws->ln_partial, M, H,
-                                   ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre2_d : nullptr, H, &d_so, h16);
+                                   ln_eps, accumulate, stream, p_hidden > 0.f ? ws->g_pre2_d : nullptr, H, &d_so, h16,
+                                   pf == 4 ? &pf_ln1 : nullptr);
     if (rc) return rc;
     // through attention.output.dense: dL/d(ctx)
     rc = vt_gemm_dispatch(g_pre2_dn, H, wt.wt_ao, H, nullptr, nullptr, 0, ws->g_ctx, H, M, H, H, VT_ACT_NONE, 0, 0, 0, stream);
     if (rc) return rc;
+    if (pf == 3) {   // beside the attention backward: this layer's last dgrad weight and the three of the layer below
+      const vt_layer_weights_t* nx = l > 0 ? &layers_t[l - 1] : nullptr;
+      rc = prefetch4_side(wt.wt_qkv, b_qkv, nx ? nx->wt_out : nullptr, b_ffn, nx ? nx->wt_in : nullptr, b_ffn,
+                          nx ? nx->wt_ao : nullptr, b_ao, stream);
+      if (rc) return rc;
+    }
     rc = vt_attention_bwd_dispatch(a.qkv, 3L * H, ws->g_ctx, H, a.ctx, H, mask, mask_additive, a.lse, ws->delta, ws->g_qkv,
                                    3L * H, ws->dq32, B, S, nh, 64, stream, &d_att, rows ? seq_start : nullptr,
                                    rows ? seq_len : nullptr, rows, a.keep_bits);

@@ -325,6 +325,36 @@ __host__ __forceinline__ DropCfg vt_make_drop_attn(float p, uint64_t step_seed, 
   d.scale = pq > 0.f ? 1.0f / (1.0f - pq) : 1.0f;
   return d;
 }
+// ---- weight prefetch (round 6; rowops.hip has the why) -----------------------------------------------------------------
+// Up to four byte ranges that a kernel's spare workgroups (or a launch of their own) read and drop, so that the lines sit in
+// the Infinity Cache when the next GEMM's one round of tiles asks for them.
+struct PrefetchArgs {
+  const void* p[4];
+  long bytes[4];
+  int n;
+};
+#ifdef __HIPCC__
+// workgroup `wg` of `nwg` (256 lanes each): 16 KiB blocks round-robin, four 16-byte loads per lane in flight
+__device__ __forceinline__ void vt_prefetch_role(const PrefetchArgs& a, int wg, int nwg) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  const int lane = threadIdx.x & 255;
+  for (int r = 0; r < a.n; ++r) {
+    const char* base = (const char*)a.p[r];
+    const long bytes = a.bytes[r] & ~15L;
+    const long nblk = (bytes + 16383) >> 14;
+    for (long blk = wg; blk < nblk; blk += nwg) {
+      const long off = (blk << 14) + lane * 16;
+      u4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+      if (off < bytes) v0 = *(const u4*)(base + off);
+      if (off + 4096 < bytes) v1 = *(const u4*)(base + off + 4096);
+      if (off + 8192 < bytes) v2 = *(const u4*)(base + off + 8192);
+      if (off + 12288 < bytes) v3 = *(const u4*)(base + off + 12288);
+      asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));   // the loads must be issued and waited for; nothing is kept
+    }
+  }
+}
+#endif
+
 // dropout sites: layer l uses 8*l + {0: attention probs, 1: attention.output dropout, 2: output dropout};
 // 0xE0 = embeddings, 0xE1 = image embedding
 #define VT_SITE_ATTN(l) (8u * (l) + 0u)

@@ -11,6 +11,8 @@
 //                       operand, so img_embedding + location_embeds (encoder.py:277-279) is ONE GEMM.
 #include "common.hpp"
 
+__global__ void prefetch_ranges(PrefetchArgs a);   // (defined at the end of this file)
+
 struct LnArgs {
   const bf16_t* x; long ldx;   // bf16, or fp16 (template parameter XF16: the training layer's pre-LayerNorm sums)
   bf16_t* y; long ldy;
@@ -20,6 +22,10 @@ struct LnArgs {
   int M, H;
   int grp_rows, grp_stride;  // row remap as in the GEMM (0: identity); applies to x and y
   float eps;
+  // layernorm_rows_full only: workgroups n_main .. gridDim.x - 1 do not normalise rows but read `pf`'s ranges (the weights of
+  // the GEMMs that follow: vt_prefetch_role); n_main == gridDim.x and pf.n == 0 without a prefetch
+  int n_main;
+  PrefetchArgs pf;
 };
 
 template <int CH, bool XF16>
@@ -130,6 +136,10 @@ __global__ __launch_bounds__(256) void layernorm_rows(LnArgs a) {
 template <int C8, int C4, int R, bool XF16>
 __global__ __launch_bounds__(256) void layernorm_rows_full(LnArgs a) {
   constexpr int E = 8 * C8 + 4 * C4, H = 512 * C8 + 256 * C4, W = E / 2;
+  if ((int)blockIdx.x >= a.n_main) {   // a spare workgroup: the weight prefetch riding along (uniform per workgroup)
+    vt_prefetch_role(a.pf, (int)blockIdx.x - a.n_main, (int)gridDim.x - a.n_main);
+    return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col4 = 512 * C8 + lane * 4;
   float gam[E], bet[E];
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_full(LnArgs a) {
     for (int i = 0; i < 4; ++i) { gam[8 * C8 + i] = g0[i]; bet[8 * C8 + i] = b0[i]; }
   }
   const float invH = 1.0f / (float)H;
-  const long ngroups = ((long)a.M + R - 1) / R, stride = (long)gridDim.x * 4;
+  const long ngroups = ((long)a.M + R - 1) / R, stride = (long)a.n_main * 4;
   uint32_t xw[R][W];
   auto load_rows = [&](long g) {
 #pragma unroll
@@ -234,7 +244,8 @@ __global__ __launch_bounds__(256) void layernorm_rows_full(LnArgs a) {
 
 int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const float* gamma, const float* beta,
                           float* mean, float* rstd, int M, int H, float eps, int grp_rows, int grp_stride,
-                          hipStream_t stream, int x_f16 = 0, void* y_f16 = nullptr, long ldyh = 0) {
+                          hipStream_t stream, int x_f16 = 0, void* y_f16 = nullptr, long ldyh = 0,
+                          const PrefetchArgs* pf = nullptr) {
   if (!x || !y || !gamma || !beta) return VT_ERR_NULL;
   if (M <= 0 || H <= 0 || (H % 8) || H > 64 * 8 * 4) return VT_ERR_BAD_SHAPE;
   if ((ldx % 8) || (ldy % 8) || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15)) return VT_ERR_BAD_ALIGN;
@@ -252,6 +263,14 @@ int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const floa
     long nb = (((long)M + R - 1) / R + 3) / 4;
     static const int max_blocks = [] { const char* e = getenv("VT_LN_FWD_BLOCKS"); return e ? atoi(e) : 1024; }();
     if (nb > max_blocks) nb = max_blocks;
+    a.n_main = (int)nb;
+    a.pf.n = 0;
+    if (pf && pf->n > 0) {   // spare workgroups behind the row workgroups read the ranges (16 KiB per workgroup and pass)
+      long extra = 0;
+      for (int i = 0; i < pf->n; ++i) extra += (pf->bytes[i] + 16383) >> 14;
+      a.pf = *pf;
+      nb += extra < 1 ? 1 : (extra > 640 ? 640 : extra);
+    }
 #define VT_LNF_LAUNCH(C8, C4, RR)                                                                                          \
     do {                                                                                                                   \
       if (x_f16) hipLaunchKernelGGL((layernorm_rows_full<C8, C4, RR, true>), dim3((unsigned)nb), dim3(256), 0, stream, a);  \
@@ -267,6 +286,7 @@ int vt_layernorm_dispatch(const void* x, long ldx, void* y, long ldy, const floa
 #undef VT_LNF_LAUNCH
     return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
   }
+  if (pf && pf->n > 0) hipLaunchKernelGGL(prefetch_ranges, dim3(256), dim3(256), 0, stream, *pf);   // (no spare workgroups in the chunked kernel)
   const dim3 grid((M + 15) / 16), block(256);   // 4 waves x 4 rows per workgroup
   const int ch = (H + 511) / 512;
 #define VT_LN_LAUNCH(CH_)                                                                     \
@@ -736,8 +756,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_full(LnBwdArgs a) {
 // at a small batch.)
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ partial, int nblocks, int n,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int H,
-                                                     int accumulate) {
+                                                     int accumulate, int n_main, PrefetchArgs pf) {
   __shared__ f32x4 red[64][4];
+  if ((int)blockIdx.x >= n_main) {   // a spare workgroup: the weight prefetch riding along (see LnArgs::pf)
+    vt_prefetch_role(pf, (int)blockIdx.x - n_main, (int)gridDim.x - n_main);
+    return;
+  }
   const int cg = threadIdx.x & 3, part = threadIdx.x >> 2;
   const int j = blockIdx.x * 16 + cg * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -771,7 +795,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ p
 int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy, const float* gamma, void* dx, long lddx,
                               float* dgamma, float* dbeta, float* partial_ws, int M, int H, float eps, int accumulate,
                               hipStream_t stream, void* dx2 = nullptr, long lddx2 = 0, const DropCfg* drop = nullptr,
-                              int x_f16 = 0) {
+                              int x_f16 = 0, const PrefetchArgs* pf = nullptr) {
   if (!x || !dy || !gamma || !dx || !dgamma || !dbeta || !partial_ws) return VT_ERR_NULL;
   if (M <= 0 || H <= 0 || (H % 8) || H > 1024) return VT_ERR_BAD_SHAPE;
   if ((ldx % 8) || (ldy % 8) || (lddx % 8) || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15)) return VT_ERR_BAD_ALIGN;
@@ -811,8 +835,19 @@ int vt_layernorm_bwd_dispatch(const void* x, long ldx, const void* dy, long ldy,
     if (x_f16) hipLaunchKernelGGL((layernorm_bwd_rows<2, true>), dim3(nblocks), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((layernorm_bwd_rows<2, false>), dim3(nblocks), dim3(256), 0, stream, a);
   }
-  hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 15) / 16), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
-                     dbeta, H, accumulate);
+  {
+    const int n_main = (2 * H + 15) / 16;
+    PrefetchArgs none;
+    none.n = 0;
+    for (int i = 0; i < 4; ++i) { none.p[i] = nullptr; none.bytes[i] = 0; }
+    long extra = 0;
+    if (pf && pf->n > 0) {
+      for (int i = 0; i < pf->n; ++i) extra += (pf->bytes[i] + 16383) >> 14;
+      extra = extra < 1 ? 1 : (extra > 640 ? 640 : extra);
+    }
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((unsigned)(n_main + extra)), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
+                       dbeta, H, accumulate, n_main, extra ? *pf : none);
+  }
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 // workspace floats needed by vt_layernorm_bwd: LN_BWD_MAX_BLOCKS * 2 * H
@@ -991,8 +1026,11 @@ int vt_embed_layernorm_bwd_dispatch(const int64_t* ids, const int64_t* type_ids,
   const int nblocks = (int)(nb > LN_BWD_MAX_BLOCKS ? LN_BWD_MAX_BLOCKS : nb);
   if (H <= 512) hipLaunchKernelGGL(embed_layernorm_bwd<1>, dim3(nblocks), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(embed_layernorm_bwd<2>, dim3(nblocks), dim3(256), 0, stream, a);
+  PrefetchArgs none;
+  none.n = 0;
+  for (int i = 0; i < 4; ++i) { none.p[i] = nullptr; none.bytes[i] = 0; }
   hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * H + 15) / 16), dim3(256), 0, stream, partial_ws, nblocks, 2 * H, dgamma,
-                     dbeta, H, accumulate);
+                     dbeta, H, accumulate, (2 * H + 15) / 16, none);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
@@ -1904,5 +1942,41 @@ int vt_action_head_dispatch(const float* z, long ldz, const long* y, int B, int 
   if (!z || !y || !dz || !out) return VT_ERR_NULL;
   if (B <= 0 || A <= 0 || A > 64 || Ap < A || Ap > 64 || ldz < A || lddz < Ap) return VT_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(action_head_rows, dim3(1), dim3(1024), 0, stream, z, ldz, y, B, A, grad_scale, (bf16_t*)dz, lddz, Ap, out);
+  return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
+}
+
+// ---- weight prefetch (round 6) --------------------------------------------------------------------------------------------------
+// At small batch the layer GEMMs are ONE round of tiles whose K loop prefetches two K-steps ahead; a weight matrix that was last
+// touched a step ago comes from HBM, not from the Infinity Cache (the step streams ~1.5 GB of activations through its 256 MB
+// between two uses of a weight), and a K = 3 072 tile then stalls on most of its 48 dependent K-steps: FFN-down 45 us on warm
+// weights, 67 us in the step (tools/r6/pair_cold.py: distinct weights AND distinct activations per layer reproduce it, either
+// alone does not; reading W2 once before FFN-up gives the 12 us back).  This kernel reads up to four byte ranges and drops
+// the data: what it leaves behind is the lines in the Infinity Cache (and in the L2 of the XCD that happened to read them).
+__global__ __launch_bounds__(256) void prefetch_ranges(PrefetchArgs a) { vt_prefetch_role(a, blockIdx.x, gridDim.x); }
+
+// host side: the ranges a caller names (null / empty ones dropped), and how many workgroups they are worth
+static bool prefetch_pack(const void* const* ptrs, const long* bytes, int n, PrefetchArgs& a, long& wgs) {
+  long total = 0;
+  a.n = 0;
+  for (int i = 0; i < n && i < 4; ++i) {
+    if (!ptrs[i] || bytes[i] <= 0 || ((uintptr_t)ptrs[i] & 15)) continue;
+    a.p[a.n] = ptrs[i];
+    a.bytes[a.n] = bytes[i];
+    total += bytes[i];
+    ++a.n;
+  }
+  for (int i = a.n; i < 4; ++i) { a.p[i] = nullptr; a.bytes[i] = 0; }
+  wgs = (total + 16383) >> 14;
+  return a.n > 0;
+}
+
+int vt_prefetch_dispatch(const void* const* ptrs, const long* bytes, int n, hipStream_t stream) {
+  if (n <= 0) return VT_OK;
+  if (n > 4 || !ptrs || !bytes) return VT_ERR_BAD_SHAPE;
+  PrefetchArgs a;
+  long grid;
+  if (!prefetch_pack(ptrs, bytes, n, a, grid)) return VT_OK;
+  grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+  hipLaunchKernelGGL(prefetch_ranges, dim3((unsigned)grid), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }

@@ -965,6 +965,18 @@ def attn_drop_p(p):
     return float(min(int(n) - 1, max(1, int(p * n + 0.5)))) / n
 
 
+def set_weight_prefetch(training=-1, inference=-1):
+    """The layer loops' weight prefetch (include/visitron_hip.h, vt_set_weight_prefetch): training 0 off .. 4 riding in the
+    LayerNorm kernels (default), inference 0 off .. 3 riding in the attention kernel (default); -1 keeps a setting."""
+    _lib.check(_lib.load().vt_set_weight_prefetch(int(training), int(inference)), "vt_set_weight_prefetch")
+
+
+def weight_prefetch():
+    """(training mode, inference mode) in force."""
+    lib = _lib.load()
+    return int(lib.vt_get_weight_prefetch(0)), int(lib.vt_get_weight_prefetch(1))
+
+
 def attn_dropout_bits():
     """16 (default: exact p) or 8 (rounds 4-5's faster form): the width of the attention-probability dropout's hash fields."""
     try:
