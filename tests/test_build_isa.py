@@ -108,7 +108,7 @@ def test_attention_kernels_register_budgets_and_the_writelane_hazard(tmp_path):
     asm = _device_asm(os.path.join(CSRC, "attention_fwd.hip"), tmp_path)
     ks = _kernels(asm)
     fwd = {n: t for n, t in ks.items() if "attention_fwd_d64" in n}
-    assert len(fwd) == 4                                        # (keep words | none) x (per-query bias | none)
+    assert len(fwd) == 8            # (keep words | none) x (per-query bias | none) x (8-bit | 16-bit dropout fields: round 6)
     for name, text in fwd.items():
         assert int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", text).group(1)) <= 128, name
         keep = "ILb1E" in name
