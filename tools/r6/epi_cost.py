@@ -46,7 +46,7 @@ for M in [int(x) for x in sys.argv[1:]] or [7091]:
             ("+lnres+drop", lambda: ops.linear(x, w, b, residual=rh, out=yh, residual_ln=(mean, rstd, gamma, beta), drop=drop)),
         )
         print("M=%d N=%d K=%d" % (M, N, K))
-        for v in (1, 14, 35, 15, 22, 23, 20, 21, 33, -1):
+        for v in ([int(t) for t in os.environ["VARIANTS"].split(",")] if os.environ.get("VARIANTS") else (1, 14, 35, 15, 22, 23, 20, 21, 33, -1)):
             ops.set_gemm_variant(v)
             row = []
             for name, fn in modes:

@@ -23,7 +23,7 @@ y = [torch.empty(M, H, device=dev, dtype=F16) for _ in range(L)]
 mean, rstd = torch.zeros(M, device=dev), torch.ones(M, device=dev)
 gamma, beta = torch.ones(H, device=dev), torch.zeros(H, device=dev)
 drop = (0.1, 1234, ops.site_out(0))
-VU, VD = (19, 21) if M < 16384 else (-1, -1)
+VU, VD = [int(t) for t in os.environ.get("VUVD", "19,21" if M < 16384 else "18,18").split(",")]
 
 
 def up(i):
