@@ -72,6 +72,10 @@ int64_t vt_gemm_workspace_region_bytes(void);
  * *host_count = how many ran out of it on the current device since the last call (then cleared): non-zero = some GEMM
  * output of an earlier launch is unreliable.  Blocking (4-byte copies): call it where the host synchronises anyway. */
 int vt_gemm_shared_tile_timeouts(unsigned* host_count);
+/* Both counters above (vt_wgrad_turn_timeouts first, vt_gemm_shared_tile_timeouts second) read and cleared by a one-thread
+ * kernel on `stream` into the DEVICE int64 pair out2 -- for callers that read something back at that point anyway (the
+ * training step's row counts): no host round trip of its own (ABI 12). */
+int vt_step_counters(int64_t* out2, vt_stream_t stream);
 /* Attention-probability dropout (oscar/modeling_bert.py:62, nn.Dropout(attention_probs_dropout_prob)): how finely the drop
  * probability is resolved.  16 (default since ABI 12): steps of 1/65536 -- two neighbouring keys share one hash word, a 16-bit
  * field each -- so the reference's 0.1 runs as 6554/65536 = 0.100006.  8 (the form of ABI 8 .. 11): steps of 1/256 -- four

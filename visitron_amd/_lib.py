@@ -82,6 +82,7 @@ SIGNATURES = {
     "vt_gemm_set_workspace": (c_int, [c_void_p, c_int64]),
     "vt_gemm_workspace_region_bytes": (c_int64, []),
     "vt_gemm_shared_tile_timeouts": (c_int, [ctypes.POINTER(ctypes.c_uint)]),
+    "vt_step_counters": (c_int, [c_void_p, c_void_p]),
     "vt_linear_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "vt_linear_bf16_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,

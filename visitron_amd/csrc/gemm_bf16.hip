@@ -894,7 +894,7 @@ int vt_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const flo
   if (drop) g.drop = *drop; else { g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f; }
   g.trace = (unsigned long long*)g_gemm_trace;
   g.ln_mode = 0; g.ln_np = 0; g.ln_rows = 0; g.ln_inv_n = 0.f; g.ln_eps = 0.f; g.ln_stats = nullptr; g.colv = nullptr;
-  g.Rs = nullptr; g.Cs = nullptr; g.stats_out = nullptr; g.ldrs = 0; g.ldcs = 0; g.ksplit = 0; g.c_plane = 0;
+  g.Rs = nullptr; g.Cs = nullptr; g.stats_out = nullptr; g.ldrs = 0; g.ldcs = 0; g.ksplit = 0; g.reverse = 0; g.c_plane = 0;
   g.r_f16 = r_f16; g.c_f16 = c_f16;
   if (rln) {   // residual = LayerNorm(R) from saved row statistics (GemmArgs::r_mean)
     if (!rln->mean || !rln->rstd || !rln->gamma || !rln->beta) return VT_ERR_NULL;
@@ -983,7 +983,7 @@ int vt_gemm_ln_dispatch(const void* A, long lda, const void* W, long ldw, const 
   g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f;
   g.ln_mode = ln_mode; g.ln_np = np; g.ln_rows = (int)stat_rows; g.ln_inv_n = 1.0f / (float)row_len; g.ln_eps = eps;
   g.ln_stats = stats_in; g.colv = colv; g.Rs = (const uint16_t*)Rs; g.Cs = (uint16_t*)Cs; g.stats_out = stats_out; g.ldrs = ldrs; g.ldcs = ldcs;
-  g.ksplit = 0; g.c_plane = 0; g.r_f16 = 0; g.c_f16 = 0;
+  g.ksplit = 0; g.reverse = 0; g.c_plane = 0; g.r_f16 = 0; g.c_f16 = 0;
   int variant = g_gemm_variant >= 0 ? g_gemm_variant : vt_gemm_pick_variant(M, N, K, VT_TUNE_KIND(act, 0, 0, 0, ln_mode));
   if (variant != 15 && variant != 16 && (variant < 18 || variant > 23) && (variant < 28 || variant > 32)) variant = 16;   // only the 256x256-tile kernels
   return vt_gemm_ln_launch(g, act, variant, stream);
@@ -1025,7 +1025,7 @@ int vt_gemm_splitk_dispatch(const void* A, long lda, const void* W, long ldw, vo
   g.drop.thresh = 0; g.drop.seed = 0; g.drop.scale = 1.0f;
   g.ln_mode = 0; g.ln_np = 0; g.ln_rows = 0; g.ln_inv_n = 0.f; g.ln_eps = 0.f; g.ln_stats = nullptr; g.colv = nullptr;
   g.Rs = nullptr; g.Cs = nullptr; g.stats_out = nullptr; g.ldrs = 0; g.ldcs = 0;
-  g.ksplit = ksplit; g.c_plane = (long)M * N; g.r_f16 = 0; g.c_f16 = 0;
+  g.ksplit = ksplit; g.reverse = 0; g.c_plane = (long)M * N; g.r_f16 = 0; g.c_f16 = 0;
   const int rc = vt_gemm_v7_launch(g, ACT_NONE, 1, stream, 8);
   if (rc) return rc;
   const long n4 = ((long)M * N + 3) / 4;

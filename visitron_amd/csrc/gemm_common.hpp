@@ -42,6 +42,8 @@ struct GemmArgs {
   // a reduce pass sums the planes.  For the shapes whose tile count leaves most of the chip idle and whose K is long:
   // the MLM decoder's dgrad, [4 272, 30 528] x [30 528, 768] = 51 tiles of 256 x 256 with 477 K-steps each.
   int ksplit;                // 0 / 1: off
+  int reverse;               // persistent kernel: walk the tile order backwards (experiment: consume a > 256 MB operand in the reverse
+                             // of the order its producer wrote it, so that the rows still in the Infinity Cache are read first)
   long c_plane;
   // ---- fp16 copies of the residual stream in the seven-launch (training) layer ------------------------------------
   // r_f16: the residual operand R holds fp16 (the previous LayerNorm's output, kept beside its bf16 copy);

@@ -53,6 +53,15 @@ int vt_gemm_shared_tile_timeouts_impl(unsigned* out) {
   }
   return VT_OK;
 }
+// the regions' error counters on the current device (vt_step_counters): how many, at most `max`
+int vt_gemm_sk_counter_ptrs(unsigned** ptrs, int max) {
+  const int dev = vt_current_device();
+  if (dev < 0 || dev >= VT_MAX_DEVICES || g_sk_ws[dev].regions <= 0) return 0;
+  int n = 0;
+  for (int r = 0; r < g_sk_ws[dev].regions && n < max; ++r)
+    ptrs[n++] = (unsigned*)(g_sk_ws[dev].base + (long)(r + 1) * V8_SK_REGION_BYTES - 4096 + 2048);
+  return n;
+}
 // fills the shared-tile fields of a launch's arguments; false: no workspace on this device
 static bool v8_take_region(GemmArgs& g) {
   const int dev = vt_current_device();
@@ -99,6 +108,10 @@ static int launch_v8(const GemmArgs& g, hipStream_t stream, int mtn, bool shared
   if (shared_tiles && fast && mtn <= 5 && !v8_take_region(g8)) return VT_ERR_UNSUPPORTED;
   const int th = 32 * mtn;
   g8.tiles_m = (g.M + th - 1) / th;
+  {   // experiment switch: VT_GEMM_REVERSE_K = k walks the tiles of launches with K >= k backwards (0 / unset: never)
+    static const int rev_k = [] { const char* e = getenv("VT_GEMM_REVERSE_K"); return e ? atoi(e) : 0; }();
+    g8.reverse = (rev_k > 0 && g.K >= rev_k) ? 1 : 0;
+  }
   int grid = v8_grid(g8.tiles_m * g8.tiles_n);
   if (grid <= 0) return VT_ERR_HIP;
   // the stream-K region spreads a chunk's tiles over every workgroup of the XCD: launch the whole grid even for fewer

@@ -661,6 +661,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_bf16_v8(GemmArgs g) {
   };
 
   auto tile_origin = [&](int t, int& m0, int& n0) {   // grouped order: bands of 8 row-tiles, column-tile major inside
+    if (g.reverse) t = T - 1 - t;
     const int band = t / band_tiles;
     const int within = t - band * band_tiles;
     const int rows_left = g.tiles_m - band * 8;

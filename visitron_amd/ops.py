@@ -753,21 +753,54 @@ def embed_layernorm_bwd(ids, type_ids, pos_ids, word, pos, typ, gamma, eps, g, S
     return de
 
 
-def batch_row_counts(labels, token_labels, mask, err_flag, B, S):
-    """-> ([err, #labels != -1, #token_labels != -1, #mask != 0, bad] as Python ints, per-tile counts for batch_row_lists):
-    the one host synchronisation of a training step (labels / token_labels int64 [B*S] or None, mask fp32 [B,S] or None,
-    err_flag int32 [1] or None)."""
+_readback = {}   # per device: (side stream, pinned int64[8]) of the step's one read-back
+
+
+def batch_row_counts_begin(labels, token_labels, mask, err_flag, B, S):
+    """Launch the step's counting kernel (and the one-thread kernel that reads and clears the two bounded-wait counters,
+    vt_step_counters) and start copying the seven numbers to pinned host memory on a SIDE stream behind an event -- the
+    caller's stream goes on with work that does not need them (the step's weight transposes) while the host waits in
+    batch_row_counts_end.  Returns a handle for it."""
     _require_hip(labels, token_labels, mask, err_flag)
     ref = next(t for t in (labels, token_labels, mask, err_flag) if t is not None)
     for t in (labels, token_labels):
         assert t is None or (t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B * S)
     assert mask is None or (mask.dtype == torch.float32 and mask.is_contiguous() and mask.numel() == B * S)
-    out = torch.zeros(5, dtype=torch.int64, device=ref.device)
-    tiles = torch.empty(3 * ((B * S + 1023) // 1024), dtype=torch.int32, device=ref.device)
-    rc = _lib.load().vt_batch_row_counts(_ptr(labels), _ptr(token_labels), _ptr(mask), _ptr(err_flag), B, S, _ptr(out), _ptr(tiles),
-                                         _stream())
+    dev = ref.device
+    out = torch.zeros(8, dtype=torch.int64, device=dev)
+    tiles = torch.empty(3 * ((B * S + 1023) // 1024), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    rc = lib.vt_batch_row_counts(_ptr(labels), _ptr(token_labels), _ptr(mask), _ptr(err_flag), B, S, _ptr(out), _ptr(tiles),
+                                 _stream())
     _lib.check(rc, "vt_batch_row_counts")
-    return out.tolist(), tiles
+    _lib.check(lib.vt_step_counters(out.data_ptr() + 5 * 8, _stream()), "vt_step_counters")
+    rb = _readback.get(dev.index)
+    if rb is None:
+        rb = _readback[dev.index] = (torch.cuda.Stream(device=dev), torch.zeros(8, dtype=torch.int64).pin_memory())
+    side, host = rb
+    ready = torch.cuda.Event()
+    ready.record()
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        host.copy_(out, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(side)
+    out.record_stream(side)
+    return done, host, tiles
+
+
+def batch_row_counts_end(handle):
+    """-> ([err, #labels != -1, #token_labels != -1, #mask != 0, bad, wgrad waits that ran out, shared-tile waits that ran
+    out] as Python ints, per-tile counts for batch_row_lists): the one host synchronisation of a training step."""
+    done, host, tiles = handle
+    done.synchronize()
+    return host[:7].tolist(), tiles
+
+
+def batch_row_counts(labels, token_labels, mask, err_flag, B, S):
+    """batch_row_counts_begin + batch_row_counts_end (labels / token_labels int64 [B*S] or None, mask fp32 [B,S] or None,
+    err_flag int32 [1] or None)."""
+    return batch_row_counts_end(batch_row_counts_begin(labels, token_labels, mask, err_flag, B, S))
 
 
 def batch_row_lists(labels, token_labels, mask, B, S, n_w, n_t, n_keep, tiles):

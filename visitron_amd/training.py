@@ -409,7 +409,6 @@ class PretrainEngine(object):
         token_labels (optional): the supervised rows are located here, where the host synchronises anyway."""
         m, cfg, f = self.model, self.cfg, self.flat
         self._require_ownership()
-        self.refresh_derived_weights()
         f.reattach_grads()
         ids = _i64(batch["input_ids"])
         dev = ids.device
@@ -465,18 +464,27 @@ class PretrainEngine(object):
         try_compact = (allow_compact and self.compact_rows and mask is not None and mask.dim() == 2 and hs is None
                        and M >= self.compact_min_rows)
         cmask = mask.contiguous() if try_compact else None
-        vals, tiles = ops.batch_row_counts(lab, tl, cmask, err, B, S)   # one launch, the step's one host synchronisation
+        early = os.environ.get("VT_STEP_OVERLAP_READBACK", "1") == "0"   # A/B switch: the transposes first, as before round 6
+        if early:
+            self.refresh_derived_weights()
+        counts = ops.batch_row_counts_begin(lab, tl, cmask, err, B, S)   # the step's one host synchronisation ...
+        # ... and while its seven numbers travel to the host on a side stream, the device transposes the step's weights (the
+        # copies the dgrad GEMMs read: ~95 us that used to run BEFORE the counting kernel, with the GPU idle behind it for the
+        # 250 us the host needed for this read-back, three more blocking 4-byte reads and the launches that follow)
+        if not early:
+            self.refresh_derived_weights()
+        vals, tiles = ops.batch_row_counts_end(counts)
         # out-of-range input_ids / position_ids / token_type_ids: the reference's embedding lookup raises IndexError
         # (checked before anything indexes the gradient tables with those ids)
         if vals[0] != 0:
             raise IndexError("index out of range in BertEmbeddings (input_ids / position_ids / token_type_ids)")
         # the previous step's weight gradients: a workgroup of the persistent wgrad kernel that gave up its bounded wait
         # for a dW tile added out of turn (never seen; a preempted / shared GPU could do it) -- fail loudly
-        late = ops.wgrad_turn_timeouts()
+        late = int(vals[5])       # (vt_step_counters: read and cleared on the device, delivered with the row counts)
         if late:
             raise RuntimeError("vt_wgrad_bf16: %d workgroup(s) ran out of their turn wait in an earlier launch; the weight "
                                "gradients of that step are unreliable" % late)
-        late = ops.gemm_shared_tile_timeouts()   # the same for the persistent GEMM's shared tiles (kernel variants 28 .. 32)
+        late = int(vals[6])       # the same for the persistent GEMM's shared tiles (kernel variants 28 .. 32)
         if late:
             raise RuntimeError("vt_linear: %d finishing workgroup(s) of shared GEMM tiles ran out of their wait in an earlier "
                                "launch; that step's activations / gradients are unreliable" % late)
