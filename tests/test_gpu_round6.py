@@ -784,3 +784,28 @@ def test_weight_prefetch_modes_do_not_change_an_inference_forward(dev, B, T, R):
         ops.set_weight_prefetch(*before)
     for mode in (1, 2, 3):
         assert torch.equal(outs[mode][0], outs[0][0]) and torch.equal(outs[mode][1], outs[0][1]), mode
+
+
+def test_step_counters_ride_with_the_row_counts(dev):
+    """ops.batch_row_counts: five batch numbers and the two bounded-wait counters (vt_step_counters) in ONE read-back that
+    travels on a side stream; the counts against torch, the counters 0 in a healthy process and equal to what the blocking
+    entry points report; two read-backs in flight at once keep their own values."""
+    from visitron_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    B, S = 5, 37
+    labels = torch.randint(-1, 3, (B * S,), generator=g).to(dev)
+    tl = torch.randint(-1, 2, (B * S,), generator=g).to(dev)
+    mask = (torch.rand(B, S, generator=g) > 0.3).float()
+    mask[:, 0] = 1.0
+    mask_d = mask.to(dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    h1 = ops.batch_row_counts_begin(labels, tl, mask_d, err, B, S)
+    h2 = ops.batch_row_counts_begin(labels, None, None, err, B, S)      # (same pinned buffer: must be read in order)
+    vals, tiles = ops.batch_row_counts_end(h1)
+    assert len(vals) == 7 and vals[0] == 0
+    assert vals[1] == int((labels != -1).sum()) and vals[2] == int((tl != -1).sum()) and vals[3] == int((mask != 0).sum())
+    assert vals[5] == 0 and vals[6] == 0
+    assert ops.wgrad_turn_timeouts() == 0 and ops.gemm_shared_tile_timeouts() == 0
+    vals2, _ = ops.batch_row_counts_end(h2)
+    assert vals2[1] == vals[1] and vals2[2] == 0

@@ -753,7 +753,7 @@ def embed_layernorm_bwd(ids, type_ids, pos_ids, word, pos, typ, gamma, eps, g, S
     return de
 
 
-_readback = {}   # per device: (side stream, pinned int64[8]) of the step's one read-back
+_readback = {}   # per device: [side stream, pinned int64[8, 8] ring, next slot] of the step's one read-back
 
 
 def batch_row_counts_begin(labels, token_labels, mask, err_flag, B, S):
@@ -775,9 +775,10 @@ def batch_row_counts_begin(labels, token_labels, mask, err_flag, B, S):
     _lib.check(rc, "vt_batch_row_counts")
     _lib.check(lib.vt_step_counters(out.data_ptr() + 5 * 8, _stream()), "vt_step_counters")
     rb = _readback.get(dev.index)
-    if rb is None:
-        rb = _readback[dev.index] = (torch.cuda.Stream(device=dev), torch.zeros(8, dtype=torch.int64).pin_memory())
-    side, host = rb
+    if rb is None:   # a side stream and a ring of eight pinned slots (read-backs begun before an earlier one was collected)
+        rb = _readback[dev.index] = [torch.cuda.Stream(device=dev), torch.zeros((8, 8), dtype=torch.int64).pin_memory(), 0]
+    side, host = rb[0], rb[1][rb[2] & 7]
+    rb[2] += 1
     ready = torch.cuda.Event()
     ready.record()
     side.wait_event(ready)
