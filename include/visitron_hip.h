@@ -47,8 +47,10 @@ int vt_abi_version(void);
 void vt_debug_set_gemm_variant(int variant);
 /* Debug: device buffer (>= 64 * 8 B per workgroup) that the persistent GEMM fills with phase timestamps; NULL = off. */
 void vt_debug_set_gemm_trace(void* buf);
-/* Tuning/test hook for vt_wgrad_bf16: 0 automatic (persistent stream-K kernel where N, K are multiples of 256),
-   128 / 256 force the one-tile-per-workgroup kernel with that n-tile width, -8 never the persistent kernel. */
+/* Tuning/test hook for vt_wgrad_bf16: 0 automatic (the persistent kernel where N, K are multiples of 256 and the group has
+   at least 12 288 token rows -- below that the one-tile-per-workgroup kernel is 7 ... 38 % faster, round 6;
+   VT_WGRAD_PERSISTENT_MIN_ROWS), 128 / 256 force the one-tile-per-workgroup kernel with that n-tile width, -8 never the
+   persistent kernel, 8 the persistent kernel wherever it is eligible. */
 void vt_debug_set_wgrad_kernel(int mode);
 /* Autotuner result: on the calling thread's CURRENT DEVICE use kernel `variant` for linear layers of exactly this
  * shape and epilogue (filled by the host before the shape is used; one table per device, mutex-guarded).

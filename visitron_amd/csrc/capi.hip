@@ -201,8 +201,9 @@ int vt_embed_table_grad(const int32_t* sorted_ids, const int64_t* perm, const fl
 void vt_debug_set_gemm_variant(int variant) { vt_gemm_set_variant(variant); }
 void vt_debug_set_gemm_trace(void* buf) { vt_gemm_set_trace(buf); }
 void vt_debug_set_wgrad_kernel(int mode) {
-  // 0: automatic; 128 / 256: the 128(k)-tile kernel with that n-tile width; 8: automatic (alias); -8: never the persistent kernel
-  vt_wgrad_set_tile(mode == 128 || mode == 256 ? mode : 0);
+  // 0: automatic; 128 / 256: the 128(k)-tile kernel with that n-tile width; 8: the persistent kernel wherever it is eligible
+  // (also below its row threshold); -8: never the persistent kernel
+  vt_wgrad_set_tile(mode == 128 || mode == 256 || mode == 8 ? mode : 0);
   vt_wgrad_v8_enable(mode == -8 ? 0 : 1);
 }
 void vt_gemm_tune(int M, int N, int K, int kind, int variant) { vt_gemm_tune_set(M, N, K, kind, variant); }

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_tn_bf16(WgradArgs a) { wgra
 __global__ __launch_bounds__(512, 2) void gemm_wgrad_tn_bf16_w256(WgradArgs a) { wgrad_body<256>(a); }
 
 // Host entry.  problems: array of `nprob` WgradProblem-like records filled by capi.hip.
-static int g_wgrad_tn = 0;  // 0: choose; 128 / 256: forced (tuning hook)
+static int g_wgrad_tn = 0;  // 0: choose; 128 / 256: forced tile width, -8 never / 8 always the persistent kernel (tuning hook)
 void vt_wgrad_set_tile(int tn) { g_wgrad_tn = tn; }
 
 template <int TN>
@@ -228,7 +228,7 @@ static int wgrad_launch(WgradArgs& a, int total, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_HIP;
 }
 
-int vt_wgrad_v8_dispatch(WgradArgs& a, hipStream_t stream);   // gemm_wgrad_v8.hip
+int vt_wgrad_v8_dispatch(WgradArgs& a, hipStream_t stream, bool force);   // gemm_wgrad_v8.hip
 
 int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream) {
   if (a.nprob <= 0 || a.nprob > WG_MAX_PROBLEMS || a.M <= 0) return VT_ERR_BAD_SHAPE;
@@ -246,8 +246,8 @@ int vt_wgrad_dispatch(WgradArgs& a, hipStream_t stream) {
     if ((long)a.M * P.ldy * 2 >= (1L << 31) || (long)a.M * P.ldx * 2 >= (1L << 31)) return VT_ERR_UNSUPPORTED;
   }
   // groups whose matrices are whole 256x256 tiles: the persistent stream-K kernel (long reductions, every CU busy)
-  if (g_wgrad_tn == 0) {
-    const int rc8 = vt_wgrad_v8_dispatch(a, stream);
+  if (g_wgrad_tn == 0 || g_wgrad_tn == 8) {   // (8: the persistent kernel wherever it is eligible, whatever the row count)
+    const int rc8 = vt_wgrad_v8_dispatch(a, stream, g_wgrad_tn == 8);
     if (rc8 != VT_ERR_UNSUPPORTED) return rc8;
   }
   for (int i = 0; i < a.nprob; ++i) {

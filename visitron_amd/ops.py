@@ -1103,7 +1103,8 @@ def encoder_backward(layer_weights, layer_weights_t, layer_acts, layer_grads, x,
 
 
 def set_wgrad_kernel(mode):
-    """Tuning/test hook: 0 automatic, 128 / 256 the one-tile-per-workgroup kernel, -8 never the persistent kernel."""
+    """Tuning/test hook: 0 automatic (persistent kernel from 12 288 rows), 128 / 256 the one-tile-per-workgroup kernel, -8 never /
+    8 always (where eligible) the persistent kernel."""
     _lib.load().vt_debug_set_wgrad_kernel(int(mode))
 
 
