@@ -7,6 +7,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The tests' forwards are small (a few hundred token rows).  In the product an inference forward below 2 800 rows takes the
+# seven-launch layer (round 6: faster there); the tests keep sending theirs through the deferred-LayerNorm loop -- the path
+# large forwards run and most inference tests were written against -- unless a test sets the encoder's
+# `deferred_ln_min_rows` itself (tests/test_gpu_round6.py does, for the rule).  The seven-launch layer has its own tests
+# (`deferred_ln = False`, the compacted / training-mode forwards).
+os.environ.setdefault("VT_DEFERRED_LN_MIN_ROWS", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); run with -m gpu")

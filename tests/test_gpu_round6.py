@@ -809,3 +809,33 @@ def test_step_counters_ride_with_the_row_counts(dev):
     assert ops.wgrad_turn_timeouts() == 0 and ops.gemm_shared_tile_timeouts() == 0
     vals2, _ = ops.batch_row_counts_end(h2)
     assert vals2[1] == vals[1] and vals2[2] == 0
+
+
+def test_small_inference_forwards_take_the_seven_launch_layer(dev):
+    """The product's rule (CaptionBertEncoder.serves_deferred_ln): an eval forward below deferred_ln_min_rows (2 800) padded
+    token rows runs the seven-launch layer -- bit for bit what `deferred_ln = False` returns -- and the deferred-LayerNorm
+    loop from there on; both inside 5e-2 of the oracle on the base configuration's width (B = 2 and B = 13 sequences of 228)."""
+    from oracle.modeling import BertImgModelwithLocationEmbeds as OTrunk
+    from helpers import check_close, model_pair
+    from visitron_amd.config import BertConfig
+    from visitron_amd.modeling import BertImgModelwithLocationEmbeds
+    from visitron_amd.synth import make_batch
+
+    cfg = BertConfig(num_hidden_layers=3, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ref, prod = model_pair(OTrunk, BertImgModelwithLocationEmbeds, cfg, seed=2, device=dev)
+    enc = prod.encoder
+    enc.deferred_ln_min_rows = 2800                       # the product's default (the test session sets 0: tests/conftest.py)
+    keys = ("input_ids", "token_type_ids", "attention_mask", "img_feats", "img_location_embeddings")
+    for B, deferred in ((2, False), (13, True)):
+        b = make_batch(cfg, B, seed=5, with_labels=False)
+        kw = {k: b[k] for k in keys if k in b}
+        assert enc.serves_deferred_ln(rows=B * 228) is deferred
+        with torch.no_grad():
+            want = ref(**kw)[0]
+            got = prod(**{k: v.to(dev) for k, v in kw.items()})[0]
+            enc.deferred_ln = False
+            seven = prod(**{k: v.to(dev) for k, v in kw.items()})[0]
+            enc.deferred_ln = True
+        check_close("inference B=%d x 228 under the row rule (%s)" % (B, "deferred loop" if deferred else "seven-launch layer"),
+                    got, want, 5e-2)
+        assert torch.equal(got, seven) is (not deferred)

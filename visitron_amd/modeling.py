@@ -644,6 +644,7 @@ class CaptionBertEncoder(nn.Module):
         # inference, default: the layer loop with its LayerNorms deferred (run_ln): no LayerNorm pass, fp16 residual stream.
         # VT_DEFERRED_LN=0 (or the attribute) keeps the seven-launch layer with bf16 activations between all kernels.
         self.deferred_ln = os.environ.get("VT_DEFERRED_LN", "1") != "0"
+        self.deferred_ln_min_rows = int(os.environ.get("VT_DEFERRED_LN_MIN_ROWS", "2800"))   # see serves_deferred_ln
         self._packed_ln = None
         self._packed_ln_key = None
 
@@ -662,9 +663,16 @@ class CaptionBertEncoder(nn.Module):
             self._packed_ln_key = key
         return self._packed_ln
 
-    def serves_deferred_ln(self, history=None, seq=None):
+    def serves_deferred_ln(self, history=None, seq=None, rows=None):
         """The deferred-LayerNorm loop serves the plain eval forward (padded rows with a mask, or compacted rows: run_ln's
-        seq): hidden size a multiple of 128 (<= 1024: eight statistics slices), no per-layer outputs asked for."""
+        seq): hidden size a multiple of 128 (<= 1024: eight statistics slices), no per-layer outputs asked for -- and, when
+        the caller says how many token rows (padded) the forward has, at least deferred_ln_min_rows of them: below ~2 800
+        rows the seven-launch layer is faster (its plain GEMMs may take the split-K and three-stage kernels; the LN-mode
+        GEMMs exist in the 256-wide kernels only: forward B = 1 ... 10 x 228 rows 1.01 ... 1.32 ms against 1.36 ... 1.47,
+        round 6, tools/r6/deferred_ab2.sh) and as accurate (fp16 residual stream since round 4: 3.6e-2 against 3.4e-2 on
+        the base configuration's hidden states, bound 5e-2)."""
+        if rows is not None and rows < self.deferred_ln_min_rows:
+            return False
         return (self.deferred_ln and history is None and seq is None and not self.output_attentions
                 and not self.output_hidden_states and self._hidden == self._heads * 64 and self._hidden % 128 == 0
                 and self._hidden <= 1024 and self._inter % 128 == 0)
@@ -911,7 +919,7 @@ class CaptionBertEncoder(nn.Module):
                                 history=encoder_history_states)
             if not self.output_hidden_states:
                 outs = outs[-1:]
-        elif self.serves_deferred_ln(history=encoder_history_states):
+        elif self.serves_deferred_ln(history=encoder_history_states, rows=B * S):
             ops._require_hip(hidden_states)
             out16, _ = self.run_ln(hidden_states.detach().reshape(B * S, H).float().contiguous(), B, S, mask, True, hs)
             outs = [out16]
@@ -1040,7 +1048,14 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                 raise NotImplementedError("compacted rows are served by the bf16 path")
             return self._run_trunk_f32(input_ids, token_type_ids, position_ids, img_feats, img_location_embeddings,
                                        encoder_history_states, mask_f32, mask_is_additive, hs, B, T, R, S, H)
-        if (keep is None or not ops.profiling()) and self.encoder.serves_deferred_ln(history=encoder_history_states):
+        # compacted rows (the rollout's eval forward): the layout first -- its row count, not the padded one, picks the layer loop
+        lay = None
+        if keep is not None:
+            if encoder_history_states is not None or self.encoder.output_attentions or self.encoder.output_hidden_states:
+                raise NotImplementedError("compacted rows: plain forward only")
+            lay = ops.SeqLayout(keep.to(device=dev, dtype=torch.bool))
+        rows_eff = B * S if lay is None else lay.rows
+        if (keep is None or not ops.profiling()) and self.encoder.serves_deferred_ln(history=encoder_history_states, rows=rows_eff):
             # default inference path: the embedding output in fp32, the encoder's residual stream in fp16 (not bf16)
             emb = self.embeddings
             _no_train_dropout(emb, emb.dropout.p)
@@ -1063,7 +1078,6 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                                        self.LayerNorm.variance_epsilon, out=x32[T:], M=B * R, grp_rows=R, grp_stride=S)
             self._last_layout = None
             if keep is not None:   # compacted rows (the rollout's eval forward): the same loop on the rows that exist
-                lay = ops.SeqLayout(keep.to(device=dev, dtype=torch.bool))
                 self._last_layout = lay
                 out16, _ = self.encoder.run_ln(x32.index_select(0, lay.index), B, S, None, False, hs, seq=lay)
                 cls = out16[:lay.rows].index_select(0, lay.start.to(torch.int64))
@@ -1089,9 +1103,6 @@ class BertImgModelwithLocationEmbeds(BertPreTrainedModel):
                               self.LayerNorm.variance_epsilon, out=x[T:], M=B * R, grp_rows=R, grp_stride=S)
         self._last_layout = None
         if keep is not None:
-            if encoder_history_states is not None or self.encoder.output_attentions or self.encoder.output_hidden_states:
-                raise NotImplementedError("compacted rows: plain forward only")
-            lay = ops.SeqLayout(keep.to(device=dev, dtype=torch.bool))
             self._last_layout = lay
             xc = x.index_select(0, lay.index)
             # the row count decides the tile quantisation: tune once per 256-row bucket (512 below 16 384 rows; nearest tuned
